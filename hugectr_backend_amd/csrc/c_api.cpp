@@ -1,0 +1,318 @@
+// extern "C" surface of libhps_amd.so — see include/hps_amd.h for the contract and the reference
+// call site each function replaces.
+#include "../../include/hps_amd.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <string>
+
+#include "cache/engine.h"
+
+using namespace hps;
+
+struct hps_server { std::shared_ptr<HierParameterServer> ps; std::vector<std::string> names; };
+struct hps_cache { std::shared_ptr<EmbeddingCache> cache; };
+struct hps_session { std::shared_ptr<HierParameterServer> ps; std::unique_ptr<LookupSession> s; };
+
+namespace {
+thread_local std::string g_err;
+
+int Fail(const Status& st) {
+  g_err = st.message();
+  const int c = (int)st.code();
+  return c < 0 ? HPS_ERR_UNKNOWN : c + 1;
+}
+int FailMsg(int code, const std::string& m) { g_err = m; return code; }
+
+template <typename F>
+int Guard(F&& f) {
+  try {
+    const Status st = f();
+    if (st.ok()) return HPS_OK;
+    return Fail(st);
+  } catch (const std::exception& e) {
+    return FailMsg(HPS_ERR_INTERNAL, std::string("exception: ") + e.what());
+  } catch (...) {
+    return FailMsg(HPS_ERR_INTERNAL, "unknown exception");
+  }
+}
+
+Status FindModel(hps_server_t* sv, const char* model, const InferenceParams** out) {
+  if (!sv || !model) return Error(Code::kInvalidArg, "null argument");
+  const auto& m = sv->ps->get_hps_model_configuration_map();
+  auto it = m.find(model);
+  if (it == m.end()) return Error(Code::kNotFound, "model '", model, "' is not in the parameter server configuration");
+  *out = &it->second;
+  return Status::Ok();
+}
+}  // namespace
+
+extern "C" {
+
+const char* hps_last_error(void) { return g_err.c_str(); }
+
+int hps_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int hps_server_create(const char* path, hps_server_t** out) {
+  return Guard([&]() -> Status {
+    if (!path || !out) return Error(Code::kInvalidArg, "null argument");
+    std::shared_ptr<HierParameterServer> ps;
+    HPS_RETURN_IF_ERROR(HierParameterServer::create(path, &ps));
+    *out = new hps_server{std::move(ps), {}};
+    return Status::Ok();
+  });
+}
+
+int hps_server_create_from_text(const char* text, int load_tables, hps_server_t** out) {
+  return Guard([&]() -> Status {
+    if (!text || !out) return Error(Code::kInvalidArg, "null argument");
+    ParameterServerConfig cfg;
+    HPS_RETURN_IF_ERROR(ParseParameterServerText(text, &cfg));
+    std::shared_ptr<HierParameterServer> ps;
+    HPS_RETURN_IF_ERROR(HierParameterServer::create_from_config(cfg, load_tables != 0, &ps));
+    *out = new hps_server{std::move(ps), {}};
+    return Status::Ok();
+  });
+}
+
+void hps_server_destroy(hps_server_t* sv) { delete sv; }
+
+int hps_server_model_count(hps_server_t* sv) {
+  if (!sv) return 0;
+  return (int)sv->ps->get_hps_model_configuration_map().size();
+}
+
+const char* hps_server_model_name(hps_server_t* sv, int index) {
+  if (!sv) return nullptr;
+  sv->names.clear();
+  for (const auto& kv : sv->ps->get_hps_model_configuration_map()) sv->names.push_back(kv.first);
+  if (index < 0 || (size_t)index >= sv->names.size()) return nullptr;
+  return sv->names[(size_t)index].c_str();
+}
+
+int hps_server_model_info(hps_server_t* sv, const char* model, hps_model_info_t* out) {
+  return Guard([&]() -> Status {
+    const InferenceParams* p = nullptr;
+    HPS_RETURN_IF_ERROR(FindModel(sv, model, &p));
+    if (!out) return Error(Code::kInvalidArg, "null argument");
+    memset(out, 0, sizeof *out);
+    out->max_batch_size = p->max_batchsize;
+    out->num_tables = (uint32_t)p->num_tables();
+    out->use_gpu_embedding_cache = p->use_gpu_embedding_cache;
+    out->hit_rate_threshold = p->hit_rate_threshold;
+    out->cache_size_percentage = p->cache_size_percentage;
+    out->i64_input_key = p->i64_input_key;
+    out->number_of_worker_buffers_in_pool = p->number_of_worker_buffers_in_pool;
+    out->number_of_refresh_buffers_in_pool = p->number_of_refresh_buffers_in_pool;
+    out->cache_refresh_percentage_per_iteration = p->cache_refresh_percentage_per_iteration;
+    out->device_id = p->device_id;
+    out->num_deployed_devices = (uint32_t)p->deployed_devices.size();
+    out->refresh_delay = p->refresh_delay;
+    out->refresh_interval = p->refresh_interval;
+    for (size_t c : p->maxnum_catfeature_query_per_table_per_sample) out->cat_num += c;
+    for (size_t d : p->embedding_vecsize_per_table) out->embedding_size += d;
+    return Status::Ok();
+  });
+}
+
+int hps_server_table_info(hps_server_t* sv, const char* model, uint32_t table, hps_table_info_t* out) {
+  return Guard([&]() -> Status {
+    const InferenceParams* p = nullptr;
+    HPS_RETURN_IF_ERROR(FindModel(sv, model, &p));
+    if (!out || table >= p->num_tables()) return Error(Code::kInvalidArg, "table index out of range");
+    out->embedding_vecsize = (uint32_t)p->embedding_vecsize_per_table[table];
+    out->maxnum_catfeature = p->maxnum_catfeature_query_per_table_per_sample[table];
+    out->default_value = p->default_value_for_each_table[table];
+    auto tabs = sv->ps->tables_of(model);
+    out->rows_loaded = table < tabs.size() ? tabs[table]->size() : 0;
+    return Status::Ok();
+  });
+}
+
+int hps_server_deployed_device(hps_server_t* sv, const char* model, uint32_t index, int32_t* device) {
+  return Guard([&]() -> Status {
+    const InferenceParams* p = nullptr;
+    HPS_RETURN_IF_ERROR(FindModel(sv, model, &p));
+    if (!device || index >= p->deployed_devices.size()) return Error(Code::kInvalidArg, "device index out of range");
+    *device = p->deployed_devices[index];
+    return Status::Ok();
+  });
+}
+
+int hps_server_parse_config(hps_server_t* sv, const char* path) {
+  return Guard([&]() -> Status {
+    if (!sv || !path) return Error(Code::kInvalidArg, "null argument");
+    return sv->ps->parse_config(path);
+  });
+}
+
+int hps_server_update_database_per_model(hps_server_t* sv, const char* model) {
+  return Guard([&]() -> Status {
+    const InferenceParams* p = nullptr;
+    HPS_RETURN_IF_ERROR(FindModel(sv, model, &p));
+    const InferenceParams copy = *p;
+    return sv->ps->update_database_per_model(copy);
+  });
+}
+
+int hps_server_create_embedding_cache_per_model(hps_server_t* sv, const char* model) {
+  return Guard([&]() -> Status {
+    const InferenceParams* p = nullptr;
+    HPS_RETURN_IF_ERROR(FindModel(sv, model, &p));
+    const InferenceParams copy = *p;
+    return sv->ps->create_embedding_cache_per_model(copy);
+  });
+}
+
+int hps_server_destroy_embedding_cache_per_model(hps_server_t* sv, const char* model) {
+  return Guard([&]() -> Status {
+    if (!sv || !model) return Error(Code::kInvalidArg, "null argument");
+    return sv->ps->destory_embedding_cache_per_model(model);
+  });
+}
+
+int hps_server_refresh_embedding_cache(hps_server_t* sv, const char* model, int32_t device) {
+  return Guard([&]() -> Status {
+    if (!sv || !model) return Error(Code::kInvalidArg, "null argument");
+    return sv->ps->refresh_embedding_cache(model, device);
+  });
+}
+
+int hps_server_get_embedding_cache(hps_server_t* sv, const char* model, int32_t device, hps_cache_t** out) {
+  return Guard([&]() -> Status {
+    if (!sv || !model || !out) return Error(Code::kInvalidArg, "null argument");
+    auto c = sv->ps->get_embedding_cache(model, device);
+    *out = c ? new hps_cache{std::move(c)} : nullptr;
+    return Status::Ok();
+  });
+}
+
+int hps_server_load_table_arrays(hps_server_t* sv, const char* model, uint32_t table, const int64_t* keys,
+                                 const float* rows, uint64_t R, int borrow) {
+  return Guard([&]() -> Status {
+    if (!sv || !model || (R && (!keys || !rows))) return Error(Code::kInvalidArg, "null argument");
+    return sv->ps->load_table_from_arrays(model, table, keys, rows, R, borrow != 0);
+  });
+}
+
+int hps_server_load_table_synthetic(hps_server_t* sv, const char* model, uint32_t table, uint64_t seed, int64_t key0,
+                                    uint64_t R) {
+  return Guard([&]() -> Status {
+    if (!sv || !model) return Error(Code::kInvalidArg, "null argument");
+    return sv->ps->load_table_synthetic(model, table, seed, key0, R);
+  });
+}
+
+int hps_server_fetch(hps_server_t* sv, const char* model, uint32_t table, const int64_t* keys, uint64_t n, float* out,
+                     uint8_t* found) {
+  return Guard([&]() -> Status {
+    const InferenceParams* p = nullptr;
+    HPS_RETURN_IF_ERROR(FindModel(sv, model, &p));
+    auto tabs = sv->ps->tables_of(model);
+    if (table >= tabs.size()) return Error(Code::kInvalidArg, "table index out of range");
+    if (n && (!keys || !out)) return Error(Code::kInvalidArg, "null argument");
+    return sv->ps->Fetch(*tabs[table], keys, n, out, tabs[table]->dim(), p->default_value_for_each_table[table], found,
+                         nullptr);
+  });
+}
+
+int hps_cache_num_tables(hps_cache_t* c) { return c ? (int)c->cache->num_tables() : 0; }
+
+int hps_cache_table_info(hps_cache_t* c, uint32_t table, hps_cache_table_info_t* out) {
+  return Guard([&]() -> Status {
+    if (!c || !out || table >= c->cache->num_tables()) return Error(Code::kInvalidArg, "bad cache/table");
+    const auto& cfg = c->cache->get_cache_config();
+    out->embedding_vecsize = cfg.embedding_vec_size_[table];
+    out->num_buckets = cfg.num_set_in_cache_[table];
+    out->capacity_rows = cfg.capacity_rows_[table];
+    return Status::Ok();
+  });
+}
+
+int hps_cache_counters(hps_cache_t* c, hps_cache_counters_t* out) {
+  return Guard([&]() -> Status {
+    if (!c || !out) return Error(Code::kInvalidArg, "null argument");
+    const CacheCounters k = c->cache->counters();
+    out->lookups = k.lookups; out->keys = k.keys; out->misses = k.misses; out->unique_misses = k.unique_misses;
+    out->inserted = k.inserted; out->refreshed = k.refreshed; out->dropped = k.dropped; out->async_calls = k.async_calls;
+    return Status::Ok();
+  });
+}
+
+int hps_cache_query(hps_cache_t* c, uint32_t table, const int64_t* h_keys, uint64_t n, int32_t* h_slots) {
+  return Guard([&]() -> Status {
+    if (!c || (n && (!h_keys || !h_slots))) return Error(Code::kInvalidArg, "null argument");
+    return c->cache->Query(table, h_keys, n, h_slots);
+  });
+}
+
+int hps_cache_wait_async(hps_cache_t* c) {
+  return Guard([&]() -> Status {
+    if (!c) return Error(Code::kInvalidArg, "null argument");
+    c->cache->WaitAsync();
+    return Status::Ok();
+  });
+}
+
+void hps_cache_release(hps_cache_t* c) { delete c; }
+
+int hps_session_create(hps_server_t* sv, const char* model, hps_cache_t* cache, hps_session_t** out) {
+  return Guard([&]() -> Status {
+    if (!sv || !model || !out) return Error(Code::kInvalidArg, "null argument");
+    std::unique_ptr<LookupSession> s;
+    HPS_RETURN_IF_ERROR(sv->ps->create_lookup_session(model, cache ? cache->cache : nullptr, &s));
+    *out = new hps_session{sv->ps, std::move(s)};
+    return Status::Ok();
+  });
+}
+
+void hps_session_destroy(hps_session_t* s) { delete s; }
+
+int hps_session_lookup(hps_session_t* s, const void* const* h_keys_per_table, float* const* vectors_per_table,
+                       const size_t* num_keys_per_table, size_t num_tables) {
+  return Guard([&]() -> Status {
+    if (!s || !h_keys_per_table || !vectors_per_table || !num_keys_per_table) return Error(Code::kInvalidArg, "null argument");
+    return s->s->lookup(h_keys_per_table, vectors_per_table, num_keys_per_table, num_tables);
+  });
+}
+
+int hps_session_lookup_device(hps_session_t* s, const int64_t* d_keys_flat, float* const* d_vectors_per_table,
+                              const size_t* num_keys_per_table, size_t num_tables) {
+  return Guard([&]() -> Status {
+    if (!s || !d_keys_flat || !d_vectors_per_table || !num_keys_per_table) return Error(Code::kInvalidArg, "null argument");
+    return s->s->lookup_from_device(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
+  });
+}
+
+int hps_session_last_stats(hps_session_t* s, hps_lookup_stats_t* out) {
+  return Guard([&]() -> Status {
+    if (!s || !out) return Error(Code::kInvalidArg, "null argument");
+    out->misses = s->s->last_miss_count();
+    out->unique_misses = s->s->last_unique_miss_count();
+    out->async_insert = s->s->last_call_async() ? 1 : 0;
+    out->probe_gather_ms = s->s->last_gpu_ms();
+    return Status::Ok();
+  });
+}
+
+int hps_session_set_option(hps_session_t* s, const char* name, int value) {
+  return Guard([&]() -> Status {
+    if (!s || !name) return Error(Code::kInvalidArg, "null argument");
+    const std::string n(name);
+    if (n == "timing") s->s->set_timing(value != 0);
+    else if (n == "probe_unroll") {
+      if (value != 1 && value != 2 && value != 4 && value != 8) return Error(Code::kInvalidArg, "probe_unroll must be 1, 2, 4 or 8");
+      s->s->set_probe_unroll(value);
+    } else return Error(Code::kInvalidArg, "unknown option '", n, "'");
+    return Status::Ok();
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,566 @@
+#include "engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "kernels.h"
+
+namespace hps {
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return ::hps::Error(::hps::Code::kInternal, #expr, " failed: ", hipGetErrorString(_e), " (", \
+                          __FILE__, ":", __LINE__, ")");                                           \
+  } while (0)
+
+namespace {
+
+constexpr size_t kStagingCapBytes = 256ull << 20;  // per-session staging chunk for missed rows
+
+Status RequireDevice(int device) {
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return Error(Code::kUnavailable,
+                 "the GPU embedding cache needs a HIP device and none is visible (hipGetDeviceCount: ",
+                 e == hipSuccess ? "0 devices" : hipGetErrorString(e),
+                 "); there is no CPU fallback for gpucache=true models");
+  if (device < 0 || device >= n)
+    return Error(Code::kInvalidArg, "device ", device, " is not visible (", n, " HIP devices)");
+  return Status::Ok();
+}
+
+template <typename T>
+Status DevAlloc(T** p, size_t count) {
+  void* v = nullptr;
+  HIP_TRY(hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(T)));
+  *p = (T*)v;
+  return Status::Ok();
+}
+template <typename T>
+Status PinAlloc(T** p, size_t count, unsigned flags = hipHostMallocDefault) {
+  void* v = nullptr;
+  HIP_TRY(hipHostMalloc(&v, std::max<size_t>(count, 1) * sizeof(T), flags));
+  *p = (T*)v;
+  return Status::Ok();
+}
+
+}  // namespace
+
+// =================================================================================================
+// EmbeddingCache
+// =================================================================================================
+EmbeddingCache::~EmbeddingCache() { Release(); }
+
+void EmbeddingCache::Release() {
+  if (allocations_.empty() && !d_tables_) return;
+  (void)hipSetDevice(cfg_.device_id_);
+  (void)hipDeviceSynchronize();
+  FreeInserter();
+  for (void* p : allocations_) (void)hipFree(p);
+  allocations_.clear();
+  if (d_tables_) (void)hipFree(d_tables_);
+  d_tables_ = nullptr;
+  if (last_write_) (void)hipEventDestroy(last_write_);
+  last_write_ = nullptr;
+}
+
+CacheCounters EmbeddingCache::counters() const {
+  std::lock_guard<std::mutex> lk(stat_mu_);
+  return counters_;
+}
+
+uint32_t EmbeddingCache::NextEpoch() { return epoch_.fetch_add(1, std::memory_order_relaxed) + 1; }
+
+void EmbeddingCache::BeginRead(hipStream_t stream) {
+  order_mu_.lock();
+  if (has_write_) (void)hipStreamWaitEvent(stream, last_write_, 0);
+}
+void EmbeddingCache::EndRead(hipStream_t stream, hipEvent_t reader_done) {
+  (void)hipEventRecord(reader_done, stream);
+  if (std::find(readers_.begin(), readers_.end(), reader_done) == readers_.end()) readers_.push_back(reader_done);
+  order_mu_.unlock();
+}
+void EmbeddingCache::BeginWrite(hipStream_t stream) {
+  order_mu_.lock();
+  if (has_write_) (void)hipStreamWaitEvent(stream, last_write_, 0);
+  for (hipEvent_t e : readers_) (void)hipStreamWaitEvent(stream, e, 0);
+}
+void EmbeddingCache::EndWrite(hipStream_t stream) {
+  (void)hipEventRecord(last_write_, stream);
+  has_write_ = true;
+  readers_.clear();
+  order_mu_.unlock();
+}
+
+Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
+                            const std::vector<std::shared_ptr<HostTable>>& tables, int device) {
+  HPS_RETURN_IF_ERROR(RequireDevice(device));
+  HIP_TRY(hipSetDevice(device));
+  model_ = model;
+  const size_t T = tables.size();
+  if (T == 0 || T > (size_t)kMaxTables)
+    return Error(Code::kInvalidArg, "model '", model, "': ", T, " tables (supported: 1..", kMaxTables, ")");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  static_ = p.embedding_cache_type == EmbeddingCacheType::Static;
+
+  cfg_.num_emb_table_ = T;
+  cfg_.use_gpu_embedding_cache_ = true;
+  cfg_.device_id_ = device;
+  h_tables_.resize(T);
+  HIP_TRY(hipEventCreateWithFlags(&last_write_, hipEventDisableTiming));
+
+  for (size_t t = 0; t < T; ++t) {
+    const uint32_t D = tables[t]->dim();
+    const size_t R = tables[t]->size();
+    // capacity = ceil(gpucacheper * rows) (docs/architecture.md:50), at least one bucket
+    size_t cap = (size_t)std::ceil((double)p.cache_size_percentage * (double)R);
+    if (cap < 1) cap = 1;
+    size_t slots = (size_t)std::ceil((double)cap / p.cache_load_factor);
+    slots = (slots + kBucketSlots - 1) / kBucketSlots * kBucketSlots;
+    const size_t buckets = slots / kBucketSlots;
+    if (buckets > (1ull << 27))
+      return Error(Code::kUnsupported, "model '", model, "' table ", t, ": cache of ", slots,
+                   " slots exceeds the 2^31-slot limit of one table");
+    TableCacheDev& tb = h_tables_[t];
+    int64_t* dk = nullptr; uint32_t* ds = nullptr; float* dr = nullptr;
+    HPS_RETURN_IF_ERROR(DevAlloc(&dk, slots)); allocations_.push_back(dk);
+    HPS_RETURN_IF_ERROR(DevAlloc(&ds, slots)); allocations_.push_back(ds);
+    HPS_RETURN_IF_ERROR(DevAlloc(&dr, slots * (size_t)D)); allocations_.push_back(dr);
+    HIP_TRY(LaunchCacheClear(dk, ds, slots, nullptr));
+    tb.bucket_keys = dk; tb.stamps = ds; tb.rows = dr;
+    tb.num_buckets = (uint32_t)buckets;
+    tb.dim = D;
+    tb.default_value = p.default_value_for_each_table[t];
+    tb.flags = static_ ? 1u : 0u;
+    cfg_.embedding_vec_size_.push_back(D);
+    cfg_.num_set_in_cache_.push_back(buckets);
+    cfg_.capacity_rows_.push_back(cap);
+    cfg_.default_value_.push_back(tb.default_value);
+  }
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_tables_, T));
+  HIP_TRY(hipMemcpy(d_tables_, h_tables_.data(), T * sizeof(TableCacheDev), hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+
+  if (!p.init_ec) return Status::Ok();
+
+  // ---- warm-up: the first `capacity` rows of each table in file order ----
+  // Static caches are filled here too (flag cleared for the duration of the warm-up).
+  std::vector<TableCacheDev> warm = h_tables_;
+  for (auto& w : warm) w.flags = 0;
+  TableCacheDev* d_warm = nullptr;
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_warm, T));
+  HIP_TRY(hipMemcpy(d_warm, warm.data(), T * sizeof(TableCacheDev), hipMemcpyHostToDevice));
+
+  const size_t chunk_rows_max = 1u << 20;
+  MissDesc* d_md = nullptr; uint64_t* d_zero_ks = nullptr; uint32_t* d_stats = nullptr;
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_md, 1));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_zero_ks, (size_t)kMaxTables + 1));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_stats, 4));
+  HIP_TRY(hipMemset(d_zero_ks, 0, sizeof(uint64_t) * ((size_t)kMaxTables + 1)));
+  HIP_TRY(hipMemset(d_stats, 0, 4 * sizeof(uint32_t)));
+  int64_t* d_keys = nullptr; float* d_rows = nullptr;
+  size_t maxD = 1;
+  for (size_t t = 0; t < T; ++t) maxD = std::max<size_t>(maxD, tables[t]->dim());
+  size_t chunk_rows = std::min(chunk_rows_max, std::max<size_t>(1, kStagingCapBytes / (maxD * sizeof(float))));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_keys, chunk_rows));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_rows, chunk_rows * maxD));
+  std::vector<int64_t> hk;
+  std::vector<float> hr;
+  const uint32_t epoch = 1;
+  Status st = Status::Ok();
+  for (size_t t = 0; t < T && st.ok(); ++t) {
+    const HostTable& ht = *tables[t];
+    const uint32_t D = ht.dim();
+    const size_t want = std::min(cfg_.capacity_rows_[t], ht.size());
+    for (size_t r0 = 0; r0 < want && st.ok(); r0 += chunk_rows) {
+      const size_t n = std::min(chunk_rows, want - r0);
+      // canonical rows only: a key repeated in the file is represented by its last row
+      hk.clear(); hr.clear();
+      const int64_t* src_keys = ht.keys() + r0;
+      const float* src_rows = ht.row_at(r0);
+      const bool contiguous = !ht.has_duplicate_keys();
+      size_t m = n;
+      if (!contiguous) {
+        for (size_t i = 0; i < n; ++i) {
+          if (ht.Find(src_keys[i]) != (int64_t)(r0 + i)) continue;
+          hk.push_back(src_keys[i]);
+          hr.insert(hr.end(), ht.row_at(r0 + i), ht.row_at(r0 + i) + D);
+        }
+        m = hk.size(); src_keys = hk.data(); src_rows = hr.data();
+      }
+      if (m == 0) continue;
+      if (hipMemcpy(d_keys, src_keys, m * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(d_rows, src_rows, m * (size_t)D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        st = Error(Code::kInternal, "cache warm-up: H2D copy failed");
+        break;
+      }
+      MissDesc md;
+      memset(&md, 0, sizeof md);
+      for (size_t u = 0; u <= T; ++u) md.useg_start[u] = u > t ? m : 0;
+      md.chunk_lo[t] = 0; md.chunk_hi[t] = (uint32_t)m; md.stage_off[t] = 0;
+      if (hipMemcpy(d_md, &md, sizeof md, hipMemcpyHostToDevice) != hipSuccess) { st = Error(Code::kInternal, "cache warm-up: H2D copy failed"); break; }
+      const hipError_t e = LaunchCacheInsert(d_warm, (uint32_t)T, d_md, m, d_zero_ks, d_keys, d_rows, nullptr, epoch,
+                                             d_stats, cu_count_, nullptr);
+      if (e != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        st = Error(Code::kInternal, "cache warm-up: insert kernel failed: ", hipGetErrorString(e));
+        break;
+      }
+    }
+  }
+  uint32_t stats[4] = {0, 0, 0, 0};
+  (void)hipMemcpy(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost);
+  {
+    std::lock_guard<std::mutex> lk(stat_mu_);
+    counters_.dropped += stats[0];
+    counters_.inserted += stats[1];
+    counters_.refreshed += stats[2];
+  }
+  (void)hipFree(d_keys); (void)hipFree(d_rows); (void)hipFree(d_md); (void)hipFree(d_zero_ks); (void)hipFree(d_stats);
+  (void)hipFree(d_warm);
+  epoch_.store(1);
+  return st;
+}
+
+Status EmbeddingCache::Query(uint32_t table, const int64_t* h_keys, size_t n, int32_t* h_slots) {
+  if (table >= num_tables()) return Error(Code::kInvalidArg, "table index out of range");
+  if (n == 0) return Status::Ok();
+  HIP_TRY(hipSetDevice(cfg_.device_id_));
+  int64_t* dk = nullptr; int32_t* ds = nullptr;
+  HPS_RETURN_IF_ERROR(DevAlloc(&dk, n));
+  HPS_RETURN_IF_ERROR(DevAlloc(&ds, n));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(dk, h_keys, n * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIP_TRY(LaunchCacheQuery(h_tables_[table], dk, n, ds, nullptr));
+  HIP_TRY(hipMemcpy(h_slots, ds, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  (void)hipFree(dk); (void)hipFree(ds);
+  return Status::Ok();
+}
+
+Status EmbeddingCache::DumpKeys(uint32_t table, std::vector<int64_t>* keys) {
+  if (table >= num_tables()) return Error(Code::kInvalidArg, "table index out of range");
+  HIP_TRY(hipSetDevice(cfg_.device_id_));
+  const size_t slots = (size_t)h_tables_[table].num_buckets * kBucketSlots;
+  std::vector<int64_t> all(slots);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(all.data(), h_tables_[table].bucket_keys, slots * sizeof(int64_t), hipMemcpyDeviceToHost));
+  keys->clear();
+  for (int64_t k : all) if (k != HPS_EMPTY_KEY) keys->push_back(k);
+  return Status::Ok();
+}
+
+// =================================================================================================
+// LookupSession
+// =================================================================================================
+LookupSession::~LookupSession() { Release(); }
+
+void LookupSession::Release() {
+  if (!cache_) return;
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  {
+    // our reader event may still be registered with the cache
+    std::lock_guard<std::mutex> lk(cache_->order_mu_);
+    auto& r = cache_->readers_;
+    r.erase(std::remove(r.begin(), r.end(), ev_read_), r.end());
+  }
+  auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
+  auto dfree = [](void* p) { if (p) (void)hipFree(p); };
+  hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_call_); dfree(d_call_); hfree(h_md_); dfree(d_md_);
+  dfree(d_slot_); dfree(d_block_miss_); dfree(d_set_); dfree(d_counts_); hfree(h_counts_);
+  dfree(d_uniq_keys_); hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
+  if (ev_done_) (void)hipEventDestroy(ev_done_);
+  if (ev_read_) (void)hipEventDestroy(ev_read_);
+  if (ev_t0_) (void)hipEventDestroy(ev_t0_);
+  if (ev_t1_) (void)hipEventDestroy(ev_t1_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+  stream_ = nullptr;
+  cache_.reset();
+}
+
+Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, std::shared_ptr<EmbeddingCache> cache) {
+  ps_ = ps;
+  params_ = p;
+  tables_ = ps->tables_of(p.model_name);
+  const size_t T = tables_.size();
+  if (T == 0) return Error(Code::kNotFound, "model '", p.model_name, "' has no tables loaded in the parameter server");
+  size_t per_sample = 0;
+  for (size_t c : p.maxnum_catfeature_query_per_table_per_sample) per_sample += c;
+  max_keys_ = p.max_batchsize * per_sample;  // model_instance_state.cpp:98-99
+  if (max_keys_ == 0) return Error(Code::kInvalidArg, "model '", p.model_name, "': max_batch_size * sum(maxnum_catfeature...) is 0");
+  if (max_keys_ >= (1ull << 31) - 2) return Error(Code::kUnsupported, "more than 2^31 keys per request are not supported");
+  if (!p.use_gpu_embedding_cache) return Status::Ok();  // host-tier session: no device state at all
+
+  if (!cache) return Error(Code::kInvalidArg, "model '", p.model_name, "' uses the GPU cache but no EmbeddingCache was given");
+  cache_ = std::move(cache);
+  device_ = cache_->device();
+  HIP_TRY(hipSetDevice(device_));
+  HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ev_read_, hipEventDisableTiming));
+  HIP_TRY(hipEventCreate(&ev_t0_));
+  HIP_TRY(hipEventCreate(&ev_t1_));
+
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_keys_, max_keys_));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_call_, 1));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_call_, 1));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_md_, 1));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_md_, 1));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_slot_, max_keys_));
+  probe_blocks_cap_ = ProbeGridBlocks(max_keys_, cache_->cu_count());
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_block_miss_, probe_blocks_cap_));
+  set_cap_ = 1024;
+  while (set_cap_ < 2 * (uint64_t)max_keys_) set_cap_ <<= 1;
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_set_, set_cap_));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_counts_, (size_t)kMaxTables + 8));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_counts_, (size_t)kMaxTables + 8));
+  HIP_TRY(hipMemset(d_counts_, 0, ((size_t)kMaxTables + 8) * sizeof(uint32_t)));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_uniq_keys_, max_keys_));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_uniq_keys_, max_keys_, hipHostMallocMapped));
+  void* dv = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&dv, h_uniq_keys_, 0));
+  h_uniq_keys_devptr_ = (int64_t*)dv;
+  HIP_TRY(hipDeviceSynchronize());
+  return Status::Ok();
+}
+
+Status LookupSession::EnsureStaging(size_t floats, size_t uniq) {
+  if (floats > staging_floats_) {
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (h_staging_) (void)hipHostFree(h_staging_);
+    if (d_staging_) (void)hipFree(d_staging_);
+    h_staging_ = nullptr; d_staging_ = nullptr;
+    size_t want = std::max(floats, staging_floats_ * 2);
+    want = std::max<size_t>(want, 1u << 16);
+    HPS_RETURN_IF_ERROR(PinAlloc(&h_staging_, want));
+    HPS_RETURN_IF_ERROR(DevAlloc(&d_staging_, want));
+    staging_floats_ = want;
+  }
+  if (uniq > staging_uniq_) {
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (h_found_) (void)hipHostFree(h_found_);
+    if (d_found_) (void)hipFree(d_found_);
+    h_found_ = nullptr; d_found_ = nullptr;
+    size_t want = std::max(uniq, staging_uniq_ * 2);
+    want = std::max<size_t>(want, 1u << 12);
+    HPS_RETURN_IF_ERROR(PinAlloc(&h_found_, want));
+    HPS_RETURN_IF_ERROR(DevAlloc(&d_found_, want));
+    staging_uniq_ = want;
+  }
+  return Status::Ok();
+}
+
+Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* vectors_per_table,
+                             const size_t* num_keys_per_table, size_t num_tables) {
+  if (num_tables != tables_.size())
+    return Error(Code::kInvalidArg, "lookup: got ", num_tables, " tables, model '", params_.model_name, "' has ",
+                 tables_.size());
+  if (!cache_) return LookupHostTier(h_keys_per_table, vectors_per_table, num_keys_per_table, num_tables);
+  size_t N = 0;
+  for (size_t t = 0; t < num_tables; ++t) N += num_keys_per_table[t];
+  if (N > max_keys_)
+    return Error(Code::kInvalidArg, "lookup: ", N, " keys exceed the session capacity of ", max_keys_,
+                 " (max_batch_size x sum(maxnum_catfeature_query_per_table_per_sample))");
+  if (N == 0) return Status::Ok();
+  HIP_TRY(hipSetDevice(device_));
+  // stage keys: pageable -> pinned (the reference memcpy's into its key buffer too, hps.cc:595-597,
+  // but its "PIN" buffer is plain malloc: hps_buffer.hpp:114-123) -> one async H2D copy.
+  size_t off = 0;
+  for (size_t t = 0; t < num_tables; ++t) {
+    if (num_keys_per_table[t]) {
+      if (!h_keys_per_table[t]) return Error(Code::kInvalidArg, "lookup: null key pointer for table ", t);
+      memcpy(h_keys_pinned_ + off, h_keys_per_table[t], num_keys_per_table[t] * sizeof(int64_t));
+    }
+    off += num_keys_per_table[t];
+  }
+  HIP_TRY(hipMemcpyAsync(d_keys_, h_keys_pinned_, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+  return LookupDevice(d_keys_, vectors_per_table, num_keys_per_table, num_tables);
+}
+
+Status LookupSession::lookup_from_device(const int64_t* d_keys_flat, float* const* d_vectors_per_table,
+                                         const size_t* num_keys_per_table, size_t num_tables) {
+  if (!cache_) return Error(Code::kUnsupported, "lookup_from_device needs a GPU-cache session (gpucache=true)");
+  if (num_tables != tables_.size())
+    return Error(Code::kInvalidArg, "lookup: got ", num_tables, " tables, model '", params_.model_name, "' has ",
+                 tables_.size());
+  size_t N = 0;
+  for (size_t t = 0; t < num_tables; ++t) N += num_keys_per_table[t];
+  if (N > max_keys_) return Error(Code::kInvalidArg, "lookup: ", N, " keys exceed the session capacity of ", max_keys_);
+  if (N == 0) return Status::Ok();
+  HIP_TRY(hipSetDevice(device_));
+  return LookupDevice(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
+}
+
+Status LookupSession::LookupHostTier(const void* const* h_keys_per_table, float* const* h_vectors_per_table,
+                                     const size_t* num_keys_per_table, size_t num_tables) {
+  // gpucache=false: rows come straight from the parameter server into host memory
+  // (docs/architecture.md:72; model_instance_state.cpp:114-133).
+  for (size_t t = 0; t < num_tables; ++t) {
+    const size_t n = num_keys_per_table[t];
+    if (n == 0) continue;
+    if (!h_keys_per_table[t] || !h_vectors_per_table[t]) return Error(Code::kInvalidArg, "lookup: null pointer for table ", t);
+    HPS_RETURN_IF_ERROR(ps_->Fetch(*tables_[t], (const int64_t*)h_keys_per_table[t], n, h_vectors_per_table[t],
+                                   tables_[t]->dim(), params_.default_value_for_each_table[t], nullptr, nullptr));
+  }
+  return Status::Ok();
+}
+
+Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
+  // ---- call descriptor: the per-table slicing of ProcessRequest (model_instance_state.cpp:180-193) ----
+  CallDesc& c = *h_call_;
+  c.num_tables = (uint32_t)T;
+  c.keys = d_keys_flat;
+  uint64_t N = 0;
+  for (size_t t = 0; t < T; ++t) {
+    c.key_start[t] = N;
+    N += n[t];
+    c.out[t] = d_out[t];
+    if (n[t] && !d_out[t]) return Error(Code::kInvalidArg, "lookup: null output pointer for table ", t);
+    const uint32_t D = tables_[t]->dim();
+    c.vec_ok[t] = ((D & 3u) == 0 && ((uintptr_t)d_out[t] & 15u) == 0) ? 1 : 0;
+  }
+  c.key_start[T] = N;
+  c.total_keys = N;
+  const uint32_t epoch = cache_->NextEpoch();
+  c.epoch = epoch;
+  const size_t desc_bytes = sizeof(CallDesc);
+  HIP_TRY(hipMemcpyAsync(d_call_, h_call_, desc_bytes, hipMemcpyHostToDevice, stream_));
+
+  // ---- K_A: probe + gather hits ----
+  const int cu = cache_->cu_count();
+  const uint32_t probe_blocks = ProbeGridBlocks(N, cu);
+  cache_->BeginRead(stream_);
+  if (timing_) (void)hipEventRecord(ev_t0_, stream_);
+  hipError_t e = LaunchProbeGather(d_call_, cache_->device_tables(), (uint32_t)T, N, d_slot_, d_block_miss_, cu,
+                                   probe_unroll_, stream_);
+  if (timing_) (void)hipEventRecord(ev_t1_, stream_);
+  cache_->EndRead(stream_, ev_read_);
+  if (e != hipSuccess) return Error(Code::kInternal, "probe/gather launch failed: ", hipGetErrorString(e));
+
+  // ---- K_B: unique missed keys (all three kernels exit at once when nothing missed) ----
+  e = LaunchMissDedup(d_call_, c.key_start, (uint32_t)T, probe_blocks, d_slot_, d_block_miss_, d_set_, set_cap_,
+                      d_counts_, d_uniq_keys_, h_uniq_keys_devptr_, cu, stream_);
+  if (e != hipSuccess) return Error(Code::kInternal, "miss dedup launch failed: ", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, (1 + T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipEventRecord(ev_done_, stream_));
+  HIP_TRY(hipEventSynchronize(ev_done_));
+  if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
+
+  const uint64_t misses = h_counts_[0];
+  uint64_t uniq = 0;
+  for (size_t t = 0; t < T; ++t) uniq += h_counts_[1 + t];
+  last_misses_ = misses;
+  last_unique_ = uniq;
+  last_async_ = false;
+  {
+    std::lock_guard<std::mutex> lk(cache_->stat_mu_);
+    cache_->counters_.lookups += 1;
+    cache_->counters_.keys += N;
+    cache_->counters_.misses += misses;
+    cache_->counters_.unique_misses += uniq;
+  }
+  if (misses == 0) return Status::Ok();
+
+  // ---- insertion policy (docs/architecture.md:65-67) ----
+  const double hit_rate = 1.0 - (double)misses / (double)N;
+  const bool async = hit_rate >= (double)params_.hit_rate_threshold;
+  if (async) {
+    last_async_ = true;
+    e = LaunchMissFillDefault(d_call_, cache_->device_tables(), N, d_slot_, cu, stream_);
+    if (e != hipSuccess) return Error(Code::kInternal, "default fill launch failed: ", hipGetErrorString(e));
+    // hand the unique missed keys to the background inserter (best effort)
+    std::vector<std::vector<int64_t>> job(T);
+    for (size_t t = 0; t < T; ++t) {
+      const uint32_t cnt = h_counts_[1 + t];
+      job[t].assign(h_uniq_keys_ + c.key_start[t], h_uniq_keys_ + c.key_start[t] + cnt);
+    }
+    ps_->SubmitAsyncInsert(cache_, std::move(job));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    std::lock_guard<std::mutex> lk(cache_->stat_mu_);
+    cache_->counters_.async_calls += 1;
+    return Status::Ok();
+  }
+  return HandleMisses(N, epoch);
+}
+
+// Synchronous miss path: parameter-server gather of the unique missed keys into pinned staging,
+// one H2D copy per chunk, missed rows scattered to the output, then inserted into the cache.
+Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
+  const size_t T = tables_.size();
+  const CallDesc& c = *h_call_;
+  const int cu = cache_->cu_count();
+  std::vector<uint32_t> ucnt(T), done(T, 0);
+  size_t total_floats = 0, total_uniq = 0;
+  for (size_t t = 0; t < T; ++t) {
+    ucnt[t] = h_counts_[1 + t];
+    total_floats += (size_t)ucnt[t] * tables_[t]->dim();
+    total_uniq += ucnt[t];
+  }
+  const size_t cap_floats = kStagingCapBytes / sizeof(float);
+  HPS_RETURN_IF_ERROR(EnsureStaging(std::min(total_floats, cap_floats), total_uniq));
+  HIP_TRY(hipMemsetAsync(d_counts_ + kMaxTables + 1, 0, 4 * sizeof(uint32_t), stream_));
+
+  for (;;) {
+    // ---- assemble the next chunk: whole tables while they fit, else a slice of one table ----
+    MissDesc& md = *h_md_;
+    size_t fl = 0, uq = 0;
+    bool any = false;
+    for (size_t t = 0; t < T; ++t) {
+      const uint32_t D = tables_[t]->dim();
+      md.useg_start[t] = uq;
+      md.chunk_lo[t] = done[t];
+      // keep every table's staging offset 16-B aligned so the float4 path stays usable
+      fl = (fl + 3) & ~(size_t)3;
+      md.stage_off[t] = fl;
+      const size_t room_rows = fl < staging_floats_ ? (staging_floats_ - fl) / D : 0;
+      const uint32_t take = (uint32_t)std::min<size_t>(ucnt[t] - done[t], room_rows);
+      md.chunk_hi[t] = done[t] + take;
+      fl += (size_t)take * D;
+      uq += take;
+      any |= take > 0;
+    }
+    md.useg_start[T] = uq;
+    if (!any) break;
+
+    // ---- host parameter-server gather (multi-threaded) into pinned staging ----
+    for (size_t t = 0; t < T; ++t) {
+      const uint32_t lo = md.chunk_lo[t], hi = md.chunk_hi[t];
+      if (hi == lo) continue;
+      HPS_RETURN_IF_ERROR(ps_->Fetch(*tables_[t], h_uniq_keys_ + c.key_start[t] + lo, hi - lo,
+                                     h_staging_ + md.stage_off[t], tables_[t]->dim(),
+                                     params_.default_value_for_each_table[t], h_found_ + md.useg_start[t], nullptr));
+    }
+    HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(d_staging_, h_staging_, fl * sizeof(float), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(d_found_, h_found_, uq, hipMemcpyHostToDevice, stream_));
+
+    hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, N, d_slot_, d_staging_, cu, stream_);
+    if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
+    cache_->BeginWrite(stream_);
+    e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, uq, d_call_->key_start, d_uniq_keys_,
+                          d_staging_, d_found_, epoch, d_counts_ + kMaxTables + 1, cu, stream_);
+    cache_->EndWrite(stream_);
+    if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
+    // staging is reused by the next chunk
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (size_t t = 0; t < T; ++t) done[t] = md.chunk_hi[t];
+  }
+  HIP_TRY(hipMemcpyAsync(h_counts_ + kMaxTables + 1, d_counts_ + kMaxTables + 1, 4 * sizeof(uint32_t),
+                         hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipStreamSynchronize(stream_));
+  std::lock_guard<std::mutex> lk(cache_->stat_mu_);
+  cache_->counters_.dropped += h_counts_[kMaxTables + 1];
+  cache_->counters_.inserted += h_counts_[kMaxTables + 2];
+  cache_->counters_.refreshed += h_counts_[kMaxTables + 3];
+  return Status::Ok();
+}
+
+}  // namespace hps

@@ -1,0 +1,253 @@
+// The HPS engine: the three objects the reference's backend shell talks to
+// (/root/reference/hps_backend/include/backend.hpp:31-32, model_instance_state.hpp:33-35):
+//
+//   HierParameterServer  <->  HugeCTR::HierParameterServerBase   (call sites: backend.cpp:68-71,
+//                              model_state.cpp:111,132,135,160,379-392,411)
+//   EmbeddingCache       <->  HugeCTR::EmbeddingCacheBase        (model_instance_state.cpp:107-109,168-169)
+//   LookupSession        <->  HugeCTR::LookupSessionBase         (model_instance_state.cpp:170-171,194-195)
+//
+// The implementation behind them is new: host tier = partitioned hash tables (ps/host_table.h),
+// device tier = bucketed HBM cache driven by the HIP kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../common/config.h"
+#include "../common/status.h"
+#include "../ps/host_table.h"
+#include "../ps/thread_pool.h"
+#include "device_types.h"
+
+namespace hps {
+
+class HierParameterServer;
+
+struct EmbeddingCacheConfig {  // get_cache_config() of the reference (only num_emb_table_ is read there)
+  size_t num_emb_table_ = 0;
+  std::vector<uint32_t> embedding_vec_size_;
+  std::vector<size_t> num_set_in_cache_;       // buckets per table
+  std::vector<size_t> capacity_rows_;          // ceil(gpucacheper * R_t)
+  std::vector<float> default_value_;
+  bool use_gpu_embedding_cache_ = true;
+  int device_id_ = 0;
+};
+
+struct CacheCounters {
+  uint64_t lookups = 0;           // lookup calls
+  uint64_t keys = 0;              // keys looked up
+  uint64_t misses = 0;            // keys not resident at probe time
+  uint64_t unique_misses = 0;
+  uint64_t inserted = 0;
+  uint64_t refreshed = 0;         // key already resident at insert time: row refreshed in place
+  uint64_t dropped = 0;           // insert skipped: bucket full of current-epoch keys
+  uint64_t async_calls = 0;       // lookups answered in async-insert mode
+};
+
+// Per-(model, device) GPU embedding cache shared by every lookup session of that model on that device
+// (docs/architecture.md:20,29).
+class EmbeddingCache {
+ public:
+  ~EmbeddingCache();
+  const EmbeddingCacheConfig& get_cache_config() const { return cfg_; }
+  int device() const { return cfg_.device_id_; }
+  const std::string& model_name() const { return model_; }
+  uint32_t num_tables() const { return (uint32_t)cfg_.num_emb_table_; }
+  const TableCacheDev* device_tables() const { return d_tables_; }
+  const std::vector<TableCacheDev>& host_tables() const { return h_tables_; }
+  int cu_count() const { return cu_count_; }
+  CacheCounters counters() const;
+
+  // slot index (>=0) or -1 per key, straight from the device tables; no LRU side effect (tests, refresh)
+  Status Query(uint32_t table, const int64_t* h_keys, size_t n, int32_t* h_slots);
+  // every resident key of one table (order unspecified)
+  Status DumpKeys(uint32_t table, std::vector<int64_t>* keys);
+  // Fetch `keys_per_table` from the parameter server and insert them (keys already resident get their
+  // row refreshed in place).  Used by the async-insert path and by refresh_embedding_cache; runs on
+  // the cache's own stream and staging buffers, serialised by a mutex.
+  Status InsertKeys(HierParameterServer* ps, const std::vector<std::vector<int64_t>>& keys_per_table);
+  // blocks until every queued async insertion has finished
+  void WaitAsync();
+
+ private:
+  friend class HierParameterServer;
+  friend class LookupSession;
+  EmbeddingCache() = default;
+  Status Init(const std::string& model, const InferenceParams& p, const std::vector<std::shared_ptr<HostTable>>& tables,
+              int device);
+  void Release();
+  void FreeInserter();
+
+  // ---- ordering of kernels from different sessions on the shared device tables ----
+  // readers = probe/gather kernels, writers = insert/refresh kernels.  Enqueue-side only: the lock is
+  // held while stream-waits and the kernel launch are enqueued, never while the GPU runs.
+  void BeginRead(hipStream_t stream);                       // stream waits for the last writer
+  void EndRead(hipStream_t stream, hipEvent_t reader_done); // records + registers the reader event
+  void BeginWrite(hipStream_t stream);                      // stream waits for last writer + all readers
+  void EndWrite(hipStream_t stream);                        // records the writer event
+  uint32_t NextEpoch();
+
+  std::string model_;
+  EmbeddingCacheConfig cfg_;
+  std::vector<TableCacheDev> h_tables_;
+  TableCacheDev* d_tables_ = nullptr;
+  std::vector<void*> allocations_;
+  int cu_count_ = 256;
+  bool static_ = false;
+
+  std::mutex order_mu_;
+  hipEvent_t last_write_ = nullptr;
+  bool has_write_ = false;
+  std::vector<hipEvent_t> readers_;
+  std::atomic<uint32_t> epoch_{1};
+
+  mutable std::mutex stat_mu_;
+  CacheCounters counters_;
+
+  struct Inserter;  // stream + staging of the background insert path
+  Inserter* ins_ = nullptr;
+  std::mutex ins_mu_;
+  std::mutex pend_mu_;
+  std::condition_variable pend_cv_;
+  int pending_async_ = 0;
+};
+
+// One lookup session = one worker buffer set + one HIP stream.  Thread-compatible: Triton never runs
+// one instance concurrently (hps.cc:353-359); different sessions run concurrently.
+class LookupSession {
+ public:
+  ~LookupSession();
+
+  // The reference signature (docs/architecture.md:308-323, model_instance_state.cpp:194-195):
+  // host key pointers in, device (gpucache) or host (no gpucache) vector pointers out; blocking.
+  Status lookup(const void* const* h_keys_per_table, float* const* vectors_per_table,
+                const size_t* num_keys_per_table, size_t num_tables);
+
+  // Keys already resident in HBM, flat + table-major (the bench path: nothing crosses PCIe except
+  // missed rows).  d_vectors_per_table are device pointers.  Blocking unless `stream_out` is given,
+  // in which case the hit path is enqueued and the call returns after the miss path completed.
+  Status lookup_from_device(const int64_t* d_keys_flat, float* const* d_vectors_per_table,
+                            const size_t* num_keys_per_table, size_t num_tables);
+
+  const InferenceParams& params() const { return params_; }
+  bool uses_gpu_cache() const { return cache_ != nullptr; }
+  // last call's numbers
+  uint64_t last_miss_count() const { return last_misses_; }
+  uint64_t last_unique_miss_count() const { return last_unique_; }
+  bool last_call_async() const { return last_async_; }
+  float last_gpu_ms() const { return last_gpu_ms_; }      // probe+gather kernel time of the last call (HIP events)
+  void set_probe_unroll(int u) { probe_unroll_ = u; }
+  void set_timing(bool on) { timing_ = on; }
+
+ private:
+  friend class HierParameterServer;
+  LookupSession() = default;
+  Status Init(HierParameterServer* ps, const InferenceParams& p, std::shared_ptr<EmbeddingCache> cache);
+  Status LookupHostTier(const void* const* h_keys_per_table, float* const* h_vectors_per_table,
+                        const size_t* num_keys_per_table, size_t num_tables);
+  Status LookupDevice(const int64_t* d_keys_flat, float* const* d_vectors_per_table, const size_t* n, size_t T);
+  Status HandleMisses(uint64_t N, uint32_t epoch);
+  Status EnsureStaging(size_t floats, size_t uniq);
+  void Release();
+
+  HierParameterServer* ps_ = nullptr;
+  InferenceParams params_;
+  std::shared_ptr<EmbeddingCache> cache_;
+  std::vector<std::shared_ptr<HostTable>> tables_;
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr;
+
+  size_t max_keys_ = 0;           // max_batch * sum(maxnum_catfeature)
+  int64_t* h_keys_pinned_ = nullptr;
+  int64_t* d_keys_ = nullptr;
+  CallDesc* h_call_ = nullptr;    // pinned
+  CallDesc* d_call_ = nullptr;
+  MissDesc* h_md_ = nullptr;      // pinned
+  MissDesc* d_md_ = nullptr;
+  int32_t* d_slot_ = nullptr;
+  uint32_t* d_block_miss_ = nullptr;
+  uint32_t probe_blocks_cap_ = 0;
+  int32_t* d_set_ = nullptr;
+  uint64_t set_cap_ = 0;
+  uint32_t* d_counts_ = nullptr;  // [0]=misses, [1..T]=unique misses per table, [T+1..T+3] insert stats
+  uint32_t* h_counts_ = nullptr;  // pinned mirror
+  int64_t* d_uniq_keys_ = nullptr;
+  int64_t* h_uniq_keys_ = nullptr;        // pinned, device-mapped
+  int64_t* h_uniq_keys_devptr_ = nullptr; // device view of the same memory
+  float* h_staging_ = nullptr;    // pinned
+  float* d_staging_ = nullptr;
+  uint8_t* h_found_ = nullptr;    // pinned
+  uint8_t* d_found_ = nullptr;
+  size_t staging_floats_ = 0, staging_uniq_ = 0;
+
+  uint64_t last_misses_ = 0, last_unique_ = 0;
+  bool last_async_ = false;
+  float last_gpu_ms_ = 0.f;
+  int probe_unroll_ = 4;
+  bool timing_ = false;
+};
+
+// The process-wide parameter server (one per backend: backend.cpp:68-69).
+class HierParameterServer : public std::enable_shared_from_this<HierParameterServer> {
+ public:
+  // HierParameterServerBase::create(ps_json_config_file): parse, load every model's tables into the host
+  // tier, build + warm GPU caches on each model's deployed devices (docs/architecture.md:246-260).
+  static Status create(const std::string& ps_json_config_file, std::shared_ptr<HierParameterServer>* out);
+  static Status create_from_text(const std::string& ps_json_text, std::shared_ptr<HierParameterServer>* out);
+  // No files: models get their tables later through load_table_* (tests, bench).
+  static Status create_from_config(const ParameterServerConfig& cfg, bool load_tables,
+                                   std::shared_ptr<HierParameterServer>* out);
+  ~HierParameterServer();
+
+  const std::map<std::string, InferenceParams>& get_hps_model_configuration_map() const { return cfg_.models; }
+  const ParameterServerConfig& config() const { return cfg_; }
+
+  std::shared_ptr<EmbeddingCache> get_embedding_cache(const std::string& model, int device);
+  Status update_database_per_model(const InferenceParams& p);          // (re)load sparse files into the host tier
+  Status create_embedding_cache_per_model(const InferenceParams& p);   // build caches on deployed_devices
+  Status destory_embedding_cache_per_model(const std::string& model);  // [sic] reference spelling
+  Status refresh_embedding_cache(const std::string& model, int device);
+  Status add_model(const InferenceParams& p);  // online deployment: register a model parsed later
+  // Re-read ps.json and (re)register every model in it (HPSBackend::ParseParameterServer, hps.cc:210-219)
+  Status parse_config(const std::string& ps_json_config_file);
+
+  Status create_lookup_session(const std::string& model, std::shared_ptr<EmbeddingCache> cache,
+                               std::unique_ptr<LookupSession>* out);
+
+  // table injection without files
+  Status load_table_from_arrays(const std::string& model, size_t table, const int64_t* keys, const float* rows,
+                                size_t R, bool borrow);
+  Status load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0, size_t R);
+  std::vector<std::shared_ptr<HostTable>> tables_of(const std::string& model);
+
+  // Host-tier fetch of one table's keys: rows or default, multi-threaded.
+  Status Fetch(const HostTable& tb, const int64_t* keys, size_t n, float* out, size_t stride, float default_value,
+               uint8_t* found, size_t* nfound);
+
+  // async-insert mode: queue "fetch these keys and insert them" for a cache; dropped (best effort)
+  // when more than number_of_worker_buffers_in_pool jobs are already waiting.
+  void SubmitAsyncInsert(std::shared_ptr<EmbeddingCache> cache, std::vector<std::vector<int64_t>> keys_per_table);
+
+  ThreadPool* pool() { return pool_; }
+
+ private:
+  HierParameterServer() = default;
+  Status Build(bool load_tables);
+  Status EnsureTables(const InferenceParams& p, bool load);
+
+  ParameterServerConfig cfg_;
+  ThreadPool* pool_ = nullptr;
+  std::mutex mu_;
+  std::map<std::string, std::vector<std::shared_ptr<HostTable>>> tables_;
+  std::map<std::pair<std::string, int>, std::shared_ptr<EmbeddingCache>> caches_;
+};
+
+}  // namespace hps

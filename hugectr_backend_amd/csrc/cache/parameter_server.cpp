@@ -1,0 +1,367 @@
+// HierParameterServer + the background insert path of EmbeddingCache.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "engine.h"
+#include "kernels.h"
+
+namespace hps {
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return ::hps::Error(::hps::Code::kInternal, #expr, " failed: ", hipGetErrorString(_e), " (", \
+                          __FILE__, ":", __LINE__, ")");                                           \
+  } while (0)
+
+// =================================================================================================
+// EmbeddingCache: background insertion (async-insert mode, refresh)
+// =================================================================================================
+struct EmbeddingCache::Inserter {
+  hipStream_t stream = nullptr;
+  int64_t* h_keys = nullptr;  // pinned
+  int64_t* d_keys = nullptr;
+  float* h_rows = nullptr;    // pinned
+  float* d_rows = nullptr;
+  uint8_t* h_found = nullptr; // pinned
+  uint8_t* d_found = nullptr;
+  MissDesc* h_md = nullptr;   // pinned
+  MissDesc* d_md = nullptr;
+  uint64_t* h_ks = nullptr;   // pinned  key_start for the insert kernel (= useg_start)
+  uint64_t* d_ks = nullptr;
+  uint32_t* d_stats = nullptr;
+  uint32_t* h_stats = nullptr;
+  size_t cap_keys = 0, cap_floats = 0;
+};
+
+static constexpr size_t kInsChunkKeys = 1u << 18;
+
+void EmbeddingCache::FreeInserter() {
+  if (!ins_) return;
+  Inserter& I = *ins_;
+  if (I.stream) { (void)hipStreamSynchronize(I.stream); (void)hipStreamDestroy(I.stream); }
+  for (void* p : {(void*)I.h_keys, (void*)I.h_rows, (void*)I.h_found, (void*)I.h_md, (void*)I.h_ks, (void*)I.h_stats})
+    if (p) (void)hipHostFree(p);
+  for (void* p : {(void*)I.d_keys, (void*)I.d_rows, (void*)I.d_found, (void*)I.d_md, (void*)I.d_ks, (void*)I.d_stats})
+    if (p) (void)hipFree(p);
+  delete ins_;
+  ins_ = nullptr;
+}
+
+void EmbeddingCache::WaitAsync() {
+  std::unique_lock<std::mutex> lk(pend_mu_);
+  pend_cv_.wait(lk, [&] { return pending_async_ == 0; });
+}
+
+Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std::vector<int64_t>>& keys_per_table) {
+  const size_t T = num_tables();
+  if (keys_per_table.size() != T) return Error(Code::kInvalidArg, "InsertKeys: table count mismatch");
+  if (static_) return Status::Ok();
+  auto tables = ps->tables_of(model_);
+  if (tables.size() != T) return Error(Code::kNotFound, "InsertKeys: model '", model_, "' is not loaded");
+  std::lock_guard<std::mutex> lk(ins_mu_);
+  HIP_TRY(hipSetDevice(cfg_.device_id_));
+  size_t maxD = 1;
+  for (size_t t = 0; t < T; ++t) maxD = std::max<size_t>(maxD, cfg_.embedding_vec_size_[t]);
+  if (!ins_) {
+    ins_ = new Inserter();
+    Inserter& I = *ins_;
+    HIP_TRY(hipStreamCreateWithFlags(&I.stream, hipStreamNonBlocking));
+    I.cap_keys = kInsChunkKeys;
+    I.cap_floats = kInsChunkKeys * maxD + 4 * T;
+    HIP_TRY(hipHostMalloc((void**)&I.h_keys, I.cap_keys * sizeof(int64_t), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&I.d_keys, I.cap_keys * sizeof(int64_t)));
+    HIP_TRY(hipHostMalloc((void**)&I.h_rows, I.cap_floats * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&I.d_rows, I.cap_floats * sizeof(float)));
+    HIP_TRY(hipHostMalloc((void**)&I.h_found, I.cap_keys, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&I.d_found, I.cap_keys));
+    HIP_TRY(hipHostMalloc((void**)&I.h_md, sizeof(MissDesc), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&I.d_md, sizeof(MissDesc)));
+    HIP_TRY(hipHostMalloc((void**)&I.h_ks, sizeof(uint64_t) * ((size_t)kMaxTables + 1), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&I.d_ks, sizeof(uint64_t) * ((size_t)kMaxTables + 1)));
+    HIP_TRY(hipMalloc((void**)&I.d_stats, 4 * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void**)&I.h_stats, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  Inserter& I = *ins_;
+  std::vector<size_t> done(T, 0);
+  HIP_TRY(hipMemsetAsync(I.d_stats, 0, 4 * sizeof(uint32_t), I.stream));
+  for (;;) {
+    MissDesc& md = *I.h_md;
+    size_t uq = 0, fl = 0;
+    for (size_t t = 0; t < T; ++t) {
+      const uint32_t D = cfg_.embedding_vec_size_[t];
+      fl = (fl + 3) & ~(size_t)3;
+      md.useg_start[t] = uq;
+      I.h_ks[t] = uq;
+      md.chunk_lo[t] = 0;
+      md.stage_off[t] = fl;
+      const size_t take = std::min(keys_per_table[t].size() - done[t], I.cap_keys - uq);
+      md.chunk_hi[t] = (uint32_t)take;
+      if (take) {
+        memcpy(I.h_keys + uq, keys_per_table[t].data() + done[t], take * sizeof(int64_t));
+        HPS_RETURN_IF_ERROR(ps->Fetch(*tables[t], I.h_keys + uq, take, I.h_rows + fl, D, cfg_.default_value_[t],
+                                      I.h_found + uq, nullptr));
+      }
+      done[t] += take;
+      uq += take;
+      fl += take * D;
+    }
+    md.useg_start[T] = uq;
+    I.h_ks[T] = uq;
+    if (uq == 0) break;
+    HIP_TRY(hipMemcpyAsync(I.d_md, I.h_md, sizeof(MissDesc), hipMemcpyHostToDevice, I.stream));
+    HIP_TRY(hipMemcpyAsync(I.d_ks, I.h_ks, sizeof(uint64_t) * (T + 1), hipMemcpyHostToDevice, I.stream));
+    HIP_TRY(hipMemcpyAsync(I.d_keys, I.h_keys, uq * sizeof(int64_t), hipMemcpyHostToDevice, I.stream));
+    HIP_TRY(hipMemcpyAsync(I.d_rows, I.h_rows, fl * sizeof(float), hipMemcpyHostToDevice, I.stream));
+    HIP_TRY(hipMemcpyAsync(I.d_found, I.h_found, uq, hipMemcpyHostToDevice, I.stream));
+    const uint32_t epoch = NextEpoch();
+    BeginWrite(I.stream);
+    const hipError_t e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, uq, I.d_ks, I.d_keys, I.d_rows, I.d_found,
+                                           epoch, I.d_stats, cu_count_, I.stream);
+    EndWrite(I.stream);
+    if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(I.stream));
+  }
+  HIP_TRY(hipMemcpyAsync(I.h_stats, I.d_stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, I.stream));
+  HIP_TRY(hipStreamSynchronize(I.stream));
+  std::lock_guard<std::mutex> sl(stat_mu_);
+  counters_.dropped += I.h_stats[0];
+  counters_.inserted += I.h_stats[1];
+  counters_.refreshed += I.h_stats[2];
+  return Status::Ok();
+}
+
+// =================================================================================================
+// HierParameterServer
+// =================================================================================================
+HierParameterServer::~HierParameterServer() {
+  for (auto& kv : caches_) kv.second->WaitAsync();
+  caches_.clear();
+}
+
+Status HierParameterServer::create(const std::string& path, std::shared_ptr<HierParameterServer>* out) {
+  ParameterServerConfig cfg;
+  HPS_RETURN_IF_ERROR(ParseParameterServerFile(path, &cfg));
+  return create_from_config(cfg, true, out);
+}
+
+Status HierParameterServer::create_from_text(const std::string& text, std::shared_ptr<HierParameterServer>* out) {
+  ParameterServerConfig cfg;
+  HPS_RETURN_IF_ERROR(ParseParameterServerText(text, &cfg));
+  return create_from_config(cfg, true, out);
+}
+
+Status HierParameterServer::create_from_config(const ParameterServerConfig& cfg, bool load_tables,
+                                               std::shared_ptr<HierParameterServer>* out) {
+  std::shared_ptr<HierParameterServer> ps(new HierParameterServer());
+  ps->cfg_ = cfg;
+  ps->pool_ = &ThreadPool::Global();
+  if (!cfg.support_int64_key)
+    return Error(Code::kUnsupported,
+                 "supportlonglong=false: only 64-bit keys are supported (as in the reference backend, "
+                 "model_state.cpp:213-218, hps.cc:573)");
+  HPS_RETURN_IF_ERROR(ps->Build(load_tables));
+  *out = std::move(ps);
+  return Status::Ok();
+}
+
+Status HierParameterServer::EnsureTables(const InferenceParams& p, bool load) {
+  std::vector<std::shared_ptr<HostTable>> tabs;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = tables_.find(p.model_name);
+    if (it != tables_.end()) tabs = it->second;
+  }
+  const size_t T = p.num_tables();
+  if (tabs.size() != T) {
+    tabs.clear();
+    for (size_t t = 0; t < T; ++t)
+      tabs.emplace_back(std::make_shared<HostTable>(p.embedding_table_names[t],
+                                                    (uint32_t)p.embedding_vecsize_per_table[t],
+                                                    p.volatile_db.num_partitions));
+  }
+  if (load) {
+    for (size_t t = 0; t < T; ++t) HPS_RETURN_IF_ERROR(tabs[t]->LoadFromDir(p.sparse_model_files[t], pool_));
+  }
+  std::lock_guard<std::mutex> lk(mu_);
+  tables_[p.model_name] = tabs;
+  return Status::Ok();
+}
+
+Status HierParameterServer::Build(bool load_tables) {
+  for (const auto& name : cfg_.model_order) {
+    const InferenceParams& p = cfg_.models.at(name);
+    HPS_RETURN_IF_ERROR(EnsureTables(p, load_tables));
+    if (load_tables && p.use_gpu_embedding_cache) HPS_RETURN_IF_ERROR(create_embedding_cache_per_model(p));
+  }
+  return Status::Ok();
+}
+
+Status HierParameterServer::add_model(const InferenceParams& p) {
+  std::lock_guard<std::mutex> lk(mu_);
+  if (!cfg_.models.count(p.model_name)) cfg_.model_order.push_back(p.model_name);
+  cfg_.models[p.model_name] = p;
+  return Status::Ok();
+}
+
+Status HierParameterServer::parse_config(const std::string& path) {
+  ParameterServerConfig fresh;
+  HPS_RETURN_IF_ERROR(ParseParameterServerFile(path, &fresh));
+  for (const auto& name : fresh.model_order) HPS_RETURN_IF_ERROR(add_model(fresh.models.at(name)));
+  return Status::Ok();
+}
+
+std::vector<std::shared_ptr<HostTable>> HierParameterServer::tables_of(const std::string& model) {
+  std::lock_guard<std::mutex> lk(mu_);
+  auto it = tables_.find(model);
+  return it == tables_.end() ? std::vector<std::shared_ptr<HostTable>>() : it->second;
+}
+
+std::shared_ptr<EmbeddingCache> HierParameterServer::get_embedding_cache(const std::string& model, int device) {
+  std::lock_guard<std::mutex> lk(mu_);
+  auto it = caches_.find({model, device});
+  return it == caches_.end() ? nullptr : it->second;
+}
+
+Status HierParameterServer::update_database_per_model(const InferenceParams& p) {
+  HPS_RETURN_IF_ERROR(add_model(p));
+  return EnsureTables(p, true);
+}
+
+Status HierParameterServer::create_embedding_cache_per_model(const InferenceParams& p) {
+  if (!p.use_gpu_embedding_cache) return Status::Ok();
+  auto tabs = tables_of(p.model_name);
+  if (tabs.size() != p.num_tables())
+    return Error(Code::kNotFound, "model '", p.model_name, "': tables are not loaded; call update_database_per_model first");
+  for (int dev : p.deployed_devices) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (caches_.count({p.model_name, dev})) continue;
+    }
+    std::shared_ptr<EmbeddingCache> c(new EmbeddingCache());
+    HPS_RETURN_IF_ERROR(c->Init(p.model_name, p, tabs, dev));
+    std::lock_guard<std::mutex> lk(mu_);
+    caches_[{p.model_name, dev}] = std::move(c);
+  }
+  return Status::Ok();
+}
+
+Status HierParameterServer::destory_embedding_cache_per_model(const std::string& model) {
+  std::vector<std::shared_ptr<EmbeddingCache>> victims;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto it = caches_.begin(); it != caches_.end();) {
+      if (it->first.first == model) { victims.push_back(it->second); it = caches_.erase(it); }
+      else ++it;
+    }
+  }
+  for (auto& c : victims) c->WaitAsync();
+  return Status::Ok();  // device memory goes when the last session drops its reference
+}
+
+Status HierParameterServer::refresh_embedding_cache(const std::string& model, int device) {
+  auto cache = get_embedding_cache(model, device);
+  if (!cache) return Error(Code::kNotFound, "no embedding cache for model '", model, "' on device ", device);
+  InferenceParams p;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = cfg_.models.find(model);
+    if (it == cfg_.models.end()) return Error(Code::kNotFound, "model '", model, "' is not configured");
+    p = it->second;
+  }
+  // Re-read the resident keys' vectors from the parameter server, a fraction of the cache per
+  // iteration (docs/hierarchical_parameter_server.md:234-238).
+  const size_t T = cache->num_tables();
+  std::vector<std::vector<int64_t>> resident(T);
+  for (size_t t = 0; t < T; ++t) HPS_RETURN_IF_ERROR(cache->DumpKeys((uint32_t)t, &resident[t]));
+  double frac = p.cache_refresh_percentage_per_iteration;
+  if (!(frac > 0.0) || frac > 1.0) frac = 1.0;
+  std::vector<size_t> done(T, 0);
+  for (;;) {
+    std::vector<std::vector<int64_t>> part(T);
+    bool any = false;
+    for (size_t t = 0; t < T; ++t) {
+      const size_t step = std::max<size_t>(1, (size_t)((double)resident[t].size() * frac + 0.999999));
+      const size_t n = std::min(step, resident[t].size() - done[t]);
+      part[t].assign(resident[t].begin() + done[t], resident[t].begin() + done[t] + n);
+      done[t] += n;
+      any |= n > 0;
+    }
+    if (!any) break;
+    HPS_RETURN_IF_ERROR(cache->InsertKeys(this, part));
+  }
+  return Status::Ok();
+}
+
+Status HierParameterServer::create_lookup_session(const std::string& model, std::shared_ptr<EmbeddingCache> cache,
+                                                  std::unique_ptr<LookupSession>* out) {
+  InferenceParams p;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = cfg_.models.find(model);
+    if (it == cfg_.models.end()) return Error(Code::kNotFound, "model '", model, "' is not in the parameter server configuration");
+    p = it->second;
+  }
+  std::unique_ptr<LookupSession> s(new LookupSession());
+  HPS_RETURN_IF_ERROR(s->Init(this, p, std::move(cache)));
+  *out = std::move(s);
+  return Status::Ok();
+}
+
+Status HierParameterServer::load_table_from_arrays(const std::string& model, size_t table, const int64_t* keys,
+                                                   const float* rows, size_t R, bool borrow) {
+  auto tabs = tables_of(model);
+  if (table >= tabs.size()) return Error(Code::kNotFound, "model '", model, "' has no table ", table);
+  return tabs[table]->LoadFromArrays(keys, rows, R, borrow, pool_);
+}
+
+Status HierParameterServer::load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0,
+                                                 size_t R) {
+  auto tabs = tables_of(model);
+  if (table >= tabs.size()) return Error(Code::kNotFound, "model '", model, "' has no table ", table);
+  return tabs[table]->LoadSynthetic(seed, (uint32_t)table, key0, R, pool_);
+}
+
+Status HierParameterServer::Fetch(const HostTable& tb, const int64_t* keys, size_t n, float* out, size_t stride,
+                                  float default_value, uint8_t* found, size_t* nfound) {
+  // Key ranges fan out over the pool; each task keeps 16 lookups in flight (host_table.cpp).
+  const size_t chunk = 512;
+  const size_t ntasks = (n + chunk - 1) / chunk;
+  std::atomic<size_t> total{0};
+  auto body = [&](size_t ti) {
+    const size_t b = ti * chunk, e = std::min(n, b + chunk);
+    const size_t f = tb.Fetch(keys + b, e - b, out + b * stride, stride, default_value, found ? found + b : nullptr);
+    total.fetch_add(f, std::memory_order_relaxed);
+  };
+  if (ntasks <= 1) { if (ntasks) body(0); }
+  else pool_->ParallelFor(ntasks, body);
+  if (nfound) *nfound = total.load();
+  return Status::Ok();
+}
+
+void HierParameterServer::SubmitAsyncInsert(std::shared_ptr<EmbeddingCache> cache,
+                                            std::vector<std::vector<int64_t>> keys_per_table) {
+  int limit = 2;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = cfg_.models.find(cache->model_name());
+    if (it != cfg_.models.end()) limit = std::max(1, it->second.number_of_worker_buffers_in_pool);
+  }
+  {
+    std::lock_guard<std::mutex> lk(cache->pend_mu_);
+    if (cache->pending_async_ >= limit) return;  // inserter is saturated: this batch's misses are not cached
+    ++cache->pending_async_;
+  }
+  auto self = shared_from_this();
+  pool_->Submit([self, cache, keys = std::move(keys_per_table)]() {
+    (void)cache->InsertKeys(self.get(), keys);
+    std::lock_guard<std::mutex> lk(cache->pend_mu_);
+    --cache->pending_async_;
+    cache->pend_cv_.notify_all();
+  });
+}
+
+}  // namespace hps

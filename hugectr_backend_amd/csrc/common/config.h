@@ -1,0 +1,138 @@
+// Parameter-server configuration carriers.
+//
+// Field names follow the structs the reference fills from ps.json
+// (HugeCTR::InferenceParams / VolatileDatabaseParams / PersistentDatabaseParams / UpdateSourceParams,
+// built at /root/reference/hps_backend/src/backend.cpp:128-523).  The structs themselves live in the
+// un-vendored HugeCTR headers, so only the fields the shell reads or writes are restated.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "json.h"
+#include "status.h"
+
+namespace hps {
+
+// triton_helpers.cpp:183-248
+enum class DatabaseType { Disabled, HashMap, ParallelHashMap, RedisCluster, RocksDB };
+// triton_helpers.cpp:250-298
+enum class DatabaseOverflowPolicy { EvictRandom, EvictLeastUsed, EvictOldest };
+// triton_helpers.cpp:300-339
+enum class UpdateSourceType { Null, KafkaMessageQueue };
+// backend.cpp:479-491
+enum class EmbeddingCacheType { Dynamic, Static, UVM, Stochastic };
+
+const char* ToString(DatabaseType v);
+const char* ToString(DatabaseOverflowPolicy v);
+const char* ToString(UpdateSourceType v);
+const char* ToString(EmbeddingCacheType v);
+
+struct VolatileDatabaseParams {  // backend.cpp:128-216
+  DatabaseType type = DatabaseType::ParallelHashMap;
+  std::string address = "127.0.0.1:7000";
+  std::string user_name = "default";
+  std::string password;
+  size_t num_partitions = 8;  // README.md:133
+  size_t allocation_rate = 256ull << 20;
+  size_t max_batch_size = 64 * 1024;
+  size_t overflow_margin = SIZE_MAX;
+  DatabaseOverflowPolicy overflow_policy = DatabaseOverflowPolicy::EvictRandom;
+  double overflow_resolution_target = 0.8;
+  double initial_cache_rate = 1.0;
+  bool cache_missed_embeddings = false;
+  std::vector<std::string> update_filters{"^hps_.+$"};
+};
+
+struct PersistentDatabaseParams {  // backend.cpp:218-259
+  DatabaseType type = DatabaseType::Disabled;
+  std::string path;
+  size_t num_threads = 16;
+  bool read_only = false;
+  size_t max_batch_size = 64 * 1024;
+  std::vector<std::string> update_filters{"^hps_.+$"};
+};
+
+struct UpdateSourceParams {  // backend.cpp:261-308
+  UpdateSourceType type = UpdateSourceType::Null;
+  std::string brokers = "127.0.0.1:9092";
+  size_t receive_buffer_size = 256 * 1024;
+  size_t poll_timeout_ms = 500;
+  size_t max_batch_size = 8 * 1024;
+  size_t failure_backoff_ms = 50;
+  size_t max_commit_interval = 32;
+};
+
+struct InferenceParams {  // backend.cpp:318-516
+  std::string model_name;
+  std::string network_file;
+  size_t max_batchsize = 0;
+  float hit_rate_threshold = 0.55f;       // backend.cpp:372
+  std::string dense_model_file;
+  std::vector<std::string> sparse_model_files;
+  int device_id = 0;
+  bool use_gpu_embedding_cache = true;
+  float cache_size_percentage = 0.55f;    // backend.cpp:380
+  bool i64_input_key = true;
+  bool use_mixed_precision = false;       // model_state.cpp:279 (never set by ps.json)
+  int number_of_worker_buffers_in_pool = 2;
+  int number_of_refresh_buffers_in_pool = 1;
+  float cache_refresh_percentage_per_iteration = 0.1f;
+  std::vector<int> deployed_devices{0};
+  std::vector<float> default_value_for_each_table;
+  int maxnum_des_feature_per_sample = 26;
+  float refresh_delay = 0.0f;             // model_state.cpp:327
+  float refresh_interval = 0.0f;          // model_state.cpp:319
+  std::vector<size_t> maxnum_catfeature_query_per_table_per_sample;
+  std::vector<size_t> embedding_vecsize_per_table;
+  std::vector<std::string> embedding_table_names;
+  int label_dim = 1;
+  int slot_num = 10;
+  EmbeddingCacheType embedding_cache_type = EmbeddingCacheType::Dynamic;
+  bool init_ec = true;
+  bool fp8_quant = false;
+  bool enable_pagelock = false;
+  VolatileDatabaseParams volatile_db;
+  PersistentDatabaseParams persistent_db;
+  UpdateSourceParams update_source;
+
+  // --- additions of this build (MI355X engine knobs; all optional in ps.json) ---
+  double cache_load_factor = 0.75;  // "gpucache_load_factor": slots = ceil(capacity / load_factor)
+  size_t num_tables() const { return sparse_model_files.size(); }
+};
+
+struct ParameterServerConfig {
+  bool support_int64_key = true;  // "supportlonglong" (backend.cpp:124-126)
+  VolatileDatabaseParams volatile_db;
+  PersistentDatabaseParams persistent_db;
+  UpdateSourceParams update_source;
+  std::vector<std::string> model_order;
+  std::map<std::string, InferenceParams> models;
+};
+
+// Restatement of HPSBackend::ParseParameterServer (backend.cpp:102-526): same keys, same
+// required/optional split, same defaults, same tolerant scalar conversion.  Unlike the reference it
+// also validates list lengths against the table count (SURVEY.md App. C6/C9 hardening).
+Status ParseParameterServerJson(const Json& root, ParameterServerConfig* out);
+Status ParseParameterServerFile(const std::string& path, ParameterServerConfig* out);
+Status ParseParameterServerText(const std::string& text, ParameterServerConfig* out);
+
+// Typed, tolerant field readers = TritonJsonHelper::parse overloads (triton_helpers.cpp:42-442).
+// `required`==true and key absent -> INVALID_ARG "The parameter '<key>' is mandatory...".
+Status ParseField(bool& v, const Json& j, const char* key, bool required);
+Status ParseField(double& v, const Json& j, const char* key, bool required);
+Status ParseField(float& v, const Json& j, const char* key, bool required);
+Status ParseField(int32_t& v, const Json& j, const char* key, bool required);
+Status ParseField(int64_t& v, const Json& j, const char* key, bool required);
+Status ParseField(size_t& v, const Json& j, const char* key, bool required);
+Status ParseField(std::string& v, const Json& j, const char* key, bool required);
+Status ParseField(DatabaseType& v, const Json& j, const char* key, bool required);
+Status ParseField(DatabaseOverflowPolicy& v, const Json& j, const char* key, bool required);
+Status ParseField(UpdateSourceType& v, const Json& j, const char* key, bool required);
+Status ParseField(std::vector<float>& v, const Json& j, const char* key, bool required);
+Status ParseField(std::vector<int32_t>& v, const Json& j, const char* key, bool required);
+Status ParseField(std::vector<size_t>& v, const Json& j, const char* key, bool required);
+Status ParseField(std::vector<std::string>& v, const Json& j, const char* key, bool required);
+
+}  // namespace hps

@@ -1,0 +1,345 @@
+#include "host_table.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "../common/hps_hash.h"
+
+namespace hps {
+
+namespace {
+
+constexpr size_t kHuge = 2ull << 20;
+
+void* SlabAlloc(size_t bytes) {
+  if (bytes == 0) bytes = 64;
+  void* p = nullptr;
+  const size_t align = bytes >= kHuge ? kHuge : 64;
+  const size_t rounded = (bytes + align - 1) / align * align;
+  if (posix_memalign(&p, align, rounded) != 0) return nullptr;
+#ifdef MADV_HUGEPAGE
+  if (rounded >= kHuge) madvise(p, rounded, MADV_HUGEPAGE);
+#endif
+  return p;
+}
+
+Status ReadFileParallel(const std::string& path, void* dst, size_t bytes, ThreadPool* pool) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return Error(Code::kNotFound, "cannot open '", path, "': ", strerror(errno));
+  const size_t chunk = 64ull << 20;
+  const size_t ntasks = (bytes + chunk - 1) / chunk;
+  std::atomic<int> bad{0};
+  auto body = [&](size_t ti) {
+    size_t off = ti * chunk;
+    const size_t end = std::min(bytes, off + chunk);
+    while (off < end) {
+      const ssize_t r = pread(fd, (char*)dst + off, end - off, (off_t)off);
+      if (r <= 0) { bad.store(1); return; }
+      off += (size_t)r;
+    }
+  };
+  if (pool) pool->ParallelFor(ntasks, body);
+  else for (size_t i = 0; i < ntasks; ++i) body(i);
+  close(fd);
+  if (bad.load()) return Error(Code::kInternal, "short read on '", path, "'");
+  return Status::Ok();
+}
+
+Status FileSize(const std::string& path, size_t* out) {
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) return Error(Code::kNotFound, "cannot stat '", path, "': ", strerror(errno));
+  *out = (size_t)st.st_size;
+  return Status::Ok();
+}
+
+}  // namespace
+
+HostTable::HostTable(std::string name, uint32_t dim, size_t num_partitions)
+    : name_(std::move(name)), dim_(dim) {
+  if (num_partitions == 0) num_partitions = 1;
+  for (size_t p = 0; p < num_partitions; ++p) parts_.emplace_back(new Partition());
+  pow2_parts_ = (num_partitions & (num_partitions - 1)) == 0;
+}
+
+HostTable::~HostTable() { FreeAll(); }
+
+void HostTable::FreeAll() {
+  for (auto& p : parts_) { free(p->slots); p->slots = nullptr; p->mask = 0; p->used.store(0); }
+  if (owns_keys_) free(keys_);
+  if (owns_rows_) free(rows_);
+  keys_ = nullptr; rows_ = nullptr; num_rows_ = cap_rows_ = 0;
+  owns_keys_ = owns_rows_ = false;
+  has_sentinel_ = false; sentinel_row_ = -1; has_dups_ = false;
+}
+
+uint64_t HostTable::SlotOf(int64_t key, uint64_t mask) { return (hps_mix64((uint64_t)key) >> 20) & mask; }
+
+size_t HostTable::PartitionOf(int64_t key) const {
+  const uint64_t k = (uint64_t)key;
+  return pow2_parts_ ? (size_t)(k & (parts_.size() - 1)) : (size_t)(k % parts_.size());
+}
+
+Status HostTable::AllocPartitions(const std::vector<size_t>& counts) {
+  for (size_t p = 0; p < parts_.size(); ++p) {
+    uint64_t cap = 16;
+    while (cap < counts[p] * 2) cap <<= 1;
+    free(parts_[p]->slots);
+    parts_[p]->slots = (Entry*)SlabAlloc(cap * sizeof(Entry));
+    if (!parts_[p]->slots) return Error(Code::kInternal, "host table '", name_, "': out of memory for index");
+    parts_[p]->mask = cap - 1;
+    parts_[p]->used.store(0);
+  }
+  return Status::Ok();
+}
+
+void HostTable::InsertConcurrent(int64_t key, int64_t row) {
+  if (key == HPS_EMPTY_KEY) {  // legal key that collides with the empty marker: kept on the side
+    has_sentinel_ = true;
+    int64_t cur = __atomic_load_n(&sentinel_row_, __ATOMIC_RELAXED);
+    while (cur < row && !__atomic_compare_exchange_n(&sentinel_row_, &cur, row, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return;
+  }
+  Partition& P = *parts_[PartitionOf(key)];
+  uint64_t s = SlotOf(key, P.mask);
+  for (;;) {
+    int64_t k = __atomic_load_n(&P.slots[s].key, __ATOMIC_ACQUIRE);
+    if (k == HPS_EMPTY_KEY) {
+      int64_t expected = HPS_EMPTY_KEY;
+      if (__atomic_compare_exchange_n(&P.slots[s].key, &expected, key, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+        P.used.fetch_add(1, std::memory_order_relaxed);
+        k = key;
+      } else {
+        k = expected;
+      }
+    }
+    if (k == key) {
+      // duplicate keys in one load: the later row wins -> atomic max of the row number
+      int64_t cur = __atomic_load_n(&P.slots[s].row, __ATOMIC_RELAXED);
+      while (cur < row && !__atomic_compare_exchange_n(&P.slots[s].row, &cur, row, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+      return;
+    }
+    s = (s + 1) & P.mask;
+  }
+}
+
+Status HostTable::BuildIndex(ThreadPool* pool) {
+  const size_t R = num_rows_;
+  const size_t P = parts_.size();
+  const size_t chunk = 1 << 16;
+  const size_t ntasks = (R + chunk - 1) / chunk;
+  // 1) rows per partition
+  std::vector<size_t> counts(P, 0);
+  {
+    std::mutex mu;
+    auto body = [&](size_t ti) {
+      std::vector<size_t> local(P, 0);
+      const size_t b = ti * chunk, e = std::min(R, b + chunk);
+      for (size_t r = b; r < e; ++r) if (keys_[r] != HPS_EMPTY_KEY) ++local[PartitionOf(keys_[r])];
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t p = 0; p < P; ++p) counts[p] += local[p];
+    };
+    if (pool) pool->ParallelFor(ntasks, body); else for (size_t i = 0; i < ntasks; ++i) body(i);
+  }
+  HPS_RETURN_IF_ERROR(AllocPartitions(counts));
+  // 2) clear
+  {
+    struct Span { Entry* p; size_t n; };
+    std::vector<Span> spans;
+    for (auto& part : parts_) {
+      const size_t cap = part->mask + 1;
+      for (size_t o = 0; o < cap; o += chunk) spans.push_back({part->slots + o, std::min(chunk, cap - o)});
+    }
+    auto body = [&](size_t ti) {
+      Entry* p = spans[ti].p;
+      for (size_t i = 0; i < spans[ti].n; ++i) { p[i].key = HPS_EMPTY_KEY; p[i].row = -1; }
+    };
+    if (pool) pool->ParallelFor(spans.size(), body); else for (size_t i = 0; i < spans.size(); ++i) body(i);
+  }
+  // 3) concurrent insert
+  has_sentinel_ = false; sentinel_row_ = -1;
+  {
+    auto body = [&](size_t ti) {
+      const size_t b = ti * chunk, e = std::min(R, b + chunk);
+      for (size_t r = b; r < e; ++r) InsertConcurrent(keys_[r], (int64_t)r);
+    };
+    if (pool) pool->ParallelFor(ntasks, body); else for (size_t i = 0; i < ntasks; ++i) body(i);
+  }
+  size_t uniq = has_sentinel_ ? 1 : 0;
+  for (auto& part : parts_) uniq += part->used.load();
+  has_dups_ = uniq != R;
+  return Status::Ok();
+}
+
+Status HostTable::LoadFromDir(const std::string& dir, ThreadPool* pool) {
+  size_t kb = 0, vb = 0;
+  HPS_RETURN_IF_ERROR(FileSize(dir + "/key", &kb));
+  HPS_RETURN_IF_ERROR(FileSize(dir + "/emb_vector", &vb));
+  if (kb % sizeof(int64_t) != 0)
+    return Error(Code::kInvalidArg, "'", dir, "/key': size ", kb, " is not a multiple of 8 (int64 keys)");
+  const size_t R = kb / sizeof(int64_t);
+  if (vb != R * (size_t)dim_ * sizeof(float))
+    return Error(Code::kInvalidArg, "'", dir, "/emb_vector': size ", vb, " != rows(", R, ") x embedding_vecsize(",
+                 dim_, ") x 4; check embedding_vecsize_per_table");
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  FreeAll();
+  keys_ = (int64_t*)SlabAlloc(kb);
+  rows_ = (float*)SlabAlloc(vb);
+  owns_keys_ = owns_rows_ = true;
+  if (!keys_ || !rows_) return Error(Code::kInternal, "host table '", name_, "': out of memory (", kb + vb, " bytes)");
+  num_rows_ = cap_rows_ = R;
+  HPS_RETURN_IF_ERROR(ReadFileParallel(dir + "/key", keys_, kb, pool));
+  HPS_RETURN_IF_ERROR(ReadFileParallel(dir + "/emb_vector", rows_, vb, pool));
+  return BuildIndex(pool);
+}
+
+Status HostTable::LoadFromArrays(const int64_t* keys, const float* rows, size_t R, bool borrow, ThreadPool* pool) {
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  FreeAll();
+  if (borrow) {
+    keys_ = const_cast<int64_t*>(keys);
+    rows_ = const_cast<float*>(rows);
+  } else {
+    keys_ = (int64_t*)SlabAlloc(R * sizeof(int64_t));
+    rows_ = (float*)SlabAlloc(R * (size_t)dim_ * sizeof(float));
+    owns_keys_ = owns_rows_ = true;
+    if (!keys_ || !rows_) return Error(Code::kInternal, "host table '", name_, "': out of memory");
+    memcpy(keys_, keys, R * sizeof(int64_t));
+    memcpy(rows_, rows, R * (size_t)dim_ * sizeof(float));
+  }
+  num_rows_ = cap_rows_ = R;
+  return BuildIndex(pool);
+}
+
+Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, size_t R, ThreadPool* pool) {
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  FreeAll();
+  keys_ = (int64_t*)SlabAlloc(R * sizeof(int64_t));
+  rows_ = (float*)SlabAlloc(R * (size_t)dim_ * sizeof(float));
+  owns_keys_ = owns_rows_ = true;
+  if (!keys_ || !rows_) return Error(Code::kInternal, "host table '", name_, "': out of memory");
+  num_rows_ = cap_rows_ = R;
+  const uint64_t tb = hps_synth_table_base(seed, table_id);
+  const size_t chunk = 4096;
+  const size_t ntasks = (R + chunk - 1) / chunk;
+  const uint32_t D = dim_;
+  auto body = [&](size_t ti) {
+    const size_t b = ti * chunk, e = std::min(R, b + chunk);
+    for (size_t r = b; r < e; ++r) {
+      const int64_t key = key0 + (int64_t)r;
+      keys_[r] = key;
+      const uint64_t rb = hps_synth_row_base(tb, key);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(rows_ + r * D);
+      for (uint32_t j = 0; j + 1 < D; j += 2) {
+        const uint64_t w = hps_mix64(rb + (uint64_t)(j >> 1));
+        dst[j] = 0x3F000000u | ((uint32_t)w & 0x007FFFFFu);
+        dst[j + 1] = 0x3F000000u | ((uint32_t)(w >> 32) & 0x007FFFFFu);
+      }
+      if (D & 1u) dst[D - 1] = hps_synth_elem_bits(rb, D - 1);
+    }
+  };
+  if (pool) pool->ParallelFor(ntasks, body); else for (size_t i = 0; i < ntasks; ++i) body(i);
+  return BuildIndex(pool);
+}
+
+int64_t HostTable::FindUnlocked(int64_t key) const {
+  if (key == HPS_EMPTY_KEY) return has_sentinel_ ? sentinel_row_ : -1;
+  const Partition& P = *parts_[PartitionOf(key)];
+  if (!P.slots) return -1;
+  uint64_t s = SlotOf(key, P.mask);
+  for (;;) {
+    const int64_t k = P.slots[s].key;
+    if (k == key) return P.slots[s].row;
+    if (k == HPS_EMPTY_KEY) return -1;
+    s = (s + 1) & P.mask;
+  }
+}
+
+int64_t HostTable::Find(int64_t key) const {
+  std::shared_lock<std::shared_mutex> lk(mu_);
+  return FindUnlocked(key);
+}
+
+size_t HostTable::Fetch(const int64_t* keys, size_t n, float* out, size_t stride, float default_value,
+                        uint8_t* found) const {
+  std::shared_lock<std::shared_mutex> lk(mu_);
+  const uint32_t D = dim_;
+  const size_t row_bytes = (size_t)D * sizeof(float);
+  size_t nfound = 0;
+  constexpr size_t B = 16;  // keys in flight per thread: hides DRAM latency of the index and the row
+  for (size_t base = 0; base < n; base += B) {
+    const size_t m = std::min(B, n - base);
+    const Entry* slot[B];
+    int64_t row[B];
+    for (size_t i = 0; i < m; ++i) {
+      const int64_t key = keys[base + i];
+      if (key == HPS_EMPTY_KEY) { slot[i] = nullptr; continue; }
+      const Partition& P = *parts_[PartitionOf(key)];
+      slot[i] = P.slots ? &P.slots[SlotOf(key, P.mask)] : nullptr;
+      if (slot[i]) __builtin_prefetch(slot[i], 0, 0);
+    }
+    for (size_t i = 0; i < m; ++i) {
+      const int64_t key = keys[base + i];
+      row[i] = FindUnlocked(key);
+      if (row[i] >= 0) {
+        const char* p = reinterpret_cast<const char*>(rows_ + (size_t)row[i] * D);
+        for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(p + o, 0, 0);
+      }
+    }
+    for (size_t i = 0; i < m; ++i) {
+      float* dst = out + (base + i) * stride;
+      if (row[i] >= 0) {
+        memcpy(dst, rows_ + (size_t)row[i] * D, row_bytes);
+        ++nfound;
+      } else {
+        for (uint32_t j = 0; j < D; ++j) dst[j] = default_value;
+      }
+      if (found) found[base + i] = row[i] >= 0 ? 1 : 0;
+    }
+  }
+  return nfound;
+}
+
+Status HostTable::Upsert(const int64_t* keys, const float* rows, size_t n) {
+  std::unique_lock<std::shared_mutex> lk(mu_);
+  const uint32_t D = dim_;
+  // overwrite existing, collect new
+  std::vector<size_t> fresh;
+  for (size_t i = 0; i < n; ++i) {
+    const int64_t r = FindUnlocked(keys[i]);
+    if (r >= 0) memcpy(rows_ + (size_t)r * D, rows + i * D, (size_t)D * sizeof(float));
+    else fresh.push_back(i);
+  }
+  if (fresh.empty()) return Status::Ok();
+  // grow slab (always into owned memory) and rebuild the index; updates are rare relative to lookups
+  const size_t newR = num_rows_ + fresh.size();
+  if (newR > cap_rows_ || !owns_keys_ || !owns_rows_) {
+    const size_t cap = std::max(newR, cap_rows_ + cap_rows_ / 2);
+    int64_t* nk = (int64_t*)SlabAlloc(cap * sizeof(int64_t));
+    float* nr = (float*)SlabAlloc(cap * (size_t)D * sizeof(float));
+    if (!nk || !nr) { free(nk); free(nr); return Error(Code::kInternal, "host table '", name_, "': out of memory"); }
+    if (num_rows_) {
+      memcpy(nk, keys_, num_rows_ * sizeof(int64_t));
+      memcpy(nr, rows_, num_rows_ * (size_t)D * sizeof(float));
+    }
+    if (owns_keys_) free(keys_);
+    if (owns_rows_) free(rows_);
+    keys_ = nk; rows_ = nr; owns_keys_ = owns_rows_ = true; cap_rows_ = cap;
+  }
+  for (size_t i : fresh) {
+    // a key may repeat inside `fresh`; BuildIndex resolves to the last row
+    keys_[num_rows_] = keys[i];
+    memcpy(rows_ + num_rows_ * D, rows + i * D, (size_t)D * sizeof(float));
+    ++num_rows_;
+  }
+  return BuildIndex(nullptr);
+}
+
+}  // namespace hps

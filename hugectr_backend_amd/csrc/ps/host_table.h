@@ -1,0 +1,89 @@
+// One embedding table in the host (CPU RAM) tier of the parameter server: the build's restatement of
+// the reference's `hash_map` / `parallel_hash_map` volatile database
+// (/root/reference/docs/hierarchical_parameter_server.md:380-412; README.md:127-135).
+//
+// Layout: rows live in one slab in load order (R x D fp32); the index is `num_partitions`
+// open-addressing tables (key -> row number), partition = key mod num_partitions ("the last couple
+// of bits of your embedding keys", docs/architecture.md:131).  Readers are lock-free; loads and
+// upserts take the table's writer lock.
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <memory>
+#include <shared_mutex>
+#include <string>
+#include <vector>
+
+#include "../common/status.h"
+#include "thread_pool.h"
+
+namespace hps {
+
+class HostTable {
+ public:
+  HostTable(std::string name, uint32_t dim, size_t num_partitions);
+  ~HostTable();
+  HostTable(const HostTable&) = delete;
+  HostTable& operator=(const HostTable&) = delete;
+
+  // "<dir>/key" = R native-endian int64, "<dir>/emb_vector" = R*D native-endian fp32, same order
+  // (docs/architecture.md:185-218).  Replaces the current contents.
+  Status LoadFromDir(const std::string& dir, ThreadPool* pool);
+  // Copies (or, with borrow=true, references) caller memory.  Replaces the current contents.
+  Status LoadFromArrays(const int64_t* keys, const float* rows, size_t R, bool borrow, ThreadPool* pool);
+  // Synthetic table (bench): keys key0..key0+R-1, rows from the SURVEY.md §8d recipe, generated in
+  // parallel straight into the slab.
+  Status LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, size_t R, ThreadPool* pool);
+  // Insert-or-overwrite rows (online update path; duplicate keys: last wins).
+  Status Upsert(const int64_t* keys, const float* rows, size_t n);
+
+  const std::string& name() const { return name_; }
+  uint32_t dim() const { return dim_; }
+  size_t size() const { return num_rows_; }          // rows in the slab (file order)
+  size_t num_partitions() const { return parts_.size(); }
+  // true when the loaded data held the same key more than once (only the last row is live)
+  bool has_duplicate_keys() const { return has_dups_; }
+  int64_t key_at(size_t r) const { return keys_[r]; }
+  const int64_t* keys() const { return keys_; }
+  const float* row_at(size_t r) const { return rows_ + r * dim_; }
+
+  // Row number of `key`, or -1.
+  int64_t Find(int64_t key) const;
+
+  // out + i*stride  <-  row(keys[i])  or  default_value broadcast.  found[i] (optional) = 1/0.
+  // Single-threaded; callers parallelise over key ranges (ParameterServer::Fetch).
+  // Returns the number of keys found.
+  size_t Fetch(const int64_t* keys, size_t n, float* out, size_t stride, float default_value,
+               uint8_t* found) const;
+
+ private:
+  struct Entry { int64_t key; int64_t row; };
+  struct Partition {
+    Entry* slots = nullptr;
+    uint64_t mask = 0;  // capacity - 1
+    std::atomic<size_t> used{0};
+  };
+  void FreeAll();
+  Status BuildIndex(ThreadPool* pool);
+  Status AllocPartitions(const std::vector<size_t>& counts);
+  static uint64_t SlotOf(int64_t key, uint64_t mask);
+  size_t PartitionOf(int64_t key) const;
+  void InsertConcurrent(int64_t key, int64_t row);
+  int64_t FindUnlocked(int64_t key) const;
+
+  std::string name_;
+  uint32_t dim_;
+  std::vector<std::unique_ptr<Partition>> parts_;
+  bool pow2_parts_;
+  int64_t* keys_ = nullptr;
+  float* rows_ = nullptr;
+  size_t num_rows_ = 0;
+  size_t cap_rows_ = 0;
+  bool owns_keys_ = false, owns_rows_ = false;
+  bool has_dups_ = false;
+  bool has_sentinel_ = false;  // HPS_EMPTY_KEY itself stored as a legal key
+  int64_t sentinel_row_ = -1;
+  mutable std::shared_mutex mu_;
+};
+
+}  // namespace hps

@@ -1,0 +1,114 @@
+#include "thread_pool.h"
+
+#include <cstdlib>
+
+namespace hps {
+
+size_t ThreadPool::DefaultConcurrency() {
+  // thread_pool.cpp:25-41 of the reference: env override, else hardware_concurrency.
+  if (const char* e = std::getenv("HCTR_DEFAULT_CONCURRENCY")) {
+    const long v = std::strtol(e, nullptr, 10);
+    if (v > 0) return (size_t)v;
+  }
+  const unsigned hc = std::thread::hardware_concurrency();
+  return hc ? hc : 4;
+}
+
+ThreadPool& ThreadPool::Global() {
+  static ThreadPool pool(DefaultConcurrency() > 1 ? DefaultConcurrency() - 1 : 1);
+  return pool;
+}
+
+ThreadPool::ThreadPool(size_t num_workers) {
+  workers_.reserve(num_workers);
+  for (size_t i = 0; i < num_workers; ++i) workers_.emplace_back([this] { WorkerMain(); });
+}
+
+ThreadPool::~ThreadPool() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+  }
+  cv_.notify_all();
+  for (auto& t : workers_) t.join();
+}
+
+void ThreadPool::RunLoop(Loop* l) {
+  size_t mine = 0;
+  for (;;) {
+    const size_t i = l->next.fetch_add(1, std::memory_order_relaxed);
+    if (i >= l->n) break;
+    (*l->fn)(i);
+    ++mine;
+  }
+  if (mine) {
+    const size_t d = l->done.fetch_add(mine, std::memory_order_acq_rel) + mine;
+    if (d == l->n) {
+      std::lock_guard<std::mutex> lk(l->mu);
+      l->cv.notify_all();
+    }
+  }
+}
+
+void ThreadPool::WorkerMain() {
+  for (;;) {
+    std::shared_ptr<Loop> loop;
+    std::function<void()> task;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      for (;;) {
+        // drop loops whose tasks are all claimed
+        while (!loops_.empty() && loops_.front()->next.load(std::memory_order_relaxed) >= loops_.front()->n)
+          loops_.pop_front();
+        for (auto& l : loops_) {
+          if (l->next.load(std::memory_order_relaxed) < l->n &&
+              l->helpers.load(std::memory_order_relaxed) < l->max_helpers) {
+            l->helpers.fetch_add(1, std::memory_order_relaxed);
+            loop = l;
+            break;
+          }
+        }
+        if (loop) break;
+        if (!tasks_.empty()) { task = std::move(tasks_.front()); tasks_.pop_front(); break; }
+        if (stop_) return;
+        cv_.wait(lk);
+      }
+    }
+    if (loop) RunLoop(loop.get());
+    else if (task) task();
+  }
+}
+
+void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>& fn, size_t max_parallel) {
+  if (num_tasks == 0) return;
+  if (num_tasks == 1 || workers_.empty() || max_parallel == 1) {
+    for (size_t i = 0; i < num_tasks; ++i) fn(i);
+    return;
+  }
+  auto loop = std::make_shared<Loop>();
+  loop->fn = &fn;
+  loop->n = num_tasks;
+  size_t helpers = workers_.size();
+  if (max_parallel && max_parallel - 1 < helpers) helpers = max_parallel - 1;
+  if (num_tasks - 1 < helpers) helpers = num_tasks - 1;
+  loop->max_helpers = helpers;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    loops_.push_back(loop);
+  }
+  if (helpers >= workers_.size()) cv_.notify_all();
+  else for (size_t i = 0; i < helpers; ++i) cv_.notify_one();
+  RunLoop(loop.get());
+  std::unique_lock<std::mutex> lk(loop->mu);
+  loop->cv.wait(lk, [&] { return loop->done.load(std::memory_order_acquire) == loop->n; });
+}
+
+void ThreadPool::Submit(std::function<void()> fn) {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    tasks_.push_back(std::move(fn));
+  }
+  cv_.notify_one();
+}
+
+}  // namespace hps

@@ -1,0 +1,362 @@
+"""ctypes binding of libhps_amd.so (include/hps_amd.h).
+
+Host-side mirror of the three HugeCTR classes the reference backend drives
+(/root/reference/docs/architecture.md:232-323): ``HierParameterServer.create`` →
+``get_embedding_cache`` → ``LookupSession.create`` → ``lookup``.  Names, argument meaning and error
+behaviour follow the reference; the arithmetic happens in the native library (HIP kernels for the GPU
+cache, C++ for the host tier).  There is no Python fallback: if the library is missing, import fails.
+
+torch is used only to hold device memory in the convenience wrappers; the C ABI takes raw pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from pathlib import Path
+from typing import Sequence
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_LIBPATH = _PKG / "lib" / "libhps_amd.so"
+
+
+class HpsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[hps error {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+# TRITONSERVER_Error_Code + 1
+ERR_UNKNOWN, ERR_INTERNAL, ERR_NOT_FOUND, ERR_INVALID_ARG, ERR_UNAVAILABLE, ERR_UNSUPPORTED, ERR_ALREADY_EXISTS = range(1, 8)
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [
+        ("max_batch_size", C.c_uint64), ("num_tables", C.c_uint32), ("use_gpu_embedding_cache", C.c_int32),
+        ("hit_rate_threshold", C.c_float), ("cache_size_percentage", C.c_float), ("i64_input_key", C.c_int32),
+        ("number_of_worker_buffers_in_pool", C.c_int32), ("number_of_refresh_buffers_in_pool", C.c_int32),
+        ("cache_refresh_percentage_per_iteration", C.c_float), ("device_id", C.c_int32),
+        ("num_deployed_devices", C.c_uint32), ("refresh_delay", C.c_float), ("refresh_interval", C.c_float),
+        ("cat_num", C.c_uint64), ("embedding_size", C.c_uint64),
+    ]
+
+
+class TableInfo(C.Structure):
+    _fields_ = [("embedding_vecsize", C.c_uint32), ("maxnum_catfeature", C.c_uint64), ("default_value", C.c_float),
+                ("rows_loaded", C.c_uint64)]
+
+
+class CacheTableInfo(C.Structure):
+    _fields_ = [("embedding_vecsize", C.c_uint32), ("num_buckets", C.c_uint64), ("capacity_rows", C.c_uint64)]
+
+
+class CacheCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("lookups", "keys", "misses", "unique_misses", "inserted", "refreshed", "dropped", "async_calls")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class LookupStats(C.Structure):
+    _fields_ = [("misses", C.c_uint64), ("unique_misses", C.c_uint64), ("async_insert", C.c_int32),
+                ("probe_gather_ms", C.c_float)]
+
+
+def _load() -> C.CDLL:
+    if not _LIBPATH.exists():
+        raise ImportError(
+            f"{_LIBPATH} is missing: build it with `python -m hugectr_backend_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no Python/CPU fallback for the engine.")
+    L = C.CDLL(str(_LIBPATH), mode=C.RTLD_GLOBAL)
+    P, cp, i32, u32, u64, i64 = C.c_void_p, C.c_char_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_int64
+    sig = {
+        "hps_last_error": (cp, []),
+        "hps_device_count": (C.c_int, []),
+        "hps_server_create": (C.c_int, [cp, C.POINTER(P)]),
+        "hps_server_create_from_text": (C.c_int, [cp, C.c_int, C.POINTER(P)]),
+        "hps_server_destroy": (None, [P]),
+        "hps_server_model_count": (C.c_int, [P]),
+        "hps_server_model_name": (cp, [P, C.c_int]),
+        "hps_server_model_info": (C.c_int, [P, cp, C.POINTER(ModelInfo)]),
+        "hps_server_table_info": (C.c_int, [P, cp, u32, C.POINTER(TableInfo)]),
+        "hps_server_deployed_device": (C.c_int, [P, cp, u32, C.POINTER(i32)]),
+        "hps_server_parse_config": (C.c_int, [P, cp]),
+        "hps_server_update_database_per_model": (C.c_int, [P, cp]),
+        "hps_server_create_embedding_cache_per_model": (C.c_int, [P, cp]),
+        "hps_server_destroy_embedding_cache_per_model": (C.c_int, [P, cp]),
+        "hps_server_refresh_embedding_cache": (C.c_int, [P, cp, i32]),
+        "hps_server_get_embedding_cache": (C.c_int, [P, cp, i32, C.POINTER(P)]),
+        "hps_server_load_table_arrays": (C.c_int, [P, cp, u32, P, P, u64, C.c_int]),
+        "hps_server_load_table_synthetic": (C.c_int, [P, cp, u32, u64, i64, u64]),
+        "hps_server_fetch": (C.c_int, [P, cp, u32, P, u64, P, P]),
+        "hps_cache_num_tables": (C.c_int, [P]),
+        "hps_cache_table_info": (C.c_int, [P, u32, C.POINTER(CacheTableInfo)]),
+        "hps_cache_counters": (C.c_int, [P, C.POINTER(CacheCounters)]),
+        "hps_cache_query": (C.c_int, [P, u32, P, u64, P]),
+        "hps_cache_wait_async": (C.c_int, [P]),
+        "hps_cache_release": (None, [P]),
+        "hps_session_create": (C.c_int, [P, cp, P, C.POINTER(P)]),
+        "hps_session_destroy": (None, [P]),
+        "hps_session_lookup": (C.c_int, [P, P, P, P, C.c_size_t]),
+        "hps_session_lookup_device": (C.c_int, [P, P, P, P, C.c_size_t]),
+        "hps_session_last_stats": (C.c_int, [P, C.POINTER(LookupStats)]),
+        "hps_session_set_option": (C.c_int, [P, cp, C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = symbol missing from the library
+        fn.restype, fn.argtypes = res, args
+    return L
+
+
+LIB = _load()
+EXPORTED_SYMBOLS = [
+    "hps_last_error", "hps_device_count", "hps_server_create", "hps_server_create_from_text", "hps_server_destroy",
+    "hps_server_model_count", "hps_server_model_name", "hps_server_model_info", "hps_server_table_info",
+    "hps_server_deployed_device", "hps_server_parse_config", "hps_server_update_database_per_model",
+    "hps_server_create_embedding_cache_per_model", "hps_server_destroy_embedding_cache_per_model",
+    "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
+    "hps_server_load_table_synthetic", "hps_server_fetch", "hps_cache_num_tables", "hps_cache_table_info",
+    "hps_cache_counters", "hps_cache_query", "hps_cache_wait_async", "hps_cache_release", "hps_session_create",
+    "hps_session_destroy", "hps_session_lookup", "hps_session_lookup_device", "hps_session_last_stats",
+    "hps_session_set_option",
+]
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise HpsError(rc, (LIB.hps_last_error() or b"").decode(errors="replace"))
+
+
+def device_count() -> int:
+    return int(LIB.hps_device_count())
+
+
+class EmbeddingCache:
+    """HugeCTR::EmbeddingCacheBase handle (shared by every session of one model on one device)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @property
+    def num_tables(self) -> int:
+        return int(LIB.hps_cache_num_tables(self._h))
+
+    def table_info(self, t: int) -> CacheTableInfo:
+        ti = CacheTableInfo()
+        _check(LIB.hps_cache_table_info(self._h, t, C.byref(ti)))
+        return ti
+
+    def counters(self) -> dict:
+        c = CacheCounters()
+        _check(LIB.hps_cache_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def query(self, table: int, keys) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        out = np.empty(keys.size, dtype=np.int32)
+        _check(LIB.hps_cache_query(self._h, table, keys.ctypes.data, keys.size, out.ctypes.data))
+        return out
+
+    def wait_async(self):
+        _check(LIB.hps_cache_wait_async(self._h))
+
+    def release(self):
+        if self._h:
+            LIB.hps_cache_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class HierParameterServer:
+    """HugeCTR::HierParameterServerBase (docs/architecture.md:246-274)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def create(cls, ps_json_config_file: str) -> "HierParameterServer":
+        h = C.c_void_p()
+        _check(LIB.hps_server_create(str(ps_json_config_file).encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def create_from_dict(cls, cfg: dict, load_tables: bool = True) -> "HierParameterServer":
+        h = C.c_void_p()
+        _check(LIB.hps_server_create_from_text(json.dumps(cfg).encode(), int(load_tables), C.byref(h)))
+        return cls(h)
+
+    def get_hps_model_configuration_map(self) -> dict:
+        out = {}
+        for i in range(LIB.hps_server_model_count(self._h)):
+            name = LIB.hps_server_model_name(self._h, i).decode()
+            out[name] = self.model_info(name)
+        return out
+
+    def model_info(self, model: str) -> ModelInfo:
+        mi = ModelInfo()
+        _check(LIB.hps_server_model_info(self._h, model.encode(), C.byref(mi)))
+        return mi
+
+    def table_info(self, model: str, t: int) -> TableInfo:
+        ti = TableInfo()
+        _check(LIB.hps_server_table_info(self._h, model.encode(), t, C.byref(ti)))
+        return ti
+
+    def parse_config(self, path: str):
+        _check(LIB.hps_server_parse_config(self._h, str(path).encode()))
+
+    def update_database_per_model(self, model: str):
+        _check(LIB.hps_server_update_database_per_model(self._h, model.encode()))
+
+    def create_embedding_cache_per_model(self, model: str):
+        _check(LIB.hps_server_create_embedding_cache_per_model(self._h, model.encode()))
+
+    def destory_embedding_cache_per_model(self, model: str):  # [sic] reference spelling
+        _check(LIB.hps_server_destroy_embedding_cache_per_model(self._h, model.encode()))
+
+    def refresh_embedding_cache(self, model: str, device: int):
+        _check(LIB.hps_server_refresh_embedding_cache(self._h, model.encode(), device))
+
+    def get_embedding_cache(self, model: str, device: int):
+        h = C.c_void_p()
+        _check(LIB.hps_server_get_embedding_cache(self._h, model.encode(), device, C.byref(h)))
+        return EmbeddingCache(h) if h else None
+
+    def load_table_arrays(self, model: str, table: int, keys, rows):
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        assert rows.ndim == 2 and rows.shape[0] == keys.size
+        _check(LIB.hps_server_load_table_arrays(self._h, model.encode(), table, keys.ctypes.data, rows.ctypes.data,
+                                                keys.size, 0))
+
+    def load_table_synthetic(self, model: str, table: int, seed: int, key0: int, rows: int):
+        _check(LIB.hps_server_load_table_synthetic(self._h, model.encode(), table, seed, key0, rows))
+
+    def fetch(self, model: str, table: int, keys, return_found: bool = False):
+        """Host-tier (volatile database) lookup of one table: rows or the table's default value."""
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        D = self.table_info(model, table).embedding_vecsize
+        out = np.empty((keys.size, D), dtype=np.float32)
+        found = np.empty(keys.size, dtype=np.uint8) if return_found else None
+        _check(LIB.hps_server_fetch(self._h, model.encode(), table, keys.ctypes.data, keys.size, out.ctypes.data,
+                                    found.ctypes.data if return_found else None))
+        return (out, found) if return_found else out
+
+    def close(self):
+        if self._h:
+            LIB.hps_server_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LookupSession:
+    """HugeCTR::LookupSessionBase (docs/architecture.md:291-323)."""
+
+    def __init__(self, handle, server: HierParameterServer, model: str):
+        self._h = handle
+        self._server = server  # keep alive
+        self.model = model
+        mi = server.model_info(model)
+        self.num_tables = int(mi.num_tables)
+        self.dims = [int(server.table_info(model, t).embedding_vecsize) for t in range(self.num_tables)]
+        self.use_gpu_cache = bool(mi.use_gpu_embedding_cache)
+
+    @classmethod
+    def create(cls, server: HierParameterServer, model: str, embedding_cache: EmbeddingCache | None) -> "LookupSession":
+        h = C.c_void_p()
+        _check(LIB.hps_session_create(server._h, model.encode(), embedding_cache._h if embedding_cache else None,
+                                      C.byref(h)))
+        return cls(h, server, model)
+
+    # -- the reference signature: lists of per-table pointers ---------------------------------------
+    def lookup_ptrs(self, h_keys_ptrs: Sequence[int], vec_ptrs: Sequence[int], num_keys: Sequence[int]):
+        T = len(num_keys)
+        kp = (C.c_void_p * T)(*[C.c_void_p(p) for p in h_keys_ptrs])
+        vp = (C.c_void_p * T)(*[C.c_void_p(p) for p in vec_ptrs])
+        nk = (C.c_size_t * T)(*[int(n) for n in num_keys])
+        _check(LIB.hps_session_lookup(self._h, kp, vp, nk, T))
+
+    def lookup_device_ptrs(self, d_keys_ptr: int, vec_ptrs: Sequence[int], num_keys: Sequence[int]):
+        T = len(num_keys)
+        vp = (C.c_void_p * T)(*[C.c_void_p(p) for p in vec_ptrs])
+        nk = (C.c_size_t * T)(*[int(n) for n in num_keys])
+        _check(LIB.hps_session_lookup_device(self._h, C.c_void_p(d_keys_ptr), vp, nk, T))
+
+    # -- conveniences --------------------------------------------------------------------------------
+    def _slices(self, num_keys):
+        koff, ooff, ko, oo = [], [], 0, 0
+        for n, d in zip(num_keys, self.dims):
+            koff.append(ko)
+            ooff.append(oo)
+            ko += int(n)
+            oo += int(n) * d
+        return koff, ooff, ko, oo
+
+    def lookup(self, keys, num_keys, out=None):
+        """KEYS flat table-major int64 (host), NUMKEYS per table → OUTPUT0 flat fp32.
+
+        gpucache=true: ``out`` is a torch CUDA tensor (allocated if None); gpucache=false: numpy array.
+        Pointer slicing = ModelInstanceState::ProcessRequest (model_instance_state.cpp:180-193)."""
+        keys = np.ascontiguousarray(keys, dtype=np.int64).ravel()
+        num_keys = [int(n) for n in num_keys]
+        koff, ooff, nk, no = self._slices(num_keys)
+        if nk != keys.size:
+            raise HpsError(ERR_INVALID_ARG, f"sum(NUMKEYS)={nk} != len(KEYS)={keys.size}")
+        kptrs = [keys.ctypes.data + 8 * o for o in koff]
+        if self.use_gpu_cache:
+            import torch
+            if out is None:
+                out = torch.empty(no, dtype=torch.float32, device="cuda")
+            assert out.is_cuda and out.dtype == torch.float32 and out.numel() >= no
+            base = out.data_ptr()
+        else:
+            if out is None:
+                out = np.empty(no, dtype=np.float32)
+            assert out.dtype == np.float32 and out.size >= no
+            base = out.ctypes.data
+        self.lookup_ptrs(kptrs, [base + 4 * o for o in ooff], num_keys)
+        return out
+
+    def lookup_device(self, d_keys, num_keys, out=None):
+        """Same with KEYS already on the device (torch int64 CUDA tensor, flat table-major)."""
+        import torch
+        num_keys = [int(n) for n in num_keys]
+        _, ooff, nk, no = self._slices(num_keys)
+        assert d_keys.is_cuda and d_keys.dtype == torch.int64 and d_keys.numel() == nk
+        if out is None:
+            out = torch.empty(no, dtype=torch.float32, device=d_keys.device)
+        base = out.data_ptr()
+        self.lookup_device_ptrs(d_keys.data_ptr(), [base + 4 * o for o in ooff], num_keys)
+        return out
+
+    def last_stats(self) -> LookupStats:
+        s = LookupStats()
+        _check(LIB.hps_session_last_stats(self._h, C.byref(s)))
+        return s
+
+    def set_option(self, name: str, value: int):
+        _check(LIB.hps_session_set_option(self._h, name.encode(), int(value)))
+
+    def close(self):
+        if self._h:
+            LIB.hps_session_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,160 @@
+/*
+ * hps_amd.h — C ABI of the MI355X-native Hierarchical Parameter Server engine (libhps_amd.so).
+ *
+ * This is the drop-in boundary *under* the Triton shell: every entry point replaces one call the
+ * reference backend makes into NVIDIA/HugeCTR's libhuge_ctr_hps.so (C++ ABI, not vendored in
+ * /root/reference).  The reference call site each function stands for is cited (paths relative to
+ * /root/reference/hps_backend).  The boundary *above* the shell — the seven TRITONBACKEND_* exports
+ * of libtriton_hps.so — is declared in include/tritonbackend_hps.h.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * TRITONSERVER_Error_Code-compatible positive code + 1 (see HPS_ERR_*), with the message available
+ * from hps_last_error() on the calling thread.  No function throws across this boundary.
+ * There is no CPU fallback for GPU-cache models: without a HIP device the cache constructors fail
+ * with HPS_ERR_UNAVAILABLE.
+ */
+#ifndef HPS_AMD_H_
+#define HPS_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPS_OK 0
+#define HPS_ERR_UNKNOWN 1        /* TRITONSERVER_ERROR_UNKNOWN + 1 */
+#define HPS_ERR_INTERNAL 2
+#define HPS_ERR_NOT_FOUND 3
+#define HPS_ERR_INVALID_ARG 4
+#define HPS_ERR_UNAVAILABLE 5
+#define HPS_ERR_UNSUPPORTED 6
+#define HPS_ERR_ALREADY_EXISTS 7
+
+typedef struct hps_server hps_server_t;   /* HugeCTR::HierParameterServerBase  include/backend.hpp:62 */
+typedef struct hps_cache hps_cache_t;     /* HugeCTR::EmbeddingCacheBase       include/model_state.hpp:171-172 */
+typedef struct hps_session hps_session_t; /* HugeCTR::LookupSessionBase        include/model_instance_state.hpp:117 */
+
+/* Subset of HugeCTR::InferenceParams the shell reads (src/backend.cpp:390-516, src/model_state.cpp:278-366). */
+typedef struct hps_model_info {
+  uint64_t max_batch_size;                   /* "max_batch_size"                     backend.cpp:341-344 */
+  uint32_t num_tables;                       /* len("sparse_files")                  backend.cpp:353-358 */
+  int32_t use_gpu_embedding_cache;           /* "gpucache"                           backend.cpp:364-369 */
+  float hit_rate_threshold;                  /* "hit_rate_threshold"                 backend.cpp:372-377 */
+  float cache_size_percentage;               /* "gpucacheper"                        backend.cpp:380-385 */
+  int32_t i64_input_key;                     /* "supportlonglong"                    backend.cpp:124-126,388 */
+  int32_t number_of_worker_buffers_in_pool;  /* "num_of_worker_buffer_in_pool"       backend.cpp:397-402 */
+  int32_t number_of_refresh_buffers_in_pool; /* "num_of_refresher_buffer_in_pool"    backend.cpp:404-409 */
+  float cache_refresh_percentage_per_iteration; /*                                   backend.cpp:411-416 */
+  int32_t device_id;                         /* last of "deployed_device_list"       backend.cpp:422 */
+  uint32_t num_deployed_devices;
+  float refresh_delay, refresh_interval;     /*                                      model_state.cpp:319,327 */
+  uint64_t cat_num;                          /* sum maxnum_catfeature_query...       model_state.cpp:337-344 */
+  uint64_t embedding_size;                   /* sum embedding_vecsize_per_table      model_state.cpp:352-356 */
+} hps_model_info_t;
+
+typedef struct hps_table_info {
+  uint32_t embedding_vecsize;   /* embedding_vecsize_per_table[t]                      backend.cpp:454-460 */
+  uint64_t maxnum_catfeature;   /* maxnum_catfeature_query_per_table_per_sample[t]     backend.cpp:443-452 */
+  float default_value;          /* default_value_for_each_table[t]                     backend.cpp:427-433 */
+  uint64_t rows_loaded;         /* rows currently in the host tier */
+} hps_table_info_t;
+
+typedef struct hps_cache_table_info {
+  uint32_t embedding_vecsize;
+  uint64_t num_buckets;     /* 16-key buckets */
+  uint64_t capacity_rows;   /* ceil(gpucacheper * rows) */
+} hps_cache_table_info_t;
+
+typedef struct hps_cache_counters {
+  uint64_t lookups, keys, misses, unique_misses, inserted, refreshed, dropped, async_calls;
+} hps_cache_counters_t;
+
+typedef struct hps_lookup_stats {
+  uint64_t misses;         /* keys of the last call that were not resident */
+  uint64_t unique_misses;
+  int32_t async_insert;    /* 1: answered in async-insert mode (missed keys returned the default vector) */
+  float probe_gather_ms;   /* HIP-event time of the probe+gather kernel (option "timing"=1), else 0 */
+} hps_lookup_stats_t;
+
+const char* hps_last_error(void);
+/* number of visible HIP devices (0 when none / no driver); never fails */
+int hps_device_count(void);
+
+/* ---- HierParameterServerBase ------------------------------------------------------------------ */
+/* HierParameterServerBase::create(ps_json_config_file): parse ps.json, load every model's sparse files
+ * into the host tier, build + warm GPU caches on the deployed devices.        src/backend.cpp:68-69 */
+int hps_server_create(const char* ps_json_path, hps_server_t** out);
+/* Same from JSON text.  load_tables=0 registers the models but loads nothing (tables are injected with
+ * hps_server_load_table_*; caches are built with hps_server_create_embedding_cache_per_model). */
+int hps_server_create_from_text(const char* ps_json_text, int load_tables, hps_server_t** out);
+void hps_server_destroy(hps_server_t* server);
+
+/* get_hps_model_configuration_map()                                          src/backend.cpp:70-71 */
+int hps_server_model_count(hps_server_t* server);
+const char* hps_server_model_name(hps_server_t* server, int index);
+int hps_server_model_info(hps_server_t* server, const char* model, hps_model_info_t* out);
+int hps_server_table_info(hps_server_t* server, const char* model, uint32_t table, hps_table_info_t* out);
+int hps_server_deployed_device(hps_server_t* server, const char* model, uint32_t index, int32_t* device);
+/* Re-read ps.json and (re)register the models found in it — HPSBackend::ParseParameterServer used for
+ * online deployment of a new model/version.                                  src/hps.cc:210-219 */
+int hps_server_parse_config(hps_server_t* server, const char* ps_json_path);
+
+/* update_database_per_model(InferenceParams)                                 src/model_state.cpp:132,389 */
+int hps_server_update_database_per_model(hps_server_t* server, const char* model);
+/* create_embedding_cache_per_model(InferenceParams)                          src/model_state.cpp:391-392 */
+int hps_server_create_embedding_cache_per_model(hps_server_t* server, const char* model);
+/* destory_embedding_cache_per_model(name)  [sic]                             src/model_state.cpp:111 */
+int hps_server_destroy_embedding_cache_per_model(hps_server_t* server, const char* model);
+/* refresh_embedding_cache(model, device)                                     src/model_state.cpp:135,160 */
+int hps_server_refresh_embedding_cache(hps_server_t* server, const char* model, int32_t device);
+/* get_embedding_cache(model, device): *out = NULL (and HPS_OK) when there is none, like the
+ * reference's nullptr.                                                       src/model_state.cpp:379,411 */
+int hps_server_get_embedding_cache(hps_server_t* server, const char* model, int32_t device, hps_cache_t** out);
+
+/* Table injection without files (tests / bench).  rows: R x D fp32, keys: R int64. */
+int hps_server_load_table_arrays(hps_server_t* server, const char* model, uint32_t table, const int64_t* keys,
+                                 const float* rows, uint64_t R, int borrow);
+/* keys key0..key0+R-1, rows from the synthetic recipe of SURVEY.md §8d, generated in parallel. */
+int hps_server_load_table_synthetic(hps_server_t* server, const char* model, uint32_t table, uint64_t seed,
+                                    int64_t key0, uint64_t R);
+/* Host-tier fetch of one table (the volatile-database lookup): out[i*D..] = row or default; found optional. */
+int hps_server_fetch(hps_server_t* server, const char* model, uint32_t table, const int64_t* keys, uint64_t n,
+                     float* out, uint8_t* found);
+
+/* ---- EmbeddingCacheBase ----------------------------------------------------------------------- */
+/* get_cache_config().num_emb_table_                                src/model_instance_state.cpp:107-109,169 */
+int hps_cache_num_tables(hps_cache_t* cache);
+int hps_cache_table_info(hps_cache_t* cache, uint32_t table, hps_cache_table_info_t* out);
+int hps_cache_counters(hps_cache_t* cache, hps_cache_counters_t* out);
+/* residency probe without side effects: slots[i] = slot index or -1 */
+int hps_cache_query(hps_cache_t* cache, uint32_t table, const int64_t* h_keys, uint64_t n, int32_t* h_slots);
+/* wait for queued async insertions */
+int hps_cache_wait_async(hps_cache_t* cache);
+/* drop this handle's reference (the shared_ptr copy the shell holds)         src/model_instance_state.cpp:158 */
+void hps_cache_release(hps_cache_t* cache);
+
+/* ---- LookupSessionBase ------------------------------------------------------------------------ */
+/* LookupSessionBase::create(InferenceParams, embedding_cache)                src/model_instance_state.cpp:170-171
+ * cache may be NULL for gpucache=false models. */
+int hps_session_create(hps_server_t* server, const char* model, hps_cache_t* cache, hps_session_t** out);
+void hps_session_destroy(hps_session_t* session);
+/* lookup(h_keys_per_table, d_vectors_per_table, num_keys_per_table): host key pointers in; device
+ * (gpucache) or host (gpucache=false) vector pointers out; blocking.        src/model_instance_state.cpp:194-195
+ * spec docs/architecture.md:308-323 */
+int hps_session_lookup(hps_session_t* session, const void* const* h_keys_per_table, float* const* vectors_per_table,
+                       const size_t* num_keys_per_table, size_t num_tables);
+/* Same lookup with KEYS already resident in HBM (flat, table-major int64).  Not in the reference API: it
+ * removes the host->device key copy the reference pays inside lookup() when the caller (a Triton
+ * ensemble step, the benchmark) already holds the keys on the device. */
+int hps_session_lookup_device(hps_session_t* session, const int64_t* d_keys_flat, float* const* d_vectors_per_table,
+                              const size_t* num_keys_per_table, size_t num_tables);
+int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
+/* options: "timing" (0/1), "probe_unroll" (1,2,4,8) */
+int hps_session_set_option(hps_session_t* session, const char* name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPS_AMD_H_ */

@@ -1,0 +1,224 @@
+"""CPU oracle for the HPS lookup path — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  It is the checker, never the thing measured as the product or shipped.
+
+PARITY UNPINNED (see the header of ``hps_oracle.c`` and DESIGN.md §Oracle): the reference's arithmetic
+lives in the un-vendored NVIDIA/HugeCTR ``libhuge_ctr_hps.so``; /root/reference holds no numeric golden
+vectors for the path.  The oracle is pinned only on the structural facts the reference states
+(file format, request layout, output shape, default fill, response parameters).
+
+Two independent restatements live here:
+  * ``COracle`` — ctypes binding of ``hps_oracle.c`` (hash-map find per key, the timed CPU baseline);
+  * ``np_*``    — NumPy restatement (sort + searchsorted; no hashing at all), used to cross-check the C
+                  oracle and to generate the fixtures in tests/golden/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = _HERE / "_build" / "libhps_oracle.so"
+
+SEED = 20260929
+_M64 = (1 << 64) - 1
+
+
+def build(force: bool = False) -> Path:
+    """Compile hps_oracle.c with gcc (make -C oracle)."""
+    src = _HERE / "hps_oracle.c"
+    if force or not _LIB.exists() or _LIB.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
+    return _LIB
+
+
+# --------------------------------------------------------------------------------------------------
+# NumPy restatement
+# --------------------------------------------------------------------------------------------------
+def np_mix64(x):
+    """splitmix64 finalizer on uint64 arrays (wrapping arithmetic)."""
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def np_synth_rows(seed: int, t: int, keys, D: int) -> np.ndarray:
+    """row(t,k)[j] of the synthetic table recipe: fp32 in [0.5,1) with hashed mantissa."""
+    keys = np.asarray(keys, dtype=np.int64)
+    with np.errstate(over="ignore"):
+        tb = np_mix64(np.uint64(seed) ^ np_mix64(np.uint64(t + 1)))
+        rb = np_mix64(tb + keys.astype(np.uint64))  # [R]
+        j = np.arange(D, dtype=np.uint64)
+        w = np_mix64(rb[:, None] + (j >> np.uint64(1))[None, :])  # [R, D]
+    lo = (w & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (w >> np.uint64(32)).astype(np.uint32)
+    m = np.where((j & np.uint64(1)).astype(bool)[None, :], hi, lo)
+    bits = np.uint32(0x3F000000) | (m & np.uint32(0x007FFFFF))
+    return bits.view(np.float32)
+
+
+def np_write_table(dirpath, keys, rows) -> None:
+    """<dir>/key = int64[R], <dir>/emb_vector = fp32[R,D], native endian, same order
+    (/root/reference/docs/architecture.md:185-218; 01_model_training.ipynb:498-504)."""
+    d = Path(dirpath)
+    d.mkdir(parents=True, exist_ok=True)
+    np.asarray(keys, dtype=np.int64).tofile(d / "key")
+    np.asarray(rows, dtype=np.float32).tofile(d / "emb_vector")
+
+
+def np_read_table(dirpath, D: int):
+    d = Path(dirpath)
+    keys = np.fromfile(d / "key", dtype=np.int64)
+    rows = np.fromfile(d / "emb_vector", dtype=np.float32)
+    if rows.size != keys.size * D:
+        raise ValueError(f"{d}: emb_vector has {rows.size} floats, expected {keys.size}*{D}")
+    return keys, rows.reshape(keys.size, D)
+
+
+def np_find(table_keys, query) -> np.ndarray:
+    """Row index of each query key in the table (last duplicate wins), -1 when absent."""
+    table_keys = np.asarray(table_keys, dtype=np.int64)
+    query = np.asarray(query, dtype=np.int64)
+    if table_keys.size == 0:
+        return np.full(query.shape, -1, dtype=np.int64)
+    order = np.argsort(table_keys, kind="stable")
+    sk = table_keys[order]
+    pos = np.searchsorted(sk, query, side="right") - 1  # last occurrence
+    ok = (pos >= 0) & (sk[np.clip(pos, 0, sk.size - 1)] == query)
+    return np.where(ok, order[np.clip(pos, 0, sk.size - 1)], -1)
+
+
+def np_lookup(tables, keys, num_keys, defaults, resident=None) -> np.ndarray:
+    """The whole request (hps.cc:573-630 + model_instance_state.cpp:177-197).
+
+    tables  : list of (table_keys[R], rows[R,D])
+    keys    : flat int64, table-major        num_keys: T ints         defaults: T floats
+    resident: optional list of per-table int64 arrays = keys currently in the GPU cache.  When given,
+              models the ASYNC-insert return (docs/architecture.md:32,65-67): a key that is not
+              resident returns the default vector even if the parameter server holds it.
+    """
+    keys = np.asarray(keys, dtype=np.int64).ravel()
+    out, off = [], 0
+    for t, ((tk, rows), n) in enumerate(zip(tables, num_keys)):
+        q = keys[off:off + n]
+        off += n
+        D = rows.shape[1]
+        idx = np_find(tk, q)
+        found = idx >= 0
+        if resident is not None:
+            found &= np.isin(q, np.asarray(resident[t], dtype=np.int64))
+        o = np.full((n, D), np.float32(defaults[t]), dtype=np.float32)
+        o[found] = rows[idx[found]]
+        out.append(o.ravel())
+    if off != keys.size:
+        raise ValueError("sum(NUMKEYS) != len(KEYS)")
+    return np.concatenate(out) if out else np.zeros(0, np.float32)
+
+
+# --------------------------------------------------------------------------------------------------
+# C oracle binding
+# --------------------------------------------------------------------------------------------------
+class COracle:
+    """ctypes view of hps_oracle.c.  One instance per model (list of tables)."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            L = C.CDLL(str(build()))
+            L.oracle_mix64.restype = C.c_uint64
+            L.oracle_mix64.argtypes = [C.c_uint64]
+            L.oracle_synth_rows.restype = None
+            L.oracle_synth_rows.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]
+            L.oracle_table_from_arrays.restype = C.c_void_p
+            L.oracle_table_from_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32]
+            L.oracle_table_load.restype = C.c_void_p
+            L.oracle_table_load.argtypes = [C.c_char_p, C.c_uint32]
+            L.oracle_table_free.restype = None
+            L.oracle_table_free.argtypes = [C.c_void_p]
+            L.oracle_table_rows.restype = C.c_int64
+            L.oracle_table_rows.argtypes = [C.c_void_p]
+            L.oracle_table_find.restype = C.c_int64
+            L.oracle_table_find.argtypes = [C.c_void_p, C.c_int64]
+            L.oracle_output_elems.restype = C.c_int64
+            L.oracle_output_elems.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            L.oracle_lookup.restype = C.c_int64
+            L.oracle_lookup.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.oracle_lookup_mt.restype = C.c_int64
+            L.oracle_lookup_mt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            L.oracle_write_table.restype = C.c_int
+            L.oracle_write_table.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self):
+        self.L = self.lib()
+        self._tables = []  # (handle, D)
+        self._keep = []    # numpy arrays borrowed by the C side
+
+    def add_table_arrays(self, keys, rows):
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        R, D = rows.shape
+        assert keys.shape == (R,)
+        h = self.L.oracle_table_from_arrays(keys.ctypes.data, rows.ctypes.data, R, D)
+        if not h:
+            raise MemoryError("oracle_table_from_arrays")
+        self._tables.append((h, D))
+        self._keep.append((keys, rows))
+
+    def add_table_dir(self, dirpath, D):
+        h = self.L.oracle_table_load(os.fsencode(str(dirpath)), D)
+        if not h:
+            raise OSError(f"oracle_table_load({dirpath}, D={D}) failed")
+        self._tables.append((h, D))
+
+    @property
+    def dims(self):
+        return [d for _, d in self._tables]
+
+    def _handles(self):
+        return (C.c_void_p * len(self._tables))(*[h for h, _ in self._tables])
+
+    def lookup(self, keys, num_keys, defaults, threads: int = 1, out=None) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, dtype=np.int64).ravel()
+        nk = np.ascontiguousarray(num_keys, dtype=np.int32).ravel()
+        df = np.ascontiguousarray(defaults, dtype=np.float32).ravel()
+        T = len(self._tables)
+        assert nk.size == T and df.size == T and int(nk.sum()) == keys.size
+        hs = self._handles()
+        n = self.L.oracle_output_elems(hs, nk.ctypes.data, T)
+        if out is None:
+            out = np.empty(n, dtype=np.float32)
+        assert out.size == n and out.dtype == np.float32
+        w = self.L.oracle_lookup_mt(hs, T, keys.ctypes.data, nk.ctypes.data, df.ctypes.data, out.ctypes.data, threads)
+        assert w == n
+        return out
+
+    def close(self):
+        for h, _ in self._tables:
+            self.L.oracle_table_free(h)
+        self._tables, self._keep = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def c_synth_rows(seed: int, t: int, key0: int, count: int, D: int, out=None) -> np.ndarray:
+    L = COracle.lib()
+    if out is None:
+        out = np.empty((count, D), dtype=np.float32)
+    L.oracle_synth_rows(seed, t, key0, count, D, out.ctypes.data)
+    return out

@@ -1,0 +1,74 @@
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu() -> bool:
+    try:
+        from hugectr_backend_amd import hps
+        return hps.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libs():
+    """Build (if stale) the native libraries and the C oracle once per test session."""
+    from hugectr_backend_amd import build as _b
+    _b.build()
+    from oracle import hps_oracle
+    hps_oracle.build()
+
+
+def make_tables(spec, seed=20260929, key_space_mult=3, rng=None):
+    """spec: list of (R, D).  Keys are a random subset of [0, key_space_mult*R) in random order."""
+    from oracle import hps_oracle as O
+    rng = rng or np.random.default_rng(seed)
+    out = []
+    for t, (R, D) in enumerate(spec):
+        keys = rng.permutation(R * key_space_mult)[:R].astype(np.int64)
+        rows = O.np_synth_rows(seed, t, keys, D)
+        out.append((keys, rows))
+    return out
+
+
+def ps_config(model, tables, dirs=None, gpucache=True, gpucacheper=0.5, hit_rate_threshold=1.0, defaults=None,
+              maxcat=None, max_batch=1024, extra=None, device=0):
+    T = len(tables)
+    m = {
+        "model": model,
+        "sparse_files": dirs or [f"/nonexistent/{model}_{t}" for t in range(T)],
+        "num_of_worker_buffer_in_pool": 3,
+        "embedding_vecsize_per_table": [int(r.shape[1]) for _, r in tables],
+        "maxnum_catfeature_query_per_table_per_sample": maxcat or [1] * T,
+        "default_value_for_each_table": defaults or [0.0] * T,
+        "deployed_device_list": [device],
+        "max_batch_size": max_batch,
+        "gpucache": gpucache,
+    }
+    if gpucache:
+        m["hit_rate_threshold"] = hit_rate_threshold
+        m["gpucacheper"] = gpucacheper
+    if extra:
+        m.update(extra)
+    return {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8}, "models": [m]}
