@@ -1,0 +1,368 @@
+#!/usr/bin/env python3
+"""Headline benchmark: embedding lookups/s on Criteo-shaped key batches (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the lookup hot path over one batch of synthetic keys that already sit in HBM
+(26 tables x 65,536 keys): cache probe + hit gather (HIP), unique-miss extraction (HIP), host
+parameter-server gather of the missed rows, H2D of those rows, scatter + cache insert (HIP).
+Results are the exact fp32 rows (sync-insert mode, hit_rate_threshold=1.0), checked against the CPU
+oracle on a slice of every run.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): the reference's multi-GPU mode is
+"replicas only" (independent cache per GPU) — each rank serves its own batches, no
+data-path collective; RCCL is used for the barriers and the max-over-ranks time only.  scaling = weak.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+SEED = 20260929
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--tables", type=int, default=26)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per table (BASELINE config 2: 1e7)")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=65536, help="samples per batch; one key per table per sample")
+    ap.add_argument("--cache-frac", type=float, default=0.2, help="gpucacheper")
+    ap.add_argument("--hit", type=float, default=0.95, help="probability that a key is drawn from the resident set")
+    ap.add_argument("--zipf", type=float, default=1.05)
+    ap.add_argument("--sessions", type=int, default=3, help="concurrent lookup sessions (Triton instance count)")
+    ap.add_argument("--mode", choices=["sync", "async"], default="sync",
+                    help="sync: exact rows (threshold 1.0); async: misses return default, inserted in background")
+    ap.add_argument("--distinct-batches", type=int, default=0,
+                    help="0: one fresh batch per step (warmup+steps distinct batches)")
+    ap.add_argument("--unroll", type=int, default=4)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the untimed all-hit and async-insert legs reported next to the headline")
+    return ap.parse_args()
+
+
+def zipf_cdf(n: int, alpha: float) -> np.ndarray:
+    w = 1.0 / np.power(np.arange(1, n + 1, dtype=np.float64), alpha)
+    c = np.cumsum(w)
+    return c / c[-1]
+
+
+def make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, hit, nbatches):
+    """Key batches generated on the device (every step gets fresh cold keys, so the hit rate is not
+    inflated by re-running a batch whose misses were inserted the first time).
+    per table: B keys; with prob `hit` a Zipf-ranked resident key, else uniform from the cold range [C,R)."""
+    out = []
+    for _ in range(nbatches):
+        parts = []
+        for res in resident_d:
+            u = torch.rand(B, generator=gen, device="cuda", dtype=torch.float64)
+            ranks = torch.searchsorted(cdf_d, u).clamp_(max=res.numel() - 1)
+            hot = torch.rand(B, generator=gen, device="cuda") < hit
+            if R > C:
+                cold = torch.randint(C, R, (B,), generator=gen, device="cuda", dtype=torch.int64)
+            else:
+                cold = res[ranks]
+            parts.append(torch.where(hot, res[ranks], cold))
+        out.append(torch.cat(parts).contiguous())
+    return out
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # share the host cores between the ranks' parameter-server pools
+        os.environ.setdefault("HCTR_DEFAULT_CONCURRENCY", str(max(8, (os.cpu_count() or 8) // world)))
+
+    import torch
+    import torch.distributed as dist
+    from hugectr_backend_amd import build as hb
+    if rank == 0:
+        hb.build()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    from hugectr_backend_amd import hps
+
+    T, R, D, B = a.tables, a.rows, a.dim, a.batch
+    N = T * B
+    model = "criteo_dlrm"
+    cfg = {
+        "supportlonglong": True,
+        "volatile_db": {"type": "hash_map", "num_partitions": 8},
+        "models": [{
+            "model": model,
+            "sparse_files": [f"synthetic://{t}" for t in range(T)],
+            "num_of_worker_buffer_in_pool": max(3, a.sessions),
+            "embedding_vecsize_per_table": [D] * T,
+            "maxnum_catfeature_query_per_table_per_sample": [1] * T,
+            "default_value_for_each_table": [0.0] * T,
+            "deployed_device_list": [local_rank],
+            "max_batch_size": B,
+            "gpucache": True,
+            "gpucacheper": a.cache_frac,
+            "hit_rate_threshold": 1.0 if a.mode == "sync" else 0.5,
+        }],
+    }
+    t_setup = time.time()
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    for t in range(T):
+        ps.load_table_synthetic(model, t, SEED, 0, R)
+    t_tables = time.time() - t_setup
+    ps.create_embedding_cache_per_model(model)
+    cache = ps.get_embedding_cache(model, local_rank)
+    t_cache = time.time() - t_setup - t_tables
+    sessions = [hps.LookupSession.create(ps, model, cache) for _ in range(a.sessions)]
+    for s in sessions:
+        s.set_option("timing", 1)
+        s.set_option("probe_unroll", a.unroll)
+
+    # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
+    C = int(np.ceil(a.cache_frac * R))
+    resident = []
+    for t in range(T):
+        k = np.arange(C, dtype=np.int64)
+        resident.append(k[cache.query(t, k) >= 0])
+    resident_frac = float(np.mean([r.size / C for r in resident]))
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(SEED + rank)
+    cdf_d = torch.from_numpy(zipf_cdf(C, a.zipf)).cuda()
+    resident_d = [torch.from_numpy(r).cuda() for r in resident]
+    nb = min(a.distinct_batches, a.steps + a.warmup) if a.distinct_batches > 0 else a.steps + a.warmup
+    batches_d = make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, a.hit, nb)
+    batches_h = [b.cpu().numpy() for b in batches_d[: min(8, nb)]]
+    del cdf_d, resident_d
+    outs = [torch.empty(N * D, dtype=torch.float32, device="cuda") for _ in sessions]
+    nk = [B] * T
+    torch.cuda.synchronize()
+
+    lat_ms, kern_ms, miss_ct, phases = [], [], [], []
+    lock = threading.Lock()
+
+    def run_steps(count, record, first=0):
+        nxt = [0]
+
+        def worker(si):
+            s = sessions[si]
+            while True:
+                with lock:
+                    i = nxt[0]
+                    if i >= count:
+                        return
+                    nxt[0] += 1
+                t0 = time.perf_counter()
+                s.lookup_device(batches_d[(first + i) % len(batches_d)], nk, out=outs[si])
+                dt = (time.perf_counter() - t0) * 1e3
+                st = s.last_stats()
+                if record:
+                    with lock:
+                        lat_ms.append(dt)
+                        kern_ms.append(st.probe_gather_ms)
+                        miss_ct.append(st.misses)
+                        phases.append([float(x) for x in st.phase_ms])
+
+        th = [threading.Thread(target=worker, args=(si,)) for si in range(len(sessions))]
+        [x.start() for x in th]
+        [x.join() for x in th]
+
+    run_steps(a.warmup, False)
+    if a.mode == "async":
+        cache.wait_async()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(a.steps, True, first=a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- extra legs (outside the timed region; per-GPU numbers of this rank) --------------------------------
+    extra = {}
+    main_lat, main_kern, main_miss, main_phases = list(lat_ms), list(kern_ms), list(miss_ct), list(phases)
+    if not a.no_extra_legs:
+        def leg(batches, steps, sess_list):
+            lat_ms.clear(); kern_ms.clear(); miss_ct.clear(); phases.clear()
+            saved = sessions[:]
+            sessions[:] = sess_list
+            batches_d_saved = batches_d[:]
+            batches_d[:] = batches
+            run_steps(4, False)
+            torch.cuda.synchronize()
+            tl0 = time.perf_counter()
+            run_steps(steps, True, first=4)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - tl0
+            sessions[:] = saved
+            batches_d[:] = batches_d_saved
+            k = float(np.mean(kern_ms))
+            return {"lookups_per_s": steps * N / dt, "ms_per_step": dt / steps * 1e3, "avg_kernel_ms": k,
+                    "kernel_frac_of_hbm_peak": N * (8 + 8 * D) / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "measured_hit_rate": 1.0 - float(np.mean(miss_ct)) / N}
+
+        gen2 = torch.Generator(device="cuda")
+        gen2.manual_seed(SEED + 1000 + rank)
+        cdf_d = torch.from_numpy(zipf_cdf(C, a.zipf)).cuda()
+        resident_d = [torch.from_numpy(r).cuda() for r in resident]
+        # (1) every key resident: the GPU-side ceiling of the path, one session (kernel runs alone)
+        hot_batches = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, 1.1, 8)
+        extra["all_hit_one_session"] = leg(hot_batches, 24, sessions[:1])
+        # (2) the reference's default policy at this hit rate (hit_rate_threshold 0.9 < 0.95): missed keys
+        #     return the default vector now and are fetched + inserted in the background
+        fresh = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
+        for s in sessions:
+            s.set_option("hit_rate_threshold_permille", 900)
+        extra["async_insert_threshold_0.9"] = leg(fresh, 24, sessions)
+        cache.wait_async()
+        for s in sessions:
+            s.set_option("hit_rate_threshold_permille", 1000 if a.mode == "sync" else 500)
+        del cdf_d, resident_d, hot_batches, fresh
+
+    # ---- untimed parity check of the last step of session 0 against the CPU oracle (tables 0..1) ----
+    parity = None
+    cpu = None
+    if rank == 0:
+        from oracle import hps_oracle as O
+        chk_tables = min(2, T)
+        # which batch did session 0 run last?  re-run one known batch to be sure
+        sessions[0].lookup_device(batches_d[0], nk, out=outs[0])
+        torch.cuda.synchronize()
+        got = outs[0][: chk_tables * B * D].cpu().numpy()
+        co = O.COracle()
+        sample_rows = []
+        for t in range(chk_tables):
+            rows = np.empty((R, D), dtype=np.float32)
+            # generate the oracle's copy of the table in parallel slabs (C code releases the GIL)
+            nth = min(64, os.cpu_count() or 8)
+            step = (R + nth - 1) // nth
+
+            def gen(lo, t=t, rows=rows):
+                hi = min(R, lo + step)
+                if hi > lo:
+                    O.c_synth_rows(SEED, t, lo, hi - lo, D, out=rows[lo:hi])
+
+            th = [threading.Thread(target=gen, args=(lo,)) for lo in range(0, R, step)]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            sample_rows.append(rows)
+        keys_seq = np.arange(R, dtype=np.int64)
+        for t in range(chk_tables):
+            co.add_table_arrays(keys_seq, sample_rows[t])
+        q = batches_h[0][: chk_tables * B]
+        ref = co.lookup(q, [B] * chk_tables, [0.0] * chk_tables, threads=min(32, os.cpu_count() or 8))
+        if a.mode == "sync":
+            parity = bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
+        else:
+            # async mode: resident keys exact, others default
+            same = got.view(np.uint32).reshape(-1, D) == ref.view(np.uint32).reshape(-1, D)
+            is_default = (got.reshape(-1, D) == 0.0).all(axis=1)
+            parity = bool((same.all(axis=1) | is_default).all())
+
+        if not a.no_cpu_baseline:
+            # ---- cpu_baseline: the oracle (a port of the reference's hash_map parameter-server lookup)
+            # on the same key batches, tables 0..chk_tables-1 only (bounded sample), all host cores ----
+            threads = os.cpu_count() or 8
+            nkc = [B] * chk_tables
+            outc = np.empty(chk_tables * B * D, dtype=np.float32)
+            done, tc0 = 0, time.perf_counter()
+            reps = 0
+            while time.perf_counter() - tc0 < a.cpu_seconds and reps < 2000:
+                qb = batches_h[reps % len(batches_h)][: chk_tables * B]
+                co.lookup(qb, nkc, [0.0] * chk_tables, threads=threads, out=outc)
+                done += qb.size
+                reps += 1
+            tcpu = time.perf_counter() - tc0
+            cpu = {
+                "value": done / tcpu, "unit": "lookups/s", "cores": threads, "kind": "port",
+                "sample": f"{reps} passes over the first {chk_tables} of {T} tables' key slices "
+                          f"({chk_tables * B} keys/pass, {R} rows x {D} fp32 per table), oracle/hps_oracle.c "
+                          f"oracle_lookup_mt with {threads} threads",
+            }
+
+    if rank == 0:
+        lat_ms, kern_ms, miss_ct, phases = main_lat, main_kern, main_miss, main_phases
+        k_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
+        alg_bytes = N * (8 + 8 * D)  # 8 B key + 4D row read + 4D row write per lookup
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        value = world * a.steps * N / elapsed
+        res = {
+            "metric": "embedding lookups/sec, Criteo 26-slot 64K batch",
+            "value": value,
+            "unit": "lookups/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "fp32 rows / int64 keys (moved, never computed)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Criteo DLRM {T} sparse slots, {R} rows/table x {D}-dim, {B} batch ({N} keys), "
+                            f"gpucacheper {a.cache_frac}, target hit {a.hit}, zipf {a.zipf} within the resident set, "
+                            f"{a.mode} insert, {a.sessions} lookup sessions, keys resident in HBM",
+                "parallelism": "replicas" if world > 1 else "single",
+            },
+            "p50_batch_latency_ms": float(np.percentile(lat_ms, 50)) if lat_ms else None,
+            "p99_batch_latency_ms": float(np.percentile(lat_ms, 99)) if lat_ms else None,
+            "measured_hit_rate": 1.0 - float(np.mean(miss_ct)) / N if miss_ct else None,
+            "resident_fraction_after_warmup": resident_frac,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "hps_probe_gather_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_kernel_ms": k_ms,
+            },
+            "mean_phase_ms": dict(zip(["probe_gather_dedup_until_counts", "host_ps_gather", "h2d_scatter_insert", "call"],
+                                      [float(x) for x in np.mean(np.array(phases), axis=0)])) if phases else None,
+            "extra_legs": extra or None,
+            "cpu_baseline": cpu,
+            "parity_vs_oracle_bit_exact": parity,
+            "setup_seconds": {"host_tables": t_tables, "gpu_cache_warmup": t_cache},
+            "cache_counters": cache.counters(),
+        }
+        print(json.dumps(res))
+    for s in sessions:
+        s.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

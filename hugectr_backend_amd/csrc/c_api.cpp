@@ -298,6 +298,7 @@ int hps_session_last_stats(hps_session_t* s, hps_lookup_stats_t* out) {
     out->unique_misses = s->s->last_unique_miss_count();
     out->async_insert = s->s->last_call_async() ? 1 : 0;
     out->probe_gather_ms = s->s->last_gpu_ms();
+    for (int i = 0; i < 4; ++i) out->phase_ms[i] = s->s->last_phase_ms()[i];
     return Status::Ok();
   });
 }
@@ -310,6 +311,9 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
     else if (n == "probe_unroll") {
       if (value != 1 && value != 2 && value != 4 && value != 8) return Error(Code::kInvalidArg, "probe_unroll must be 1, 2, 4 or 8");
       s->s->set_probe_unroll(value);
+    } else if (n == "hit_rate_threshold_permille") {
+      if (value < 0) return Error(Code::kInvalidArg, "hit_rate_threshold_permille must be >= 0");
+      s->s->set_hit_rate_threshold((float)value / 1000.0f);
     } else return Error(Code::kInvalidArg, "unknown option '", n, "'");
     return Status::Ok();
   });

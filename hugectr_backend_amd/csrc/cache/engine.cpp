@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -403,18 +404,24 @@ Status LookupSession::LookupHostTier(const void* const* h_keys_per_table, float*
                                      const size_t* num_keys_per_table, size_t num_tables) {
   // gpucache=false: rows come straight from the parameter server into host memory
   // (docs/architecture.md:72; model_instance_state.cpp:114-133).
+  std::vector<HierParameterServer::FetchJob> jobs;
   for (size_t t = 0; t < num_tables; ++t) {
     const size_t n = num_keys_per_table[t];
     if (n == 0) continue;
     if (!h_keys_per_table[t] || !h_vectors_per_table[t]) return Error(Code::kInvalidArg, "lookup: null pointer for table ", t);
-    HPS_RETURN_IF_ERROR(ps_->Fetch(*tables_[t], (const int64_t*)h_keys_per_table[t], n, h_vectors_per_table[t],
-                                   tables_[t]->dim(), params_.default_value_for_each_table[t], nullptr, nullptr));
+    jobs.push_back({tables_[t].get(), (const int64_t*)h_keys_per_table[t], n, h_vectors_per_table[t],
+                    tables_[t]->dim(), params_.default_value_for_each_table[t], nullptr});
   }
-  return Status::Ok();
+  return ps_->FetchMulti(jobs);
 }
 
 Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
   // ---- call descriptor: the per-table slicing of ProcessRequest (model_instance_state.cpp:180-193) ----
+  const auto tc0 = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
+  phase_ms_[0] = phase_ms_[1] = phase_ms_[2] = phase_ms_[3] = 0.f;
   CallDesc& c = *h_call_;
   c.num_tables = (uint32_t)T;
   c.keys = d_keys_flat;
@@ -467,6 +474,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     cache_->counters_.misses += misses;
     cache_->counters_.unique_misses += uniq;
   }
+  phase_ms_[0] = phase_ms_[3] = ms_since(tc0);
   if (misses == 0) return Status::Ok();
 
   // ---- insertion policy (docs/architecture.md:65-67) ----
@@ -488,7 +496,10 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     cache_->counters_.async_calls += 1;
     return Status::Ok();
   }
-  return HandleMisses(N, epoch);
+  const Status st = HandleMisses(N, epoch);
+  phase_ms_[3] = ms_since(tc0);
+  phase_ms_[2] = phase_ms_[3] - phase_ms_[0] - phase_ms_[1];
+  return st;
 }
 
 // Synchronous miss path: parameter-server gather of the unique missed keys into pinned staging,
@@ -531,15 +542,41 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     if (!any) break;
 
     // ---- host parameter-server gather (multi-threaded) into pinned staging ----
+    // Gather and upload in pieces of a few MB (runs of consecutive tables): the H2D copy of piece p runs
+    // on the copy engine while the host threads gather piece p+1, so the PCIe time (the floor of this
+    // path: every missed row crosses the link once) hides most of the DRAM-latency-bound gather.
+    HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, stream_));
+    constexpr size_t kPieceFloats = (4u << 20) / sizeof(float);
+    std::vector<HierParameterServer::FetchJob> jobs;
+    size_t piece_begin = SIZE_MAX, piece_end = 0;
+    auto flush = [&]() -> Status {
+      if (jobs.empty()) return Status::Ok();
+      const auto tf0 = std::chrono::steady_clock::now();
+      HPS_RETURN_IF_ERROR(ps_->FetchMulti(jobs));
+      phase_ms_[1] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tf0).count();
+      HIP_TRY(hipMemcpyAsync(d_staging_ + piece_begin, h_staging_ + piece_begin, (piece_end - piece_begin) * sizeof(float),
+                             hipMemcpyHostToDevice, stream_));
+      jobs.clear();
+      piece_begin = SIZE_MAX; piece_end = 0;
+      return Status::Ok();
+    };
     for (size_t t = 0; t < T; ++t) {
       const uint32_t lo = md.chunk_lo[t], hi = md.chunk_hi[t];
       if (hi == lo) continue;
-      HPS_RETURN_IF_ERROR(ps_->Fetch(*tables_[t], h_uniq_keys_ + c.key_start[t] + lo, hi - lo,
-                                     h_staging_ + md.stage_off[t], tables_[t]->dim(),
-                                     params_.default_value_for_each_table[t], h_found_ + md.useg_start[t], nullptr));
+      const uint32_t D = tables_[t]->dim();
+      // a big table is cut into several pieces of its own
+      const uint32_t rows_per_piece = (uint32_t)std::max<size_t>(1, kPieceFloats / D);
+      for (uint32_t r = lo; r < hi; r += rows_per_piece) {
+        const uint32_t re = std::min(hi, r + rows_per_piece);
+        const size_t off = md.stage_off[t] + (size_t)(r - lo) * D;
+        jobs.push_back({tables_[t].get(), h_uniq_keys_ + c.key_start[t] + r, re - r, h_staging_ + off, D,
+                        params_.default_value_for_each_table[t], h_found_ + md.useg_start[t] + (r - lo)});
+        piece_begin = std::min(piece_begin, off);
+        piece_end = std::max(piece_end, off + (size_t)(re - r) * D);
+        if (piece_end - piece_begin >= kPieceFloats) HPS_RETURN_IF_ERROR(flush());
+      }
     }
-    HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipMemcpyAsync(d_staging_, h_staging_, fl * sizeof(float), hipMemcpyHostToDevice, stream_));
+    HPS_RETURN_IF_ERROR(flush());
     HIP_TRY(hipMemcpyAsync(d_found_, h_found_, uq, hipMemcpyHostToDevice, stream_));
 
     hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, N, d_slot_, d_staging_, cu, stream_);

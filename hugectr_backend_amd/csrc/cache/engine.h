@@ -143,8 +143,13 @@ class LookupSession {
   uint64_t last_unique_miss_count() const { return last_unique_; }
   bool last_call_async() const { return last_async_; }
   float last_gpu_ms() const { return last_gpu_ms_; }      // probe+gather kernel time of the last call (HIP events)
+  // host wall-clock phases of the last call (ms): [0] enqueue -> miss counts known, [1] parameter-server
+  // gather, [2] H2D + scatter + insert until the stream drained, [3] whole call
+  const float* last_phase_ms() const { return phase_ms_; }
   void set_probe_unroll(int u) { probe_unroll_ = u; }
   void set_timing(bool on) { timing_ = on; }
+  // per-session override of the model's hit_rate_threshold (sync vs async insertion, docs/architecture.md:65-67)
+  void set_hit_rate_threshold(float v) { params_.hit_rate_threshold = v; }
 
  private:
   friend class HierParameterServer;
@@ -191,6 +196,7 @@ class LookupSession {
   uint64_t last_misses_ = 0, last_unique_ = 0;
   bool last_async_ = false;
   float last_gpu_ms_ = 0.f;
+  float phase_ms_[4] = {0, 0, 0, 0};
   int probe_unroll_ = 4;
   bool timing_ = false;
 };
@@ -231,6 +237,18 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   // Host-tier fetch of one table's keys: rows or default, multi-threaded.
   Status Fetch(const HostTable& tb, const int64_t* keys, size_t n, float* out, size_t stride, float default_value,
                uint8_t* found, size_t* nfound);
+  // Several tables' fetches as ONE fork-join over the pool (a request touches every table of the model;
+  // 26 separate fork-joins of a few thousand keys each would leave most cores idle).
+  struct FetchJob {
+    const HostTable* table;
+    const int64_t* keys;
+    size_t n;
+    float* out;
+    size_t stride;
+    float default_value;
+    uint8_t* found;  // optional
+  };
+  Status FetchMulti(const std::vector<FetchJob>& jobs);
 
   // async-insert mode: queue "fetch these keys and insert them" for a cache; dropped (best effort)
   // when more than number_of_worker_buffers_in_pool jobs are already waiting.

@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
   const int lane = lane_id();
   const int g = lane >> 4, lig = lane & 15;
   const uint64_t groups_total = (uint64_t)gridDim.x * 16;
+  uint32_t n_dropped = 0, n_inserted = 0, n_refreshed = 0;  // counted by each group's lane 0
   for (uint64_t f = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4); f < total; f += groups_total) {
     const int t = find_table(md->useg_start, (int)T, f);
     const TableCacheDev tb = tables[t];
@@ -457,8 +458,16 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
     const uint32_t present = (uint32_t)(__ballot(bk == key) >> (g * 16)) & 0xFFFFu;
     int victim = -1;
     if (present) {
-      victim = __builtin_ctz(present);
-      if (lig == victim) tb.stamps[base + lig] = epoch;
+      // Already resident (another session inserted it after our probe): refresh the row in place, but
+      // only after claiming the slot like any other writer — a second group of this launch may be
+      // about to evict exactly this slot, and an unclaimed refresh would interleave its row with the
+      // evictor's key (key/row mismatch = poisoned slot).  Losing the claim just skips the refresh.
+      const int v = __builtin_ctz(present);
+      uint32_t old = epoch;
+      if (lig == v && st != epoch) old = atomicCAS(&tb.stamps[base + v], st, epoch);
+      old = __shfl(old, g * 16 + v, 64);
+      const uint32_t expect = __shfl(st, g * 16 + v, 64);
+      if (expect != epoch && old == expect) victim = v;
     } else {
       for (int tries = 0; tries < kBucketSlots; ++tries) {
         // min over the group of (stamp, lane) among slots not used in this epoch
@@ -481,12 +490,26 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
       if (victim >= 0 && lig == victim) tb.bucket_keys[base + victim] = key;
     }
     if (victim < 0) {
-      if (lig == 0) atomicAdd(&stats[0], 1u);  // dropped: bucket full of this epoch's keys
+      n_dropped += (lig == 0);  // bucket full of this epoch's keys (or lost the claim)
       continue;
     }
     float* dst = tb.rows + (base + (uint64_t)victim) * D;
     copy_row<false>(row, dst, D, lig, (D & 3u) == 0 && (md->stage_off[t] & 3) == 0);
-    if (lig == 0) atomicAdd(&stats[present ? 2 : 1], 1u);
+    if (lig == 0) { if (present) ++n_refreshed; else ++n_inserted; }
+  }
+  // one atomic per block and counter (a per-key atomic on one word serialises the whole launch)
+  __shared__ uint32_t sh_stat[3][4];
+  uint32_t c0 = n_dropped, c1 = n_inserted, c2 = n_refreshed;
+  for (int off = 32; off > 0; off >>= 1) {
+    c0 += __shfl_down(c0, off, 64);
+    c1 += __shfl_down(c1, off, 64);
+    c2 += __shfl_down(c2, off, 64);
+  }
+  if (lane == 0) { sh_stat[0][threadIdx.x >> 6] = c0; sh_stat[1][threadIdx.x >> 6] = c1; sh_stat[2][threadIdx.x >> 6] = c2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const uint32_t v = sh_stat[threadIdx.x][0] + sh_stat[threadIdx.x][1] + sh_stat[threadIdx.x][2] + sh_stat[threadIdx.x][3];
+    if (v) atomicAdd(&stats[threadIdx.x], v);
   }
 }
 

@@ -91,6 +91,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
   for (;;) {
     MissDesc& md = *I.h_md;
     size_t uq = 0, fl = 0;
+    std::vector<HierParameterServer::FetchJob> jobs;
     for (size_t t = 0; t < T; ++t) {
       const uint32_t D = cfg_.embedding_vec_size_[t];
       fl = (fl + 3) & ~(size_t)3;
@@ -102,8 +103,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
       md.chunk_hi[t] = (uint32_t)take;
       if (take) {
         memcpy(I.h_keys + uq, keys_per_table[t].data() + done[t], take * sizeof(int64_t));
-        HPS_RETURN_IF_ERROR(ps->Fetch(*tables[t], I.h_keys + uq, take, I.h_rows + fl, D, cfg_.default_value_[t],
-                                      I.h_found + uq, nullptr));
+        jobs.push_back({tables[t].get(), I.h_keys + uq, take, I.h_rows + fl, D, cfg_.default_value_[t], I.h_found + uq});
       }
       done[t] += take;
       uq += take;
@@ -112,6 +112,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
     md.useg_start[T] = uq;
     I.h_ks[T] = uq;
     if (uq == 0) break;
+    HPS_RETURN_IF_ERROR(ps->FetchMulti(jobs));
     HIP_TRY(hipMemcpyAsync(I.d_md, I.h_md, sizeof(MissDesc), hipMemcpyHostToDevice, I.stream));
     HIP_TRY(hipMemcpyAsync(I.d_ks, I.h_ks, sizeof(uint64_t) * (T + 1), hipMemcpyHostToDevice, I.stream));
     HIP_TRY(hipMemcpyAsync(I.d_keys, I.h_keys, uq * sizeof(int64_t), hipMemcpyHostToDevice, I.stream));
@@ -339,6 +340,23 @@ Status HierParameterServer::Fetch(const HostTable& tb, const int64_t* keys, size
   if (ntasks <= 1) { if (ntasks) body(0); }
   else pool_->ParallelFor(ntasks, body);
   if (nfound) *nfound = total.load();
+  return Status::Ok();
+}
+
+Status HierParameterServer::FetchMulti(const std::vector<FetchJob>& jobs) {
+  struct Task { uint32_t job; size_t begin, end; };
+  const size_t chunk = 256;
+  std::vector<Task> tasks;
+  for (size_t j = 0; j < jobs.size(); ++j)
+    for (size_t b = 0; b < jobs[j].n; b += chunk) tasks.push_back({(uint32_t)j, b, std::min(jobs[j].n, b + chunk)});
+  auto body = [&](size_t ti) {
+    const Task& k = tasks[ti];
+    const FetchJob& J = jobs[k.job];
+    J.table->Fetch(J.keys + k.begin, k.end - k.begin, J.out + k.begin * J.stride, J.stride, J.default_value,
+                   J.found ? J.found + k.begin : nullptr);
+  };
+  if (tasks.size() <= 1) { if (!tasks.empty()) body(0); }
+  else ThreadPool::Serving().ParallelFor(tasks.size(), body);
   return Status::Ok();
 }
 

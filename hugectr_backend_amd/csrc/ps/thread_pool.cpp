@@ -1,5 +1,7 @@
 #include "thread_pool.h"
 
+#include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 namespace hps {
@@ -15,11 +17,16 @@ size_t ThreadPool::DefaultConcurrency() {
 }
 
 ThreadPool& ThreadPool::Global() {
-  static ThreadPool pool(DefaultConcurrency() > 1 ? DefaultConcurrency() - 1 : 1);
+  static ThreadPool pool(DefaultConcurrency() > 1 ? DefaultConcurrency() - 1 : 1, 0);
   return pool;
 }
 
-ThreadPool::ThreadPool(size_t num_workers) {
+ThreadPool& ThreadPool::Serving() {
+  static ThreadPool pool(std::max<size_t>(1, std::min<size_t>(32, DefaultConcurrency() / 2)), 200);
+  return pool;
+}
+
+ThreadPool::ThreadPool(size_t num_workers, unsigned spin_us) : spin_us_(spin_us) {
   workers_.reserve(num_workers);
   for (size_t i = 0; i < num_workers; ++i) workers_.emplace_back([this] { WorkerMain(); });
 }
@@ -28,6 +35,7 @@ ThreadPool::~ThreadPool() {
   {
     std::lock_guard<std::mutex> lk(mu_);
     stop_ = true;
+    seq_.fetch_add(1, std::memory_order_release);
   }
   cv_.notify_all();
   for (auto& t : workers_) t.join();
@@ -50,32 +58,50 @@ void ThreadPool::RunLoop(Loop* l) {
   }
 }
 
+static inline void CpuRelax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
+
 void ThreadPool::WorkerMain() {
+  uint64_t seen = 0;
   for (;;) {
     std::shared_ptr<Loop> loop;
     std::function<void()> task;
     {
       std::unique_lock<std::mutex> lk(mu_);
-      for (;;) {
-        // drop loops whose tasks are all claimed
-        while (!loops_.empty() && loops_.front()->next.load(std::memory_order_relaxed) >= loops_.front()->n)
-          loops_.pop_front();
-        for (auto& l : loops_) {
-          if (l->next.load(std::memory_order_relaxed) < l->n &&
-              l->helpers.load(std::memory_order_relaxed) < l->max_helpers) {
-            l->helpers.fetch_add(1, std::memory_order_relaxed);
-            loop = l;
-            break;
-          }
+      seen = seq_.load(std::memory_order_acquire);
+      // drop loops whose tasks are all claimed
+      while (!loops_.empty() && loops_.front()->next.load(std::memory_order_relaxed) >= loops_.front()->n)
+        loops_.pop_front();
+      for (auto& l : loops_) {
+        if (l->next.load(std::memory_order_relaxed) < l->n &&
+            l->helpers.load(std::memory_order_relaxed) < l->max_helpers) {
+          l->helpers.fetch_add(1, std::memory_order_relaxed);
+          loop = l;
+          break;
         }
-        if (loop) break;
-        if (!tasks_.empty()) { task = std::move(tasks_.front()); tasks_.pop_front(); break; }
-        if (stop_) return;
-        cv_.wait(lk);
       }
+      if (!loop && !tasks_.empty()) { task = std::move(tasks_.front()); tasks_.pop_front(); }
+      if (!loop && !task && stop_) return;
     }
-    if (loop) RunLoop(loop.get());
-    else if (task) task();
+    if (loop) { RunLoop(loop.get()); continue; }
+    if (task) { task(); continue; }
+    // idle: spin on the enqueue counter for a while (serving pool), then sleep
+    if (spin_us_) {
+      const auto t0 = std::chrono::steady_clock::now();
+      bool woke = false;
+      for (unsigned it = 0;; ++it) {
+        if (seq_.load(std::memory_order_acquire) != seen) { woke = true; break; }
+        CpuRelax();
+        if ((it & 63) == 63 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) break;
+      }
+      if (woke) continue;
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return stop_ || seq_.load(std::memory_order_acquire) != seen; });
   }
 }
 
@@ -95,10 +121,16 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
   {
     std::lock_guard<std::mutex> lk(mu_);
     loops_.push_back(loop);
+    seq_.fetch_add(1, std::memory_order_release);
   }
-  if (helpers >= workers_.size()) cv_.notify_all();
+  if (helpers >= workers_.size() / 2) cv_.notify_all();
   else for (size_t i = 0; i < helpers; ++i) cv_.notify_one();
   RunLoop(loop.get());
+  // the stragglers usually finish within microseconds: poll before paying for a futex sleep + wake
+  for (int it = 0; it < 20000; ++it) {
+    if (loop->done.load(std::memory_order_acquire) == loop->n) return;
+    CpuRelax();
+  }
   std::unique_lock<std::mutex> lk(loop->mu);
   loop->cv.wait(lk, [&] { return loop->done.load(std::memory_order_acquire) == loop->n; });
 }
@@ -107,6 +139,7 @@ void ThreadPool::Submit(std::function<void()> fn) {
   {
     std::lock_guard<std::mutex> lk(mu_);
     tasks_.push_back(std::move(fn));
+    seq_.fetch_add(1, std::memory_order_release);
   }
   cv_.notify_one();
 }

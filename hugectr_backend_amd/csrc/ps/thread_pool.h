@@ -5,10 +5,15 @@
 // data-parallel loops: ParallelFor splits [0,n) into tasks claimed with one atomic each, the calling
 // thread works too, and several callers (lookup sessions) can have loops in flight at once.
 // Submit() runs a detached task (async cache insertion / refresh).
+//
+// Two instances exist: Global() (all cores, sleeps when idle: table loading, index builds) and
+// Serving() (a few dozen workers that spin briefly after each job, so that the per-request
+// parameter-server gather does not pay a futex wake-up per worker per request).
 #pragma once
 #include <atomic>
 #include <condition_variable>
 #include <cstddef>
+#include <cstdint>
 #include <deque>
 #include <functional>
 #include <memory>
@@ -20,12 +25,13 @@ namespace hps {
 
 class ThreadPool {
  public:
-  explicit ThreadPool(size_t num_workers);
+  explicit ThreadPool(size_t num_workers, unsigned spin_us = 0);
   ~ThreadPool();
   ThreadPool(const ThreadPool&) = delete;
   ThreadPool& operator=(const ThreadPool&) = delete;
 
-  static ThreadPool& Global();          // lazily built, DefaultConcurrency() workers
+  static ThreadPool& Global();          // lazily built, DefaultConcurrency()-1 workers, no spinning
+  static ThreadPool& Serving();         // lazily built, min(32, cores/2) workers, spin 200 us
   static size_t DefaultConcurrency();   // HCTR_DEFAULT_CONCURRENCY env, else hardware_concurrency
 
   size_t size() const { return workers_.size(); }
@@ -56,6 +62,8 @@ class ThreadPool {
   std::condition_variable cv_;
   std::deque<std::shared_ptr<Loop>> loops_;
   std::deque<std::function<void()>> tasks_;
+  std::atomic<uint64_t> seq_{0};  // bumped on every enqueue; spinning workers poll it
+  unsigned spin_us_ = 0;
   bool stop_ = false;
 };
 

@@ -76,6 +76,8 @@ typedef struct hps_lookup_stats {
   uint64_t unique_misses;
   int32_t async_insert;    /* 1: answered in async-insert mode (missed keys returned the default vector) */
   float probe_gather_ms;   /* HIP-event time of the probe+gather kernel (option "timing"=1), else 0 */
+  float phase_ms[4];       /* host wall clock of the last call: [0] until miss counts are known,
+                              [1] host parameter-server gather, [2] H2D + scatter + insert, [3] whole call */
 } hps_lookup_stats_t;
 
 const char* hps_last_error(void);
@@ -151,7 +153,8 @@ int hps_session_lookup(hps_session_t* session, const void* const* h_keys_per_tab
 int hps_session_lookup_device(hps_session_t* session, const int64_t* d_keys_flat, float* const* d_vectors_per_table,
                               const size_t* num_keys_per_table, size_t num_tables);
 int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
-/* options: "timing" (0/1), "probe_unroll" (1,2,4,8) */
+/* options: "timing" (0/1), "probe_unroll" (1,2,4,8), "hit_rate_threshold_permille" (per-session override of
+ * the model's hit_rate_threshold: 1000 = always synchronous insertion, 0 = always asynchronous) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 #ifdef __cplusplus
