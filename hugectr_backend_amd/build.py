@@ -45,7 +45,7 @@ TRITON_SRCS = [
     "triton/model_instance_state.cpp",
     "triton/timer.cpp",
 ]
-MOCK_SRCS = ["mock_triton/mock_core.cpp", "common/json.cpp"]
+MOCK_SRCS = ["mock_triton/mock_core.cpp"]
 
 
 def _run(cmd):

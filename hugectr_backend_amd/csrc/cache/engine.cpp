@@ -581,6 +581,10 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
 
     hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, N, d_slot_, d_staging_, cu, stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
+    // Other sessions' probes wait for our writer event.  Let the PCIe copy and the scatter drain first,
+    // so that the window in which the cache is "being written" is the insert kernel alone (tens of
+    // microseconds) and not insert + the millisecond of H2D queued ahead of it on this stream.
+    HIP_TRY(hipStreamSynchronize(stream_));
     cache_->BeginWrite(stream_);
     e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, uq, d_call_->key_start, d_uniq_keys_,
                           d_staging_, d_found_, epoch, d_counts_ + kMaxTables + 1, cu, stream_);

@@ -215,6 +215,8 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
 
   const std::map<std::string, InferenceParams>& get_hps_model_configuration_map() const { return cfg_.models; }
   const ParameterServerConfig& config() const { return cfg_; }
+  // thread-safe copy of one model's parameters; false when the model is not configured
+  bool model_params(const std::string& model, InferenceParams* out);
 
   std::shared_ptr<EmbeddingCache> get_embedding_cache(const std::string& model, int device);
   Status update_database_per_model(const InferenceParams& p);          // (re)load sparse files into the host tier

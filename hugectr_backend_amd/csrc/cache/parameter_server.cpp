@@ -119,6 +119,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
     HIP_TRY(hipMemcpyAsync(I.d_rows, I.h_rows, fl * sizeof(float), hipMemcpyHostToDevice, I.stream));
     HIP_TRY(hipMemcpyAsync(I.d_found, I.h_found, uq, hipMemcpyHostToDevice, I.stream));
     const uint32_t epoch = NextEpoch();
+    HIP_TRY(hipStreamSynchronize(I.stream));  // copies done: keep the writer window = the insert kernel only
     BeginWrite(I.stream);
     const hipError_t e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, uq, I.d_ks, I.d_keys, I.d_rows, I.d_found,
                                            epoch, I.d_stats, cu_count_, I.stream);
@@ -206,6 +207,14 @@ Status HierParameterServer::add_model(const InferenceParams& p) {
   if (!cfg_.models.count(p.model_name)) cfg_.model_order.push_back(p.model_name);
   cfg_.models[p.model_name] = p;
   return Status::Ok();
+}
+
+bool HierParameterServer::model_params(const std::string& model, InferenceParams* out) {
+  std::lock_guard<std::mutex> lk(mu_);
+  auto it = cfg_.models.find(model);
+  if (it == cfg_.models.end()) return false;
+  if (out) *out = it->second;
+  return true;
 }
 
 Status HierParameterServer::parse_config(const std::string& path) {

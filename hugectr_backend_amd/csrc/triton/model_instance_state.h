@@ -1,0 +1,56 @@
+// Per-instance state: one lookup session (worker buffers + stream) and the staging the shell needs.
+// Counterpart of the reference's ModelInstanceState (/root/reference/hps_backend/include/model_instance_state.hpp,
+// src/model_instance_state.cpp).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "model_state.h"
+
+namespace hps { namespace triton {
+
+class ModelInstanceState {
+ public:
+  static TRITONSERVER_Error* Create(ModelState* model_state, TRITONBACKEND_ModelInstance* triton_model_instance,
+                                    ModelInstanceState** state);                          // model_instance_state.cpp:44-70
+  ~ModelInstanceState();
+
+  // Fetch the model's cache for this instance's device and create the lookup session.   model_instance_state.cpp:162-174
+  TRITONSERVER_Error* LoadHPSInstance();
+
+  // One request: slice the flat KEYS / OUTPUT0 buffers per table and run the lookup.     model_instance_state.cpp:177-197
+  //   keys        flat table-major int64; host memory unless keys_on_device
+  //   out         fp32 output; device memory when the model uses the GPU cache and out_on_device,
+  //               host memory otherwise (gpucache models then go through the instance's device buffer)
+  TRITONSERVER_Error* ProcessRequest(const int64_t* keys, bool keys_on_device, const std::vector<size_t>& num_keys_per_table,
+                                     float* out, bool out_on_device, size_t out_elems);
+
+  const std::string& Name() const { return name_; }
+  int32_t DeviceId() const { return device_id_; }
+  TRITONSERVER_InstanceGroupKind Kind() const { return kind_; }
+  ModelState* StateForModel() const { return model_state_; }
+  TRITONBACKEND_ModelInstance* TritonModelInstance() { return triton_model_instance_; }
+  const InferenceParams& GetModelConfigutation() const { return model_state_->ModelInferencePara(); }
+  size_t NumTables() const { return model_state_->ModelInferencePara().num_tables(); }
+  // host staging for KEYS that arrive in several buffers (or in device memory for a CPU-only model)
+  int64_t* KeyStaging(size_t count);
+
+ private:
+  ModelInstanceState(ModelState* model_state, TRITONBACKEND_ModelInstance* inst, const char* name,
+                     TRITONSERVER_InstanceGroupKind kind, int32_t device_id)
+      : model_state_(model_state), triton_model_instance_(inst), name_(name), kind_(kind), device_id_(device_id) {}
+
+  ModelState* model_state_;
+  TRITONBACKEND_ModelInstance* triton_model_instance_;
+  std::string name_;
+  TRITONSERVER_InstanceGroupKind kind_;
+  int32_t device_id_;
+  std::shared_ptr<EmbeddingCache> embedding_cache_;
+  std::unique_ptr<LookupSession> lookupsession_;
+  std::vector<int64_t> key_staging_;
+  float* d_result_ = nullptr;  // device result buffer, only when Triton hands out a host output buffer
+  size_t d_result_elems_ = 0;
+};
+
+}}  // namespace hps::triton

@@ -1,0 +1,94 @@
+"""Host (CPU RAM) tier of the parameter server — the `hash_map` volatile database of the reference
+(docs/hierarchical_parameter_server.md:380-412) — against the oracle.  This is BASELINE config 1's path."""
+import numpy as np
+import pytest
+
+from tests.conftest import make_tables, ps_config
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _server(tables, partitions=8, **kw):
+    from hugectr_backend_amd import hps
+    cfg = ps_config("m", tables, gpucache=False, **kw)
+    cfg["volatile_db"]["num_partitions"] = partitions
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    for t, (k, r) in enumerate(tables):
+        ps.load_table_arrays("m", t, k, r)
+    return ps
+
+
+@pytest.mark.parametrize("partitions", [1, 3, 8, 64])
+def test_fetch_matches_oracle_for_any_partition_count(partitions):
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(partitions)
+    tables = make_tables([(20000, 16), (777, 5)])
+    ps = _server(tables, partitions, defaults=[0.5, -2.0])
+    for t, (k, r) in enumerate(tables):
+        q = np.concatenate([rng.choice(k, 5000), rng.integers(10**9, 10**10, 500)]).astype(np.int64)
+        rng.shuffle(q)
+        out, found = ps.fetch("m", t, q, return_found=True)
+        ref = O.np_lookup([(k, r)], q, [q.size], [[0.5, -2.0][t]]).reshape(q.size, -1)
+        assert np.array_equal(_bits(out), _bits(ref))
+        assert np.array_equal(found.astype(bool), np.isin(q, k))
+
+
+def test_config1_shape_single_table_4k_batch():
+    """BASELINE config 1 at reduced rows: one table x 16-dim, 4,096-key batch, CPU parameter server only."""
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    R = 1 << 16
+    keys = np.arange(R, dtype=np.int64)
+    rows = O.c_synth_rows(O.SEED, 0, 0, R, 16)
+    ps = _server([(keys, rows)], max_batch=4096)
+    s = hps.LookupSession.create(ps, "m", None)
+    rng = np.random.default_rng(0)
+    co = O.COracle()
+    co.add_table_arrays(keys, rows)
+    for _ in range(5):
+        q = rng.integers(0, R, 4096).astype(np.int64)
+        assert np.array_equal(_bits(s.lookup(q, [4096])), _bits(co.lookup(q, [4096], [0.0])))
+
+
+def test_synthetic_table_loader_matches_oracle_generator():
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    tables = [(np.arange(10), np.zeros((10, 128), np.float32)), (np.arange(10), np.zeros((10, 3), np.float32))]
+    ps = hps.HierParameterServer.create_from_dict(ps_config("m", tables, gpucache=False), load_tables=False)
+    ps.load_table_synthetic("m", 0, O.SEED, 100, 5000)
+    ps.load_table_synthetic("m", 1, O.SEED, 0, 333)
+    q = np.array([100, 101, 5099, 5100, 99, 2500], np.int64)
+    out, found = ps.fetch("m", 0, q, return_found=True)
+    assert found.tolist() == [1, 1, 1, 0, 0, 1]
+    ref = O.np_synth_rows(O.SEED, 0, q, 128)
+    assert np.array_equal(_bits(out[found.astype(bool)]), _bits(ref[found.astype(bool)]))
+    out1 = ps.fetch("m", 1, np.arange(333, dtype=np.int64))
+    assert np.array_equal(_bits(out1), _bits(O.np_synth_rows(O.SEED, 1, np.arange(333), 3)))  # odd D
+    assert ps.table_info("m", 0).rows_loaded == 5000
+
+
+def test_duplicate_keys_last_wins_and_sentinel_key():
+    from oracle import hps_oracle as O
+    k = np.array([9, 4, 9, 7, 4, np.iinfo(np.int64).min, 9], np.int64)
+    r = O.np_synth_rows(1, 0, np.arange(k.size), 4)
+    ps = _server([(k, r)], defaults=[3.0])
+    q = np.array([9, 4, 7, np.iinfo(np.int64).min, 1], np.int64)
+    out = ps.fetch("m", 0, q)
+    assert np.array_equal(_bits(out), _bits(np.stack([r[6], r[4], r[3], r[5], np.full(4, 3.0, np.float32)])))
+
+
+def test_host_tier_lookup_errors():
+    from hugectr_backend_amd import hps
+    tables = make_tables([(100, 4), (100, 4)])
+    ps = _server(tables, maxcat=[1, 1], max_batch=16)
+    s = hps.LookupSession.create(ps, "m", None)
+    with pytest.raises(hps.HpsError) as e:
+        s.lookup_ptrs([0], [0], [1])  # wrong table count
+    assert e.value.code == hps.ERR_INVALID_ARG
+    with pytest.raises(hps.HpsError):
+        s.lookup(np.arange(5), [2, 2])  # sum(NUMKEYS) != len(KEYS)
+    with pytest.raises(hps.HpsError) as e:
+        hps.LookupSession.create(ps, "ghost", None)
+    assert e.value.code == hps.ERR_NOT_FOUND

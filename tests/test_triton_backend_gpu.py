@@ -1,0 +1,168 @@
+"""TRITONBACKEND_ModelInstanceExecute of libtriton_hps.so on a real MI355X, driven by the mock Triton core:
+GPU embedding cache enabled, OUTPUT0 in device memory (hps.cc:638-648).  Bit-exact against the CPU oracle."""
+import json
+import threading
+
+import numpy as np
+import pytest
+
+from tests import triton_mock as tm
+from tests.conftest import make_tables, ps_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _deploy(tmp_path, models, **ps_kw):
+    """models: {name: (tables, maxcat, defaults)} -> (Server, ps_path)"""
+    from oracle import hps_oracle as O
+    cfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8}, "models": []}
+    for name, (tables, maxcat, defaults) in models.items():
+        dirs = []
+        for t, (k, r) in enumerate(tables):
+            d = tmp_path / f"{name}_{t}"
+            O.np_write_table(d, k, r)
+            dirs.append(str(d))
+        cfg["models"].append(ps_config(name, tables, dirs=dirs, gpucache=True, maxcat=maxcat, defaults=defaults, **ps_kw)["models"][0])
+    ps_path = tmp_path / "ps.json"
+    ps_path.write_text(json.dumps(cfg))
+    return tm.Server(ps_path), ps_path
+
+
+def _request(q, nk, out_elems, device_out=True, device_keys=False, rid="1"):
+    import torch
+    req = tm.Request(rid)
+    if device_keys:
+        dk = torch.from_numpy(q).cuda()
+        req.add_input_raw("KEYS", tm.TYPE_INT64, [1, q.size], dk.data_ptr(), q.nbytes, tm.MEM_GPU, 0)
+        req._keep.append(dk)
+    else:
+        req.add_input("KEYS", q.reshape(1, -1))
+    req.add_input("NUMKEYS", np.asarray([nk], np.int32)).request_output("OUTPUT0")
+    out = None
+    if device_out:
+        out = torch.full((max(out_elems, 1),), float("nan"), dtype=torch.float32, device="cuda")
+        req.set_output_buffer(out.data_ptr(), out_elems * 4, tm.MEM_GPU, 0, keep=out)
+    return req, out
+
+
+def _result(req, out, n):
+    import torch
+    if out is not None:
+        torch.cuda.synchronize()
+        return out[:n].cpu().numpy()
+    return req.output_numpy()
+
+
+def test_wdl_gpu_cache_device_output_exact(tmp_path):
+    from oracle import hps_oracle as O
+    tables = make_tables([(3000, 1), (2000, 16)])
+    srv, _ = _deploy(tmp_path, {"hps_wdl": (tables, [2, 26], [0.0, 0.0])}, gpucacheper=0.5, hit_rate_threshold=1.0)
+    try:
+        inst = srv.load_model("hps_wdl", tm.model_config("hps_wdl", gpus=[0])).create_instance("hps_wdl_0", tm.KIND_GPU, 0)
+        rng = np.random.default_rng(0)
+        for batch, device_out, device_keys in [(10, True, False), (10, True, True), (10, False, False), (1024, True, False), (1, True, True)]:
+            nk = [batch * 2, batch * 26]
+            q = np.concatenate([rng.choice(tables[0][0], nk[0]), rng.choice(tables[1][0], nk[1])]).astype(np.int64)
+            q[::11] = -3 - np.arange(q[::11].size)  # absent keys -> default
+            n = nk[0] * 1 + nk[1] * 16
+            req, out = _request(q, nk, n, device_out, device_keys)
+            inst.execute([req])
+            assert (req.response_count, req.release_count, req.final, req.error_code) == (1, 1, True, -1), req.error_message
+            name, dt, shape, ptr, nbytes, mt, mid = req.output(0)
+            assert (name, dt, shape, nbytes) == ("OUTPUT0", tm.TYPE_FP32, [n], n * 4)
+            assert mt == (tm.MEM_GPU if device_out else tm.MEM_CPU)
+            assert req.int_param("NumSample") == batch and req.int_param("DeviceID") == 0
+            ref = O.np_lookup(tables, q, nk, [0.0, 0.0])
+            assert np.array_equal(_bits(_result(req, out, n)), _bits(ref)), (batch, device_out, device_keys)
+    finally:
+        srv.shutdown()
+
+
+def test_two_models_share_the_device_concurrently(tmp_path):
+    """BASELINE config 4 shape: two W&D models (D=[1,16], keys/sample [2,26], batch 1024), two instances each,
+    mixed hit rate, concurrent Execute calls on one device."""
+    from oracle import hps_oracle as O
+    models = {m: (make_tables([(20000, 1), (20000, 16)], seed=s), [2, 26], [0.0, 0.0]) for m, s in (("wdl_a", 1), ("wdl_b", 2))}
+    srv, _ = _deploy(tmp_path, models, gpucacheper=0.1, hit_rate_threshold=1.0, max_batch=1024)
+    try:
+        insts = {}
+        for m in models:
+            mod = srv.load_model(m, tm.model_config(m, gpus=[0], count=2))
+            insts[m] = [mod.create_instance(f"{m}_{i}", tm.KIND_GPU, 0) for i in range(2)]
+        errs = []
+
+        def work(m, inst, seed):
+            tables = models[m][0]
+            rng = np.random.default_rng(seed)
+            for it in range(10):
+                batch = 1024
+                nk = [batch * 2, batch * 26]
+                # hot head (cached after first touch) + cold tail: hit rate between 50 and 99 %
+                hot_frac = rng.uniform(0.5, 0.99)
+                def draw(keys, n):
+                    hot = rng.random(n) < hot_frac
+                    return np.where(hot, rng.choice(keys[:1500], n), rng.choice(keys, n))
+                q = np.concatenate([draw(tables[0][0], nk[0]), draw(tables[1][0], nk[1])]).astype(np.int64)
+                n = nk[0] + nk[1] * 16
+                req, out = _request(q, nk, n, True, it % 2 == 0, rid=f"{m}-{seed}-{it}")
+                inst.execute([req])
+                ref = O.np_lookup(tables, q, nk, [0.0, 0.0])
+                if req.error_code != -1 or not np.array_equal(_bits(_result(req, out, n)), _bits(ref)):
+                    errs.append((m, seed, it, req.error_message))
+        th = [threading.Thread(target=work, args=(m, inst, 10 * j + i)) for j, m in enumerate(models) for i, inst in enumerate(insts[m])]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs[:3]
+    finally:
+        srv.shutdown()
+
+
+def test_new_model_version_refreshes_the_cache(tmp_path):
+    """Loading version 2 of a served model re-reads the sparse files and refreshes the device cache
+    asynchronously (hps.cc:207-226, model_state.cpp:124-142,413-418)."""
+    import time
+    from oracle import hps_oracle as O
+    tables = make_tables([(1000, 16)])
+    keys, rows = tables[0]
+    srv, ps_path = _deploy(tmp_path, {"m": (tables, [1], [0.0])}, gpucacheper=1.0, hit_rate_threshold=1.0, max_batch=2048)
+    try:
+        m1 = srv.load_model("m", tm.model_config("m", gpus=[0]), version=1)
+        i1 = m1.create_instance("m_v1", tm.KIND_GPU, 0)
+        q = keys[:256].astype(np.int64)
+        req, out = _request(q, [256], 256 * 16)
+        i1.execute([req])
+        assert np.array_equal(_bits(_result(req, out, 256 * 16)), _bits(rows[:256]))
+        # retrained model: same keys, new vectors written over the sparse files, deployed as version 2
+        rows2 = (rows * 0.5 + 0.125).astype(np.float32)
+        O.np_write_table(tmp_path / "m_0", keys, rows2)
+        m2 = srv.load_model("m", tm.model_config("m", gpus=[0]), version=2)
+        i2 = m2.create_instance("m_v2", tm.KIND_GPU, 0)
+        deadline = time.time() + 30
+        ok = False
+        while time.time() < deadline and not ok:
+            req, out = _request(q, [256], 256 * 16)
+            i2.execute([req])
+            ok = np.array_equal(_bits(_result(req, out, 256 * 16)), _bits(rows2[:256]))
+            if not ok:
+                time.sleep(0.2)
+        assert ok, "cache was not refreshed with the new version's vectors"
+    finally:
+        srv.shutdown()
+
+
+def test_instance_on_undeployed_device_is_rejected(tmp_path):
+    tables = make_tables([(100, 4)])
+    srv, _ = _deploy(tmp_path, {"m": (tables, [1], [0.0])})
+    try:
+        with pytest.raises(tm.TritonError) as e:   # model_state.cpp:396-402
+            srv.load_model("m", tm.model_config("m", gpus=[3]))
+        assert e.value.code == tm.ERR["INVALID_ARG"] and "deployed_device_list" in e.value.msg
+        with pytest.raises(tm.TritonError) as e:   # KIND_CPU instance for a GPU-cache model (model_state.cpp:287-290)
+            srv.load_model("m", tm.model_config("m", kind="KIND_CPU", gpus=[]))
+        assert "GPU kind" in e.value.msg
+    finally:
+        srv.shutdown()
