@@ -135,7 +135,7 @@ def test_new_model_version_refreshes_the_cache(tmp_path):
         q = keys[:256].astype(np.int64)
         req, out = _request(q, [256], 256 * 16)
         i1.execute([req])
-        assert np.array_equal(_bits(_result(req, out, 256 * 16)), _bits(rows[:256]))
+        assert np.array_equal(_bits(_result(req, out, 256 * 16)), _bits(rows[:256].ravel()))
         # retrained model: same keys, new vectors written over the sparse files, deployed as version 2
         rows2 = (rows * 0.5 + 0.125).astype(np.float32)
         O.np_write_table(tmp_path / "m_0", keys, rows2)
@@ -146,7 +146,7 @@ def test_new_model_version_refreshes_the_cache(tmp_path):
         while time.time() < deadline and not ok:
             req, out = _request(q, [256], 256 * 16)
             i2.execute([req])
-            ok = np.array_equal(_bits(_result(req, out, 256 * 16)), _bits(rows2[:256]))
+            ok = np.array_equal(_bits(_result(req, out, 256 * 16)), _bits(rows2[:256].ravel()))
             if not ok:
                 time.sleep(0.2)
         assert ok, "cache was not refreshed with the new version's vectors"
