@@ -51,7 +51,7 @@ def parse_args():
                     help="sync: exact rows (threshold 1.0); async: misses return default, inserted in background")
     ap.add_argument("--distinct-batches", type=int, default=0,
                     help="0: one fresh batch per step (warmup+steps distinct batches)")
-    ap.add_argument("--unroll", type=int, default=4)
+    ap.add_argument("--unroll", type=int, default=1102, help="probe+gather kernel variant (tools/kbench.py)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
@@ -310,6 +310,16 @@ def main():
 
     if rank == 0:
         lat_ms, kern_ms, miss_ct, phases = main_lat, main_kern, main_miss, main_phases
+        # HBM traffic of the kernel comes from the committed rocprofv3 PMC passes (bench.py cannot run the
+        # profiler on itself): profiles/pmc_latest.json, written by tools/summarize_profile.py
+        traffic, traffic_src = None, None
+        try:
+            pj = json.loads((ROOT / "profiles" / "pmc_latest.json").read_text())
+            if pj.get("workload_keys") == N and pj.get("dim") == D:
+                traffic = pj["pmc"]["hbm_bytes_per_launch_fetch_doubled"]
+                traffic_src = pj.get("source")
+        except Exception:
+            pass
         k_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
         alg_bytes = N * (8 + 8 * D)  # 8 B key + 4D row read + 4D row write per lookup
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -344,7 +354,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": k_ms,
             },

@@ -309,8 +309,13 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
     const std::string n(name);
     if (n == "timing") s->s->set_timing(value != 0);
     else if (n == "probe_unroll") {
-      if (value != 1 && value != 2 && value != 4 && value != 8) return Error(Code::kInvalidArg, "probe_unroll must be 1, 2, 4 or 8");
+      // U + 100*rolled_outer_loop + 1000*sampled_stamps  (kernel variant selector, see LaunchProbeGather)
+      const int u = value % 100;
+      if (value < 0 || (u != 1 && u != 2 && u != 4 && u != 8) || (value / 100) % 10 > 2 || value / 1000 > 2)
+        return Error(Code::kInvalidArg, "probe_unroll must be U + 100*mode + 1000*stamp_mode with U in {1,2,4,8}, mode 0..2, stamp_mode 0..2");
       s->s->set_probe_unroll(value);
+    } else if (n == "probe_balanced") {
+      s->s->set_probe_balanced(value != 0);
     } else if (n == "hit_rate_threshold_permille") {
       if (value < 0) return Error(Code::kInvalidArg, "hit_rate_threshold_permille must be >= 0");
       s->s->set_hit_rate_threshold((float)value / 1000.0f);

@@ -81,11 +81,22 @@ uint32_t EmbeddingCache::NextEpoch() { return epoch_.fetch_add(1, std::memory_or
 void EmbeddingCache::BeginRead(hipStream_t stream) {
   order_mu_.lock();
   if (has_write_) (void)hipStreamWaitEvent(stream, last_write_, 0);
+  // One probe/gather at a time per cache: every launch already fills all CUs and saturates HBM, so two of
+  // them side by side only interleave (each takes twice as long, no throughput gained).  Chaining them keeps
+  // the first caller's latency at one kernel time.
+  if (last_reader_ != nullptr && last_reader_stream_ != stream) (void)hipStreamWaitEvent(stream, last_reader_, 0);
 }
 void EmbeddingCache::EndRead(hipStream_t stream, hipEvent_t reader_done) {
   (void)hipEventRecord(reader_done, stream);
   if (std::find(readers_.begin(), readers_.end(), reader_done) == readers_.end()) readers_.push_back(reader_done);
+  last_reader_ = reader_done;
+  last_reader_stream_ = stream;
   order_mu_.unlock();
+}
+void EmbeddingCache::ForgetReader(hipEvent_t reader_done) {
+  std::lock_guard<std::mutex> lk(order_mu_);
+  readers_.erase(std::remove(readers_.begin(), readers_.end(), reader_done), readers_.end());
+  if (last_reader_ == reader_done) { last_reader_ = nullptr; last_reader_stream_ = nullptr; }
 }
 void EmbeddingCache::BeginWrite(hipStream_t stream) {
   order_mu_.lock();
@@ -266,12 +277,7 @@ void LookupSession::Release() {
   if (!cache_) return;
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
-  {
-    // our reader event may still be registered with the cache
-    std::lock_guard<std::mutex> lk(cache_->order_mu_);
-    auto& r = cache_->readers_;
-    r.erase(std::remove(r.begin(), r.end(), ev_read_), r.end());
-  }
+  cache_->ForgetReader(ev_read_);  // our reader event may still be registered with the cache
   auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
   auto dfree = [](void* p) { if (p) (void)hipFree(p); };
   hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_call_); dfree(d_call_); hfree(h_md_); dfree(d_md_);
@@ -443,10 +449,10 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
 
   // ---- K_A: probe + gather hits ----
   const int cu = cache_->cu_count();
-  const uint32_t probe_blocks = ProbeGridBlocks(N, cu);
+  const uint32_t probe_blocks = ProbeGridBlocks(N, cu, probe_balanced_);
   cache_->BeginRead(stream_);
   if (timing_) (void)hipEventRecord(ev_t0_, stream_);
-  hipError_t e = LaunchProbeGather(d_call_, cache_->device_tables(), (uint32_t)T, N, d_slot_, d_block_miss_, cu,
+  hipError_t e = LaunchProbeGather(d_call_, cache_->device_tables(), (uint32_t)T, N, d_slot_, d_block_miss_, probe_blocks,
                                    probe_unroll_, stream_);
   if (timing_) (void)hipEventRecord(ev_t1_, stream_);
   cache_->EndRead(stream_, ev_read_);

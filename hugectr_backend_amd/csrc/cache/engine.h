@@ -92,6 +92,7 @@ class EmbeddingCache {
   void EndRead(hipStream_t stream, hipEvent_t reader_done); // records + registers the reader event
   void BeginWrite(hipStream_t stream);                      // stream waits for last writer + all readers
   void EndWrite(hipStream_t stream);                        // records the writer event
+  void ForgetReader(hipEvent_t reader_done);                // a session is going away: drop its event
   uint32_t NextEpoch();
 
   std::string model_;
@@ -106,6 +107,8 @@ class EmbeddingCache {
   hipEvent_t last_write_ = nullptr;
   bool has_write_ = false;
   std::vector<hipEvent_t> readers_;
+  hipEvent_t last_reader_ = nullptr;        // most recent probe/gather of any session (probes are chained)
+  hipStream_t last_reader_stream_ = nullptr;
   std::atomic<uint32_t> epoch_{1};
 
   mutable std::mutex stat_mu_;
@@ -147,6 +150,7 @@ class LookupSession {
   // gather, [2] H2D + scatter + insert until the stream drained, [3] whole call
   const float* last_phase_ms() const { return phase_ms_; }
   void set_probe_unroll(int u) { probe_unroll_ = u; }
+  void set_probe_balanced(bool b) { probe_balanced_ = b; }
   void set_timing(bool on) { timing_ = on; }
   // per-session override of the model's hit_rate_threshold (sync vs async insertion, docs/architecture.md:65-67)
   void set_hit_rate_threshold(float v) { params_.hit_rate_threshold = v; }
@@ -197,7 +201,8 @@ class LookupSession {
   bool last_async_ = false;
   float last_gpu_ms_ = 0.f;
   float phase_ms_[4] = {0, 0, 0, 0};
-  int probe_unroll_ = 4;
+  int probe_unroll_ = 1102;  // U=2, rolled key-group loop (8 waves/SIMD), LRU stamp on 1/4 of the hits (tools/kbench.py)
+  bool probe_balanced_ = false;  // equal chunks per wave costs more in occupancy than the tail it removes (kbench A/B)
   bool timing_ = false;
 };
 

@@ -7,10 +7,10 @@
 
 namespace hps {
 
-uint32_t ProbeGridBlocks(uint64_t N, int cu_count);
+uint32_t ProbeGridBlocks(uint64_t N, int cu_count, bool balanced = false);
 
 hipError_t LaunchProbeGather(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                             int32_t* d_slot, uint32_t* d_block_miss, int cu_count, int unroll, hipStream_t stream);
+                             int32_t* d_slot, uint32_t* d_block_miss, uint32_t grid, int unroll, hipStream_t stream);
 
 hipError_t LaunchMissDedup(const CallDesc* d_call, const uint64_t* h_key_start, uint32_t T, uint32_t probe_blocks,
                            int32_t* d_slot, const uint32_t* d_block_miss, int32_t* d_set, uint64_t set_cap,

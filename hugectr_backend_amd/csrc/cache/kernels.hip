@@ -103,7 +103,20 @@ __device__ __forceinline__ void copy_row(const float* __restrict__ src, float* _
 // Algorithmic bytes per key: 8 (key) + 4D (row read) + 4D (row write).
 // Overhead traffic: 128-B bucket line per key, 4-B slot index write, 4-B stamp write per hit.
 // ------------------------------------------------------------------------------------------------
-template <int kUnroll>
+template <int U>
+struct ProbeGroup {  // one key group in flight: keys, their tables, bucket ids and the loaded bucket lane
+  int64_t k[U];
+  int tt[U];
+  uint32_t b[U];
+  int64_t bk[U];
+};
+
+// kOuter: unroll factor of the loop over the 16/kUnroll key groups of a chunk (1 = rolled: fewer VGPRs,
+// more waves per SIMD; 16/kUnroll = fully unrolled: the compiler overlaps consecutive groups;
+// 0 = rolled and software-pipelined by hand: next group's bucket loads issued before this group's rows).
+// kStampShift: the LRU stamp of a hit slot is rewritten for 1 in 2^kStampShift hits (hashed on key and
+// epoch): a blind 4-B store per hit is a read-modify-write of a whole DRAM sector.
+template <int kUnroll, int kOuter, int kStampShift>
 __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_gather_kernel(
     const CallDesc* __restrict__ call, const TableCacheDev* __restrict__ tables,
     int32_t* __restrict__ slot_out, uint32_t* __restrict__ block_miss) {
@@ -135,45 +148,64 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_gather_kernel(
     if (valid) { while (i >= sh_ks[t + 1]) ++t; }
     int32_t my_slot = kSlotMiss;
 
-#pragma unroll
-    for (int jb = 0; jb < 16; jb += kUnroll) {
-      int64_t k[kUnroll];
-      int tt[kUnroll];
-      uint32_t b[kUnroll];
-      int64_t bk[kUnroll];
-      int32_t s[kUnroll];
-      // phase 1: kUnroll independent bucket-line loads
+    // phase 1 of a key group: kUnroll independent bucket-line loads
+    auto issue = [&](int jb, ProbeGroup<kUnroll>& G) {
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int src = g * 16 + jb + u;
-        k[u] = shfl_i64(key, src);
-        tt[u] = __shfl(t, src, 64);
-        const TableLds& d = sh_tab[tt[u]];
-        b[u] = hps_bucket_of(k[u], d.num_buckets);
-        bk[u] = d.bucket_keys[(uint64_t)b[u] * kBucketSlots + lig];
+        G.k[u] = shfl_i64(key, src);
+        G.tt[u] = __shfl(t, src, 64);
+        const TableLds& d = sh_tab[G.tt[u]];
+        G.b[u] = hps_bucket_of(G.k[u], d.num_buckets);
+        G.bk[u] = d.bucket_keys[(uint64_t)G.b[u] * kBucketSlots + lig];
       }
-      // phase 2: compare, group ballot -> slot
+    };
+    // phases 2-4: compare + group ballot -> slot; row loads; streaming stores (hit rows only)
+    auto finish = [&](int jb, const ProbeGroup<kUnroll>& G) {
+      int32_t s[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        const bool match = (bk[u] == k[u]) && (k[u] != HPS_EMPTY_KEY);
+        const bool match = (G.bk[u] == G.k[u]) && (G.k[u] != HPS_EMPTY_KEY);
         const uint64_t m = __ballot(match);
         const uint32_t m16 = (uint32_t)(m >> (g * 16)) & 0xFFFFu;
-        s[u] = m16 ? (int32_t)(b[u] * kBucketSlots + (uint32_t)__builtin_ctz(m16)) : kSlotMiss;
+        s[u] = m16 ? (int32_t)(G.b[u] * kBucketSlots + (uint32_t)__builtin_ctz(m16)) : kSlotMiss;
       }
-      // phase 3+4: row loads then streaming stores (hit rows only)
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int src = g * 16 + jb + u;
         if (s[u] >= 0) {
-          const TableLds& d = sh_tab[tt[u]];
+          const TableLds& d = sh_tab[G.tt[u]];
           const uint32_t D = d.dim;
           const uint64_t gi = chunk * 64 + (uint64_t)src;
           const float* row = d.rows + (uint64_t)(uint32_t)s[u] * D;
           float* dst = d.out + (gi - d.key_start) * D;
           copy_row<true>(row, dst, D, lig, (d.flags & 2u) != 0);
-          if (lig == 0 && !(d.flags & 1u)) d.stamps[(uint32_t)s[u]] = epoch;
+          if (lig == 0 && !(d.flags & 1u)) {
+            bool touch = true;
+            if (kStampShift > 0)
+              touch = (((uint32_t)hps_mix64((uint64_t)G.k[u] ^ ((uint64_t)epoch << 32)) >> 7) & ((1u << kStampShift) - 1u)) == 0u;
+            if (touch) d.stamps[(uint32_t)s[u]] = epoch;
+          }
         }
         if (lane == src) my_slot = s[u];
+      }
+    };
+    if (kOuter == 0) {
+      // rolled + software-pipelined: the bucket loads of group j+1 are in flight while group j's rows move
+      ProbeGroup<kUnroll> cur, nxt;
+      issue(0, cur);
+#pragma unroll 1
+      for (int jb = 0; jb < 16; jb += kUnroll) {
+        if (jb + kUnroll < 16) issue(jb + kUnroll, nxt);
+        finish(jb, cur);
+        cur = nxt;
+      }
+    } else {
+#pragma unroll(kOuter > 0 ? kOuter : 1)
+      for (int jb = 0; jb < 16; jb += kUnroll) {
+        ProbeGroup<kUnroll> G;
+        issue(jb, G);
+        finish(jb, G);
       }
     }
     if (valid) {
@@ -546,19 +578,48 @@ static inline uint32_t probe_grid(uint64_t N, int cu_count) {
   return (uint32_t)(want < cap ? (want ? want : 1) : cap);
 }
 
-uint32_t ProbeGridBlocks(uint64_t N, int cu_count) { return probe_grid(N, cu_count); }
+// Grid of the probe/gather kernel.  Every wave walks 64-key chunks with stride = number of waves, and all
+// blocks are resident at once (<= 8 blocks of 4 waves per CU), so the launch ends when the waves with the
+// most chunks end.  balanced: pick the wave count so that every wave gets the same number of chunks
+// (config 2: 26,624 chunks -> 6,656 waves x 4 chunks) instead of filling the machine (8,192 waves, a quarter
+// of which run a 4th chunk while the rest of the chip idles).
+uint32_t ProbeGridBlocks(uint64_t N, int cu_count, bool balanced) {
+  if (!balanced) return probe_grid(N, cu_count);
+  const uint64_t chunks = (N + 63) / 64;
+  const uint64_t cap_waves = (uint64_t)cu_count * 8 * (kProbeBlockThreads / 64);
+  if (chunks <= cap_waves) return probe_grid(N, cu_count);
+  const uint64_t k = (chunks + cap_waves - 1) / cap_waves;  // chunks per wave
+  const uint64_t waves = (chunks + k - 1) / k;
+  return (uint32_t)((waves + 3) / 4);
+}
 
 hipError_t LaunchProbeGather(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                             int32_t* d_slot, uint32_t* d_block_miss, int cu_count, int unroll, hipStream_t stream) {
-  const uint32_t grid = probe_grid(N, cu_count);
+                             int32_t* d_slot, uint32_t* d_block_miss, uint32_t grid, int unroll, hipStream_t stream) {
   const size_t smem = sizeof(TableLds) * (size_t)num_tables + sizeof(uint64_t) * ((size_t)num_tables + 1) +
                       sizeof(uint32_t) * (kProbeBlockThreads / 64);
-  switch (unroll) {
-    case 1: hipLaunchKernelGGL(hps_probe_gather_kernel<1>, dim3(grid), dim3(kProbeBlockThreads), smem, stream, d_call, d_tables, d_slot, d_block_miss); break;
-    case 2: hipLaunchKernelGGL(hps_probe_gather_kernel<2>, dim3(grid), dim3(kProbeBlockThreads), smem, stream, d_call, d_tables, d_slot, d_block_miss); break;
-    case 8: hipLaunchKernelGGL(hps_probe_gather_kernel<8>, dim3(grid), dim3(kProbeBlockThreads), smem, stream, d_call, d_tables, d_slot, d_block_miss); break;
-    default: hipLaunchKernelGGL(hps_probe_gather_kernel<4>, dim3(grid), dim3(kProbeBlockThreads), smem, stream, d_call, d_tables, d_slot, d_block_miss); break;
+  // `unroll` encodes the variant: U + 100*mode + 1000*stamp_mode  (U in {1,2,4,8};
+  //  mode 0 full unroll, 1 rolled, 2 rolled + pipelined; stamp_mode 0 every hit, 1 = 1/4 of hits, 2 = 1/16)
+  const int U = unroll % 100, mode = (unroll / 100) % 10, smode = unroll / 1000;
+#define HPS_PG(UU, OO, SS)                                                                                          \
+  hipLaunchKernelGGL((hps_probe_gather_kernel<UU, OO, SS>), dim3(grid), dim3(kProbeBlockThreads), smem, stream, d_call, \
+                     d_tables, d_slot, d_block_miss)
+#define HPS_PG_S(UU, OO) \
+  do { if (smode == 0) HPS_PG(UU, OO, 0); else if (smode == 1) HPS_PG(UU, OO, 2); else HPS_PG(UU, OO, 4); } while (0)
+#define HPS_PG_U(UU)                                 \
+  do {                                               \
+    if (mode == 1) HPS_PG_S(UU, 1);                  \
+    else if (mode == 2) HPS_PG_S(UU, 0);             \
+    else HPS_PG_S(UU, 16 / UU);                      \
+  } while (0)
+  switch (U) {
+    case 1: HPS_PG_U(1); break;
+    case 2: HPS_PG_U(2); break;
+    case 8: HPS_PG_U(8); break;
+    default: HPS_PG_U(4); break;
   }
+#undef HPS_PG_U
+#undef HPS_PG_S
+#undef HPS_PG
   return hipGetLastError();
 }
 

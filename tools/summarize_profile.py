@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories into the small summaries committed under profiles/.
+
+    python tools/summarize_profile.py <dir with kt/ pmc_FETCH_SIZE/ pmc_WRITE_SIZE/> <out.json>
+
+Kernel stats: top rows of *_kernel_stats.csv (names shortened).  PMC: mean FETCH_SIZE / WRITE_SIZE of the
+probe+gather kernel, converted as MI355X_MICROARCH.md §HBM prescribes: both counters are in KiB; on gfx950
+FETCH_SIZE counts 128-B coalesced requests as 64 B, so wide streaming reads are doubled.  Reported both ways.
+"""
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    return name.replace("void ", "")[:80]
+
+
+def main(d, out):
+    res = {"kernel_stats": [], "pmc": {}}
+    for f in glob.glob(f"{d}/kt/*kernel_stats.csv"):
+        rows = list(csv.DictReader(open(f)))
+        for r in rows:
+            if "hps::" in r["Name"]:
+                res["kernel_stats"].append({"kernel": short(r["Name"]), "calls": int(r["Calls"]),
+                                            "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                                            "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])})
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        vals = []
+        for f in glob.glob(f"{d}/pmc_{c}/*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == c and "hps_probe_gather" in r["Kernel_Name"]:
+                    vals.append(float(r["Counter_Value"]))
+        if vals:
+            res["pmc"][c] = {"launches": len(vals), "mean_KiB": sum(vals) / len(vals), "min_KiB": min(vals), "max_KiB": max(vals)}
+    if "FETCH_SIZE" in res["pmc"] and "WRITE_SIZE" in res["pmc"]:
+        f, w = res["pmc"]["FETCH_SIZE"]["mean_KiB"] * 1024, res["pmc"]["WRITE_SIZE"]["mean_KiB"] * 1024
+        res["pmc"]["hbm_bytes_per_launch_raw"] = f + w
+        res["pmc"]["hbm_bytes_per_launch_fetch_doubled"] = 2 * f + w
+        res["pmc"]["note"] = ("probe+gather kernel only, one session; FETCH_SIZE and WRITE_SIZE from separate --pmc passes; "
+                              "reads are 16 B/lane coalesced (rows) and 8 B/lane (bucket lines), so the gfx950 x2 correction "
+                              "applies to the bulk of FETCH_SIZE")
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res)[:1500])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
