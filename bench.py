@@ -97,12 +97,24 @@ def main():
     import torch
     import torch.distributed as dist
     from hugectr_backend_amd import build as hb
+    ndev = torch.cuda.device_count()
+    assert ndev > 0, "bench.py needs an MI355X"
+    # one rank per GPU over RCCL ("nccl" on ROCm).  Only when fewer GPUs than ranks are visible (the 1-GPU
+    # development box) do the ranks share devices and rendezvous over gloo, to exercise the same control flow.
+    shared_gpu = world > ndev
+    dev = local_rank % ndev
+    local_rank = dev
+    torch.cuda.set_device(dev)
+    coll_dev = "cpu" if shared_gpu else "cuda"
+    if world > 1:
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
     if rank == 0:
         hb.build()
-    torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
+        dist.barrier()  # the other ranks load the libraries only after rank 0 has (re)built them
     from hugectr_backend_amd import hps
 
     T, R, D, B = a.tables, a.rows, a.dim, a.batch
@@ -202,7 +214,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -287,7 +299,7 @@ def main():
             is_default = (got.reshape(-1, D) == 0.0).all(axis=1)
             parity = bool((same.all(axis=1) | is_default).all())
 
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # timed on rank 0 at N=1 only (the other ranks' pools share the cores)
             # ---- cpu_baseline: the oracle (a port of the reference's hash_map parameter-server lookup)
             # on the same key batches, tables 0..chk_tables-1 only (bounded sample), all host cores ----
             threads = os.cpu_count() or 8
