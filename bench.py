@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--cache-frac", type=float, default=0.2, help="gpucacheper")
     ap.add_argument("--hit", type=float, default=0.95, help="probability that a key is drawn from the resident set")
     ap.add_argument("--zipf", type=float, default=1.05)
-    ap.add_argument("--sessions", type=int, default=3, help="concurrent lookup sessions (Triton instance count)")
+    ap.add_argument("--sessions", type=int, default=2, help="concurrent lookup sessions (Triton instance count)")
     ap.add_argument("--mode", choices=["sync", "async"], default="sync",
                     help="sync: exact rows (threshold 1.0); async: misses return default, inserted in background")
     ap.add_argument("--distinct-batches", type=int, default=0,
@@ -57,6 +57,37 @@ def parse_args():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the untimed all-hit and async-insert legs reported next to the headline")
     return ap.parse_args()
+
+
+def effective_cpus() -> int:
+    """CPUs this process may really use: affinity mask clipped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(np.ceil(int(q) / int(p)))))
+    except Exception:
+        pass
+    return n
+
+
+def host_memory_budget() -> int:
+    """Bytes of host RAM this container may still take: MemAvailable clipped by the cgroup limit."""
+    avail = 1 << 62
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        mx = open("/sys/fs/cgroup/memory.max").read().strip()
+        if mx != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+            avail = min(avail, int(mx) - cur)
+    except Exception:
+        pass
+    return avail
 
 
 def zipf_cdf(n: int, alpha: float) -> np.ndarray:
@@ -92,7 +123,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         # share the host cores between the ranks' parameter-server pools
-        os.environ.setdefault("HCTR_DEFAULT_CONCURRENCY", str(max(8, (os.cpu_count() or 8) // world)))
+        os.environ.setdefault("HCTR_DEFAULT_CONCURRENCY", str(max(2, effective_cpus() // world)))
 
     import torch
     import torch.distributed as dist
@@ -118,6 +149,18 @@ def main():
     from hugectr_backend_amd import hps
 
     T, R, D, B = a.tables, a.rows, a.dim, a.batch
+    # host-memory guard: every rank keeps the full tables in its parameter server (replicas).  If the box
+    # cannot hold them for all ranks, rows/table shrinks and the workload string says so.
+    rows_requested = R
+    per_row = T * (4 * D + 64) + (2 * (4 * D + 48) if rank == 0 else 0)   # tables + index (+ oracle sample on rank 0)
+    budget = int(host_memory_budget() * 0.85 / world) - (8 << 30)
+    if world > 1:
+        bt = torch.tensor([budget], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(bt, op=dist.ReduceOp.MIN)
+        budget = int(bt.item())
+    per_row = T * (4 * D + 64) + 2 * (4 * D + 48)
+    if R * per_row > budget:
+        R = max(B, int(budget // per_row))
     N = T * B
     model = "criteo_dlrm"
     cfg = {
@@ -170,6 +213,7 @@ def main():
     nk = [B] * T
     torch.cuda.synchronize()
 
+    ncpu = effective_cpus()
     lat_ms, kern_ms, miss_ct, phases = [], [], [], []
     lock = threading.Lock()
 
@@ -274,7 +318,7 @@ def main():
         for t in range(chk_tables):
             rows = np.empty((R, D), dtype=np.float32)
             # generate the oracle's copy of the table in parallel slabs (C code releases the GIL)
-            nth = min(64, os.cpu_count() or 8)
+            nth = ncpu
             step = (R + nth - 1) // nth
 
             def gen(lo, t=t, rows=rows):
@@ -290,7 +334,7 @@ def main():
         for t in range(chk_tables):
             co.add_table_arrays(keys_seq, sample_rows[t])
         q = batches_h[0][: chk_tables * B]
-        ref = co.lookup(q, [B] * chk_tables, [0.0] * chk_tables, threads=min(32, os.cpu_count() or 8))
+        ref = co.lookup(q, [B] * chk_tables, [0.0] * chk_tables, threads=ncpu)
         if a.mode == "sync":
             parity = bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
         else:
@@ -302,7 +346,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:  # timed on rank 0 at N=1 only (the other ranks' pools share the cores)
             # ---- cpu_baseline: the oracle (a port of the reference's hash_map parameter-server lookup)
             # on the same key batches, tables 0..chk_tables-1 only (bounded sample), all host cores ----
-            threads = os.cpu_count() or 8
+            threads = ncpu  # the CPUs the container may use (cgroup quota), not the visible hardware threads
             nkc = [B] * chk_tables
             outc = np.empty(chk_tables * B * D, dtype=np.float32)
             done, tc0 = 0, time.perf_counter()
@@ -350,7 +394,9 @@ def main():
             "dtype": "fp32 rows / int64 keys (moved, never computed)",
             "data": "synthetic",
             "config": {
-                "workload": f"Criteo DLRM {T} sparse slots, {R} rows/table x {D}-dim, {B} batch ({N} keys), "
+                "workload": f"Criteo DLRM {T} sparse slots, {R} rows/table"
+                            + (f" (requested {rows_requested}; reduced to fit the host-memory budget of {world} replicas)" if R != rows_requested else "")
+                            + f" x {D}-dim, {B} batch ({N} keys), "
                             f"gpucacheper {a.cache_frac}, target hit {a.hit}, zipf {a.zipf} within the resident set, "
                             f"{a.mode} insert, {a.sessions} lookup sessions, keys resident in HBM",
                 "parallelism": "replicas" if world > 1 else "single",

@@ -34,6 +34,7 @@ ENGINE_SRCS = [
     "ps/thread_pool.cpp",
     "ps/host_table.cpp",
     "cache/kernels.hip",
+    "cache/shard_kernels.hip",
     "cache/engine.cpp",
     "cache/parameter_server.cpp",
 ]

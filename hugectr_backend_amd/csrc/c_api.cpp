@@ -10,6 +10,7 @@
 #include <string>
 
 #include "cache/engine.h"
+#include "cache/shard_kernels.h"
 
 using namespace hps;
 
@@ -320,6 +321,30 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       if (value < 0) return Error(Code::kInvalidArg, "hit_rate_threshold_permille must be >= 0");
       s->s->set_hit_rate_threshold((float)value / 1000.0f);
     } else return Error(Code::kInvalidArg, "unknown option '", n, "'");
+    return Status::Ok();
+  });
+}
+
+uint32_t hps_shard_owner(int64_t key, uint32_t num_shards) { return num_shards ? ShardOwnerHost(key, num_shards) : 0; }
+
+uint64_t hps_shard_bucket_workspace_bytes(uint64_t n, uint32_t num_shards) { return ShardBucketWorkspaceBytes(n, num_shards); }
+
+int hps_shard_bucket_device(const int64_t* d_keys, uint64_t n, uint32_t num_shards, int64_t* d_keys_sorted, int32_t* d_perm,
+                            uint64_t* d_totals, void* d_workspace, void* stream) {
+  return Guard([&]() -> Status {
+    if (n >= (1ull << 31)) return Error(Code::kUnsupported, "more than 2^31 keys per call");
+    if ((n && (!d_keys || !d_keys_sorted || !d_perm)) || !d_totals || !d_workspace) return Error(Code::kInvalidArg, "null argument");
+    const hipError_t e = LaunchShardBucket(d_keys, n, num_shards, d_keys_sorted, d_perm, d_totals, d_workspace, (hipStream_t)stream);
+    if (e != hipSuccess) return Error(Code::kInternal, "shard bucket launch failed: ", hipGetErrorString(e));
+    return Status::Ok();
+  });
+}
+
+int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint64_t n, uint32_t dim, float* d_out, void* stream) {
+  return Guard([&]() -> Status {
+    if (n && (!d_rows || !d_perm || !d_out)) return Error(Code::kInvalidArg, "null argument");
+    const hipError_t e = LaunchShardUnpermute(d_rows, d_perm, n, dim, d_out, (hipStream_t)stream);
+    if (e != hipSuccess) return Error(Code::kInternal, "shard unpermute launch failed: ", hipGetErrorString(e));
     return Status::Ok();
   });
 }

@@ -1,0 +1,131 @@
+// Kernels of the table-sharded (model-parallel) lookup — BASELINE config 3, a north-star addition (the
+// reference itself is replicas-only).  Rows of one table are partitioned over P ranks by
+// owner(key) = mix64(key) mod P; a rank buckets its local keys by owner, exchanges keys and rows with RCCL
+// all-to-all (done by the host layer, hugectr_backend_amd/sharded.py) and restores the input order.
+//
+//   hps_shard_hist      per-block histogram of owners (1024 keys per block)
+//   hps_shard_scan      exclusive scan -> write offset of every (shard, block) pair; totals per shard
+//   hps_shard_scatter   stable counting-sort scatter: keys grouped by owner + permutation
+//   hps_shard_unpermute out[perm[j]] = rows[j]   (16-lane group per row, 16 B per lane)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../common/hps_hash.h"
+#include "shard_kernels.h"
+
+namespace hps {
+
+typedef float f4s __attribute__((ext_vector_type(4)));
+constexpr int kShardBlock = 1024;
+constexpr int kMaxShards = 64;
+
+__device__ __forceinline__ uint32_t owner_of(int64_t key, uint32_t P) { return (uint32_t)(hps_mix64((uint64_t)key) % P); }
+
+__global__ __launch_bounds__(kShardBlock) void hps_shard_hist_kernel(const int64_t* __restrict__ keys, uint64_t n, uint32_t P,
+                                                                    uint32_t* __restrict__ hist /*[blocks][P]*/) {
+  __shared__ uint32_t sh[kMaxShards];
+  if (threadIdx.x < P) sh[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * kShardBlock + threadIdx.x;
+  if (i < n) atomicAdd(&sh[owner_of(keys[i], P)], 1u);
+  __syncthreads();
+  if (threadIdx.x < P) hist[(uint64_t)blockIdx.x * P + threadIdx.x] = sh[threadIdx.x];
+}
+
+// one block; offsets[b][s] = sum_{s'<s} total[s'] + sum_{b'<b} hist[b'][s]
+__global__ __launch_bounds__(64) void hps_shard_scan_kernel(const uint32_t* __restrict__ hist, uint32_t blocks, uint32_t P,
+                                                            uint64_t* __restrict__ offsets, uint64_t* __restrict__ totals) {
+  __shared__ uint64_t tot[kMaxShards];
+  const uint32_t s = threadIdx.x;
+  if (s < P) {
+    uint64_t run = 0;
+    for (uint32_t b = 0; b < blocks; ++b) { offsets[(uint64_t)b * P + s] = run; run += hist[(uint64_t)b * P + s]; }
+    tot[s] = run;
+    totals[s] = run;
+  }
+  __syncthreads();
+  if (s < P) {
+    uint64_t base = 0;
+    for (uint32_t q = 0; q < s; ++q) base += tot[q];
+    for (uint32_t b = 0; b < blocks; ++b) offsets[(uint64_t)b * P + s] += base;
+  }
+}
+
+__global__ __launch_bounds__(kShardBlock) void hps_shard_scatter_kernel(const int64_t* __restrict__ keys, uint64_t n, uint32_t P,
+                                                                       const uint64_t* __restrict__ offsets,
+                                                                       int64_t* __restrict__ keys_sorted,
+                                                                       int32_t* __restrict__ perm) {
+  // stable inside the block: rank of a key among the block's earlier keys with the same owner, computed with
+  // one ballot per shard value present in the wave + per-wave counts in LDS
+  __shared__ uint32_t wave_cnt[kShardBlock / 64][kMaxShards];
+  const uint64_t i = (uint64_t)blockIdx.x * kShardBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool valid = i < n;
+  const int64_t key = valid ? keys[i] : 0;
+  const uint32_t own = valid ? owner_of(key, P) : 0xFFFFFFFFu;
+  for (uint32_t s = lane; s < P; s += 64) wave_cnt[wave][s] = 0;
+  __syncthreads();
+  uint32_t rank_in_wave = 0;
+  for (uint32_t s = 0; s < P; ++s) {
+    const uint64_t m = __ballot(own == s);
+    if (own == s) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave][s] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (valid) {
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w][own];
+    const uint64_t pos = offsets[(uint64_t)blockIdx.x * P + own] + before + rank_in_wave;
+    keys_sorted[pos] = key;
+    perm[pos] = (int32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(256) void hps_shard_unpermute_kernel(const float* __restrict__ rows, const int32_t* __restrict__ perm,
+                                                                  uint64_t n, uint32_t D, float* __restrict__ out, int vec) {
+  const int lig = threadIdx.x & 15;
+  const uint64_t groups_total = (uint64_t)gridDim.x * 16;
+  for (uint64_t j = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4); j < n; j += groups_total) {
+    const float* src = rows + j * D;
+    float* dst = out + (uint64_t)(uint32_t)perm[j] * D;
+    if (vec) {
+      for (uint32_t c = (uint32_t)lig * 4; c < D; c += 64)
+        __builtin_nontemporal_store(*reinterpret_cast<const f4s*>(src + c), reinterpret_cast<f4s*>(dst + c));
+    } else {
+      for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = src[c];
+    }
+  }
+}
+
+uint32_t ShardOwnerHost(int64_t key, uint32_t P) { return (uint32_t)(hps_mix64((uint64_t)key) % P); }
+
+size_t ShardBucketWorkspaceBytes(uint64_t n, uint32_t P) {
+  const uint64_t blocks = (n + kShardBlock - 1) / kShardBlock;
+  return (size_t)(blocks * P * (sizeof(uint32_t) + sizeof(uint64_t)) + 256);
+}
+
+hipError_t LaunchShardBucket(const int64_t* d_keys, uint64_t n, uint32_t P, int64_t* d_keys_sorted, int32_t* d_perm,
+                             uint64_t* d_totals, void* d_workspace, hipStream_t stream) {
+  if (P == 0 || P > (uint32_t)kMaxShards) return hipErrorInvalidValue;
+  const uint32_t blocks = (uint32_t)((n + kShardBlock - 1) / kShardBlock);
+  if (blocks == 0) return hipMemsetAsync(d_totals, 0, sizeof(uint64_t) * P, stream);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(d_workspace);
+  uint64_t* offsets = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_workspace) + (((size_t)blocks * P * sizeof(uint32_t) + 15) & ~(size_t)15));
+  hipLaunchKernelGGL(hps_shard_hist_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, n, P, hist);
+  hipLaunchKernelGGL(hps_shard_scan_kernel, dim3(1), dim3(64), 0, stream, hist, blocks, P, offsets, d_totals);
+  hipLaunchKernelGGL(hps_shard_scatter_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, n, P, offsets, d_keys_sorted,
+                     d_perm);
+  return hipGetLastError();
+}
+
+hipError_t LaunchShardUnpermute(const float* d_rows, const int32_t* d_perm, uint64_t n, uint32_t D, float* d_out,
+                                hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  uint64_t want = (n + 15) / 16;
+  if (want > 2048) want = 2048;
+  const int vec = ((D & 3u) == 0 && ((uintptr_t)d_rows & 15u) == 0 && ((uintptr_t)d_out & 15u) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(hps_shard_unpermute_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_rows, d_perm, n, D, d_out, vec);
+  return hipGetLastError();
+}
+
+}  // namespace hps

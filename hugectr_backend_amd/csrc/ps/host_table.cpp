@@ -1,6 +1,7 @@
 #include "host_table.h"
 
 #include <fcntl.h>
+#include <immintrin.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -218,6 +219,29 @@ Status HostTable::LoadFromArrays(const int64_t* keys, const float* rows, size_t 
   return BuildIndex(pool);
 }
 
+// Synthetic rows, 8 splitmix64 lanes at a time (the generator is the setup cost of the benchmark: 33 G
+// elements for BASELINE config 2).  Same arithmetic as hps_synth_elem_bits: word j/2 of the row yields
+// element j (low 32 bits) and j+1 (high 32 bits), each masked to 23 mantissa bits under exponent 0x3F0.
+// Returns the number of elements written (a multiple of 16).
+__attribute__((target("avx512f,avx512dq"))) static uint32_t SynthRowAvx512(uint64_t rb, uint32_t D, uint32_t* dst) {
+  const __m512i c0 = _mm512_set1_epi64((long long)0x9E3779B97F4A7C15ull);
+  const __m512i c1 = _mm512_set1_epi64((long long)0xBF58476D1CE4E5B9ull);
+  const __m512i c2 = _mm512_set1_epi64((long long)0x94D049BB133111EBull);
+  const __m512i mant = _mm512_set1_epi64((long long)0x007FFFFF007FFFFFull);
+  const __m512i expo = _mm512_set1_epi64((long long)0x3F0000003F000000ull);
+  const __m512i lane = _mm512_set_epi64(7, 6, 5, 4, 3, 2, 1, 0);
+  uint32_t j = 0;
+  for (; j + 16 <= D; j += 16) {
+    __m512i x = _mm512_add_epi64(_mm512_add_epi64(_mm512_set1_epi64((long long)(rb + (j >> 1))), lane), c0);
+    x = _mm512_mullo_epi64(_mm512_xor_si512(x, _mm512_srli_epi64(x, 30)), c1);
+    x = _mm512_mullo_epi64(_mm512_xor_si512(x, _mm512_srli_epi64(x, 27)), c2);
+    x = _mm512_xor_si512(x, _mm512_srli_epi64(x, 31));
+    x = _mm512_or_si512(_mm512_and_si512(x, mant), expo);
+    _mm512_storeu_si512((void*)(dst + j), x);
+  }
+  return j;
+}
+
 Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, size_t R, ThreadPool* pool) {
   std::unique_lock<std::shared_mutex> lk(mu_);
   FreeAll();
@@ -230,6 +254,7 @@ Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, 
   const size_t chunk = 4096;
   const size_t ntasks = (R + chunk - 1) / chunk;
   const uint32_t D = dim_;
+  const bool use_avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
   auto body = [&](size_t ti) {
     const size_t b = ti * chunk, e = std::min(R, b + chunk);
     for (size_t r = b; r < e; ++r) {
@@ -237,7 +262,9 @@ Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, 
       keys_[r] = key;
       const uint64_t rb = hps_synth_row_base(tb, key);
       uint32_t* dst = reinterpret_cast<uint32_t*>(rows_ + r * D);
-      for (uint32_t j = 0; j + 1 < D; j += 2) {
+      uint32_t j0 = 0;
+      if (use_avx512) j0 = SynthRowAvx512(rb, D, dst);  // whole groups of 16 elements; the tail below
+      for (uint32_t j = j0; j + 1 < D; j += 2) {
         const uint64_t w = hps_mix64(rb + (uint64_t)(j >> 1));
         dst[j] = 0x3F000000u | ((uint32_t)w & 0x007FFFFFu);
         dst[j + 1] = 0x3F000000u | ((uint32_t)(w >> 32) & 0x007FFFFFu);
@@ -273,37 +300,59 @@ size_t HostTable::Fetch(const int64_t* keys, size_t n, float* out, size_t stride
   const uint32_t D = dim_;
   const size_t row_bytes = (size_t)D * sizeof(float);
   size_t nfound = 0;
-  constexpr size_t B = 16;  // keys in flight per thread: hides DRAM latency of the index and the row
-  for (size_t base = 0; base < n; base += B) {
-    const size_t m = std::min(B, n - base);
-    const Entry* slot[B];
-    int64_t row[B];
-    for (size_t i = 0; i < m; ++i) {
-      const int64_t key = keys[base + i];
-      if (key == HPS_EMPTY_KEY) { slot[i] = nullptr; continue; }
-      const Partition& P = *parts_[PartitionOf(key)];
-      slot[i] = P.slots ? &P.slots[SlotOf(key, P.mask)] : nullptr;
-      if (slot[i]) __builtin_prefetch(slot[i], 0, 0);
-    }
-    for (size_t i = 0; i < m; ++i) {
-      const int64_t key = keys[base + i];
-      row[i] = FindUnlocked(key);
-      if (row[i] >= 0) {
-        const char* p = reinterpret_cast<const char*>(rows_ + (size_t)row[i] * D);
-        for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(p + o, 0, 0);
+  // Three-stage software pipeline over blocks of B keys.  The lookup of one key is two dependent DRAM
+  // round trips (index slot, then the row = row_bytes/64 cache lines); a thread that waits for them one
+  // key at a time spends ~all of its CPU time stalled.  While block j's rows are copied, block j+1's
+  // index slots have been read and its row lines are being prefetched, and block j+2's index slots are
+  // being prefetched.  Rows are written with non-temporal stores when 16-B aligned: the destination
+  // (pinned staging / the response buffer) is not read back by this thread, and a regular store would first
+  // fetch every destination line (read-for-ownership), doubling the memory traffic of the gather.
+  constexpr size_t B = 8;
+  const size_t nb = (n + B - 1) / B;
+  int64_t row[3][B];
+  const bool nt_ok = (row_bytes % 16 == 0) && (stride % 4 == 0) && (((uintptr_t)out & 15u) == 0);
+  for (size_t j = 0; j < nb + 2; ++j) {
+    if (j < nb) {  // stage A: prefetch index slots of block j
+      const size_t base = j * B, m = std::min(B, n - base);
+      for (size_t i = 0; i < m; ++i) {
+        const int64_t key = keys[base + i];
+        if (key == HPS_EMPTY_KEY) continue;
+        const Partition& P = *parts_[PartitionOf(key)];
+        if (P.slots) __builtin_prefetch(&P.slots[SlotOf(key, P.mask)], 0, 0);
       }
     }
-    for (size_t i = 0; i < m; ++i) {
-      float* dst = out + (base + i) * stride;
-      if (row[i] >= 0) {
-        memcpy(dst, rows_ + (size_t)row[i] * D, row_bytes);
-        ++nfound;
-      } else {
-        for (uint32_t j = 0; j < D; ++j) dst[j] = default_value;
+    if (j >= 1 && j - 1 < nb) {  // stage B: resolve block j-1, prefetch its rows
+      const size_t blk = j - 1, base = blk * B, m = std::min(B, n - base);
+      int64_t* r = row[blk % 3];
+      for (size_t i = 0; i < m; ++i) {
+        r[i] = FindUnlocked(keys[base + i]);
+        if (r[i] >= 0) {
+          const char* p = reinterpret_cast<const char*>(rows_ + (size_t)r[i] * D);
+          for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(p + o, 0, 0);
+        }
       }
-      if (found) found[base + i] = row[i] >= 0 ? 1 : 0;
+    }
+    if (j >= 2) {  // stage C: copy block j-2
+      const size_t blk = j - 2, base = blk * B, m = std::min(B, n - base);
+      const int64_t* r = row[blk % 3];
+      for (size_t i = 0; i < m; ++i) {
+        float* dst = out + (base + i) * stride;
+        if (r[i] >= 0) {
+          const float* src = rows_ + (size_t)r[i] * D;
+          if (nt_ok) {
+            for (uint32_t c = 0; c < D; c += 4) _mm_stream_ps(dst + c, _mm_loadu_ps(src + c));
+          } else {
+            memcpy(dst, src, row_bytes);
+          }
+          ++nfound;
+        } else {
+          for (uint32_t c = 0; c < D; ++c) dst[c] = default_value;
+        }
+        if (found) found[base + i] = r[i] >= 0 ? 1 : 0;
+      }
     }
   }
+  if (nt_ok) _mm_sfence();  // make the streamed rows globally visible before the caller hands them to the DMA engine
   return nfound;
 }
 

@@ -1,19 +1,58 @@
 #include "thread_pool.h"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace hps {
 
+// CPUs this process may actually use: hardware threads, clipped by the scheduler affinity mask and by the
+// cgroup CPU bandwidth quota (cpu.max "quota period", cgroup v2; cfs_quota_us/cfs_period_us, v1).  A container
+// with 256 visible hardware threads and a 16-CPU quota gets 16: running 255 workers there only burns the quota
+// and gets the whole process throttled for the rest of the 100 ms period.
+static size_t EffectiveCpus() {
+  size_t n = std::thread::hardware_concurrency();
+  if (n == 0) n = 4;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) {
+    const int c = CPU_COUNT(&set);
+    if (c > 0 && (size_t)c < n) n = (size_t)c;
+  }
+  auto clip = [&](double cpus) {
+    if (cpus > 0) {
+      const size_t q = (size_t)std::ceil(cpus);
+      if (q >= 1 && q < n) n = q;
+    }
+  };
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64] = {0};
+    long long period = 0;
+    if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+      clip((double)strtoll(q, nullptr, 10) / (double)period);
+    fclose(f);
+  } else {
+    long long quota = -1, period = 0;
+    if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+    if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+    if (quota > 0 && period > 0) clip((double)quota / (double)period);
+  }
+  return n;
+}
+
 size_t ThreadPool::DefaultConcurrency() {
-  // thread_pool.cpp:25-41 of the reference: env override, else hardware_concurrency.
+  // thread_pool.cpp:25-41 of the reference: env override, else hardware_concurrency (here: the CPUs the
+  // process is really allowed to use).
   if (const char* e = std::getenv("HCTR_DEFAULT_CONCURRENCY")) {
     const long v = std::strtol(e, nullptr, 10);
     if (v > 0) return (size_t)v;
   }
-  const unsigned hc = std::thread::hardware_concurrency();
-  return hc ? hc : 4;
+  static const size_t n = EffectiveCpus();
+  return n;
 }
 
 ThreadPool& ThreadPool::Global() {
@@ -22,7 +61,18 @@ ThreadPool& ThreadPool::Global() {
 }
 
 ThreadPool& ThreadPool::Serving() {
-  static ThreadPool pool(std::max<size_t>(1, std::min<size_t>(32, DefaultConcurrency() / 2)), 200);
+  // A 512-B row is 8 cache lines and a core keeps only ~a dozen line fills in flight, so the gather is bound
+  // by line-fill buffers per core, not by DRAM: it scales with the number of physical cores working on it.
+  // HPS_SERVING_THREADS overrides the default of half the hardware threads (capped at 96).
+  static ThreadPool pool([] {
+    if (const char* e = std::getenv("HPS_SERVING_THREADS")) {
+      const long v = std::strtol(e, nullptr, 10);
+      if (v > 0) return (size_t)v;
+    }
+    // leave two CPUs of the budget to the callers (session threads, HIP runtime threads)
+    const size_t c = DefaultConcurrency();
+    return std::max<size_t>(1, std::min<size_t>(64, c > 4 ? c - 3 : c / 2));
+  }(), 100);
   return pool;
 }
 

@@ -104,6 +104,10 @@ def _load() -> C.CDLL:
         "hps_session_lookup_device": (C.c_int, [P, P, P, P, C.c_size_t]),
         "hps_session_last_stats": (C.c_int, [P, C.POINTER(LookupStats)]),
         "hps_session_set_option": (C.c_int, [P, cp, C.c_int]),
+        "hps_shard_owner": (u32, [i64, u32]),
+        "hps_shard_bucket_workspace_bytes": (u64, [u64, u32]),
+        "hps_shard_bucket_device": (C.c_int, [P, u64, u32, P, P, P, P, P]),
+        "hps_shard_unpermute_device": (C.c_int, [P, P, u64, u32, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = symbol missing from the library
@@ -121,7 +125,8 @@ EXPORTED_SYMBOLS = [
     "hps_server_load_table_synthetic", "hps_server_fetch", "hps_cache_num_tables", "hps_cache_table_info",
     "hps_cache_counters", "hps_cache_query", "hps_cache_wait_async", "hps_cache_release", "hps_session_create",
     "hps_session_destroy", "hps_session_lookup", "hps_session_lookup_device", "hps_session_last_stats",
-    "hps_session_set_option",
+    "hps_session_set_option", "hps_shard_owner", "hps_shard_bucket_workspace_bytes", "hps_shard_bucket_device",
+    "hps_shard_unpermute_device",
 ]
 
 

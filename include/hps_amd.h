@@ -157,6 +157,19 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
  * the model's hit_rate_threshold: 1000 = always synchronous insertion, 0 = always asynchronous) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
+/* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------
+ * owner(key) = mix64(key) mod num_shards.  The exchange itself (RCCL all-to-all of keys, then of rows) is driven by
+ * the host layer (hugectr_backend_amd/sharded.py, torch.distributed); these are its device-side pieces. */
+uint32_t hps_shard_owner(int64_t key, uint32_t num_shards);
+uint64_t hps_shard_bucket_workspace_bytes(uint64_t n, uint32_t num_shards);
+/* Stable bucket of n device keys by owner: d_keys_sorted grouped shard 0..P-1, d_perm[j] = input index of sorted key j,
+ * d_totals[P] = keys per shard (device, uint64).  `stream` is a hipStream_t (0 = default stream). */
+int hps_shard_bucket_device(const int64_t* d_keys, uint64_t n, uint32_t num_shards, int64_t* d_keys_sorted,
+                            int32_t* d_perm, uint64_t* d_totals, void* d_workspace, void* stream);
+/* d_out[d_perm[j]*dim ..] = d_rows[j*dim ..]  for j in [0,n) */
+int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint64_t n, uint32_t dim, float* d_out,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,138 @@
+"""Table-sharded lookup (BASELINE config 3): owner(key) = mix64(key) mod P, all-to-all of keys and rows.
+
+CPU: two gloo ranks, each serving its shard from a gpucache=false session (host tier) — runs without a GPU.
+GPU: the device bucket / unpermute kernels against NumPy, and two ranks sharing the one visible GPU (gloo
+carries the exchange through host memory there; on a multi-GPU node the same code runs over RCCL).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests.conftest import make_tables, ps_config
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_owner_function_matches_the_c_abi():
+    from hugectr_backend_amd import hps, sharded
+    rng = np.random.default_rng(0)
+    keys = np.concatenate([rng.integers(-2**62, 2**62, 2000), [0, 1, -1, np.iinfo(np.int64).min, np.iinfo(np.int64).max]]).astype(np.int64)
+    for P in (1, 2, 3, 8):
+        ref = np.array([hps.LIB.hps_shard_owner(int(k), P) for k in keys])
+        assert np.array_equal(sharded.owner_of(keys, P), ref)
+        assert ref.min() >= 0 and ref.max() < P
+    # shards are a partition of the table
+    ks, rows = keys[:1000], rng.random((1000, 4)).astype(np.float32)
+    parts = [sharded.shard_rows(ks, rows, r, 4) for r in range(4)]
+    assert sum(p[0].size for p in parts) == 1000
+    assert np.array_equal(np.sort(np.concatenate([p[0] for p in parts])), np.sort(ks))
+
+
+def _rank_main(rank, world, port, device_mode, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HCTR_DEFAULT_CONCURRENCY="2")
+        import torch
+        import torch.distributed as dist
+        from hugectr_backend_amd import hps, sharded
+        from oracle import hps_oracle as O
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        D = 128 if device_mode else 16
+        tables = make_tables([(6000, D)], seed=11)
+        keys, rows = tables[0]
+        my_k, my_r = sharded.shard_rows(keys, rows, rank, world)
+        cfg = ps_config("shard", [(my_k, my_r)], gpucache=device_mode, gpucacheper=0.3, hit_rate_threshold=1.0, defaults=[2.0],
+                        maxcat=[1], max_batch=8192)
+        ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+        ps.load_table_arrays("shard", 0, my_k, my_r)
+        cache = None
+        if device_mode:
+            ps.create_embedding_cache_per_model("shard")
+            cache = ps.get_embedding_cache("shard", 0)
+        sess = hps.LookupSession.create(ps, "shard", cache)
+        sl = sharded.ShardedLookup(sess)
+        rng = np.random.default_rng(100 + rank)
+        for it in range(4):
+            n = int(rng.integers(1, 5000)) if it else 4096
+            q_keys = np.where(rng.random(n) < 0.1, -1 - rng.integers(0, 1 << 40, n), rng.choice(keys, n)).astype(np.int64)
+            if device_mode:
+                out = sl.lookup(torch.from_numpy(q_keys).cuda()).cpu().numpy()
+            else:
+                out = sl.lookup(q_keys)
+            ref = O.np_lookup(tables, q_keys, [n], [2.0])   # oracle over the WHOLE table
+            if not np.array_equal(_bits(out), _bits(ref)):
+                q.put((rank, f"mismatch at iteration {it}"))
+                return
+            if sum(sl.last_sent) != n:
+                q.put((rank, "send counts do not add up"))
+                return
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "exception: " + repr(e) + traceback.format_exc()[-800:]))
+
+
+def _run_two_ranks(device_mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, device_mode, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=240) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_two_gloo_ranks_host_tier_shards():
+    _run_two_ranks(device_mode=False)
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharing_the_gpu_device_path():
+    _run_two_ranks(device_mode=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 2, 8, 64])
+def test_device_bucket_and_unpermute_kernels(P):
+    import ctypes as C
+    import torch
+    from hugectr_backend_amd import hps, sharded
+    rng = np.random.default_rng(P)
+    for n in (0, 1, 1023, 1024, 1025, 50000, 212992):
+        keys = rng.integers(-2**62, 2**62, n).astype(np.int64)
+        dk = torch.from_numpy(keys).cuda()
+        ks = torch.empty(n, dtype=torch.int64, device="cuda")
+        perm = torch.empty(n, dtype=torch.int32, device="cuda")
+        tot = torch.empty(P, dtype=torch.int64, device="cuda")
+        ws = torch.empty(max(int(hps.LIB.hps_shard_bucket_workspace_bytes(n, P)), 16), dtype=torch.uint8, device="cuda")
+        hps._check(hps.LIB.hps_shard_bucket_device(dk.data_ptr(), n, P, ks.data_ptr(), perm.data_ptr(), tot.data_ptr(),
+                                                   ws.data_ptr(), C.c_void_p(0)))
+        torch.cuda.synchronize()
+        own = sharded.owner_of(keys, P)
+        ref_perm = np.argsort(own, kind="stable")
+        assert np.array_equal(perm.cpu().numpy(), ref_perm.astype(np.int32))       # stable counting sort
+        assert np.array_equal(ks.cpu().numpy(), keys[ref_perm])
+        assert np.array_equal(tot.cpu().numpy(), np.bincount(own, minlength=P))
+        for D in (1, 16, 128):
+            rows = rng.random((n, D)).astype(np.float32)
+            dr = torch.from_numpy(rows).cuda()
+            out = torch.empty(max(n * D, 1), dtype=torch.float32, device="cuda")
+            hps._check(hps.LIB.hps_shard_unpermute_device(dr.data_ptr(), perm.data_ptr(), n, D, out.data_ptr(), C.c_void_p(0)))
+            torch.cuda.synchronize()
+            exp = np.empty((n, D), np.float32)
+            exp[ref_perm] = rows
+            assert np.array_equal(_bits(out[: n * D].cpu().numpy()), _bits(exp.ravel()))
