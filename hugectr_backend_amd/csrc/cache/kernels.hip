@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "device_types.h"
 #include "kernels.h"
 
@@ -41,6 +43,11 @@ __device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
   const int lo = __shfl((int)(uint32_t)(uint64_t)v, src, 64);
   const int hi = __shfl((int)(uint32_t)((uint64_t)v >> 32), src, 64);
   return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  return ((uint64_t)uniform_u32((uint32_t)(v >> 32)) << 32) | uniform_u32((uint32_t)v);
 }
 
 // Per-table values every probe step needs; kept in LDS once per block.
@@ -144,69 +151,99 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_gather_kernel(
     const bool valid = i < N;
     const int64_t key = valid ? keys[i] : HPS_EMPTY_KEY;
     // table of this lane's key: search once per wave, walk forward for lanes past a table boundary
-    int t = find_table(sh_ks, T, chunk * 64);
+    const int t0 = (int)uniform_u32((uint32_t)find_table(sh_ks, T, chunk * 64));
+    int t = t0;
     if (valid) { while (i >= sh_ks[t + 1]) ++t; }
     int32_t my_slot = kSlotMiss;
+    // every lane hashes its OWN key once (64 hashes per chunk in one pass); the groups then pick the bucket
+    // index up with one cross-lane read instead of re-hashing the shuffled key in all 16 lanes of every step
+    const uint32_t my_bucket = hps_bucket_of(key, sh_tab[t].num_buckets);
 
-    // phase 1 of a key group: kUnroll independent bucket-line loads
-    auto issue = [&](int jb, ProbeGroup<kUnroll>& G) {
+    // The body is instantiated twice: `uniform` = all 64 keys of the chunk belong to one table (every chunk
+    // except the ones that straddle a table boundary): the table descriptor sits in scalar registers, no
+    // per-key LDS reads and no table-id shuffle.
+    auto run = [&](auto uniform_tag, const TableLds& du) {
+      constexpr bool kUniform = decltype(uniform_tag)::value;
+      // phase 1 of a key group: kUnroll independent bucket-line loads
+      auto issue = [&](int jb, ProbeGroup<kUnroll>& G) {
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const int src = g * 16 + jb + u;
-        G.k[u] = shfl_i64(key, src);
-        G.tt[u] = __shfl(t, src, 64);
-        const TableLds& d = sh_tab[G.tt[u]];
-        G.b[u] = hps_bucket_of(G.k[u], d.num_buckets);
-        G.bk[u] = d.bucket_keys[(uint64_t)G.b[u] * kBucketSlots + lig];
-      }
-    };
-    // phases 2-4: compare + group ballot -> slot; row loads; streaming stores (hit rows only)
-    auto finish = [&](int jb, const ProbeGroup<kUnroll>& G) {
-      int32_t s[kUnroll];
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const bool match = (G.bk[u] == G.k[u]) && (G.k[u] != HPS_EMPTY_KEY);
-        const uint64_t m = __ballot(match);
-        const uint32_t m16 = (uint32_t)(m >> (g * 16)) & 0xFFFFu;
-        s[u] = m16 ? (int32_t)(G.b[u] * kBucketSlots + (uint32_t)__builtin_ctz(m16)) : kSlotMiss;
-      }
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const int src = g * 16 + jb + u;
-        if (s[u] >= 0) {
-          const TableLds& d = sh_tab[G.tt[u]];
-          const uint32_t D = d.dim;
-          const uint64_t gi = chunk * 64 + (uint64_t)src;
-          const float* row = d.rows + (uint64_t)(uint32_t)s[u] * D;
-          float* dst = d.out + (gi - d.key_start) * D;
-          copy_row<true>(row, dst, D, lig, (d.flags & 2u) != 0);
-          if (lig == 0 && !(d.flags & 1u)) {
-            bool touch = true;
-            if (kStampShift > 0)
-              touch = (((uint32_t)hps_mix64((uint64_t)G.k[u] ^ ((uint64_t)epoch << 32)) >> 7) & ((1u << kStampShift) - 1u)) == 0u;
-            if (touch) d.stamps[(uint32_t)s[u]] = epoch;
+        for (int u = 0; u < kUnroll; ++u) {
+          const int src = g * 16 + jb + u;
+          G.k[u] = shfl_i64(key, src);
+          G.b[u] = (uint32_t)__shfl((int)my_bucket, src, 64);
+          if (kUniform) {
+            G.tt[u] = 0;
+            G.bk[u] = du.bucket_keys[(uint64_t)G.b[u] * kBucketSlots + lig];
+          } else {
+            G.tt[u] = __shfl(t, src, 64);
+            G.bk[u] = sh_tab[G.tt[u]].bucket_keys[(uint64_t)G.b[u] * kBucketSlots + lig];
           }
         }
-        if (lane == src) my_slot = s[u];
+      };
+      // phases 2-4: compare + group ballot -> slot; row loads; streaming stores (hit rows only)
+      auto finish = [&](int jb, const ProbeGroup<kUnroll>& G) {
+        int32_t s[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const bool match = (G.bk[u] == G.k[u]) && (G.k[u] != HPS_EMPTY_KEY);
+          const uint64_t m = __ballot(match);
+          const uint32_t m16 = (uint32_t)(m >> (g * 16)) & 0xFFFFu;
+          s[u] = m16 ? (int32_t)(G.b[u] * kBucketSlots + (uint32_t)__builtin_ctz(m16)) : kSlotMiss;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int src = g * 16 + jb + u;
+          if (s[u] >= 0) {
+            const TableLds& d = kUniform ? du : sh_tab[G.tt[u]];
+            const uint32_t D = d.dim;
+            const uint64_t gi = chunk * 64 + (uint64_t)src;
+            const float* row = d.rows + (uint64_t)(uint32_t)s[u] * D;
+            float* dst = d.out + (gi - d.key_start) * D;
+            copy_row<true>(row, dst, D, lig, (d.flags & 2u) != 0);
+            if (lig == 0 && !(d.flags & 1u)) {
+              bool touch = true;
+              if (kStampShift > 0)
+                touch = ((((uint32_t)s[u] * 0x9E3779B1u + epoch * 0x85EBCA6Bu) >> 13) & ((1u << kStampShift) - 1u)) == 0u;
+              if (touch) d.stamps[(uint32_t)s[u]] = epoch;
+            }
+          }
+          if (lane == src) my_slot = s[u];
+        }
+      };
+      if (kOuter == 0) {
+        // rolled + software-pipelined: the bucket loads of group j+1 are in flight while group j's rows move
+        ProbeGroup<kUnroll> cur, nxt;
+        issue(0, cur);
+#pragma unroll 1
+        for (int jb = 0; jb < 16; jb += kUnroll) {
+          if (jb + kUnroll < 16) issue(jb + kUnroll, nxt);
+          finish(jb, cur);
+          cur = nxt;
+        }
+      } else {
+#pragma unroll(kOuter > 0 ? kOuter : 1)
+        for (int jb = 0; jb < 16; jb += kUnroll) {
+          ProbeGroup<kUnroll> G;
+          issue(jb, G);
+          finish(jb, G);
+        }
       }
     };
-    if (kOuter == 0) {
-      // rolled + software-pipelined: the bucket loads of group j+1 are in flight while group j's rows move
-      ProbeGroup<kUnroll> cur, nxt;
-      issue(0, cur);
-#pragma unroll 1
-      for (int jb = 0; jb < 16; jb += kUnroll) {
-        if (jb + kUnroll < 16) issue(jb + kUnroll, nxt);
-        finish(jb, cur);
-        cur = nxt;
-      }
+    const uint64_t chunk_last = (chunk * 64 + 63 < N ? chunk * 64 + 63 : N - 1);
+    if (chunk_last < sh_ks[t0 + 1]) {
+      TableLds du;  // wave-uniform copy in scalar registers
+      du.bucket_keys = reinterpret_cast<const int64_t*>(uniform_u64((uint64_t)sh_tab[t0].bucket_keys));
+      du.stamps = reinterpret_cast<uint32_t*>(uniform_u64((uint64_t)sh_tab[t0].stamps));
+      du.rows = reinterpret_cast<const float*>(uniform_u64((uint64_t)sh_tab[t0].rows));
+      du.out = reinterpret_cast<float*>(uniform_u64((uint64_t)sh_tab[t0].out));
+      du.key_start = uniform_u64(sh_tab[t0].key_start);
+      du.num_buckets = uniform_u32(sh_tab[t0].num_buckets);
+      du.dim = uniform_u32(sh_tab[t0].dim);
+      du.flags = uniform_u32(sh_tab[t0].flags);
+      du.pad = 0;
+      run(std::true_type{}, du);
     } else {
-#pragma unroll(kOuter > 0 ? kOuter : 1)
-      for (int jb = 0; jb < 16; jb += kUnroll) {
-        ProbeGroup<kUnroll> G;
-        issue(jb, G);
-        finish(jb, G);
-      }
+      run(std::false_type{}, sh_tab[t0]);
     }
     if (valid) {
       slot_out[i] = my_slot;
