@@ -44,7 +44,9 @@ def parse_args():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--batch", type=int, default=65536, help="samples per batch; one key per table per sample")
     ap.add_argument("--cache-frac", type=float, default=0.2, help="gpucacheper")
-    ap.add_argument("--hit", type=float, default=0.95, help="probability that a key is drawn from the resident set")
+    ap.add_argument("--hit", type=float, default=0.957,
+                    help="probability that a key is drawn from the set resident after warm-up (0.957 gives a MEASURED hit "
+                         "rate of 0.95: inserting each batch's cold keys evicts a little of the hot tail)")
     ap.add_argument("--zipf", type=float, default=1.05)
     ap.add_argument("--sessions", type=int, default=2, help="concurrent lookup sessions (Triton instance count)")
     ap.add_argument("--mode", choices=["sync", "async"], default="sync",
@@ -397,7 +399,8 @@ def main():
                 "workload": f"Criteo DLRM {T} sparse slots, {R} rows/table"
                             + (f" (requested {rows_requested}; reduced to fit the host-memory budget of {world} replicas)" if R != rows_requested else "")
                             + f" x {D}-dim, {B} batch ({N} keys), "
-                            f"gpucacheper {a.cache_frac}, target hit {a.hit}, zipf {a.zipf} within the resident set, "
+                            f"gpucacheper {a.cache_frac}, 95% cache hit (resident-draw probability {a.hit}; see measured_hit_rate), "
+                            f"zipf {a.zipf} within the resident set, "
                             f"{a.mode} insert, {a.sessions} lookup sessions, keys resident in HBM",
                 "parallelism": "replicas" if world > 1 else "single",
             },
