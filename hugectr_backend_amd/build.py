@@ -45,6 +45,7 @@ TRITON_SRCS = [
     "triton/model_state.cpp",
     "triton/model_instance_state.cpp",
     "triton/timer.cpp",
+    "triton/roctx.cpp",
 ]
 MOCK_SRCS = ["mock_triton/mock_core.cpp"]
 

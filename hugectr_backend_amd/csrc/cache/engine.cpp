@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.h"
@@ -76,7 +77,30 @@ CacheCounters EmbeddingCache::counters() const {
   return counters_;
 }
 
-uint32_t EmbeddingCache::NextEpoch() { return epoch_.fetch_add(1, std::memory_order_relaxed) + 1; }
+// LRU epochs: one per lookup call, 32 bits.  Long before the counter wraps (at 10 k lookups/s that is five
+// days) all stamps are folded back so that "smaller = older" keeps holding.  Rare and heavy-handed on purpose:
+// the device is drained, every table's stamps are rewritten, the counter restarts above the kept span.
+constexpr uint32_t kEpochRenormAt = 0xF0000000u;
+constexpr uint32_t kEpochKeepSpan = 1u << 30;
+
+uint32_t EmbeddingCache::NextEpoch() {
+  const uint32_t e = epoch_.fetch_add(1, std::memory_order_relaxed) + 1;
+  if (e >= kEpochRenormAt) {
+    std::lock_guard<std::mutex> lk(order_mu_);
+    const uint32_t cur = epoch_.load(std::memory_order_relaxed);
+    if (cur >= kEpochRenormAt) {
+      (void)hipSetDevice(cfg_.device_id_);
+      (void)hipDeviceSynchronize();
+      const uint32_t keep_from = cur - kEpochKeepSpan;
+      for (const TableCacheDev& tb : h_tables_)
+        (void)LaunchCacheRenorm(tb.stamps, (uint64_t)tb.num_buckets * kBucketSlots, keep_from, nullptr);
+      (void)hipDeviceSynchronize();
+      epoch_.store(kEpochKeepSpan + 2, std::memory_order_relaxed);
+    }
+    return epoch_.fetch_add(1, std::memory_order_relaxed) + 1;
+  }
+  return e;
+}
 
 void EmbeddingCache::BeginRead(hipStream_t stream) {
   order_mu_.lock();
@@ -238,6 +262,7 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   (void)hipFree(d_keys); (void)hipFree(d_rows); (void)hipFree(d_md); (void)hipFree(d_zero_ks); (void)hipFree(d_stats);
   (void)hipFree(d_warm);
   epoch_.store(1);
+  if (const char* e = std::getenv("HPS_TEST_EPOCH_START")) epoch_.store((uint32_t)std::strtoul(e, nullptr, 0));  // test hook: epoch wrap
   return st;
 }
 

@@ -30,6 +30,9 @@ hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const Mi
 
 hipError_t LaunchCacheClear(int64_t* d_keys, uint32_t* d_stamps, uint64_t slots, hipStream_t stream);
 
+// stamps > keep_from -> stamp - keep_from + 1 ; other used stamps -> 1 ; 0 stays 0
+hipError_t LaunchCacheRenorm(uint32_t* d_stamps, uint64_t slots, uint32_t keep_from, hipStream_t stream);
+
 hipError_t LaunchCacheQuery(const TableCacheDev& tb, const int64_t* d_keys, uint64_t n, int32_t* d_slot,
                             hipStream_t stream);
 

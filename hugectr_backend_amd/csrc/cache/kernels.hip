@@ -513,7 +513,6 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
     const int t = find_table(md->useg_start, (int)T, f);
     const TableCacheDev tb = tables[t];
     if (tb.flags & 1u) continue;  // static cache: never insert
-    if (found && !found[f]) continue;
     const uint32_t u = md->chunk_lo[t] + (uint32_t)(f - md->useg_start[t]);
     const int64_t key = uniq_keys[key_start[t] + u];
     if (key == HPS_EMPTY_KEY) continue;
@@ -525,6 +524,17 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
     uint32_t st = tb.stamps[base + lig];
 
     const uint32_t present = (uint32_t)(__ballot(bk == key) >> (g * 16)) & 0xFFFFu;
+    if (found && !found[f]) {
+      // the key exists in no parameter-server tier (any more): never cache it, and if a refresh finds it still
+      // resident, drop it so that later lookups fall through to the default value instead of a stale row
+      if (present) {
+        const int v = __builtin_ctz(present);
+        uint32_t old = epoch;
+        if (lig == v && st != epoch) old = atomicCAS(&tb.stamps[base + v], st, epoch);
+        if (lig == v && st != epoch && old == st) { tb.bucket_keys[base + v] = HPS_EMPTY_KEY; tb.stamps[base + v] = 0; }
+      }
+      continue;
+    }
     int victim = -1;
     if (present) {
       // Already resident (another session inserted it after our probe): refresh the row in place, but
@@ -579,6 +589,15 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
   if (threadIdx.x < 3) {
     const uint32_t v = sh_stat[threadIdx.x][0] + sh_stat[threadIdx.x][1] + sh_stat[threadIdx.x][2] + sh_stat[threadIdx.x][3];
     if (v) atomicAdd(&stats[threadIdx.x], v);
+  }
+}
+
+// LRU epochs are 32-bit and advance once per lookup call; long before they wrap, every stamp is folded back:
+// stamps younger than `keep_from` keep their order in [1, span], everything older becomes 1, never-used stays 0.
+__global__ void hps_cache_renorm_kernel(uint32_t* stamps, uint64_t slots, uint32_t keep_from) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t s = stamps[i];
+    if (s != 0) stamps[i] = s > keep_from ? s - keep_from + 1u : 1u;
   }
 }
 
@@ -713,6 +732,14 @@ hipError_t LaunchCacheClear(int64_t* d_keys, uint32_t* d_stamps, uint64_t slots,
   if (want > 4096) want = 4096;
   if (want == 0) want = 1;
   hipLaunchKernelGGL(hps_cache_clear_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_keys, d_stamps, slots);
+  return hipGetLastError();
+}
+
+hipError_t LaunchCacheRenorm(uint32_t* d_stamps, uint64_t slots, uint32_t keep_from, hipStream_t stream) {
+  uint64_t want = (slots + 255) / 256;
+  if (want > 4096) want = 4096;
+  if (want == 0) want = 1;
+  hipLaunchKernelGGL(hps_cache_renorm_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_stamps, slots, keep_from);
   return hipGetLastError();
 }
 

@@ -165,6 +165,24 @@ Status HierParameterServer::create_from_config(const ParameterServerConfig& cfg,
     return Error(Code::kUnsupported,
                  "supportlonglong=false: only 64-bit keys are supported (as in the reference backend, "
                  "model_state.cpp:213-218, hps.cc:573)");
+  // Tiers this build does not have must not be configured silently away: a model that relies on a Redis cluster
+  // or on RocksDB for rows the host tier does not hold would quietly serve default vectors.
+  if (cfg.volatile_db.type == DatabaseType::RedisCluster)
+    return Error(Code::kUnsupported, "volatile_db.type = redis_cluster is not implemented in this build "
+                                     "(available: hash_map, parallel_hash_map: the in-process host tier)");
+  if (cfg.volatile_db.type == DatabaseType::Disabled || cfg.volatile_db.type == DatabaseType::RocksDB)
+    return Error(Code::kUnsupported, "volatile_db.type = ", ToString(cfg.volatile_db.type),
+                 ": the in-process host tier (hash_map / parallel_hash_map) is the only volatile database of this build");
+  if (cfg.persistent_db.type != DatabaseType::Disabled)
+    return Error(Code::kUnsupported, "persistent_db.type = ", ToString(cfg.persistent_db.type),
+                 " is not implemented in this build; every table is held completely by the host tier "
+                 "(set persistent_db.type to 'disabled')");
+  if (cfg.update_source.type != UpdateSourceType::Null)
+    return Error(Code::kUnsupported, "update_source.type = ", ToString(cfg.update_source.type),
+                 " (Kafka online updates) is not implemented in this build");
+  if (cfg.volatile_db.initial_cache_rate < 1.0)
+    return Error(Code::kUnsupported, "volatile_db.initial_cache_rate = ", cfg.volatile_db.initial_cache_rate,
+                 " < 1 needs a persistent database behind the host tier, which this build does not have");
   HPS_RETURN_IF_ERROR(ps->Build(load_tables));
   *out = std::move(ps);
   return Status::Ok();

@@ -185,6 +185,7 @@ TRITONSERVER_Error* ExecuteOne(ModelInstanceState* instance_state, ModelState* m
   HPS_TRITON_LOG(VERBOSE, "*****Processing request on device***** ", instance_state->DeviceId(), " for model ",
                  instance_state->Name());
   *exec_start_ns = NowNs();
+  HPS_ROCTX_RANGE(roctx_process, "ProcessRequest " + instance_state->Name());           // hps.cc:671
   RETURN_IF_ERROR(instance_state->ProcessRequest(reinterpret_cast<const int64_t*>(key_data), keys_on_device,
                                                  num_keys_per_table, reinterpret_cast<float*>(output_buffer), out_on_device,
                                                  (size_t)output_buffer_size));
@@ -351,6 +352,7 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInstanceExecute(TRITONBACKEND_ModelInstan
   ModelState* model_state = instance_state->StateForModel();
   HPS_TRITON_LOG(VERBOSE, "model ", model_state->Name(), ", instance ", instance_state->Name(), ", executing ",
                  request_count, " requests");
+  HPS_ROCTX_RANGE(roctx_execute, "ModelInstanceExecute " + instance_state->Name());     // hps.cc:375
 
   // one response object per request; failing here fails the whole call (hps.cc:381-390)
   std::vector<TRITONBACKEND_Response*> responses;

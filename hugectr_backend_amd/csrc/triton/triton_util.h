@@ -32,6 +32,28 @@ inline uint64_t NowNs() {
              std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// roctx ranges where the reference has NVTX ranges (NVTX_RANGE at hps.cc:375,671,674,701 and
+// model_instance_state.cpp:179; compile-time opt-in there via TRITON_ENABLE_NVTX, CMakeLists.txt:45,102-104).
+// Here: run-time opt-in — HPS_ENABLE_ROCTX=1 resolves roctxRangePushA/Pop from librocprofiler-sdk-roctx.so (or
+// libroctx64.so) once; without it a range costs one predictable branch.  The ranges show up in
+// `rocprofv3 --marker-trace`.
+class RoctxRange {
+ public:
+  explicit RoctxRange(const std::string& name) {
+    const Api& a = api();
+    if (a.push) { a.push(name.c_str()); active_ = true; }
+  }
+  ~RoctxRange() { if (active_) api().pop(); }
+  RoctxRange(const RoctxRange&) = delete;
+  RoctxRange& operator=(const RoctxRange&) = delete;
+
+ private:
+  struct Api { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+  static const Api& api();
+  bool active_ = false;
+};
+#define HPS_ROCTX_RANGE(VAR, NAME) ::hps::triton::RoctxRange VAR(NAME)
+
 #define HPS_TRITON_LOG(LEVEL, ...) \
   ::hps::triton::LogMessage(TRITONSERVER_LOG_##LEVEL, __FILE__, __LINE__, ::hps::StrCat(__VA_ARGS__))
 

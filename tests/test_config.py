@@ -89,9 +89,34 @@ def test_cache_keys_are_optional_without_gpu_cache_and_supportlonglong_is_mandat
 @pytest.mark.parametrize("alias", ["hash_map", "hashmap", "hash", "map", "parallel_hash_map", "parallel-hashmap",
                                    "Parallel Hash", "redis_cluster", "redis", "rocks_db", "rocksdb", "disabled", "none"])
 def test_database_type_aliases(alias):
+    from hugectr_backend_amd import hps
     cfg = ps_config("m", _tables(), gpucache=False)
     cfg["volatile_db"]["type"] = alias   # triton_helpers.cpp:190-242 (space/dash -> underscore, lower case)
-    _mk(cfg)
+    canonical = {"redis": "redis_cluster", "rocks": "rocks_db", "disab": "disabled", "none": "disabled"}
+    want = next((v for k, v in canonical.items() if alias.lower().startswith(k)), None)
+    if want is None:
+        _mk(cfg)  # the in-process host tier
+    else:
+        # the alias parses to the right enum, and a tier this build does not have is refused, not ignored
+        with pytest.raises(hps.HpsError) as e:
+            _mk(cfg)
+        assert e.value.code == hps.ERR_UNSUPPORTED and want in e.value.msg
+
+
+def test_unimplemented_tiers_are_refused_loudly():
+    from hugectr_backend_amd import hps
+    base = ps_config("m", _tables(), gpucache=False)
+    for patch, needle in [({"persistent_db": {"type": "rocksdb", "path": "/tmp/x"}}, "persistent_db"),
+                          ({"update_source": {"type": "kafka", "brokers": "h:9092"}}, "update_source"),
+                          ({"volatile_db": {"type": "hash_map", "initial_cache_rate": 0.5}}, "initial_cache_rate")]:
+        cfg = copy.deepcopy(base)
+        cfg.update(patch)
+        with pytest.raises(hps.HpsError) as e:
+            _mk(cfg)
+        assert e.value.code == hps.ERR_UNSUPPORTED and needle in e.value.msg
+    ok = copy.deepcopy(base)
+    ok["persistent_db"] = {"type": "disabled"}
+    _mk(ok)
 
 
 def test_bad_enums_and_list_lengths_are_rejected():

@@ -251,3 +251,41 @@ def test_refresh_embedding_cache_picks_up_new_values():
     ps.refresh_embedding_cache("refresh", 0)
     out2 = s.lookup(q, [512]).cpu().numpy().reshape(512, 16)
     assert np.array_equal(_bits(out2), _bits(rows2[:512]))
+
+
+def test_refresh_drops_keys_that_left_the_parameter_server():
+    """After a model update that removed keys, a cache refresh must not keep serving their stale rows."""
+    from oracle import hps_oracle as O
+    tables = make_tables([(1000, 16)])
+    keys, rows = tables[0]
+    ps, cache, s = _mk("vanish", tables, maxcat=[1], gpucacheper=1.0, defaults=[9.0], max_batch=2048)
+    q = keys[:600].copy()
+    out = s.lookup(q, [600]).cpu().numpy()
+    assert np.array_equal(_bits(out), _bits(rows[:600].ravel()))
+    keep = np.ones(keys.size, bool)
+    keep[100:300] = False                                   # 200 keys disappear from the new model version
+    ps.load_table_arrays("vanish", 0, keys[keep], rows[keep])
+    ps.refresh_embedding_cache("vanish", 0)
+    assert (cache.query(0, keys[100:300]) < 0).all()        # evicted from the device cache
+    out2 = s.lookup(q, [600]).cpu().numpy()
+    ref = O.np_lookup([(keys[keep], rows[keep])], q, [600], [9.0])
+    assert np.array_equal(_bits(out2), _bits(ref))
+    assert (out2.reshape(600, 16)[100:300] == 9.0).all()
+
+
+def test_lru_epoch_renormalisation(monkeypatch):
+    """The 32-bit LRU epoch counter is folded back long before it wraps; results stay exact across the fold."""
+    from oracle import hps_oracle as O
+    monkeypatch.setenv("HPS_TEST_EPOCH_START", str(0xF0000000 - 4))
+    rng = np.random.default_rng(8)
+    tables = make_tables([(20000, 32)])
+    ps, cache, s = _mk("renorm", tables, maxcat=[1], gpucacheper=0.02, max_batch=4096)
+    monkeypatch.delenv("HPS_TEST_EPOCH_START")
+    co = O.COracle()
+    co.add_table_arrays(*tables[0])
+    inserted_before = cache.counters()["inserted"]
+    for it in range(10):                                    # crosses 0xF0000000 at the 4th call
+        q = _queries(rng, tables, [4096], miss_frac=0.02)
+        out = s.lookup(q, [4096]).cpu().numpy()
+        assert np.array_equal(_bits(out), _bits(co.lookup(q, [4096], [0.0]))), it
+    assert cache.counters()["inserted"] > inserted_before  # eviction/insertion keeps working after the fold
