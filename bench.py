@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--distinct-batches", type=int, default=0,
                     help="0: one fresh batch per step (warmup+steps distinct batches)")
     ap.add_argument("--unroll", type=int, default=1102, help="probe+gather kernel variant (tools/kbench.py)")
+    ap.add_argument("--direct", type=int, default=1,
+                    help="1: ps_direct_access (the GPU resolves misses itself out of pinned host memory); "
+                         "0: host threads gather the missed rows (the reference's arrangement)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
@@ -180,16 +183,46 @@ def main():
             "gpucache": True,
             "gpucacheper": a.cache_frac,
             "hit_rate_threshold": 1.0 if a.mode == "sync" else 0.5,
+            "ps_direct_access": bool(a.direct),
         }],
     }
-    t_setup = time.time()
-    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
-    for t in range(T):
-        ps.load_table_synthetic(model, t, SEED, 0, R)
-    t_tables = time.time() - t_setup
-    ps.create_embedding_cache_per_model(model)
-    cache = ps.get_embedding_cache(model, local_rank)
-    t_cache = time.time() - t_setup - t_tables
+    def setup():
+        t_setup = time.time()
+        ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+        for t in range(T):
+            ps.load_table_synthetic(model, t, SEED, 0, R)
+        t_tables = time.time() - t_setup
+        ps.create_embedding_cache_per_model(model)
+        cache = ps.get_embedding_cache(model, local_rank)
+        t_cache = time.time() - t_setup - t_tables
+        return ps, cache, t_tables, t_cache
+
+    # ps_direct_access pins the whole host tier (hipHostMalloc).  Where the box refuses that much page-locked
+    # memory, every rank falls back to the host-gather tier of the same library (never to a CPU path) and the
+    # result line says so in config.ps_tier.
+    direct_note = None
+    made = None
+    if a.direct:
+        try:
+            made = setup()
+        except Exception as e:  # noqa: BLE001
+            direct_note = f"ps_direct_access unavailable on this box ({str(e)[:160]})"
+            sys.stderr.write(f"[bench rank {rank}] {direct_note}; falling back to the host-gather tier\n")
+        ok = 1 if made is not None else 0
+        if world > 1:
+            okt = torch.tensor([ok], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = int(okt.item())
+        if not ok:
+            made = None
+            import gc
+            gc.collect()
+            a.direct = 0
+            cfg["models"][0]["ps_direct_access"] = False
+            direct_note = direct_note or "ps_direct_access unavailable on another rank"
+    if made is None:
+        made = setup()
+    ps, cache, t_tables, t_cache = made
     sessions = [hps.LookupSession.create(ps, model, cache) for _ in range(a.sessions)]
     for s in sessions:
         s.set_option("timing", 1)
@@ -267,7 +300,7 @@ def main():
     # ---- extra legs (outside the timed region; per-GPU numbers of this rank) --------------------------------
     extra = {}
     main_lat, main_kern, main_miss, main_phases = list(lat_ms), list(kern_ms), list(miss_ct), list(phases)
-    if not a.no_extra_legs:
+    if not a.no_extra_legs and world == 1:  # informational legs: single-GPU run only
         def leg(batches, steps, sess_list):
             lat_ms.clear(); kern_ms.clear(); miss_ct.clear(); phases.clear()
             saved = sessions[:]
@@ -403,6 +436,8 @@ def main():
                             f"zipf {a.zipf} within the resident set, "
                             f"{a.mode} insert, {a.sessions} lookup sessions, keys resident in HBM",
                 "parallelism": "replicas" if world > 1 else "single",
+                "ps_tier": "device-driven (ps_direct_access)" if a.direct else
+                           ("host gather" + (f" [{direct_note}]" if direct_note else "")),
             },
             "p50_batch_latency_ms": float(np.percentile(lat_ms, 50)) if lat_ms else None,
             "p99_batch_latency_ms": float(np.percentile(lat_ms, 99)) if lat_ms else None,
@@ -419,6 +454,10 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": k_ms,
+                # `frac` is measured inside the timed region, where the kernel shares the chip with the other
+                # session's PCIe fetch / dedup / insert kernels; the same kernel with nothing underneath
+                # (all-hit leg, one session) is reported next to it
+                "frac_kernel_alone": (extra.get("all_hit_one_session") or {}).get("kernel_frac_of_hbm_peak"),
             },
             "mean_phase_ms": dict(zip(["probe_gather_dedup_until_counts", "host_ps_gather", "h2d_scatter_insert", "call"],
                                       [float(x) for x in np.mean(np.array(phases), axis=0)])) if phases else None,

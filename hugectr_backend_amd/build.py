@@ -35,6 +35,7 @@ ENGINE_SRCS = [
     "ps/host_table.cpp",
     "cache/kernels.hip",
     "cache/shard_kernels.hip",
+    "cache/direct_kernels.hip",
     "cache/engine.cpp",
     "cache/parameter_server.cpp",
 ]

@@ -64,6 +64,10 @@ void EmbeddingCache::Release() {
   (void)hipSetDevice(cfg_.device_id_);
   (void)hipDeviceSynchronize();
   FreeInserter();
+  for (auto& m : index_mem_) { if (m.first) (void)hipFree(m.first); if (m.second) (void)hipFree(m.second); }
+  index_mem_.clear();
+  if (d_index_) (void)hipFree(d_index_);
+  d_index_ = nullptr;
   for (void* p : allocations_) (void)hipFree(p);
   allocations_.clear();
   if (d_tables_) (void)hipFree(d_tables_);
@@ -121,6 +125,20 @@ void EmbeddingCache::ForgetReader(hipEvent_t reader_done) {
   std::lock_guard<std::mutex> lk(order_mu_);
   readers_.erase(std::remove(readers_.begin(), readers_.end(), reader_done), readers_.end());
   if (last_reader_ == reader_done) { last_reader_ = nullptr; last_reader_stream_ = nullptr; }
+}
+void EmbeddingCache::BeginFetch(hipStream_t stream) {
+  fetch_mu_.lock();
+  if (last_fetch_ != nullptr && last_fetch_stream_ != stream) (void)hipStreamWaitEvent(stream, last_fetch_, 0);
+}
+void EmbeddingCache::EndFetch(hipStream_t stream, hipEvent_t fetch_done) {
+  (void)hipEventRecord(fetch_done, stream);
+  last_fetch_ = fetch_done;
+  last_fetch_stream_ = stream;
+  fetch_mu_.unlock();
+}
+void EmbeddingCache::ForgetFetch(hipEvent_t fetch_done) {
+  std::lock_guard<std::mutex> lk(fetch_mu_);
+  if (last_fetch_ == fetch_done) { last_fetch_ = nullptr; last_fetch_stream_ = nullptr; }
 }
 void EmbeddingCache::BeginWrite(hipStream_t stream) {
   order_mu_.lock();
@@ -184,6 +202,13 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   HPS_RETURN_IF_ERROR(DevAlloc(&d_tables_, T));
   HIP_TRY(hipMemcpy(d_tables_, h_tables_.data(), T * sizeof(TableCacheDev), hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
+  if (p.ps_direct_access) {
+    for (size_t t = 0; t < T; ++t)
+      if (!tables[t]->pinned())
+        return Error(Code::kInternal, "ps_direct_access: table ", t, " of model '", model, "' is not in pinned host memory");
+    direct_ = true;
+    HPS_RETURN_IF_ERROR(SyncDirectIndex(tables));
+  }
 
   if (!p.init_ec) return Status::Ok();
 
@@ -266,6 +291,60 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   return st;
 }
 
+Status EmbeddingCache::SyncDirectIndex(const std::vector<std::shared_ptr<HostTable>>& tables) {
+  if (!direct_) return Status::Ok();
+  const size_t T = tables.size();
+  if (T != num_tables()) return Error(Code::kInvalidArg, "SyncDirectIndex: table count mismatch");
+  HIP_TRY(hipSetDevice(cfg_.device_id_));
+  if (h_index_.size() != T) {
+    h_index_.assign(T, PsIndexDev{});
+    index_generation_.assign(T, ~0ull);
+    index_mem_.assign(T, {nullptr, nullptr});
+  }
+  uint32_t* d_sent = nullptr;
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_sent, 2));
+  bool changed = false;
+  for (size_t t = 0; t < T; ++t) {
+    const HostTable& ht = *tables[t];
+    if (!ht.pinned()) { (void)hipFree(d_sent); return Error(Code::kInternal, "ps_direct_access: table ", t, " is not pinned"); }
+    if (index_generation_[t] == ht.generation()) continue;
+    changed = true;
+    HIP_TRY(hipDeviceSynchronize());
+    if (index_mem_[t].first) (void)hipFree(index_mem_[t].first);
+    if (index_mem_[t].second) (void)hipFree(index_mem_[t].second);
+    index_mem_[t] = {nullptr, nullptr};
+    const uint64_t R = ht.size();
+    uint64_t cap = 16;
+    while (cap < 2 * R) cap <<= 1;
+    int64_t* dk = nullptr; uint32_t* dr = nullptr;
+    HPS_RETURN_IF_ERROR(DevAlloc(&dk, cap));
+    HPS_RETURN_IF_ERROR(DevAlloc(&dr, cap));
+    index_mem_[t] = {dk, dr};
+    void* keys_dev = nullptr; void* rows_dev = nullptr;
+    if (R) {
+      HIP_TRY(hipHostGetDevicePointer(&keys_dev, (void*)ht.keys(), 0));
+      HIP_TRY(hipHostGetDevicePointer(&rows_dev, (void*)ht.row_at(0), 0));
+    }
+    HIP_TRY(hipMemset(d_sent, 0, 2 * sizeof(uint32_t)));
+    HIP_TRY(LaunchPsIndexBuild((const int64_t*)keys_dev, R, dk, dr, cap, d_sent, nullptr));
+    uint32_t sent[2] = {0, 0};
+    HIP_TRY(hipMemcpy(sent, d_sent, sizeof sent, hipMemcpyDeviceToHost));
+    PsIndexDev& ix = h_index_[t];
+    ix.keys = dk; ix.rows = dr; ix.mask = cap - 1;
+    ix.host_rows = (const float*)rows_dev;
+    ix.dim = ht.dim();
+    ix.has_sentinel = sent[0];
+    ix.sentinel_row = sent[1];
+    ix.default_value = cfg_.default_value_[t];
+    index_generation_[t] = ht.generation();
+  }
+  (void)hipFree(d_sent);
+  if (!d_index_) HPS_RETURN_IF_ERROR(DevAlloc(&d_index_, T));
+  if (changed) HIP_TRY(hipMemcpy(d_index_, h_index_.data(), T * sizeof(PsIndexDev), hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  return Status::Ok();
+}
+
 Status EmbeddingCache::Query(uint32_t table, const int64_t* h_keys, size_t n, int32_t* h_slots) {
   if (table >= num_tables()) return Error(Code::kInvalidArg, "table index out of range");
   if (n == 0) return Status::Ok();
@@ -303,6 +382,7 @@ void LookupSession::Release() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   cache_->ForgetReader(ev_read_);  // our reader event may still be registered with the cache
+  cache_->ForgetFetch(ev_fetch_);
   auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
   auto dfree = [](void* p) { if (p) (void)hipFree(p); };
   hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_call_); dfree(d_call_); hfree(h_md_); dfree(d_md_);
@@ -310,6 +390,7 @@ void LookupSession::Release() {
   dfree(d_uniq_keys_); hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
   if (ev_done_) (void)hipEventDestroy(ev_done_);
   if (ev_read_) (void)hipEventDestroy(ev_read_);
+  if (ev_fetch_) (void)hipEventDestroy(ev_fetch_);
   if (ev_t0_) (void)hipEventDestroy(ev_t0_);
   if (ev_t1_) (void)hipEventDestroy(ev_t1_);
   if (ev_copy_) (void)hipEventDestroy(ev_copy_);
@@ -341,6 +422,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HIP_TRY(hipEventCreateWithFlags(&ev_copy_, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ev_read_, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ev_fetch_, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&ev_t0_));
   HIP_TRY(hipEventCreate(&ev_t1_));
 
@@ -364,32 +446,50 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   void* dv = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&dv, h_uniq_keys_, 0));
   h_uniq_keys_devptr_ = (int64_t*)dv;
+  if (cache_->direct()) {
+    // the device sizes the staging layout itself (hps_missdesc_build), so the buffer must hold the worst case:
+    // every key of a full batch missing.  Device memory only — no pinned host staging in this mode.
+    size_t worst = 4 * T;
+    for (size_t t = 0; t < T; ++t)
+      worst += p.max_batchsize * p.maxnum_catfeature_query_per_table_per_sample[t] * (size_t)tables_[t]->dim();
+    HPS_RETURN_IF_ERROR(DevAlloc(&d_staging_, worst));
+    HPS_RETURN_IF_ERROR(DevAlloc(&d_found_, max_keys_));
+    staging_floats_ = worst;
+    staging_uniq_ = max_keys_;
+  }
   HIP_TRY(hipDeviceSynchronize());
   return Status::Ok();
 }
 
 Status LookupSession::EnsureStaging(size_t floats, size_t uniq) {
-  if (floats > staging_floats_) {
+  if (floats > staging_floats_ || (!h_staging_ && floats > 0)) {
     HIP_TRY(hipStreamSynchronize(stream_));
     if (h_staging_) (void)hipHostFree(h_staging_);
-    if (d_staging_) (void)hipFree(d_staging_);
-    h_staging_ = nullptr; d_staging_ = nullptr;
-    size_t want = std::max(floats, staging_floats_ * 2);
-    want = std::max<size_t>(want, 1u << 16);
-    HPS_RETURN_IF_ERROR(PinAlloc(&h_staging_, want));
-    HPS_RETURN_IF_ERROR(DevAlloc(&d_staging_, want));
-    staging_floats_ = want;
+    h_staging_ = nullptr;
+    size_t want = std::max(floats, staging_floats_);
+    if (floats > staging_floats_) {
+      if (d_staging_) (void)hipFree(d_staging_);
+      d_staging_ = nullptr;
+      want = std::max(floats, staging_floats_ * 2);
+      want = std::max<size_t>(want, 1u << 16);
+      HPS_RETURN_IF_ERROR(DevAlloc(&d_staging_, want));
+      staging_floats_ = want;
+    }
+    HPS_RETURN_IF_ERROR(PinAlloc(&h_staging_, staging_floats_));
   }
-  if (uniq > staging_uniq_) {
+  if (uniq > staging_uniq_ || (!h_found_ && uniq > 0)) {
     HIP_TRY(hipStreamSynchronize(stream_));
     if (h_found_) (void)hipHostFree(h_found_);
-    if (d_found_) (void)hipFree(d_found_);
-    h_found_ = nullptr; d_found_ = nullptr;
-    size_t want = std::max(uniq, staging_uniq_ * 2);
-    want = std::max<size_t>(want, 1u << 12);
-    HPS_RETURN_IF_ERROR(PinAlloc(&h_found_, want));
-    HPS_RETURN_IF_ERROR(DevAlloc(&d_found_, want));
-    staging_uniq_ = want;
+    h_found_ = nullptr;
+    if (uniq > staging_uniq_) {
+      if (d_found_) (void)hipFree(d_found_);
+      d_found_ = nullptr;
+      size_t want = std::max(uniq, staging_uniq_ * 2);
+      want = std::max<size_t>(want, 1u << 12);
+      HPS_RETURN_IF_ERROR(DevAlloc(&d_found_, want));
+      staging_uniq_ = want;
+    }
+    HPS_RETURN_IF_ERROR(PinAlloc(&h_found_, staging_uniq_));
   }
   return Status::Ok();
 }
@@ -452,6 +552,12 @@ Status LookupSession::LookupHostTier(const void* const* h_keys_per_table, float*
 
 Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
   // ---- call descriptor: the per-table slicing of ProcessRequest (model_instance_state.cpp:180-193) ----
+  // direct mode: no table reload may replace a pinned slab while our kernels read it
+  std::shared_lock<std::shared_mutex> direct_lock;
+  if (cache_->direct()) {
+    while (cache_->direct_writers().load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    direct_lock = std::shared_lock<std::shared_mutex>(cache_->direct_mutex());
+  }
   const auto tc0 = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
@@ -491,24 +597,35 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   e = LaunchMissDedup(d_call_, c.key_start, (uint32_t)T, probe_blocks, d_slot_, d_block_miss_, d_set_, set_cap_,
                       d_counts_, d_uniq_keys_, h_uniq_keys_devptr_, cu, stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "miss dedup launch failed: ", hipGetErrorString(e));
-  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, (1 + T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-  HIP_TRY(hipEventRecord(ev_done_, stream_));
-  HIP_TRY(hipEventSynchronize(ev_done_));
-  if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
-
-  const uint64_t misses = h_counts_[0];
-  uint64_t uniq = 0;
-  for (size_t t = 0; t < T; ++t) uniq += h_counts_[1 + t];
-  last_misses_ = misses;
-  last_unique_ = uniq;
   last_async_ = false;
-  {
+  auto account = [&]() {
+    const uint64_t misses = h_counts_[0];
+    uint64_t uniq = 0;
+    for (size_t t = 0; t < T; ++t) uniq += h_counts_[1 + t];
+    last_misses_ = misses;
+    last_unique_ = uniq;
     std::lock_guard<std::mutex> lk(cache_->stat_mu_);
     cache_->counters_.lookups += 1;
     cache_->counters_.keys += N;
     cache_->counters_.misses += misses;
     cache_->counters_.unique_misses += uniq;
+  };
+  if (cache_->direct() && params_.hit_rate_threshold >= 1.0f) {
+    // Device-driven miss path with the insertion policy fixed to "synchronous": nothing on the host depends
+    // on the miss counts, so the whole call is enqueued without a round trip and the counts come back at the end.
+    const Status st = HandleMissesDirect(N, epoch, /*counts_known=*/false);
+    if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
+    if (st.ok()) account();
+    phase_ms_[3] = ms_since(tc0);
+    phase_ms_[2] = phase_ms_[3];
+    return st;
   }
+  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, (1 + T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipEventRecord(ev_done_, stream_));
+  HIP_TRY(hipEventSynchronize(ev_done_));
+  if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
+  account();
+  const uint64_t misses = h_counts_[0];
   phase_ms_[0] = phase_ms_[3] = ms_since(tc0);
   if (misses == 0) return Status::Ok();
 
@@ -531,10 +648,42 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     cache_->counters_.async_calls += 1;
     return Status::Ok();
   }
-  const Status st = HandleMisses(N, epoch);
+  const Status st = cache_->direct() ? HandleMissesDirect(N, epoch, /*counts_known=*/true) : HandleMisses(N, epoch);
   phase_ms_[3] = ms_since(tc0);
   phase_ms_[2] = phase_ms_[3] - phase_ms_[0] - phase_ms_[1];
   return st;
+}
+
+// Synchronous miss path, device-driven ("ps_direct_access"): the GPU resolves the unique missed keys through the
+// device-resident index of the host tier and pulls the rows out of pinned host memory itself.
+Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts_known) {
+  const size_t T = tables_.size();
+  const int cu = cache_->cu_count();
+  const uint64_t max_unique = counts_known ? (uint64_t)last_unique_ : N;
+  HIP_TRY(hipMemsetAsync(d_counts_ + kMaxTables + 1, 0, 4 * sizeof(uint32_t), stream_));
+  hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, stream_);
+  if (e == hipSuccess) {
+    cache_->BeginFetch(stream_);
+    e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, d_uniq_keys_, d_staging_,
+                            d_found_, max_unique, cu, stream_);
+    cache_->EndFetch(stream_, ev_fetch_);
+  }
+  if (e == hipSuccess) e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, N, d_slot_, d_staging_, cu, stream_);
+  if (e != hipSuccess) return Error(Code::kInternal, "direct miss path launch failed: ", hipGetErrorString(e));
+  // keep the window in which other sessions' probes wait for our writer event down to the insert kernel
+  HIP_TRY(hipStreamSynchronize(stream_));
+  cache_->BeginWrite(stream_);
+  e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, max_unique, d_call_->key_start, d_uniq_keys_,
+                        d_staging_, d_found_, epoch, d_counts_ + kMaxTables + 1, cu, stream_);
+  cache_->EndWrite(stream_);
+  if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kMaxTables + 5) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipStreamSynchronize(stream_));
+  std::lock_guard<std::mutex> lk(cache_->stat_mu_);
+  cache_->counters_.dropped += h_counts_[kMaxTables + 1];
+  cache_->counters_.inserted += h_counts_[kMaxTables + 2];
+  cache_->counters_.refreshed += h_counts_[kMaxTables + 3];
+  return Status::Ok();
 }
 
 // Synchronous miss path: parameter-server gather of the unique missed keys into pinned staging,

@@ -13,6 +13,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -25,6 +26,9 @@
 #include "../ps/host_table.h"
 #include "../ps/thread_pool.h"
 #include "device_types.h"
+#include "direct_kernels.h"
+
+#include <shared_mutex>
 
 namespace hps {
 
@@ -93,6 +97,12 @@ class EmbeddingCache {
   void BeginWrite(hipStream_t stream);                      // stream waits for last writer + all readers
   void EndWrite(hipStream_t stream);                        // records the writer event
   void ForgetReader(hipEvent_t reader_done);                // a session is going away: drop its event
+  // ps_direct_access: one PCIe fetch kernel at a time per cache.  The link is the bottleneck of the miss path;
+  // two fetches side by side only share it, while queued behind each other they alternate and every session
+  // does its HBM work (probe, dedup, scatter, insert) under the other session's fetch.
+  void BeginFetch(hipStream_t stream);
+  void EndFetch(hipStream_t stream, hipEvent_t fetch_done);
+  void ForgetFetch(hipEvent_t fetch_done);
   uint32_t NextEpoch();
 
   std::string model_;
@@ -109,10 +119,35 @@ class EmbeddingCache {
   std::vector<hipEvent_t> readers_;
   hipEvent_t last_reader_ = nullptr;        // most recent probe/gather of any session (probes are chained)
   hipStream_t last_reader_stream_ = nullptr;
+  std::mutex fetch_mu_;
+  hipEvent_t last_fetch_ = nullptr;         // most recent direct PCIe fetch of any session (fetches are chained)
+  hipStream_t last_fetch_stream_ = nullptr;
   std::atomic<uint32_t> epoch_{1};
 
   mutable std::mutex stat_mu_;
   CacheCounters counters_;
+
+  // ---- device-driven parameter-server tier ("ps_direct_access", direct_kernels.hip) ----
+ public:
+  bool direct() const { return direct_; }
+  const PsIndexDev* device_index() const { return d_index_; }
+  // (re)build the device index of every table whose host copy changed since the last build
+  Status SyncDirectIndex(const std::vector<std::shared_ptr<HostTable>>& tables);
+  // lookups hold this shared for the duration of a call; a table reload takes it exclusively, so that no kernel
+  // is reading a pinned slab while it is being replaced
+  std::shared_mutex& direct_mutex() { return direct_mu_; }
+  // a pending reload holds new lookups at the door (glibc's rwlock prefers readers: overlapping sessions would
+  // starve the writer otherwise)
+  std::atomic<int>& direct_writers() { return direct_writers_; }
+
+ private:
+  bool direct_ = false;
+  std::atomic<int> direct_writers_{0};
+  std::vector<PsIndexDev> h_index_;
+  PsIndexDev* d_index_ = nullptr;
+  std::vector<uint64_t> index_generation_;
+  std::vector<std::pair<void*, void*>> index_mem_;  // per table: device keys[], rows[]
+  std::shared_mutex direct_mu_;
 
   struct Inserter;  // stream + staging of the background insert path
   Inserter* ins_ = nullptr;
@@ -163,6 +198,7 @@ class LookupSession {
                         const size_t* num_keys_per_table, size_t num_tables);
   Status LookupDevice(const int64_t* d_keys_flat, float* const* d_vectors_per_table, const size_t* n, size_t T);
   Status HandleMisses(uint64_t N, uint32_t epoch);
+  Status HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts_known);
   Status EnsureStaging(size_t floats, size_t uniq);
   void Release();
 
@@ -174,7 +210,7 @@ class LookupSession {
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;  // second H2D queue for the missed-row pieces
   hipEvent_t ev_copy_ = nullptr;
-  hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr;
+  hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr;
 
   size_t max_keys_ = 0;           // max_batch * sum(maxnum_catfeature)
   int64_t* h_keys_pinned_ = nullptr;
@@ -269,6 +305,7 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   HierParameterServer() = default;
   Status Build(bool load_tables);
   Status EnsureTables(const InferenceParams& p, bool load);
+  Status MutateTables(const std::string& model, const std::function<Status()>& fn);
 
   ParameterServerConfig cfg_;
   ThreadPool* pool_ = nullptr;

@@ -196,19 +196,63 @@ Status HierParameterServer::EnsureTables(const InferenceParams& p, bool load) {
     if (it != tables_.end()) tabs = it->second;
   }
   const size_t T = p.num_tables();
-  if (tabs.size() != T) {
+  // ps_direct_access: the tables live in device-mapped pinned memory so the GPU can read rows in place
+  bool pinned = false;
+  if (p.ps_direct_access && p.use_gpu_embedding_cache) {
+    int ndev = 0;
+    pinned = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+    if (!pinned) return Error(Code::kUnavailable, "model '", p.model_name, "': ps_direct_access needs a GPU");
+    (void)hipSetDevice(p.deployed_devices.empty() ? p.device_id : p.deployed_devices[0]);
+  }
+  const bool fresh = tabs.size() != T || (T && tabs[0]->pinned() != pinned);
+  if (fresh) {
     tabs.clear();
     for (size_t t = 0; t < T; ++t)
       tabs.emplace_back(std::make_shared<HostTable>(p.embedding_table_names[t],
                                                     (uint32_t)p.embedding_vecsize_per_table[t],
-                                                    p.volatile_db.num_partitions));
+                                                    p.volatile_db.num_partitions, pinned));
   }
   if (load) {
-    for (size_t t = 0; t < T; ++t) HPS_RETURN_IF_ERROR(tabs[t]->LoadFromDir(p.sparse_model_files[t], pool_));
+    HPS_RETURN_IF_ERROR(MutateTables(p.model_name, [&]() -> Status {
+      for (size_t t = 0; t < T; ++t) HPS_RETURN_IF_ERROR(tabs[t]->LoadFromDir(p.sparse_model_files[t], pool_));
+      return Status::Ok();
+    }));
   }
   std::lock_guard<std::mutex> lk(mu_);
   tables_[p.model_name] = tabs;
   return Status::Ok();
+}
+
+// Runs a table mutation.  Caches in ps_direct_access mode read the host tier from the device, so their
+// lookups are fenced out (exclusive side of the cache's direct mutex) while rows move, and their device
+// index of the tier is rebuilt before lookups resume.
+Status HierParameterServer::MutateTables(const std::string& model, const std::function<Status()>& fn) {
+  std::vector<std::shared_ptr<EmbeddingCache>> direct;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto& kv : caches_)
+      if (kv.first.first == model && kv.second->direct()) direct.push_back(kv.second);
+  }
+  std::vector<std::unique_lock<std::shared_mutex>> locks;
+  for (auto& c : direct) {
+    c->direct_writers().fetch_add(1, std::memory_order_acq_rel);
+    c->WaitAsync();
+    locks.emplace_back(c->direct_mutex());
+  }
+  struct Release {
+    std::vector<std::shared_ptr<EmbeddingCache>>& v;
+    ~Release() { for (auto& c : v) c->direct_writers().fetch_sub(1, std::memory_order_acq_rel); }
+  } release{direct};
+  Status st = fn();
+  if (st.ok()) {
+    auto tabs = tables_of(model);
+    for (auto& c : direct) {
+      if (tabs.size() != c->num_tables()) continue;
+      Status s2 = c->SyncDirectIndex(tabs);
+      if (!s2.ok()) { st = s2; break; }
+    }
+  }
+  return st;
 }
 
 Status HierParameterServer::Build(bool load_tables) {
@@ -343,14 +387,14 @@ Status HierParameterServer::load_table_from_arrays(const std::string& model, siz
                                                    const float* rows, size_t R, bool borrow) {
   auto tabs = tables_of(model);
   if (table >= tabs.size()) return Error(Code::kNotFound, "model '", model, "' has no table ", table);
-  return tabs[table]->LoadFromArrays(keys, rows, R, borrow, pool_);
+  return MutateTables(model, [&]() { return tabs[table]->LoadFromArrays(keys, rows, R, borrow, pool_); });
 }
 
 Status HierParameterServer::load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0,
                                                  size_t R) {
   auto tabs = tables_of(model);
   if (table >= tabs.size()) return Error(Code::kNotFound, "model '", model, "' has no table ", table);
-  return tabs[table]->LoadSynthetic(seed, (uint32_t)table, key0, R, pool_);
+  return MutateTables(model, [&]() { return tabs[table]->LoadSynthetic(seed, (uint32_t)table, key0, R, pool_); });
 }
 
 Status HierParameterServer::Fetch(const HostTable& tb, const int64_t* keys, size_t n, float* out, size_t stride,

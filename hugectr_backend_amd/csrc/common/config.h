@@ -99,6 +99,9 @@ struct InferenceParams {  // backend.cpp:318-516
 
   // --- additions of this build (MI355X engine knobs; all optional in ps.json) ---
   double cache_load_factor = 0.75;  // "gpucache_load_factor": slots = ceil(capacity / load_factor)
+  // "ps_direct_access": the GPU resolves missed keys through a device-resident index of the host tier and reads
+  // the rows in place from pinned host memory over PCIe (no host threads, no staging copy).  Needs gpucache.
+  bool ps_direct_access = false;
   size_t num_tables() const { return sparse_model_files.size(); }
 };
 

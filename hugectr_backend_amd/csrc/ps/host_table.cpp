@@ -1,6 +1,7 @@
 #include "host_table.h"
 
 #include <fcntl.h>
+#include <hip/hip_runtime_api.h>
 #include <immintrin.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -63,8 +64,24 @@ Status FileSize(const std::string& path, size_t* out) {
 
 }  // namespace
 
-HostTable::HostTable(std::string name, uint32_t dim, size_t num_partitions)
-    : name_(std::move(name)), dim_(dim) {
+void* HostTable::DataAlloc(size_t bytes) {
+  if (!pinned_) return SlabAlloc(bytes);
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void HostTable::DataFree(void* p) {
+  if (!p) return;
+  if (pinned_) (void)hipHostFree(p);
+  else free(p);
+}
+
+HostTable::HostTable(std::string name, uint32_t dim, size_t num_partitions, bool pinned)
+    : name_(std::move(name)), dim_(dim), pinned_(pinned) {
   if (num_partitions == 0) num_partitions = 1;
   for (size_t p = 0; p < num_partitions; ++p) parts_.emplace_back(new Partition());
   pow2_parts_ = (num_partitions & (num_partitions - 1)) == 0;
@@ -74,8 +91,8 @@ HostTable::~HostTable() { FreeAll(); }
 
 void HostTable::FreeAll() {
   for (auto& p : parts_) { free(p->slots); p->slots = nullptr; p->mask = 0; p->used.store(0); }
-  if (owns_keys_) free(keys_);
-  if (owns_rows_) free(rows_);
+  if (owns_keys_) DataFree(keys_);
+  if (owns_rows_) DataFree(rows_);
   keys_ = nullptr; rows_ = nullptr; num_rows_ = cap_rows_ = 0;
   owns_keys_ = owns_rows_ = false;
   has_sentinel_ = false; sentinel_row_ = -1; has_dups_ = false;
@@ -176,6 +193,7 @@ Status HostTable::BuildIndex(ThreadPool* pool) {
   size_t uniq = has_sentinel_ ? 1 : 0;
   for (auto& part : parts_) uniq += part->used.load();
   has_dups_ = uniq != R;
+  generation_.fetch_add(1, std::memory_order_acq_rel);
   return Status::Ok();
 }
 
@@ -191,8 +209,8 @@ Status HostTable::LoadFromDir(const std::string& dir, ThreadPool* pool) {
                  dim_, ") x 4; check embedding_vecsize_per_table");
   std::unique_lock<std::shared_mutex> lk(mu_);
   FreeAll();
-  keys_ = (int64_t*)SlabAlloc(kb);
-  rows_ = (float*)SlabAlloc(vb);
+  keys_ = (int64_t*)DataAlloc(kb);
+  rows_ = (float*)DataAlloc(vb);
   owns_keys_ = owns_rows_ = true;
   if (!keys_ || !rows_) return Error(Code::kInternal, "host table '", name_, "': out of memory (", kb + vb, " bytes)");
   num_rows_ = cap_rows_ = R;
@@ -204,12 +222,12 @@ Status HostTable::LoadFromDir(const std::string& dir, ThreadPool* pool) {
 Status HostTable::LoadFromArrays(const int64_t* keys, const float* rows, size_t R, bool borrow, ThreadPool* pool) {
   std::unique_lock<std::shared_mutex> lk(mu_);
   FreeAll();
-  if (borrow) {
+  if (borrow && !pinned_) {  // a pinned table always owns its (device-mapped) storage
     keys_ = const_cast<int64_t*>(keys);
     rows_ = const_cast<float*>(rows);
   } else {
-    keys_ = (int64_t*)SlabAlloc(R * sizeof(int64_t));
-    rows_ = (float*)SlabAlloc(R * (size_t)dim_ * sizeof(float));
+    keys_ = (int64_t*)DataAlloc(R * sizeof(int64_t));
+    rows_ = (float*)DataAlloc(R * (size_t)dim_ * sizeof(float));
     owns_keys_ = owns_rows_ = true;
     if (!keys_ || !rows_) return Error(Code::kInternal, "host table '", name_, "': out of memory");
     memcpy(keys_, keys, R * sizeof(int64_t));
@@ -245,8 +263,8 @@ __attribute__((target("avx512f,avx512dq"))) static uint32_t SynthRowAvx512(uint6
 Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, size_t R, ThreadPool* pool) {
   std::unique_lock<std::shared_mutex> lk(mu_);
   FreeAll();
-  keys_ = (int64_t*)SlabAlloc(R * sizeof(int64_t));
-  rows_ = (float*)SlabAlloc(R * (size_t)dim_ * sizeof(float));
+  keys_ = (int64_t*)DataAlloc(R * sizeof(int64_t));
+  rows_ = (float*)DataAlloc(R * (size_t)dim_ * sizeof(float));
   owns_keys_ = owns_rows_ = true;
   if (!keys_ || !rows_) return Error(Code::kInternal, "host table '", name_, "': out of memory");
   num_rows_ = cap_rows_ = R;
@@ -371,15 +389,15 @@ Status HostTable::Upsert(const int64_t* keys, const float* rows, size_t n) {
   const size_t newR = num_rows_ + fresh.size();
   if (newR > cap_rows_ || !owns_keys_ || !owns_rows_) {
     const size_t cap = std::max(newR, cap_rows_ + cap_rows_ / 2);
-    int64_t* nk = (int64_t*)SlabAlloc(cap * sizeof(int64_t));
-    float* nr = (float*)SlabAlloc(cap * (size_t)D * sizeof(float));
-    if (!nk || !nr) { free(nk); free(nr); return Error(Code::kInternal, "host table '", name_, "': out of memory"); }
+    int64_t* nk = (int64_t*)DataAlloc(cap * sizeof(int64_t));
+    float* nr = (float*)DataAlloc(cap * (size_t)D * sizeof(float));
+    if (!nk || !nr) { DataFree(nk); DataFree(nr); return Error(Code::kInternal, "host table '", name_, "': out of memory"); }
     if (num_rows_) {
       memcpy(nk, keys_, num_rows_ * sizeof(int64_t));
       memcpy(nr, rows_, num_rows_ * (size_t)D * sizeof(float));
     }
-    if (owns_keys_) free(keys_);
-    if (owns_rows_) free(rows_);
+    if (owns_keys_) DataFree(keys_);
+    if (owns_rows_) DataFree(rows_);
     keys_ = nk; rows_ = nr; owns_keys_ = owns_rows_ = true; cap_rows_ = cap;
   }
   for (size_t i : fresh) {

@@ -21,7 +21,12 @@ namespace hps {
 
 class HostTable {
  public:
-  HostTable(std::string name, uint32_t dim, size_t num_partitions);
+  // pinned: keys and rows live in page-locked, device-mapped host memory (hipHostMalloc) so that the GPU can
+  // read them in place over PCIe ("ps_direct_access": the miss path then needs no host threads at all).
+  HostTable(std::string name, uint32_t dim, size_t num_partitions, bool pinned = false);
+  bool pinned() const { return pinned_; }
+  // bumped by every (re)load / growing upsert: device-side indexes built from this table compare it
+  uint64_t generation() const { return generation_.load(std::memory_order_acquire); }
   ~HostTable();
   HostTable(const HostTable&) = delete;
   HostTable& operator=(const HostTable&) = delete;
@@ -64,6 +69,10 @@ class HostTable {
     std::atomic<size_t> used{0};
   };
   void FreeAll();
+  void* DataAlloc(size_t bytes);
+  void DataFree(void* p);
+  bool pinned_ = false;
+  std::atomic<uint64_t> generation_{0};
   Status BuildIndex(ThreadPool* pool);
   Status AllocPartitions(const std::vector<size_t>& counts);
   static uint64_t SlotOf(int64_t key, uint64_t mask);
