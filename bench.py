@@ -4,8 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One "step" = one pass of the lookup hot path over one batch of synthetic keys that already sit in HBM
-(26 tables x 65,536 keys): cache probe + hit gather (HIP), unique-miss extraction (HIP), host
-parameter-server gather of the missed rows, H2D of those rows, scatter + cache insert (HIP).
+(26 tables x 65,536 keys): cache probe + hit gather (HIP), unique-miss extraction (HIP), parameter-server
+fetch of the missed rows (default: the device-driven tier, a HIP kernel reading them out of pinned host
+memory; --direct 0: host-thread gather + H2D copy), scatter + cache insert (HIP).
 Results are the exact fp32 rows (sync-insert mode, hit_rate_threshold=1.0), checked against the CPU
 oracle on a slice of every run.
 
@@ -31,6 +32,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 SEED = 20260929
+PCIE_PEAK_GBS = 63.0   # MI355X_MICROARCH.md: PCIe Gen5 x16
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
@@ -249,7 +251,7 @@ def main():
     torch.cuda.synchronize()
 
     ncpu = effective_cpus()
-    lat_ms, kern_ms, miss_ct, phases = [], [], [], []
+    lat_ms, kern_ms, miss_ct, phases, uniq_ct = [], [], [], [], []
     lock = threading.Lock()
 
     def run_steps(count, record, first=0):
@@ -272,6 +274,7 @@ def main():
                         lat_ms.append(dt)
                         kern_ms.append(st.probe_gather_ms)
                         miss_ct.append(st.misses)
+                        uniq_ct.append(st.unique_misses)
                         phases.append([float(x) for x in st.phase_ms])
 
         th = [threading.Thread(target=worker, args=(si,)) for si in range(len(sessions))]
@@ -300,6 +303,7 @@ def main():
     # ---- extra legs (outside the timed region; per-GPU numbers of this rank) --------------------------------
     extra = {}
     main_lat, main_kern, main_miss, main_phases = list(lat_ms), list(kern_ms), list(miss_ct), list(phases)
+    main_uniq = list(uniq_ct)
     if not a.no_extra_legs and world == 1:  # informational legs: single-GPU run only
         def leg(batches, steps, sess_list):
             lat_ms.clear(); kern_ms.clear(); miss_ct.clear(); phases.clear()
@@ -412,6 +416,7 @@ def main():
         except Exception:
             pass
         k_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
+        fetch_ms = float(np.mean(np.array(phases)[:, 1])) if phases else 0.0
         alg_bytes = N * (8 + 8 * D)  # 8 B key + 4D row read + 4D row write per lookup
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         value = world * a.steps * N / elapsed
@@ -458,7 +463,19 @@ def main():
                 # session's PCIe fetch / dedup / insert kernels; the same kernel with nothing underneath
                 # (all-hit leg, one session) is reported next to it
                 "frac_kernel_alone": (extra.get("all_hit_one_session") or {}).get("kernel_frac_of_hbm_peak"),
+                # the read side alone, and both against the measured copy ceiling of the part
+                "read_only_frac": N * (8 + 4 * D) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+                "frac_of_copy_ceiling_6290": achieved / 6290.0,
             },
+            # the other leg of the synchronous path: the missed rows cross PCIe once each.  Device-driven tier:
+            # HIP-event time of hps_ps_fetch_direct_kernel; bytes = unique missed rows x 4*D.
+            "roofline_pcie": ({
+                "bound": "pcie", "kernel": "hps_ps_fetch_direct_kernel",
+                "achieved": float(np.mean(main_uniq)) * 4 * D / (fetch_ms * 1e-3) / 1e9,
+                "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                "frac": float(np.mean(main_uniq)) * 4 * D / (fetch_ms * 1e-3) / 1e9 / PCIE_PEAK_GBS,
+                "avg_kernel_ms": fetch_ms, "unique_missed_rows_per_batch": float(np.mean(main_uniq)),
+            } if a.direct and fetch_ms > 0 else None),
             "mean_phase_ms": dict(zip(["probe_gather_dedup_until_counts", "host_ps_gather", "h2d_scatter_insert", "call"],
                                       [float(x) for x in np.mean(np.array(phases), axis=0)])) if phases else None,
             "extra_legs": extra or None,

@@ -393,6 +393,8 @@ void LookupSession::Release() {
   if (ev_fetch_) (void)hipEventDestroy(ev_fetch_);
   if (ev_t0_) (void)hipEventDestroy(ev_t0_);
   if (ev_t1_) (void)hipEventDestroy(ev_t1_);
+  if (ev_f0_) (void)hipEventDestroy(ev_f0_);
+  if (ev_f1_) (void)hipEventDestroy(ev_f1_);
   if (ev_copy_) (void)hipEventDestroy(ev_copy_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -425,6 +427,8 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HIP_TRY(hipEventCreateWithFlags(&ev_fetch_, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&ev_t0_));
   HIP_TRY(hipEventCreate(&ev_t1_));
+  HIP_TRY(hipEventCreate(&ev_f0_));
+  HIP_TRY(hipEventCreate(&ev_f1_));
 
   HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_keys_, max_keys_));
@@ -617,7 +621,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
     if (st.ok()) account();
     phase_ms_[3] = ms_since(tc0);
-    phase_ms_[2] = phase_ms_[3];
+    phase_ms_[2] = phase_ms_[3];  // no host phases on this path; [1] holds the fetch kernel's GPU time
     return st;
   }
   HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, (1 + T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
@@ -664,8 +668,10 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, stream_);
   if (e == hipSuccess) {
     cache_->BeginFetch(stream_);
+    if (timing_) (void)hipEventRecord(ev_f0_, stream_);
     e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, d_uniq_keys_, d_staging_,
                             d_found_, max_unique, cu, stream_);
+    if (timing_) (void)hipEventRecord(ev_f1_, stream_);
     cache_->EndFetch(stream_, ev_fetch_);
   }
   if (e == hipSuccess) e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, N, d_slot_, d_staging_, cu, stream_);
@@ -679,6 +685,7 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
   HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kMaxTables + 5) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipStreamSynchronize(stream_));
+  if (timing_) (void)hipEventElapsedTime(&phase_ms_[1], ev_f0_, ev_f1_);  // direct path: [1] = the fetch kernel (GPU time)
   std::lock_guard<std::mutex> lk(cache_->stat_mu_);
   cache_->counters_.dropped += h_counts_[kMaxTables + 1];
   cache_->counters_.inserted += h_counts_[kMaxTables + 2];

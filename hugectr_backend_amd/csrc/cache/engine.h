@@ -210,7 +210,8 @@ class LookupSession {
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;  // second H2D queue for the missed-row pieces
   hipEvent_t ev_copy_ = nullptr;
-  hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr;
+  hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr,
+             ev_f0_ = nullptr, ev_f1_ = nullptr;
 
   size_t max_keys_ = 0;           // max_batch * sum(maxnum_catfeature)
   int64_t* h_keys_pinned_ = nullptr;
