@@ -59,6 +59,12 @@ def parse_args():
     ap.add_argument("--direct", type=int, default=1,
                     help="1: ps_direct_access (the GPU resolves misses itself out of pinned host memory); "
                          "0: host threads gather the missed rows (the reference's arrangement)")
+    ap.add_argument("--no-sharded-leg", action="store_true",
+                    help="N>1: skip the BASELINE config 3 leg (one table sharded over the ranks, RCCL all-to-all)")
+    ap.add_argument("--shard-rows", type=int, default=1 << 28,
+                    help="rows of the sharded table in total (config 3 names 1e9 = 512 GB; default 2^28 = 137 GB)")
+    ap.add_argument("--sharded-steps", type=int, default=50)
+    ap.add_argument("--sharded-timeout", type=float, default=300.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
@@ -476,7 +482,8 @@ def main():
                 "frac": float(np.mean(main_uniq)) * 4 * D / (fetch_ms * 1e-3) / 1e9 / PCIE_PEAK_GBS,
                 "avg_kernel_ms": fetch_ms, "unique_missed_rows_per_batch": float(np.mean(main_uniq)),
             } if a.direct and fetch_ms > 0 else None),
-            "mean_phase_ms": dict(zip(["probe_gather_dedup_until_counts", "host_ps_gather", "h2d_scatter_insert", "call"],
+            # [1] = wall time of the host gather (host tier) or GPU time of the fetch kernel (device-driven tier)
+            "mean_phase_ms": dict(zip(["probe_gather_dedup_until_counts", "ps_fetch", "h2d_scatter_insert", "call"],
                                       [float(x) for x in np.mean(np.array(phases), axis=0)])) if phases else None,
             "extra_legs": extra or None,
             "cpu_baseline": cpu,
@@ -484,12 +491,123 @@ def main():
             "setup_seconds": {"host_tables": t_tables, "gpu_cache_warmup": t_cache},
             "cache_counters": cache.counters(),
         }
-        print(json.dumps(res))
+    else:
+        res = None
     for s in sessions:
         s.close()
+
+    # ---- BASELINE config 3 leg (N > 1 only): ONE table sharded over the ranks, RCCL all-to-all of keys and rows ----
+    # Runs after the headline measurement is complete and its resources are released; a watchdog prints the headline
+    # line and ends every rank if the leg does not finish (a collective that hangs cannot be caught any other way).
+    if world > 1 and not a.no_sharded_leg:
+        import gc
+        del sessions, outs, batches_d, cache, ps, made
+        gc.collect()
+        torch.cuda.empty_cache()
+
+        def give_up():
+            if rank == 0:
+                res.setdefault("extra_legs", None)
+                res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3={"error": f"no result within {a.sharded_timeout} s"})
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(a.sharded_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            leg = sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev)
+        except Exception as e:  # noqa: BLE001
+            leg = {"error": repr(e)[:300]}
+        dog.cancel()
+        if rank == 0:
+            res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3=leg)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev):
+    """One table of Rt rows x D sharded over the P ranks (owner = mix64(key) mod P), every rank resident at 100 % in
+    its own HBM; per step every rank looks up N/P uniform keys: counting sort by owner, all-to-all keys, local
+    lookup, all-to-all rows, un-permute (hugectr_backend_amd/sharded.py).  Global lookups/s = N x steps / time."""
+    from hugectr_backend_amd.sharded import ShardedLookup
+    P, D = world, a.dim
+    N = a.tables * a.batch
+    n_local = N // P
+    budget = int(host_memory_budget() * 0.6)          # this rank's share is checked against the minimum over ranks
+    bt = torch.tensor([budget], dtype=torch.int64, device=coll_dev)
+    dist.all_reduce(bt, op=dist.ReduceOp.MIN)
+    per_rank_rows = min(a.shard_rows // P, int(bt.item()) // P // (4 * D + 80))
+    Rt = per_rank_rows * P
+    model = "criteo_sharded"
+    recv_cap = int(n_local * 1.25) + 4096
+    cfg = {
+        "supportlonglong": True,
+        "volatile_db": {"type": "hash_map", "num_partitions": 8},
+        "models": [{
+            "model": model, "sparse_files": ["synthetic://shard"], "num_of_worker_buffer_in_pool": 2,
+            "embedding_vecsize_per_table": [D], "maxnum_catfeature_query_per_table_per_sample": [1],
+            "default_value_for_each_table": [0.0], "deployed_device_list": [local_rank], "max_batch_size": recv_cap,
+            "gpucache": True, "gpucacheper": 1.0, "hit_rate_threshold": 1.0, "ps_direct_access": bool(a.direct),
+        }],
+    }
+    t0 = time.time()
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    ps.load_table_synthetic(model, 0, SEED, 0, Rt, shard=rank, num_shards=P)
+    ps.create_embedding_cache_per_model(model)
+    cache = ps.get_embedding_cache(model, local_rank)
+    sess = hps.LookupSession.create(ps, model, cache)
+    sl = ShardedLookup(sess)
+    t_setup = time.time() - t0
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(SEED + 77 + rank)
+    steps, warm = a.sharded_steps, 5
+    batches = [torch.randint(0, Rt, (n_local,), generator=gen, device="cuda", dtype=torch.int64) for _ in range(8)]
+    for i in range(warm):
+        out = sl.lookup(batches[i % 8])
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    lat = []
+    for i in range(steps):
+        ts = time.perf_counter()
+        out = sl.lookup(batches[i % 8])
+        torch.cuda.current_stream().synchronize()
+        lat.append((time.perf_counter() - ts) * 1e3)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    # parity of this rank's last answer against the CPU oracle's row recipe (256 sampled positions)
+    from oracle import hps_oracle as O
+    kh = batches[(steps - 1) % 8].cpu().numpy()
+    got = out.view(-1, D)
+    idx = np.linspace(0, n_local - 1, 256).astype(np.int64)
+    exp = np.concatenate([O.c_synth_rows(SEED, 0, int(kh[i]), 1, D) for i in idx]).reshape(256, D)
+    ok = bool(np.array_equal(got[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint32), exp.view(np.uint32)))
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=coll_dev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    sent_remote = float(sum(c for r, c in enumerate(sl.last_sent) if r != rank))
+    res = {
+        "workload": f"one table of {Rt} rows x {D} fp32 sharded over {P} ranks by mix64(key) mod {P}, 100 % resident in HBM "
+                    f"({per_rank_rows} rows per rank), {N} uniform keys per step in total ({n_local} issued per rank)",
+        "lookups_per_s": N * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+        "p50_step_latency_ms": float(np.percentile(lat, 50)),
+        "rows_bytes_sent_per_rank_per_step": sent_remote * 4 * D,
+        "row_exchange_GBps_per_rank": sent_remote * 4 * D / (dt / steps) / 1e9,
+        "xgmi_note": "row all-to-all is bounded by 7 links x ~153 GB/s per GPU (MI355X_MICROARCH.md); the figure above "
+                     "divides by the WHOLE step time, not the collective's own",
+        "parity_vs_oracle_bit_exact": bool(okt.item()), "backend": dist.get_backend(), "setup_seconds": t_setup,
+    }
+    sess.close()
+    return res
 
 
 if __name__ == "__main__":

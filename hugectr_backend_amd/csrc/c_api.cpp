@@ -211,6 +211,15 @@ int hps_server_load_table_synthetic(hps_server_t* sv, const char* model, uint32_
   });
 }
 
+int hps_server_load_table_synthetic_shard(hps_server_t* sv, const char* model, uint32_t table, uint64_t seed,
+                                          int64_t key0, uint64_t R, uint32_t shard, uint32_t num_shards) {
+  return Guard([&]() -> Status {
+    if (!sv || !model) return Error(Code::kInvalidArg, "null argument");
+    if (num_shards == 0) return Error(Code::kInvalidArg, "num_shards must be >= 1");
+    return sv->ps->load_table_synthetic(model, table, seed, key0, R, shard, num_shards);
+  });
+}
+
 int hps_server_fetch(hps_server_t* sv, const char* model, uint32_t table, const int64_t* keys, uint64_t n, float* out,
                      uint8_t* found) {
   return Guard([&]() -> Status {

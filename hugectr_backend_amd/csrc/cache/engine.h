@@ -277,7 +277,8 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   // table injection without files
   Status load_table_from_arrays(const std::string& model, size_t table, const int64_t* keys, const float* rows,
                                 size_t R, bool borrow);
-  Status load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0, size_t R);
+  Status load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0, size_t R,
+                              uint32_t shard = 0, uint32_t num_shards = 1);
   std::vector<std::shared_ptr<HostTable>> tables_of(const std::string& model);
 
   // Host-tier fetch of one table's keys: rows or default, multi-threaded.

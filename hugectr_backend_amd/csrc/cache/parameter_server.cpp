@@ -391,10 +391,12 @@ Status HierParameterServer::load_table_from_arrays(const std::string& model, siz
 }
 
 Status HierParameterServer::load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0,
-                                                 size_t R) {
+                                                 size_t R, uint32_t shard, uint32_t num_shards) {
   auto tabs = tables_of(model);
   if (table >= tabs.size()) return Error(Code::kNotFound, "model '", model, "' has no table ", table);
-  return MutateTables(model, [&]() { return tabs[table]->LoadSynthetic(seed, (uint32_t)table, key0, R, pool_); });
+  return MutateTables(model, [&]() {
+    return tabs[table]->LoadSynthetic(seed, (uint32_t)table, key0, R, pool_, shard, num_shards);
+  });
 }
 
 Status HierParameterServer::Fetch(const HostTable& tb, const int64_t* keys, size_t n, float* out, size_t stride,

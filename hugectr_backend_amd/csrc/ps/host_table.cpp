@@ -260,7 +260,52 @@ __attribute__((target("avx512f,avx512dq"))) static uint32_t SynthRowAvx512(uint6
   return j;
 }
 
-Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, size_t R, ThreadPool* pool) {
+Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, size_t R, ThreadPool* pool,
+                                uint32_t shard, uint32_t num_shards) {
+  if (num_shards > 1) {
+    // One shard of the table key0..key0+R-1: the keys whose owner (mix64(key) mod num_shards, the function the
+    // sharded lookup routes with) is `shard`, in key order.  Pass 1 counts per chunk, pass 2 fills.
+    if (shard >= num_shards) return Error(Code::kInvalidArg, "shard ", shard, " of ", num_shards);
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    FreeAll();
+    const size_t chunk = 1u << 16;
+    const size_t ntasks = (R + chunk - 1) / chunk;
+    std::vector<size_t> start(ntasks + 1, 0);
+    auto owned = [&](int64_t key) { return hps_mix64((uint64_t)key) % num_shards == shard; };
+    auto count = [&](size_t ti) {
+      const size_t b = ti * chunk, e = std::min(R, b + chunk);
+      size_t c = 0;
+      for (size_t r = b; r < e; ++r) c += owned(key0 + (int64_t)r);
+      start[ti + 1] = c;
+    };
+    if (pool) pool->ParallelFor(ntasks, count); else for (size_t i = 0; i < ntasks; ++i) count(i);
+    for (size_t i = 0; i < ntasks; ++i) start[i + 1] += start[i];
+    const size_t Rs = start[ntasks];
+    keys_ = (int64_t*)DataAlloc(std::max<size_t>(Rs, 1) * sizeof(int64_t));
+    rows_ = (float*)DataAlloc(std::max<size_t>(Rs, 1) * (size_t)dim_ * sizeof(float));
+    owns_keys_ = owns_rows_ = true;
+    if (!keys_ || !rows_) return Error(Code::kInternal, "host table '", name_, "': out of memory");
+    num_rows_ = cap_rows_ = Rs;
+    const uint64_t tb = hps_synth_table_base(seed, table_id);
+    const uint32_t D = dim_;
+    const bool use_avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
+    auto fill = [&](size_t ti) {
+      const size_t b = ti * chunk, e = std::min(R, b + chunk);
+      size_t w = start[ti];
+      for (size_t r = b; r < e; ++r) {
+        const int64_t key = key0 + (int64_t)r;
+        if (!owned(key)) continue;
+        keys_[w] = key;
+        const uint64_t rb = hps_synth_row_base(tb, key);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(rows_ + w * D);
+        const uint32_t j0 = use_avx512 ? SynthRowAvx512(rb, D, dst) : 0u;
+        for (uint32_t j = j0; j < D; ++j) dst[j] = hps_synth_elem_bits(rb, j);
+        ++w;
+      }
+    };
+    if (pool) pool->ParallelFor(ntasks, fill); else for (size_t i = 0; i < ntasks; ++i) fill(i);
+    return BuildIndex(pool);
+  }
   std::unique_lock<std::shared_mutex> lk(mu_);
   FreeAll();
   keys_ = (int64_t*)DataAlloc(R * sizeof(int64_t));

@@ -38,7 +38,9 @@ class HostTable {
   Status LoadFromArrays(const int64_t* keys, const float* rows, size_t R, bool borrow, ThreadPool* pool);
   // Synthetic table (bench): keys key0..key0+R-1, rows from the SURVEY.md §8d recipe, generated in
   // parallel straight into the slab.
-  Status LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, size_t R, ThreadPool* pool);
+  // num_shards > 1: only the keys of key0..key0+R-1 owned by `shard` (mix64(key) mod num_shards), BASELINE config 3
+  Status LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, size_t R, ThreadPool* pool, uint32_t shard = 0,
+                       uint32_t num_shards = 1);
   // Insert-or-overwrite rows (online update path; duplicate keys: last wins).
   Status Upsert(const int64_t* keys, const float* rows, size_t n);
 

@@ -91,6 +91,7 @@ def _load() -> C.CDLL:
         "hps_server_get_embedding_cache": (C.c_int, [P, cp, i32, C.POINTER(P)]),
         "hps_server_load_table_arrays": (C.c_int, [P, cp, u32, P, P, u64, C.c_int]),
         "hps_server_load_table_synthetic": (C.c_int, [P, cp, u32, u64, i64, u64]),
+        "hps_server_load_table_synthetic_shard": (C.c_int, [P, cp, u32, u64, i64, u64, u32, u32]),
         "hps_server_fetch": (C.c_int, [P, cp, u32, P, u64, P, P]),
         "hps_cache_num_tables": (C.c_int, [P]),
         "hps_cache_table_info": (C.c_int, [P, u32, C.POINTER(CacheTableInfo)]),
@@ -122,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "hps_server_deployed_device", "hps_server_parse_config", "hps_server_update_database_per_model",
     "hps_server_create_embedding_cache_per_model", "hps_server_destroy_embedding_cache_per_model",
     "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
-    "hps_server_load_table_synthetic", "hps_server_fetch", "hps_cache_num_tables", "hps_cache_table_info",
+    "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_cache_num_tables", "hps_cache_table_info",
     "hps_cache_counters", "hps_cache_query", "hps_cache_wait_async", "hps_cache_release", "hps_session_create",
     "hps_session_destroy", "hps_session_lookup", "hps_session_lookup_device", "hps_session_last_stats",
     "hps_session_set_option", "hps_shard_owner", "hps_shard_bucket_workspace_bytes", "hps_shard_bucket_device",
@@ -242,8 +243,14 @@ class HierParameterServer:
         _check(LIB.hps_server_load_table_arrays(self._h, model.encode(), table, keys.ctypes.data, rows.ctypes.data,
                                                 keys.size, 0))
 
-    def load_table_synthetic(self, model: str, table: int, seed: int, key0: int, rows: int):
-        _check(LIB.hps_server_load_table_synthetic(self._h, model.encode(), table, seed, key0, rows))
+    def load_table_synthetic(self, model: str, table: int, seed: int, key0: int, rows: int, shard: int = 0,
+                             num_shards: int = 1):
+        """keys key0..key0+rows-1 with the synthetic rows; num_shards > 1 keeps only the keys `shard` owns."""
+        if num_shards > 1:
+            _check(LIB.hps_server_load_table_synthetic_shard(self._h, model.encode(), table, seed, key0, rows, shard,
+                                                             num_shards))
+        else:
+            _check(LIB.hps_server_load_table_synthetic(self._h, model.encode(), table, seed, key0, rows))
 
     def fetch(self, model: str, table: int, keys, return_found: bool = False):
         """Host-tier (volatile database) lookup of one table: rows or the table's default value."""

@@ -87,8 +87,8 @@ class ShardedLookup:
         # counts: what I send to each rank -> what I receive from each rank
         recv_counts = torch.empty_like(totals)
         self._a2a(recv_counts, totals)
-        send = totals.cpu().tolist()
-        recv = recv_counts.cpu().tolist()
+        both = torch.stack([totals, recv_counts]).cpu().tolist()  # one device round trip for both count vectors
+        send, recv = both[0], both[1]
         self.last_sent = send
         n_recv = int(sum(recv))
         keys_in = torch.empty(n_recv, dtype=torch.int64, device=dev)

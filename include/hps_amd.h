@@ -121,6 +121,10 @@ int hps_server_load_table_arrays(hps_server_t* server, const char* model, uint32
 /* keys key0..key0+R-1, rows from the synthetic recipe of SURVEY.md §8d, generated in parallel. */
 int hps_server_load_table_synthetic(hps_server_t* server, const char* model, uint32_t table, uint64_t seed,
                                     int64_t key0, uint64_t R);
+/* Same, keeping only the keys owned by `shard` of `num_shards` (owner = mix64(key) mod num_shards, the routing
+ * function of the sharded lookup, hps_shard_bucket_device): one rank's slice of a model-parallel table. */
+int hps_server_load_table_synthetic_shard(hps_server_t* server, const char* model, uint32_t table, uint64_t seed,
+                                          int64_t key0, uint64_t R, uint32_t shard, uint32_t num_shards);
 /* Host-tier fetch of one table (the volatile-database lookup): out[i*D..] = row or default; found optional. */
 int hps_server_fetch(hps_server_t* server, const char* model, uint32_t table, const int64_t* keys, uint64_t n,
                      float* out, uint8_t* found);

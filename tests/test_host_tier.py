@@ -69,6 +69,32 @@ def test_synthetic_table_loader_matches_oracle_generator():
     assert ps.table_info("m", 0).rows_loaded == 5000
 
 
+def test_synthetic_shard_loader_partitions_the_table_by_owner():
+    """One rank's slice of a model-parallel table (BASELINE config 3): exactly the keys mix64(key) mod P assigns to it,
+    with the rows of the unsharded recipe."""
+    from hugectr_backend_amd import hps
+    from hugectr_backend_amd.sharded import owner_of
+    from oracle import hps_oracle as O
+    P, R, key0, D = 3, 70001, 17, 20
+    tables = [(np.arange(10), np.zeros((10, D), np.float32))]
+    allk = np.arange(key0, key0 + R, dtype=np.int64)
+    own = owner_of(allk, P)
+    total = 0
+    for rank in range(P):
+        ps = hps.HierParameterServer.create_from_dict(ps_config(f"s{rank}", tables, gpucache=False), load_tables=False)
+        ps.load_table_synthetic(f"s{rank}", 0, O.SEED, key0, R, shard=rank, num_shards=P)
+        n = ps.table_info(f"s{rank}", 0).rows_loaded
+        assert n == int((own == rank).sum())
+        total += n
+        out, found = ps.fetch(f"s{rank}", 0, allk, return_found=True)
+        assert np.array_equal(found.astype(bool), own == rank)
+        mine = allk[own == rank]
+        assert np.array_equal(_bits(out[own == rank]), _bits(O.np_synth_rows(O.SEED, 0, mine, D)))
+    assert total == R
+    with pytest.raises(hps.HpsError):
+        ps.load_table_synthetic(f"s{P - 1}", 0, O.SEED, 0, 10, shard=5, num_shards=3)
+
+
 def test_duplicate_keys_last_wins_and_sentinel_key():
     from oracle import hps_oracle as O
     k = np.array([9, 4, 9, 7, 4, np.iinfo(np.int64).min, 9], np.int64)
