@@ -614,9 +614,11 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     cache_->counters_.misses += misses;
     cache_->counters_.unique_misses += uniq;
   };
-  if (cache_->direct() && params_.hit_rate_threshold >= 1.0f) {
+  if (cache_->direct() && params_.hit_rate_threshold >= 1.0f && last_misses_ > 0) {
     // Device-driven miss path with the insertion policy fixed to "synchronous": nothing on the host depends
     // on the miss counts, so the whole call is enqueued without a round trip and the counts come back at the end.
+    // (Only while the previous call of this session missed something: a fully resident working set is served
+    // faster by reading the counts first and stopping there — four empty kernels and a sync less.)
     const Status st = HandleMissesDirect(N, epoch, /*counts_known=*/false);
     if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
     if (st.ok()) account();

@@ -82,12 +82,14 @@ def test_wdl_gpu_cache_device_output_exact(tmp_path):
         srv.shutdown()
 
 
-def test_two_models_share_the_device_concurrently(tmp_path):
+@pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
+def test_two_models_share_the_device_concurrently(tmp_path, direct):
     """BASELINE config 4 shape: two W&D models (D=[1,16], keys/sample [2,26], batch 1024), two instances each,
     mixed hit rate, concurrent Execute calls on one device."""
     from oracle import hps_oracle as O
     models = {m: (make_tables([(20000, 1), (20000, 16)], seed=s), [2, 26], [0.0, 0.0]) for m, s in (("wdl_a", 1), ("wdl_b", 2))}
-    srv, _ = _deploy(tmp_path, models, gpucacheper=0.1, hit_rate_threshold=1.0, max_batch=1024)
+    srv, _ = _deploy(tmp_path, models, gpucacheper=0.1, hit_rate_threshold=1.0, max_batch=1024,
+                     extra={"ps_direct_access": direct})
     try:
         insts = {}
         for m in models:
@@ -121,14 +123,16 @@ def test_two_models_share_the_device_concurrently(tmp_path):
         srv.shutdown()
 
 
-def test_new_model_version_refreshes_the_cache(tmp_path):
+@pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
+def test_new_model_version_refreshes_the_cache(tmp_path, direct):
     """Loading version 2 of a served model re-reads the sparse files and refreshes the device cache
     asynchronously (hps.cc:207-226, model_state.cpp:124-142,413-418)."""
     import time
     from oracle import hps_oracle as O
     tables = make_tables([(1000, 16)])
     keys, rows = tables[0]
-    srv, ps_path = _deploy(tmp_path, {"m": (tables, [1], [0.0])}, gpucacheper=1.0, hit_rate_threshold=1.0, max_batch=2048)
+    srv, ps_path = _deploy(tmp_path, {"m": (tables, [1], [0.0])}, gpucacheper=1.0, hit_rate_threshold=1.0, max_batch=2048,
+                           extra={"ps_direct_access": direct})
     try:
         m1 = srv.load_model("m", tm.model_config("m", gpus=[0]), version=1)
         i1 = m1.create_instance("m_v1", tm.KIND_GPU, 0)
