@@ -259,6 +259,7 @@ def main():
     ncpu = effective_cpus()
     lat_ms, kern_ms, miss_ct, phases, uniq_ct = [], [], [], [], []
     lock = threading.Lock()
+    post_hooks = []   # per session: work appended to every step (the config-5 leg runs the dense step here)
 
     def run_steps(count, record, first=0):
         nxt = [0]
@@ -273,6 +274,8 @@ def main():
                     nxt[0] += 1
                 t0 = time.perf_counter()
                 s.lookup_device(batches_d[(first + i) % len(batches_d)], nk, out=outs[si])
+                if post_hooks:
+                    post_hooks[si](si)
                 dt = (time.perf_counter() - t0) * 1e3
                 st = s.last_stats()
                 if record:
@@ -346,6 +349,45 @@ def main():
         cache.wait_async()
         for s in sessions:
             s.set_option("hit_rate_threshold_permille", 1000 if a.mode == "sync" else 500)
+        # (3) BASELINE config 5: the dense step (bottom MLP 13-512-256-D + dot interaction, fp16 MFMA) consuming
+        #     OUTPUT0 where the lookup left it.  Kernel time alone, then lookup + dense per step with both sessions.
+        if D % 32 == 0 and D <= 512 and T <= 31:
+            from hugectr_backend_amd.dense import DenseInteraction
+            rngw = np.random.default_rng(SEED)
+            dims, k = [512, 256, D], 13
+            ws, bs = [], []
+            for n in dims:
+                ws.append(((rngw.random((k, n), dtype=np.float32) * 2 - 1) * (1.5 / np.sqrt(k))).astype(np.float32))
+                bs.append(((rngw.random(n, dtype=np.float32) - 0.3) * 0.2).astype(np.float32))
+                k = n
+            ops = [DenseInteraction(ws, bs, T, D, device=dev) for _ in sessions]
+            xd = torch.randn(B, 13, device="cuda")
+            outd = [torch.empty((B, ops[0].out_stride), dtype=torch.float16, device="cuda") for _ in sessions]
+            for _ in range(3):
+                ops[0].forward(xd, outs[0], B, out=outd[0])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                ops[0].forward(xd, outs[0], B, out=outd[0])
+            e1.record()
+            torch.cuda.synchronize()
+            dense_ms = e0.elapsed_time(e1) / 20
+            dense_bytes = N * 4 * D + B * 13 * 4 + 2 * B * D * 2 + B * ops[0].out_stride * 2
+            dense_flops = 2 * B * (16 * 512 + 512 * 256 + 256 * D) + 2 * B * 32 * 32 * D
+            post_hooks[:] = [lambda si: (ops[si].forward(xd, outs[si], B, out=outd[si]),
+                                         torch.cuda.current_stream().synchronize()) for _ in sessions]
+            fresh5 = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
+            c5 = leg(fresh5, 24, sessions)
+            post_hooks[:] = []
+            c5.update({"dense_kernels_ms": dense_ms, "dense_algorithmic_bytes": dense_bytes,
+                       "dense_frac_of_hbm_peak": dense_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "dense_mfma_tflops": dense_flops / (dense_ms * 1e-3) / 1e12,
+                       "samples_per_s": c5["lookups_per_s"] / T,
+                       "note": "lookup (sync insert, exact rows) + bottom MLP 13-512-256-%d + dot interaction per step; "
+                               "output [batch, %d] f16" % (D, ops[0].out_dim)})
+            extra["c5_lookup_plus_dense"] = c5
+            del fresh5
         del cdf_d, resident_d, hot_batches, fresh
 
     # ---- untimed parity check of the last step of session 0 against the CPU oracle (tables 0..1) ----

@@ -38,6 +38,8 @@ ENGINE_SRCS = [
     "cache/direct_kernels.hip",
     "cache/engine.cpp",
     "cache/parameter_server.cpp",
+    "dense/dense_kernels.hip",
+    "dense/dense.cpp",
 ]
 CAPI_SRCS = ["c_api.cpp"]
 TRITON_SRCS = [

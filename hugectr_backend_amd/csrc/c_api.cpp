@@ -11,12 +11,14 @@
 
 #include "cache/engine.h"
 #include "cache/shard_kernels.h"
+#include "dense/dense.h"
 
 using namespace hps;
 
 struct hps_server { std::shared_ptr<HierParameterServer> ps; std::vector<std::string> names; };
 struct hps_cache { std::shared_ptr<EmbeddingCache> cache; };
 struct hps_session { std::shared_ptr<HierParameterServer> ps; std::unique_ptr<LookupSession> s; };
+struct hps_dense { std::unique_ptr<DenseInteraction> d; };
 
 namespace {
 thread_local std::string g_err;
@@ -355,6 +357,34 @@ int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint6
     const hipError_t e = LaunchShardUnpermute(d_rows, d_perm, n, dim, d_out, (hipStream_t)stream);
     if (e != hipSuccess) return Error(Code::kInternal, "shard unpermute launch failed: ", hipGetErrorString(e));
     return Status::Ok();
+  });
+}
+
+int hps_dense_create(int device, uint32_t num_dense, uint32_t num_layers, const uint32_t* layer_dims, const float* const* weights,
+                     const float* const* biases, uint32_t num_tables, uint32_t emb_dim, hps_dense_t** out) {
+  return Guard([&]() -> Status {
+    if (!out || !layer_dims || !weights || !biases) return Error(Code::kInvalidArg, "null argument");
+    *out = nullptr;
+    std::vector<uint32_t> dims(layer_dims, layer_dims + num_layers);
+    std::vector<const float*> w(weights, weights + num_layers), b(biases, biases + num_layers);
+    DenseInteraction* d = nullptr;
+    HPS_RETURN_IF_ERROR(DenseInteraction::Create(device, num_dense, dims, w, b, num_tables, emb_dim, &d));
+    *out = new hps_dense{std::unique_ptr<DenseInteraction>(d)};
+    return Status::Ok();
+  });
+}
+
+void hps_dense_destroy(hps_dense_t* dense) { delete dense; }
+
+uint32_t hps_dense_out_dim(const hps_dense_t* dense) { return dense ? dense->d->out_dim() : 0; }
+
+uint32_t hps_dense_out_stride(const hps_dense_t* dense) { return dense ? dense->d->out_stride() : 0; }
+
+int hps_dense_forward(hps_dense_t* dense, const float* d_dense, const float* d_embeddings, uint64_t batch, void* d_out_f16,
+                      void* stream) {
+  return Guard([&]() -> Status {
+    if (!dense) return Error(Code::kInvalidArg, "null argument");
+    return dense->d->Forward(d_dense, d_embeddings, batch, d_out_f16, (hipStream_t)stream);
   });
 }
 

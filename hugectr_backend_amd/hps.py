@@ -109,6 +109,11 @@ def _load() -> C.CDLL:
         "hps_shard_bucket_workspace_bytes": (u64, [u64, u32]),
         "hps_shard_bucket_device": (C.c_int, [P, u64, u32, P, P, P, P, P]),
         "hps_shard_unpermute_device": (C.c_int, [P, P, u64, u32, P, P]),
+        "hps_dense_create": (C.c_int, [C.c_int, u32, u32, P, P, P, u32, u32, C.POINTER(P)]),
+        "hps_dense_destroy": (None, [P]),
+        "hps_dense_out_dim": (u32, [P]),
+        "hps_dense_out_stride": (u32, [P]),
+        "hps_dense_forward": (C.c_int, [P, P, P, u64, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = symbol missing from the library
@@ -127,7 +132,8 @@ EXPORTED_SYMBOLS = [
     "hps_cache_counters", "hps_cache_query", "hps_cache_wait_async", "hps_cache_release", "hps_session_create",
     "hps_session_destroy", "hps_session_lookup", "hps_session_lookup_device", "hps_session_last_stats",
     "hps_session_set_option", "hps_shard_owner", "hps_shard_bucket_workspace_bytes", "hps_shard_bucket_device",
-    "hps_shard_unpermute_device",
+    "hps_shard_unpermute_device", "hps_dense_create", "hps_dense_destroy", "hps_dense_out_dim", "hps_dense_out_stride",
+    "hps_dense_forward",
 ]
 
 

@@ -174,6 +174,26 @@ int hps_shard_bucket_device(const int64_t* d_keys, uint64_t n, uint32_t num_shar
 int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint64_t n, uint32_t dim, float* d_out,
                                void* stream);
 
+/* ---- dense step of BASELINE config 5: DLRM bottom MLP + pairwise dot interaction, consuming OUTPUT0 in place ------
+ * Not in the reference backend: there the dense model is another Triton backend reached through an ensemble
+ * hand-off (samples/hps-triton-ensemble); here it runs on the GPU that holds the lookup's output.
+ * fp16 operands, fp32 accumulation (MFMA).  Output row of sample i (f16, stride hps_dense_out_stride elements):
+ *   [ bottom(i)[0..D) | dot(z_a, z_b) for a = 1..T, b = 0..a-1 | zero padding ],  z_0 = bottom(i), z_{1+t} = row(t,i)
+ * where bottom = ReLU(..ReLU(x W_0 + b_0)..W_{L-1} + b_{L-1}) and row(t,i) is OUTPUT0[(t*batch + i)*D ..]. */
+typedef struct hps_dense hps_dense_t;
+/* weights[l]: host fp32 [K_l][layer_dims[l]] row-major (K_0 = num_dense, K_l = layer_dims[l-1]); biases[l]: [layer_dims[l]].
+ * layer widths: multiples of 32, <= 512; last width == emb_dim; emb_dim multiple of 16; num_tables <= 31. */
+int hps_dense_create(int device, uint32_t num_dense, uint32_t num_layers, const uint32_t* layer_dims,
+                     const float* const* weights, const float* const* biases, uint32_t num_tables, uint32_t emb_dim,
+                     hps_dense_t** out);
+void hps_dense_destroy(hps_dense_t* dense);
+uint32_t hps_dense_out_dim(const hps_dense_t* dense);     /* emb_dim + (T+1)T/2 */
+uint32_t hps_dense_out_stride(const hps_dense_t* dense);  /* out_dim rounded up to a multiple of 8 elements */
+/* d_dense: [batch][num_dense] fp32; d_embeddings: table-major [T][batch][emb_dim] fp32 (the lookup's OUTPUT0);
+ * d_out_f16: [batch][out_stride] f16.  All device pointers; enqueued on `stream` (a hipStream_t), not synchronised. */
+int hps_dense_forward(hps_dense_t* dense, const float* d_dense, const float* d_embeddings, uint64_t batch,
+                      void* d_out_f16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

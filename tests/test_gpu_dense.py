@@ -1,0 +1,103 @@
+"""Dense step of BASELINE config 5 (bottom MLP + dot interaction on the matrix cores) against a plain PyTorch
+reference of the same operator.
+
+This is the one floating-point kernel of the build, so the bar is a tolerance, stated here:
+  * against a reference that rounds the SAME places to fp16 (inputs, weights, activations between layers, embedding
+    rows) and accumulates in fp32: |got - ref| <= 2e-3 * max(1, |ref|)   (only summation order + the final fp16 rounding differ)
+  * against the all-fp32 reference: |got - ref| <= 2e-2 * max(1, |ref|)   (fp16 operand rounding, K <= 512)
+There is no reference implementation of this step in hugectr_backend (it lives in another Triton backend there).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(torch, x, emb, weights, biases, T, B, D, half_points: bool):
+    def q(t):
+        return t.half().float() if half_points else t
+    h = q(x)
+    for w, b in zip(weights, biases):
+        h = torch.relu(h @ q(w) + b)
+        h = q(h)
+    z = torch.cat([h.view(B, 1, D), q(emb).view(T, B, D).permute(1, 0, 2)], dim=1)  # [B, T+1, D]
+    g = torch.bmm(z, z.transpose(1, 2))
+    ia, ib = torch.tril_indices(T + 1, T + 1, offset=-1)
+    return torch.cat([h, g[:, ia, ib]], dim=1)
+
+
+def _make(torch, num_dense, dims, T, D, B, seed):
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    ws, bs = [], []
+    k = num_dense
+    for n in dims:
+        ws.append((torch.rand(k, n, generator=gen, device="cuda") * 2 - 1) * (1.5 / np.sqrt(k)))
+        bs.append((torch.rand(n, generator=gen, device="cuda") - 0.3) * 0.2)
+        k = n
+    x = torch.randn(B, num_dense, generator=gen, device="cuda")
+    emb = (torch.rand(T * B * D, generator=gen, device="cuda") - 0.5)  # asymmetric, every row different
+    return ws, bs, x, emb
+
+
+@pytest.mark.parametrize("num_dense,dims,T,D,B", [
+    (13, [512, 256, 128], 26, 128, 4096),      # the Criteo DLRM shape of config 5
+    (13, [512, 256, 128], 26, 128, 1),         # single sample
+    (13, [512, 256, 128], 26, 128, 67),        # ragged: not a multiple of the 64-row MLP tile or of 4 waves
+    (4, [64, 32], 3, 32, 300),                 # small: V = 4 rows in the 32x32 tile, D = 32
+    (40, [128, 64], 31, 64, 129),              # widest interaction (V = 32), in_pad = 48
+    (16, [32], 1, 32, 64),                     # one layer, one table
+])
+def test_dense_interaction_matches_torch(num_dense, dims, T, D, B):
+    import torch
+    from hugectr_backend_amd.dense import DenseInteraction
+    ws, bs, x, emb = _make(torch, num_dense, dims, T, D, B, seed=num_dense * 1000 + B)
+    op = DenseInteraction([w.cpu().numpy() for w in ws], [b.cpu().numpy() for b in bs], T, D)
+    assert op.out_dim == D + (T + 1) * T // 2 and op.out_stride % 8 == 0 and op.out_stride >= op.out_dim
+    out = op.forward(x, emb, B)
+    torch.cuda.synchronize()
+    got = out[:, : op.out_dim].float()
+    assert torch.count_nonzero(out[:, op.out_dim:]) == 0          # padding columns are zero
+    ref_h = _reference(torch, x, emb, ws, bs, T, B, D, half_points=True)
+    ref_f = _reference(torch, x, emb, ws, bs, T, B, D, half_points=False)
+    err_h = ((got - ref_h).abs() / ref_h.abs().clamp(min=1.0)).max().item()
+    err_f = ((got - ref_f).abs() / ref_f.abs().clamp(min=1.0)).max().item()
+    assert err_h <= 2e-3, err_h
+    assert err_f <= 2e-2, err_f
+    op.close()
+
+
+def test_dense_consumes_lookup_output_in_place():
+    """End to end on the config-5 shape at reduced rows: lookup (HIP, exact rows) -> dense step reading OUTPUT0 where
+    the lookup left it; reference = oracle rows through the torch operator."""
+    import torch
+    from hugectr_backend_amd.dense import DenseInteraction
+    from oracle import hps_oracle as O
+    from tests.conftest import make_tables
+    from tests.test_gpu_lookup import _mk
+    T, R, D, B = 26, 3000, 128, 512
+    tables = make_tables([(R, D)] * T)
+    ps, cache, s = _mk("c5", tables, maxcat=[1] * T, gpucacheper=0.3, max_batch=B)
+    rng = np.random.default_rng(5)
+    q = np.concatenate([rng.choice(k, B) for k, _ in tables]).astype(np.int64)
+    out0 = s.lookup(q, [B] * T)                                        # CUDA fp32, table-major
+    ws, bs, x, _ = _make(torch, 13, [512, 256, 128], T, D, B, seed=99)
+    op = DenseInteraction([w.cpu().numpy() for w in ws], [b.cpu().numpy() for b in bs], T, D)
+    got = op.forward(x, out0, B)[:, : op.out_dim].float()
+    rows = torch.from_numpy(O.np_lookup(tables, q, [B] * T, [0.0] * T)).cuda()
+    ref = _reference(torch, x, rows, ws, bs, T, B, D, half_points=True)
+    err = ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+    assert err <= 2e-3, err
+
+
+def test_dense_rejects_unsupported_shapes():
+    from hugectr_backend_amd import hps
+    from hugectr_backend_amd.dense import DenseInteraction
+    w = lambda k, n: np.zeros((k, n), np.float32)  # noqa: E731
+    b = lambda n: np.zeros(n, np.float32)  # noqa: E731
+    with pytest.raises(hps.HpsError):
+        DenseInteraction([w(13, 100)], [b(100)], 26, 100)          # width not a multiple of 32
+    with pytest.raises(hps.HpsError):
+        DenseInteraction([w(13, 128)], [b(128)], 32, 128)          # 33 vectors do not fit the 32x32 tile
+    with pytest.raises(hps.HpsError):
+        DenseInteraction([w(13, 64)], [b(64)], 26, 128)            # last layer != embedding width
