@@ -666,8 +666,7 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   const size_t T = tables_.size();
   const int cu = cache_->cu_count();
   const uint64_t max_unique = counts_known ? (uint64_t)last_unique_ : N;
-  HIP_TRY(hipMemsetAsync(d_counts_ + kMaxTables + 1, 0, 4 * sizeof(uint32_t), stream_));
-  hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, stream_);
+  hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, d_counts_ + kMaxTables + 1, stream_);
   if (e == hipSuccess) {
     cache_->BeginFetch(stream_);
     if (timing_) (void)hipEventRecord(ev_f0_, stream_);
@@ -678,8 +677,16 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   }
   if (e == hipSuccess) e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, N, d_slot_, d_staging_, cu, stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "direct miss path launch failed: ", hipGetErrorString(e));
-  // keep the window in which other sessions' probes wait for our writer event down to the insert kernel
-  HIP_TRY(hipStreamSynchronize(stream_));
+  // Keep the window in which other sessions' probes wait for our writer event down to the insert kernel: drain the
+  // stream first, so the event is recorded behind the insert alone and not behind a millisecond of PCIe fetch.
+  // Small requests skip the drain (their fetch is a few tens of microseconds, less than the host round trip):
+  // the estimate is this call's unique-miss count when known, else the previous call's.
+  {
+    uint64_t row_bytes = 0;
+    for (const auto& tb : tables_) row_bytes = std::max<uint64_t>(row_bytes, (uint64_t)tb->dim() * sizeof(float));
+    const uint64_t est_bytes = (uint64_t)last_unique_ * row_bytes;
+    if (est_bytes > (2u << 20)) HIP_TRY(hipStreamSynchronize(stream_));
+  }
   cache_->BeginWrite(stream_);
   e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, max_unique, d_call_->key_start, d_uniq_keys_,
                         d_staging_, d_found_, epoch, d_counts_ + kMaxTables + 1, cu, stream_);

@@ -45,6 +45,9 @@ def _request(q, nk, out_elems, device_out=True, device_keys=False, rid="1"):
     out = None
     if device_out:
         out = torch.full((max(out_elems, 1),), float("nan"), dtype=torch.float32, device="cuda")
+        # the NaN fill runs on torch's stream and the backend writes on its own streams: without this the fill may
+        # land after the lookup (Triton hands over buffers with no work pending on them)
+        torch.cuda.synchronize()
         req.set_output_buffer(out.data_ptr(), out_elems * 4, tm.MEM_GPU, 0, keep=out)
     return req, out
 

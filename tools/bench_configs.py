@@ -65,7 +65,7 @@ def c1(iters=2000, warm=200):
             "bit_exact_vs_oracle": bool(ok), "oracle_single_thread_lookups_per_s": cpu}
 
 
-def c4(iters=300, warm=30):
+def c4(iters=300, warm=30, direct=False):
     import torch
     tmp = Path(tempfile.mkdtemp())
     cfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8}, "models": []}
@@ -81,7 +81,7 @@ def c4(iters=300, warm=30):
             dirs.append(str(tmp / f"{m}_{t}"))
         tables[m] = tabs
         cfg["models"].append(ps_config(m, tabs, dirs=dirs, gpucache=True, gpucacheper=0.2, hit_rate_threshold=1.0, maxcat=[2, 26],
-                                       max_batch=1024)["models"][0])
+                                       max_batch=1024, extra={"ps_direct_access": bool(direct)})["models"][0])
     (tmp / "ps.json").write_text(json.dumps(cfg))
     srv = tm.Server(tmp / "ps.json")
     insts = {m: srv.load_model(m, tm.model_config(m, gpus=[0], max_batch_size=1024)).create_instance(f"{m}_0", tm.KIND_GPU, 0) for m in tables}
@@ -130,4 +130,10 @@ def c4(iters=300, warm=30):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "c1"
-    print(json.dumps({"c1": c1, "c4": c4}[which]()))
+    if which == "c4":
+        direct = len(sys.argv) > 2 and sys.argv[2] == "direct"
+        out = c4(direct=direct)
+        out["config"] += ", parameter-server tier: " + ("device-driven (ps_direct_access)" if direct else "host gather")
+        print(json.dumps(out))
+    else:
+        print(json.dumps(c1()))
