@@ -63,6 +63,8 @@ def parse_args():
                     help="N>1: skip the BASELINE config 3 leg (one table sharded over the ranks, RCCL all-to-all)")
     ap.add_argument("--shard-rows", type=int, default=1 << 28,
                     help="rows of the sharded table in total (config 3 names 1e9 = 512 GB; default 2^28 = 137 GB)")
+    ap.add_argument("--setup-seconds", type=float, default=150.0,
+                    help="N>1: bound on the estimated host-table generation time; rows/table shrinks to meet it")
     ap.add_argument("--sharded-steps", type=int, default=50)
     ap.add_argument("--sharded-timeout", type=float, default=300.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
@@ -174,6 +176,29 @@ def main():
     per_row = T * (4 * D + 64) + 2 * (4 * D + 48)
     if R * per_row > budget:
         R = max(B, int(budget // per_row))
+    setup_note = ""
+    if world > 1:
+        # setup-time guard: N ranks generate and pin N copies of the tables on the host cores they share.  A probe
+        # table measures this rank's generation rate under that contention; if the full tables would take longer
+        # than --setup-seconds, rows/table shrinks for every rank (same batch, same hit rate; the workload says so).
+        probe_rows = min(R, 1_000_000)
+        pcfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8},
+                "models": [{"model": "probe", "sparse_files": ["synthetic://probe"], "num_of_worker_buffer_in_pool": 1,
+                            "embedding_vecsize_per_table": [D], "maxnum_catfeature_query_per_table_per_sample": [1],
+                            "default_value_for_each_table": [0.0], "deployed_device_list": [local_rank],
+                            "max_batch_size": 1, "gpucache": False}]}
+        pps = hps.HierParameterServer.create_from_dict(pcfg, load_tables=False)
+        dist.barrier()
+        tp = time.time()
+        pps.load_table_synthetic("probe", 0, SEED, 0, probe_rows)
+        est = (time.time() - tp) / probe_rows * R * T * (1.6 if a.direct else 1.0)   # + page-locking
+        del pps
+        et = torch.tensor([est], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        est = float(et.item())
+        if est > a.setup_seconds:
+            R = max(B, int(R * a.setup_seconds / est) // 1000 * 1000)
+            setup_note = f"; setup-time guard ({est:.0f} s estimated for the full tables on this box's shared host cores)"
     N = T * B
     model = "criteo_dlrm"
     cfg = {
@@ -483,7 +508,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"Criteo DLRM {T} sparse slots, {R} rows/table"
-                            + (f" (requested {rows_requested}; reduced to fit the host-memory budget of {world} replicas)" if R != rows_requested else "")
+                            + (f" (requested {rows_requested}; reduced to fit the host memory / setup time of {world} replicas{setup_note})" if R != rows_requested else "")
                             + f" x {D}-dim, {B} batch ({N} keys), "
                             f"gpucacheper {a.cache_frac}, 95% cache hit (resident-draw probability {a.hit}; see measured_hit_rate), "
                             f"zipf {a.zipf} within the resident set, "
