@@ -64,6 +64,7 @@ void EmbeddingCache::Release() {
   (void)hipSetDevice(cfg_.device_id_);
   (void)hipDeviceSynchronize();
   FreeInserter();
+  FreeDirectInserter();
   for (auto& m : index_mem_) { if (m.first) (void)hipFree(m.first); if (m.second) (void)hipFree(m.second); }
   index_mem_.clear();
   if (d_index_) (void)hipFree(d_index_);
@@ -342,6 +343,116 @@ Status EmbeddingCache::SyncDirectIndex(const std::vector<std::shared_ptr<HostTab
   if (!d_index_) HPS_RETURN_IF_ERROR(DevAlloc(&d_index_, T));
   if (changed) HIP_TRY(hipMemcpy(d_index_, h_index_.data(), T * sizeof(PsIndexDev), hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
+  return Status::Ok();
+}
+
+// ---- background inserter of the device-driven tier (async-insert mode) --------------------------------------
+struct EmbeddingCache::DirectInserter {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_copied = nullptr, ev_done = nullptr, ev_fetch = nullptr;
+  int64_t* d_keys = nullptr;      // snapshot of the session's unique-key array (table-major, key_start offsets)
+  uint64_t* d_key_start = nullptr;
+  uint32_t* d_counts = nullptr;   // [0] misses, [1..T] unique per table, [kMaxTables+1..+4] insert statistics
+  MissDesc* d_md = nullptr;
+  float* d_staging = nullptr;
+  uint8_t* d_found = nullptr;
+  size_t cap_keys = 0, cap_floats = 0, cap_found = 0;
+  uint64_t unique_total = 0;
+  bool in_flight = false;   // one job at a time: set by SubmitDirectInsert, cleared when FinishDirectInsert returns
+};
+
+void EmbeddingCache::FreeDirectInserter() {
+  if (!dins_) return;
+  DirectInserter& I = *dins_;
+  if (I.stream) { (void)hipStreamSynchronize(I.stream); (void)hipStreamDestroy(I.stream); }
+  for (hipEvent_t e : {I.ev_copied, I.ev_done, I.ev_fetch}) if (e) (void)hipEventDestroy(e);
+  for (void* p : {(void*)I.d_keys, (void*)I.d_key_start, (void*)I.d_counts, (void*)I.d_md, (void*)I.d_staging, (void*)I.d_found})
+    if (p) (void)hipFree(p);
+  delete dins_;
+  dins_ = nullptr;
+}
+
+// Part 1, on the calling lookup's thread: claim the (single) job slot and snapshot the session's unique missed keys
+// with copies enqueued on the session's stream (ordered after its dedup kernels, before its next call reuses them).
+Status EmbeddingCache::SubmitDirectInsert(hipStream_t session_stream, const uint64_t* d_key_start, const int64_t* d_uniq_keys,
+                                          const uint32_t* d_counts, uint64_t N, uint64_t unique_total, uint64_t staging_floats,
+                                          bool* accepted) {
+  *accepted = false;
+  if (!direct_ || static_ || unique_total == 0) return Status::Ok();
+  std::unique_lock<std::mutex> lk(dins_mu_, std::try_to_lock);
+  if (!lk.owns_lock()) return Status::Ok();  // another session is submitting: this batch's misses stay uncached
+  HIP_TRY(hipSetDevice(cfg_.device_id_));
+  const size_t T = num_tables();
+  if (!dins_) {
+    dins_ = new DirectInserter();
+    HIP_TRY(hipStreamCreateWithFlags(&dins_->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&dins_->ev_copied, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&dins_->ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&dins_->ev_fetch, hipEventDisableTiming));
+    HPS_RETURN_IF_ERROR(DevAlloc(&dins_->d_key_start, (size_t)kMaxTables + 1));
+    HPS_RETURN_IF_ERROR(DevAlloc(&dins_->d_counts, (size_t)kMaxTables + 8));
+    HPS_RETURN_IF_ERROR(DevAlloc(&dins_->d_md, 1));
+  }
+  DirectInserter& I = *dins_;
+  if (I.in_flight) return Status::Ok();  // saturated: drop (best effort, like the bounded host inserter)
+  auto grow = [](auto** p, size_t* cap, size_t want) -> Status {
+    if (want <= *cap) return Status::Ok();
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t n = want + want / 4;
+    HPS_RETURN_IF_ERROR(DevAlloc(p, n));
+    *cap = n;
+    return Status::Ok();
+  };
+  HPS_RETURN_IF_ERROR(grow(&I.d_keys, &I.cap_keys, (size_t)N));
+  HPS_RETURN_IF_ERROR(grow(&I.d_staging, &I.cap_floats, (size_t)staging_floats + 4 * T));
+  HPS_RETURN_IF_ERROR(grow(&I.d_found, &I.cap_found, (size_t)unique_total));
+  HIP_TRY(hipMemcpyAsync(I.d_keys, d_uniq_keys, N * sizeof(int64_t), hipMemcpyDeviceToDevice, session_stream));
+  HIP_TRY(hipMemcpyAsync(I.d_key_start, d_key_start, (T + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, session_stream));
+  HIP_TRY(hipMemcpyAsync(I.d_counts, d_counts, (1 + T) * sizeof(uint32_t), hipMemcpyDeviceToDevice, session_stream));
+  HIP_TRY(hipEventRecord(I.ev_copied, session_stream));
+  I.unique_total = unique_total;
+  I.in_flight = true;
+  *accepted = true;
+  return Status::Ok();
+}
+
+// Part 2, on a pool thread (no CPU work, only enqueueing): fetch on the inserter's stream, and only when that has
+// drained the insert kernel, so that the writer event other sessions' probes wait for covers the insert alone.
+Status EmbeddingCache::FinishDirectInsert() {
+  DirectInserter& I = *dins_;
+  struct Done {
+    EmbeddingCache* c;
+    ~Done() { std::lock_guard<std::mutex> lk(c->dins_mu_); c->dins_->in_flight = false; }
+  } done{this};
+  // the fetch kernel reads the pinned host tables: same fence against table reloads as a lookup
+  std::shared_lock<std::shared_mutex> tables_lock(direct_mu_);
+  HIP_TRY(hipSetDevice(cfg_.device_id_));
+  const size_t T = num_tables();
+  HIP_TRY(hipStreamWaitEvent(I.stream, I.ev_copied, 0));
+  const uint32_t epoch = NextEpoch();
+  hipError_t e = LaunchMissDescBuild(d_tables_, (uint32_t)T, I.d_counts, I.d_md, I.d_counts + kMaxTables + 1, I.stream);
+  if (e == hipSuccess) {
+    BeginFetch(I.stream);
+    e = LaunchPsFetchDirect(d_index_, (uint32_t)T, I.d_md, I.d_key_start, I.d_keys, I.d_staging, I.d_found, I.unique_total, cu_count_,
+                            I.stream);
+    EndFetch(I.stream, I.ev_fetch);
+  }
+  if (e != hipSuccess) return Error(Code::kInternal, "direct background fetch launch failed: ", hipGetErrorString(e));
+  HIP_TRY(hipStreamSynchronize(I.stream));
+  BeginWrite(I.stream);
+  e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, I.unique_total, I.d_key_start, I.d_keys, I.d_staging, I.d_found, epoch,
+                        I.d_counts + kMaxTables + 1, cu_count_, I.stream);
+  EndWrite(I.stream);
+  if (e != hipSuccess) return Error(Code::kInternal, "direct background insert launch failed: ", hipGetErrorString(e));
+  uint32_t st[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(st, I.d_counts + kMaxTables + 1, sizeof st, hipMemcpyDeviceToHost, I.stream));
+  HIP_TRY(hipStreamSynchronize(I.stream));
+  std::lock_guard<std::mutex> lk2(stat_mu_);
+  counters_.dropped += st[0];
+  counters_.inserted += st[1];
+  counters_.refreshed += st[2];
   return Status::Ok();
 }
 
@@ -643,12 +754,24 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     e = LaunchMissFillDefault(d_call_, cache_->device_tables(), N, d_slot_, cu, stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "default fill launch failed: ", hipGetErrorString(e));
     // hand the unique missed keys to the background inserter (best effort)
-    std::vector<std::vector<int64_t>> job(T);
-    for (size_t t = 0; t < T; ++t) {
-      const uint32_t cnt = h_counts_[1 + t];
-      job[t].assign(h_uniq_keys_ + c.key_start[t], h_uniq_keys_ + c.key_start[t] + cnt);
+    if (cache_->direct()) {
+      // device-driven tier: the keys never leave the GPU; fetch + insert run on the cache's own stream
+      uint64_t uniq = 0, floats = 0;
+      for (size_t t = 0; t < T; ++t) {
+        uniq += h_counts_[1 + t];
+        floats = ((floats + 3) & ~(uint64_t)3) + (uint64_t)h_counts_[1 + t] * tables_[t]->dim();
+      }
+      bool accepted = false;
+      HPS_RETURN_IF_ERROR(cache_->SubmitDirectInsert(stream_, d_call_->key_start, d_uniq_keys_, d_counts_, N, uniq, floats, &accepted));
+      if (accepted) ps_->RunDirectInsert(cache_);
+    } else {
+      std::vector<std::vector<int64_t>> job(T);
+      for (size_t t = 0; t < T; ++t) {
+        const uint32_t cnt = h_counts_[1 + t];
+        job[t].assign(h_uniq_keys_ + c.key_start[t], h_uniq_keys_ + c.key_start[t] + cnt);
+      }
+      ps_->SubmitAsyncInsert(cache_, std::move(job));
     }
-    ps_->SubmitAsyncInsert(cache_, std::move(job));
     HIP_TRY(hipStreamSynchronize(stream_));
     std::lock_guard<std::mutex> lk(cache_->stat_mu_);
     cache_->counters_.async_calls += 1;

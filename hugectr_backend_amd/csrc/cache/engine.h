@@ -139,8 +139,19 @@ class EmbeddingCache {
   // a pending reload holds new lookups at the door (glibc's rwlock prefers readers: overlapping sessions would
   // starve the writer otherwise)
   std::atomic<int>& direct_writers() { return direct_writers_; }
+  // Async-insert mode of a direct cache: snapshot the calling session's unique missed keys (enqueued on the session's
+  // stream) and fetch + insert them on the cache's own stream, no host thread involved.  Best effort like the host
+  // inserter: *accepted = false when the previous job is still running (the batch's misses stay uncached).
+  Status SubmitDirectInsert(hipStream_t session_stream, const uint64_t* d_key_start, const int64_t* d_uniq_keys,
+                            const uint32_t* d_counts, uint64_t N, uint64_t unique_total, uint64_t staging_floats,
+                            bool* accepted);
 
  private:
+  struct DirectInserter;
+  DirectInserter* dins_ = nullptr;
+  std::mutex dins_mu_;
+  void FreeDirectInserter();
+  Status FinishDirectInsert();  // second half of an accepted job; runs on a pool thread (HierParameterServer::RunDirectInsert)
   bool direct_ = false;
   std::atomic<int> direct_writers_{0};
   std::vector<PsIndexDev> h_index_;
@@ -299,6 +310,7 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
 
   // async-insert mode: queue "fetch these keys and insert them" for a cache; dropped (best effort)
   // when more than number_of_worker_buffers_in_pool jobs are already waiting.
+  void RunDirectInsert(std::shared_ptr<EmbeddingCache> cache);  // device-driven tier: finish an accepted background job
   void SubmitAsyncInsert(std::shared_ptr<EmbeddingCache> cache, std::vector<std::vector<int64_t>> keys_per_table);
 
   ThreadPool* pool() { return pool_; }

@@ -239,6 +239,8 @@ Status HierParameterServer::MutateTables(const std::string& model, const std::fu
     c->WaitAsync();
     locks.emplace_back(c->direct_mutex());
   }
+  // (a lookup that was still in flight may have queued one more background job: it takes the shared side of the
+  //  mutex itself, so it simply runs after the reload, against the new tables)
   struct Release {
     std::vector<std::shared_ptr<EmbeddingCache>>& v;
     ~Release() { for (auto& c : v) c->direct_writers().fetch_sub(1, std::memory_order_acq_rel); }
@@ -431,6 +433,20 @@ Status HierParameterServer::FetchMulti(const std::vector<FetchJob>& jobs) {
   if (tasks.size() <= 1) { if (!tasks.empty()) body(0); }
   else ThreadPool::Serving().ParallelFor(tasks.size(), body);
   return Status::Ok();
+}
+
+void HierParameterServer::RunDirectInsert(std::shared_ptr<EmbeddingCache> cache) {
+  {
+    std::lock_guard<std::mutex> lk(cache->pend_mu_);
+    ++cache->pending_async_;
+  }
+  auto self = shared_from_this();
+  pool_->Submit([self, cache]() {
+    (void)cache->FinishDirectInsert();
+    std::lock_guard<std::mutex> lk(cache->pend_mu_);
+    --cache->pending_async_;
+    cache->pend_cv_.notify_all();
+  });
 }
 
 void HierParameterServer::SubmitAsyncInsert(std::shared_ptr<EmbeddingCache> cache,
