@@ -14,6 +14,13 @@ namespace hps {
 
 constexpr int kBucketSlots = HPS_BUCKET_SLOTS;  // 16
 constexpr int kMaxTables = 256;                  // per model
+// Per-call counter block of a lookup session (uint32 words, device + pinned host mirror):
+//   [0] missed keys of the call   [1 + t] unique missed keys of table t
+//   [kMaxTables + 1 .. + 4] insert statistics (dropped, inserted, refreshed, spare)
+//   [kTableMissBase + t] missed keys of table t, duplicates included (per-table hit rate); after the host has read
+//                        them the same words carry the per-table insertion mode to the kernels (1 = async, 0 = sync)
+constexpr int kTableMissBase = kMaxTables + 8;
+constexpr int kCountWords = 2 * kMaxTables + 8;
 constexpr int kProbeBlockThreads = 256;
 
 // slot_out[] encoding produced by the probe kernel and refined by the miss kernels

@@ -58,12 +58,15 @@ __global__ void hps_psindex_build_kernel(const int64_t* __restrict__ table_keys,
 // single block: staging layout of the call's unique misses, from the per-table unique counts of K_B1
 __global__ void hps_missdesc_build_kernel(const TableCacheDev* __restrict__ tables, uint32_t T,
                                           const uint32_t* __restrict__ counts, MissDesc* __restrict__ md,
-                                          uint32_t* __restrict__ insert_stats) {
+                                          uint32_t* __restrict__ insert_stats,
+                                          const uint32_t* __restrict__ table_mode) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (insert_stats) insert_stats[0] = insert_stats[1] = insert_stats[2] = insert_stats[3] = 0;  // saves a memset launch
   uint64_t fl = 0, uq = 0;
   for (uint32_t t = 0; t < T; ++t) {
-    const uint32_t c = counts[0] ? counts[1 + t] : 0u;
+    // table_mode (optional): tables in async-insert mode (1) take no part in the synchronous miss path
+    uint32_t c = counts[0] ? counts[1 + t] : 0u;
+    if (table_mode && table_mode[t] != 0) c = 0;
     fl = (fl + 3) & ~(uint64_t)3;
     md->useg_start[t] = uq;
     md->stage_off[t] = fl;
@@ -148,8 +151,9 @@ hipError_t LaunchPsIndexBuild(const int64_t* table_keys_devptr, uint64_t R, int6
 }
 
 hipError_t LaunchMissDescBuild(const TableCacheDev* d_tables, uint32_t T, const uint32_t* d_counts, MissDesc* d_md,
-                               uint32_t* d_insert_stats, hipStream_t stream) {
-  hipLaunchKernelGGL(hps_missdesc_build_kernel, dim3(1), dim3(64), 0, stream, d_tables, T, d_counts, d_md, d_insert_stats);
+                               uint32_t* d_insert_stats, const uint32_t* d_table_mode, hipStream_t stream) {
+  hipLaunchKernelGGL(hps_missdesc_build_kernel, dim3(1), dim3(64), 0, stream, d_tables, T, d_counts, d_md, d_insert_stats,
+                     d_table_mode);
   return hipGetLastError();
 }
 

@@ -315,6 +315,10 @@ Status EmbeddingCache::SyncDirectIndex(const std::vector<std::shared_ptr<HostTab
     if (index_mem_[t].second) (void)hipFree(index_mem_[t].second);
     index_mem_[t] = {nullptr, nullptr};
     const uint64_t R = ht.size();
+    if (R >= (1ull << 32)) {
+      (void)hipFree(d_sent);
+      return Error(Code::kUnsupported, "ps_direct_access: table ", t, " has ", R, " rows; the device index holds 32-bit row numbers");
+    }
     uint64_t cap = 16;
     while (cap < 2 * R) cap <<= 1;
     int64_t* dk = nullptr; uint32_t* dr = nullptr;
@@ -375,8 +379,8 @@ void EmbeddingCache::FreeDirectInserter() {
 // Part 1, on the calling lookup's thread: claim the (single) job slot and snapshot the session's unique missed keys
 // with copies enqueued on the session's stream (ordered after its dedup kernels, before its next call reuses them).
 Status EmbeddingCache::SubmitDirectInsert(hipStream_t session_stream, const uint64_t* d_key_start, const int64_t* d_uniq_keys,
-                                          const uint32_t* d_counts, uint64_t N, uint64_t unique_total, uint64_t staging_floats,
-                                          bool* accepted) {
+                                          const uint32_t* d_counts, const uint32_t* h_counts_override, uint64_t N,
+                                          uint64_t unique_total, uint64_t staging_floats, bool* accepted) {
   *accepted = false;
   if (!direct_ || static_ || unique_total == 0) return Status::Ok();
   std::unique_lock<std::mutex> lk(dins_mu_, std::try_to_lock);
@@ -410,7 +414,10 @@ Status EmbeddingCache::SubmitDirectInsert(hipStream_t session_stream, const uint
   HPS_RETURN_IF_ERROR(grow(&I.d_found, &I.cap_found, (size_t)unique_total));
   HIP_TRY(hipMemcpyAsync(I.d_keys, d_uniq_keys, N * sizeof(int64_t), hipMemcpyDeviceToDevice, session_stream));
   HIP_TRY(hipMemcpyAsync(I.d_key_start, d_key_start, (T + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, session_stream));
-  HIP_TRY(hipMemcpyAsync(I.d_counts, d_counts, (1 + T) * sizeof(uint32_t), hipMemcpyDeviceToDevice, session_stream));
+  if (h_counts_override)  // mixed call: only the async tables' counts (pinned host words, stable until the call's final sync)
+    HIP_TRY(hipMemcpyAsync(I.d_counts, h_counts_override, (1 + T) * sizeof(uint32_t), hipMemcpyHostToDevice, session_stream));
+  else
+    HIP_TRY(hipMemcpyAsync(I.d_counts, d_counts, (1 + T) * sizeof(uint32_t), hipMemcpyDeviceToDevice, session_stream));
   HIP_TRY(hipEventRecord(I.ev_copied, session_stream));
   I.unique_total = unique_total;
   I.in_flight = true;
@@ -432,7 +439,7 @@ Status EmbeddingCache::FinishDirectInsert() {
   const size_t T = num_tables();
   HIP_TRY(hipStreamWaitEvent(I.stream, I.ev_copied, 0));
   const uint32_t epoch = NextEpoch();
-  hipError_t e = LaunchMissDescBuild(d_tables_, (uint32_t)T, I.d_counts, I.d_md, I.d_counts + kMaxTables + 1, I.stream);
+  hipError_t e = LaunchMissDescBuild(d_tables_, (uint32_t)T, I.d_counts, I.d_md, I.d_counts + kMaxTables + 1, nullptr, I.stream);
   if (e == hipSuccess) {
     BeginFetch(I.stream);
     e = LaunchPsFetchDirect(d_index_, (uint32_t)T, I.d_md, I.d_key_start, I.d_keys, I.d_staging, I.d_found, I.unique_total, cu_count_,
@@ -497,7 +504,7 @@ void LookupSession::Release() {
   auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
   auto dfree = [](void* p) { if (p) (void)hipFree(p); };
   hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_call_); dfree(d_call_); hfree(h_md_); dfree(d_md_);
-  dfree(d_slot_); dfree(d_block_miss_); dfree(d_set_); dfree(d_counts_); hfree(h_counts_);
+  dfree(d_slot_); dfree(d_block_miss_); dfree(d_set_); dfree(d_counts_); hfree(h_counts_); hfree(h_mode_);
   dfree(d_uniq_keys_); hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
   if (ev_done_) (void)hipEventDestroy(ev_done_);
   if (ev_read_) (void)hipEventDestroy(ev_read_);
@@ -553,9 +560,10 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   set_cap_ = 1024;
   while (set_cap_ < 2 * (uint64_t)max_keys_) set_cap_ <<= 1;
   HPS_RETURN_IF_ERROR(DevAlloc(&d_set_, set_cap_));
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_counts_, (size_t)kMaxTables + 8));
-  HPS_RETURN_IF_ERROR(PinAlloc(&h_counts_, (size_t)kMaxTables + 8));
-  HIP_TRY(hipMemset(d_counts_, 0, ((size_t)kMaxTables + 8) * sizeof(uint32_t)));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_counts_, (size_t)kCountWords));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_counts_, (size_t)kCountWords));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_mode_, (size_t)2 * kMaxTables + 2));
+  HIP_TRY(hipMemset(d_counts_, 0, (size_t)kCountWords * sizeof(uint32_t)));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_uniq_keys_, max_keys_));
   HPS_RETURN_IF_ERROR(PinAlloc(&h_uniq_keys_, max_keys_, hipHostMallocMapped));
   void* dv = nullptr;
@@ -730,54 +738,84 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     // on the miss counts, so the whole call is enqueued without a round trip and the counts come back at the end.
     // (Only while the previous call of this session missed something: a fully resident working set is served
     // faster by reading the counts first and stopping there — four empty kernels and a sync less.)
-    const Status st = HandleMissesDirect(N, epoch, /*counts_known=*/false);
+    table_async_.assign(T, 0);
+    const Status st = HandleMissesDirect(N, epoch, /*counts_known=*/false, nullptr);
     if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
     if (st.ok()) account();
     phase_ms_[3] = ms_since(tc0);
     phase_ms_[2] = phase_ms_[3];  // no host phases on this path; [1] holds the fetch kernel's GPU time
     return st;
   }
-  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, (1 + T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kTableMissBase + T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipEventRecord(ev_done_, stream_));
   HIP_TRY(hipEventSynchronize(ev_done_));
   if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
   account();
   const uint64_t misses = h_counts_[0];
   phase_ms_[0] = phase_ms_[3] = ms_since(tc0);
+  table_async_.assign(T, 0);
   if (misses == 0) return Status::Ok();
 
-  // ---- insertion policy (docs/architecture.md:65-67) ----
-  const double hit_rate = 1.0 - (double)misses / (double)N;
-  const bool async = hit_rate >= (double)params_.hit_rate_threshold;
-  if (async) {
+  // ---- insertion policy, decided per table as the reference's per-table lookup loop does
+  //      (docs/architecture.md:65-67): a table whose hit rate in this call reaches
+  //      hit_rate_threshold returns the default vector for its misses now and has them inserted in the
+  //      background; the other tables fetch, return and insert their missed rows before the call returns ----
+  bool any_async = false, any_sync = false;
+  for (size_t t = 0; t < T; ++t) {
+    const uint64_t n_t = c.key_start[t + 1] - c.key_start[t];
+    const uint64_t m_t = h_counts_[kTableMissBase + t];
+    if (m_t == 0 || n_t == 0) continue;
+    const bool as = 1.0 - (double)m_t / (double)n_t >= (double)params_.hit_rate_threshold;
+    table_async_[t] = as ? 1 : 0;
+    any_async |= as;
+    any_sync |= !as;
+  }
+  const uint32_t* d_mode = nullptr;
+  if (any_async && any_sync) {
+    // mixed call: the per-table mode goes to the kernels through the words the per-table miss counts came back in
+    for (size_t t = 0; t < T; ++t) h_mode_[t] = table_async_[t];
+    HIP_TRY(hipMemcpyAsync(d_counts_ + kTableMissBase, h_mode_, T * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+    d_mode = d_counts_ + kTableMissBase;
+  }
+  if (any_async) {
     last_async_ = true;
-    e = LaunchMissFillDefault(d_call_, cache_->device_tables(), N, d_slot_, cu, stream_);
+    e = LaunchMissFillDefault(d_call_, cache_->device_tables(), N, d_slot_, d_mode, cu, stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "default fill launch failed: ", hipGetErrorString(e));
-    // hand the unique missed keys to the background inserter (best effort)
+    // hand the async tables' unique missed keys to the background inserter (best effort)
     if (cache_->direct()) {
       // device-driven tier: the keys never leave the GPU; fetch + insert run on the cache's own stream
       uint64_t uniq = 0, floats = 0;
+      uint32_t* job_counts = h_mode_ + kMaxTables;   // [0] any misses, [1 + t] unique misses of the async tables
+      job_counts[0] = 1;
       for (size_t t = 0; t < T; ++t) {
-        uniq += h_counts_[1 + t];
-        floats = ((floats + 3) & ~(uint64_t)3) + (uint64_t)h_counts_[1 + t] * tables_[t]->dim();
+        const uint32_t cnt = table_async_[t] ? h_counts_[1 + t] : 0u;
+        job_counts[1 + t] = cnt;
+        uniq += cnt;
+        floats = ((floats + 3) & ~(uint64_t)3) + (uint64_t)cnt * tables_[t]->dim();
       }
       bool accepted = false;
-      HPS_RETURN_IF_ERROR(cache_->SubmitDirectInsert(stream_, d_call_->key_start, d_uniq_keys_, d_counts_, N, uniq, floats, &accepted));
+      HPS_RETURN_IF_ERROR(cache_->SubmitDirectInsert(stream_, d_call_->key_start, d_uniq_keys_, d_counts_, any_sync ? job_counts : nullptr,
+                                                     N, uniq, floats, &accepted));
       if (accepted) ps_->RunDirectInsert(cache_);
     } else {
       std::vector<std::vector<int64_t>> job(T);
       for (size_t t = 0; t < T; ++t) {
+        if (!table_async_[t]) continue;
         const uint32_t cnt = h_counts_[1 + t];
         job[t].assign(h_uniq_keys_ + c.key_start[t], h_uniq_keys_ + c.key_start[t] + cnt);
       }
       ps_->SubmitAsyncInsert(cache_, std::move(job));
     }
-    HIP_TRY(hipStreamSynchronize(stream_));
-    std::lock_guard<std::mutex> lk(cache_->stat_mu_);
-    cache_->counters_.async_calls += 1;
-    return Status::Ok();
+    {
+      std::lock_guard<std::mutex> lk(cache_->stat_mu_);
+      cache_->counters_.async_calls += 1;
+    }
+    if (!any_sync) {
+      HIP_TRY(hipStreamSynchronize(stream_));
+      return Status::Ok();
+    }
   }
-  const Status st = cache_->direct() ? HandleMissesDirect(N, epoch, /*counts_known=*/true) : HandleMisses(N, epoch);
+  const Status st = cache_->direct() ? HandleMissesDirect(N, epoch, /*counts_known=*/true, d_mode) : HandleMisses(N, epoch);
   phase_ms_[3] = ms_since(tc0);
   phase_ms_[2] = phase_ms_[3] - phase_ms_[0] - phase_ms_[1];
   return st;
@@ -785,11 +823,12 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
 
 // Synchronous miss path, device-driven ("ps_direct_access"): the GPU resolves the unique missed keys through the
 // device-resident index of the host tier and pulls the rows out of pinned host memory itself.
-Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts_known) {
+Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts_known, const uint32_t* d_table_mode) {
   const size_t T = tables_.size();
   const int cu = cache_->cu_count();
   const uint64_t max_unique = counts_known ? (uint64_t)last_unique_ : N;
-  hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, d_counts_ + kMaxTables + 1, stream_);
+  hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, d_counts_ + kMaxTables + 1,
+                                     d_table_mode, stream_);
   if (e == hipSuccess) {
     cache_->BeginFetch(stream_);
     if (timing_) (void)hipEventRecord(ev_f0_, stream_);
@@ -834,7 +873,8 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
   std::vector<uint32_t> ucnt(T), done(T, 0);
   size_t total_floats = 0, total_uniq = 0;
   for (size_t t = 0; t < T; ++t) {
-    ucnt[t] = h_counts_[1 + t];
+    // tables in async-insert mode take no part here: their misses got the default vector (K_D)
+    ucnt[t] = (t < table_async_.size() && table_async_[t]) ? 0u : h_counts_[1 + t];
     total_floats += (size_t)ucnt[t] * tables_[t]->dim();
     total_uniq += ucnt[t];
   }

@@ -143,8 +143,8 @@ class EmbeddingCache {
   // stream) and fetch + insert them on the cache's own stream, no host thread involved.  Best effort like the host
   // inserter: *accepted = false when the previous job is still running (the batch's misses stay uncached).
   Status SubmitDirectInsert(hipStream_t session_stream, const uint64_t* d_key_start, const int64_t* d_uniq_keys,
-                            const uint32_t* d_counts, uint64_t N, uint64_t unique_total, uint64_t staging_floats,
-                            bool* accepted);
+                            const uint32_t* d_counts, const uint32_t* h_counts_override /*pinned, optional*/, uint64_t N,
+                            uint64_t unique_total, uint64_t staging_floats, bool* accepted);
 
  private:
   struct DirectInserter;
@@ -209,7 +209,9 @@ class LookupSession {
                         const size_t* num_keys_per_table, size_t num_tables);
   Status LookupDevice(const int64_t* d_keys_flat, float* const* d_vectors_per_table, const size_t* n, size_t T);
   Status HandleMisses(uint64_t N, uint32_t epoch);
-  Status HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts_known);
+  Status HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts_known, const uint32_t* d_table_mode);
+  std::vector<uint8_t> table_async_;   // this call: 1 = the table's misses are served in async-insert mode
+  uint32_t* h_mode_ = nullptr;         // pinned: [0, kMaxTables) per-table mode words, then 1 + kMaxTables job counts
   Status EnsureStaging(size_t floats, size_t uniq);
   void Release();
 

@@ -21,7 +21,7 @@ hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tabl
                              const int32_t* d_slot, const float* d_staging, int cu_count, hipStream_t stream);
 
 hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, uint64_t N,
-                                 const int32_t* d_slot, int cu_count, hipStream_t stream);
+                                 const int32_t* d_slot, const uint32_t* d_table_mode, int cu_count, hipStream_t stream);
 
 hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const MissDesc* d_md, uint64_t total_unique,
                              const uint64_t* d_key_start, const int64_t* d_uniq_keys, const float* d_staging,

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void hps_miss_begin_kernel(const uint32_t* __r
   const uint32_t total = block_sum_u32(v, sh);
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) counts[0] = total;
-    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) counts[1 + t] = 0;
+    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) { counts[1 + t] = 0; counts[kTableMissBase + t] = 0; }
   }
   if (total == 0) return;
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < set_cap;
@@ -344,7 +344,8 @@ __global__ __launch_bounds__(kDedupBlock) void hps_miss_dedup_kernel(
 
   bool winner = false;
   int64_t key = 0;
-  if (i < end && slot_io[i] == kSlotMiss) {
+  const bool missed = i < end && slot_io[i] == kSlotMiss;
+  if (missed) {
     key = keys[i];
     uint64_t h = set_hash(key, t) & mask;
     for (;;) {
@@ -359,16 +360,20 @@ __global__ __launch_bounds__(kDedupBlock) void hps_miss_dedup_kernel(
   }
   // rank winners inside the block
   __shared__ uint32_t sh_wave[kDedupBlock / 64];
+  __shared__ uint32_t sh_miss[kDedupBlock / 64];
   __shared__ uint32_t sh_base;
   const uint64_t bal = __ballot(winner);
+  const uint64_t bal_miss = __ballot(missed);
   const int lane = lane_id();
   const uint32_t rank_in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-  if (lane == 0) sh_wave[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+  if (lane == 0) { sh_wave[threadIdx.x >> 6] = (uint32_t)__popcll(bal); sh_miss[threadIdx.x >> 6] = (uint32_t)__popcll(bal_miss); }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int w = 0; w < kDedupBlock / 64; ++w) { const uint32_t c = sh_wave[w]; sh_wave[w] = run; run += c; }
+    uint32_t run = 0, miss = 0;
+    for (int w = 0; w < kDedupBlock / 64; ++w) { const uint32_t c = sh_wave[w]; sh_wave[w] = run; run += c; miss += sh_miss[w]; }
     sh_base = run ? atomicAdd(&counts[1 + t], run) : 0u;
+    // missed keys of the table, duplicates included: the per-table hit rate behind the insertion policy
+    if (miss) atomicAdd(&counts[kTableMissBase + t], miss);
   }
   __syncthreads();
   if (winner) {
@@ -457,7 +462,9 @@ __global__ __launch_bounds__(256) void hps_miss_scatter_kernel(const CallDesc* _
 // (docs/architecture.md:32, docs/hierarchical_parameter_server.md:244-246).
 __global__ __launch_bounds__(256) void hps_miss_fill_default_kernel(const CallDesc* __restrict__ call,
                                                                      const TableCacheDev* __restrict__ tables,
-                                                                     const int32_t* __restrict__ slot_in) {
+                                                                     const int32_t* __restrict__ slot_in,
+                                                                     const uint32_t* __restrict__ table_mode) {
+  // table_mode (optional): per table 1 = async insert (fill its misses), 0 = synchronous (leave them to K_C1)
   const uint64_t N = call->total_keys;
   const int T = (int)call->num_tables;
   const int lane = lane_id();
@@ -477,6 +484,7 @@ __global__ __launch_bounds__(256) void hps_miss_fill_default_kernel(const CallDe
       if (!have) continue;
       const uint64_t gi = chunk * 64 + (uint64_t)src;
       const int t = find_table(call->key_start, T, gi);
+      if (table_mode && table_mode[t] == 0) continue;
       const uint32_t D = tables[t].dim;
       const float dv = tables[t].default_value;
       float* dst = call->out[t] + (gi - call->key_start[t]) * D;
@@ -708,9 +716,9 @@ hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tabl
 }
 
 hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, uint64_t N,
-                                 const int32_t* d_slot, int cu_count, hipStream_t stream) {
+                                 const int32_t* d_slot, const uint32_t* d_table_mode, int cu_count, hipStream_t stream) {
   const uint32_t grid = probe_grid(N, cu_count);
-  hipLaunchKernelGGL(hps_miss_fill_default_kernel, dim3(grid), dim3(256), 0, stream, d_call, d_tables, d_slot);
+  hipLaunchKernelGGL(hps_miss_fill_default_kernel, dim3(grid), dim3(256), 0, stream, d_call, d_tables, d_slot, d_table_mode);
   return hipGetLastError();
 }
 

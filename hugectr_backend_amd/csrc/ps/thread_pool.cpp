@@ -63,7 +63,8 @@ ThreadPool& ThreadPool::Global() {
 ThreadPool& ThreadPool::Serving() {
   // A 512-B row is 8 cache lines and a core keeps only ~a dozen line fills in flight, so the gather is bound
   // by line-fill buffers per core, not by DRAM: it scales with the number of physical cores working on it.
-  // HPS_SERVING_THREADS overrides the default of half the hardware threads (capped at 96).
+  // HPS_SERVING_THREADS overrides the default: the CPUs this process may really use (affinity mask clipped by the
+  // cgroup quota) minus a few for the callers, at most 64.
   static ThreadPool pool([] {
     if (const char* e = std::getenv("HPS_SERVING_THREADS")) {
       const long v = std::strtol(e, nullptr, 10);

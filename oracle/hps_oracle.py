@@ -113,7 +113,7 @@ def np_lookup(tables, keys, num_keys, defaults, resident=None) -> np.ndarray:
         D = rows.shape[1]
         idx = np_find(tk, q)
         found = idx >= 0
-        if resident is not None:
+        if resident is not None and resident[t] is not None:   # None for a table = that table is served synchronously
             found &= np.isin(q, np.asarray(resident[t], dtype=np.int64))
         o = np.full((n, D), np.float32(defaults[t]), dtype=np.float32)
         o[found] = rows[idx[found]]
@@ -121,6 +121,26 @@ def np_lookup(tables, keys, num_keys, defaults, resident=None) -> np.ndarray:
     if off != keys.size:
         raise ValueError("sum(NUMKEYS) != len(KEYS)")
     return np.concatenate(out) if out else np.zeros(0, np.float32)
+
+
+def np_insert_modes(keys, num_keys, resident, hit_rate_threshold) -> list:
+    """Insertion policy of one call, per table (docs/architecture.md:65-67): True = async
+    (the table's hit rate in this call >= hit_rate_threshold: misses return the default vector and are inserted in
+    the background), False = synchronous (missed rows are fetched, returned exactly and inserted before the call
+    returns).  The reference loops over the tables of a request and decides for each; its hit rate is "the real hit
+    rate" of the table's lookup.  Restated here over the table's keys as sent (duplicates count); tables without
+    misses or without keys are synchronous by definition."""
+    keys = np.asarray(keys, dtype=np.int64).ravel()
+    modes, off = [], 0
+    for t, n in enumerate(num_keys):
+        q = keys[off:off + n]
+        off += n
+        if n == 0:
+            modes.append(False)
+            continue
+        misses = int((~np.isin(q, np.asarray(resident[t], dtype=np.int64))).sum())
+        modes.append(misses > 0 and 1.0 - misses / n >= hit_rate_threshold)
+    return modes
 
 
 # --------------------------------------------------------------------------------------------------

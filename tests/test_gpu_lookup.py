@@ -289,3 +289,45 @@ def test_lru_epoch_renormalisation(monkeypatch):
         out = s.lookup(q, [4096]).cpu().numpy()
         assert np.array_equal(_bits(out), _bits(co.lookup(q, [4096], [0.0]))), it
     assert cache.counters()["inserted"] > inserted_before  # eviction/insertion keeps working after the fold
+
+
+@pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
+def test_insertion_policy_is_decided_per_table(direct):
+    """hit_rate_threshold between two tables' hit rates: the hot table answers in async-insert mode (defaults for its
+    misses, background insertion), the cold table synchronously (exact rows, inserted before return) — in ONE call
+    (the reference decides inside its per-table loop)."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(77)
+    tables = make_tables([(8000, 32), (8000, 64), (500, 16)])
+    ps, cache, s = _mk("policy_d" if direct else "policy_h", tables, maxcat=[1, 1, 1], gpucacheper=0.5, hit_rate_threshold=0.8,
+                       defaults=[7.0, -3.0, 0.5], max_batch=4096, extra={"ps_direct_access": direct})
+    resident = [tk[cache.query(t, tk) >= 0] for t, (tk, _) in enumerate(tables)]
+    cold = [tk[cache.query(t, tk) < 0] for t, (tk, _) in enumerate(tables)]
+    n = 3000
+    q0 = np.concatenate([rng.choice(resident[0], n - 150), rng.choice(cold[0], 150)])      # 95 % hit -> async
+    q1 = np.concatenate([rng.choice(resident[1], n // 2), rng.choice(cold[1], n // 2)])    # 50 % hit -> sync
+    q2 = rng.choice(resident[2], 200)                                                       # all hit
+    for a in (q0, q1):
+        rng.shuffle(a)
+    nk = [q0.size, q1.size, q2.size]
+    q = np.concatenate([q0, q1, q2]).astype(np.int64)
+    modes = O.np_insert_modes(q, nk, resident, 0.8)
+    assert modes == [True, False, False]
+    out = s.lookup(q, nk).cpu().numpy()
+    st = s.last_stats()
+    assert st.async_insert == 1
+    assert st.misses == 150 + n // 2
+    ref = O.np_lookup(tables, q, nk, [7.0, -3.0, 0.5], resident=[resident[0], None, None])
+    assert np.array_equal(_bits(out), _bits(ref))
+    # the synchronous table's missed keys are resident when the call returns; the async table's after the background job
+    # (a few may have been dropped from over-full buckets, as in every insert)
+    assert (cache.query(1, cold[1]) >= 0).sum() >= 0.8 * np.unique(q1[np.isin(q1, cold[1])]).size
+    newly0 = np.unique(q0[np.isin(q0, cold[0])])
+    cache.wait_async()
+    assert (cache.query(0, newly0) >= 0).mean() > 0.8
+    # second call, same keys: everything resident now -> no async part, exact rows everywhere
+    res2 = [tk[cache.query(t, tk) >= 0] for t, (tk, _) in enumerate(tables)]
+    modes2 = O.np_insert_modes(q, nk, res2, 0.8)
+    out2 = s.lookup(q, nk).cpu().numpy()
+    ref2 = O.np_lookup(tables, q, nk, [7.0, -3.0, 0.5], resident=[res2[t] if modes2[t] else None for t in range(3)])
+    assert np.array_equal(_bits(out2), _bits(ref2))

@@ -116,3 +116,21 @@ def test_product_host_tier_against_fixtures(g, tmp_path):
     s2 = hps.LookupSession.create(ps2, "ident", None)
     assert np.array_equal(_bits(s2.lookup(g["default_keys"], [7])), _bits(g["default_expected_1"]))
     assert np.array_equal(_bits(s2.lookup(g["dups_keys"], [9])), _bits(g["dups_expected"]))
+
+
+def test_insertion_policy_per_table_restatement():
+    """np_insert_modes / np_lookup(resident=[.., None, ..]): the per-table sync/async rule the GPU tests check against."""
+    from oracle import hps_oracle as O
+    tk = np.arange(100, dtype=np.int64)
+    rows = O.np_synth_rows(O.SEED, 0, tk, 4)
+    tables = [(tk, rows), (tk, rows), (tk, rows)]
+    resident = [tk[:90], tk[:50], tk]
+    q = np.concatenate([tk, tk, tk[:10]])
+    nk = [100, 100, 10]
+    # table 0: 90 % hit, table 1: 50 %, table 2: no misses
+    assert O.np_insert_modes(q, nk, resident, 0.8) == [True, False, False]
+    assert O.np_insert_modes(q, nk, resident, 1.0) == [False, False, False]       # threshold 1.0: always synchronous
+    assert O.np_insert_modes(q, nk, resident, 0.4) == [True, True, False]
+    out = O.np_lookup(tables, q, nk, [9.0, 9.0, 9.0], resident=[resident[0], None, None]).reshape(-1, 4)
+    assert (out[90:100] == 9.0).all() and np.array_equal(out[:90], rows[:90])     # async table: defaults for non-resident keys
+    assert np.array_equal(out[100:200], rows)                                       # sync table: exact rows
