@@ -282,7 +282,7 @@ def main():
     torch.cuda.synchronize()
 
     ncpu = effective_cpus()
-    lat_ms, kern_ms, miss_ct, phases, uniq_ct = [], [], [], [], []
+    lat_ms, kern_ms, miss_ct, phases, uniq_ct, gpu_ms = [], [], [], [], [], []
     lock = threading.Lock()
     post_hooks = []   # per session: work appended to every step (the config-5 leg runs the dense step here)
 
@@ -309,6 +309,7 @@ def main():
                         kern_ms.append(st.probe_gather_ms)
                         miss_ct.append(st.misses)
                         uniq_ct.append(st.unique_misses)
+                        gpu_ms.append(st.gpu_call_ms)
                         phases.append([float(x) for x in st.phase_ms])
 
         th = [threading.Thread(target=worker, args=(si,)) for si in range(len(sessions))]
@@ -338,6 +339,7 @@ def main():
     extra = {}
     main_lat, main_kern, main_miss, main_phases = list(lat_ms), list(kern_ms), list(miss_ct), list(phases)
     main_uniq = list(uniq_ct)
+    main_gpu = list(gpu_ms)
     if not a.no_extra_legs and world == 1:  # informational legs: single-GPU run only
         def leg(batches, steps, sess_list):
             lat_ms.clear(); kern_ms.clear(); miss_ct.clear(); phases.clear()
@@ -519,6 +521,9 @@ def main():
             },
             "p50_batch_latency_ms": float(np.percentile(lat_ms, 50)) if lat_ms else None,
             "p99_batch_latency_ms": float(np.percentile(lat_ms, 99)) if lat_ms else None,
+            # GPU side of a batch (HIP events on the session's stream: probe+gather start to the last kernel of the call)
+            "p50_batch_gpu_ms": float(np.percentile(main_gpu, 50)) if main_gpu else None,
+            "p99_batch_gpu_ms": float(np.percentile(main_gpu, 99)) if main_gpu else None,
             "measured_hit_rate": 1.0 - float(np.mean(miss_ct)) / N if miss_ct else None,
             "resident_fraction_after_warmup": resident_frac,
             "roofline": {

@@ -311,6 +311,7 @@ int hps_session_last_stats(hps_session_t* s, hps_lookup_stats_t* out) {
     out->async_insert = s->s->last_call_async() ? 1 : 0;
     out->probe_gather_ms = s->s->last_gpu_ms();
     for (int i = 0; i < 4; ++i) out->phase_ms[i] = s->s->last_phase_ms()[i];
+    out->gpu_call_ms = s->s->last_gpu_call_ms();
     return Status::Ok();
   });
 }

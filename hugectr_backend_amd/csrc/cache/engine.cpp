@@ -513,6 +513,7 @@ void LookupSession::Release() {
   if (ev_t1_) (void)hipEventDestroy(ev_t1_);
   if (ev_f0_) (void)hipEventDestroy(ev_f0_);
   if (ev_f1_) (void)hipEventDestroy(ev_f1_);
+  if (ev_c1_) (void)hipEventDestroy(ev_c1_);
   if (ev_copy_) (void)hipEventDestroy(ev_copy_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -547,6 +548,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HIP_TRY(hipEventCreate(&ev_t1_));
   HIP_TRY(hipEventCreate(&ev_f0_));
   HIP_TRY(hipEventCreate(&ev_f1_));
+  HIP_TRY(hipEventCreate(&ev_c1_));
 
   HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_keys_, max_keys_));
@@ -641,7 +643,17 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     off += num_keys_per_table[t];
   }
   HIP_TRY(hipMemcpyAsync(d_keys_, h_keys_pinned_, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
-  return LookupDevice(d_keys_, vectors_per_table, num_keys_per_table, num_tables);
+  return TimedLookupDevice(d_keys_, vectors_per_table, num_keys_per_table, num_tables);
+}
+
+// LookupDevice + (option "timing") the GPU-side span of the call: probe+gather start (after the waits on other
+// sessions' kernels) to the last kernel of the call, by HIP events on the session's stream.
+Status LookupSession::TimedLookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
+  const Status st = LookupDevice(d_keys_flat, d_out, n, T);
+  last_gpu_call_ms_ = 0.f;
+  // ev_c1_ was recorded behind the last kernel of whichever exit the call took, before its final synchronisation
+  if (timing_ && st.ok()) (void)hipEventElapsedTime(&last_gpu_call_ms_, ev_t0_, ev_c1_);
+  return st;
 }
 
 Status LookupSession::lookup_from_device(const int64_t* d_keys_flat, float* const* d_vectors_per_table,
@@ -655,7 +667,7 @@ Status LookupSession::lookup_from_device(const int64_t* d_keys_flat, float* cons
   if (N > max_keys_) return Error(Code::kInvalidArg, "lookup: ", N, " keys exceed the session capacity of ", max_keys_);
   if (N == 0) return Status::Ok();
   HIP_TRY(hipSetDevice(device_));
-  return LookupDevice(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
+  return TimedLookupDevice(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
 }
 
 Status LookupSession::LookupHostTier(const void* const* h_keys_per_table, float* const* h_vectors_per_table,
@@ -746,6 +758,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     phase_ms_[2] = phase_ms_[3];  // no host phases on this path; [1] holds the fetch kernel's GPU time
     return st;
   }
+  if (timing_) (void)hipEventRecord(ev_c1_, stream_);
   HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kTableMissBase + T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipEventRecord(ev_done_, stream_));
   HIP_TRY(hipEventSynchronize(ev_done_));
@@ -811,6 +824,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
       cache_->counters_.async_calls += 1;
     }
     if (!any_sync) {
+      if (timing_) (void)hipEventRecord(ev_c1_, stream_);
       HIP_TRY(hipStreamSynchronize(stream_));
       return Status::Ok();
     }
@@ -854,6 +868,7 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
                         d_staging_, d_found_, epoch, d_counts_ + kMaxTables + 1, cu, stream_);
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
+  if (timing_) (void)hipEventRecord(ev_c1_, stream_);
   HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kMaxTables + 5) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipStreamSynchronize(stream_));
   if (timing_) (void)hipEventElapsedTime(&phase_ms_[1], ev_f0_, ev_f1_);  // direct path: [1] = the fetch kernel (GPU time)
@@ -965,6 +980,7 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     cache_->EndWrite(stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
     // staging is reused by the next chunk
+    if (timing_) (void)hipEventRecord(ev_c1_, stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
     for (size_t t = 0; t < T; ++t) done[t] = md.chunk_hi[t];
   }

@@ -192,6 +192,7 @@ class LookupSession {
   uint64_t last_unique_miss_count() const { return last_unique_; }
   bool last_call_async() const { return last_async_; }
   float last_gpu_ms() const { return last_gpu_ms_; }      // probe+gather kernel time of the last call (HIP events)
+  float last_gpu_call_ms() const { return last_gpu_call_ms_; }  // first kernel to last of the last call (HIP events)
   // host wall-clock phases of the last call (ms): [0] enqueue -> miss counts known, [1] parameter-server
   // gather, [2] H2D + scatter + insert until the stream drained, [3] whole call
   const float* last_phase_ms() const { return phase_ms_; }
@@ -224,7 +225,9 @@ class LookupSession {
   hipStream_t copy_stream_ = nullptr;  // second H2D queue for the missed-row pieces
   hipEvent_t ev_copy_ = nullptr;
   hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr,
-             ev_f0_ = nullptr, ev_f1_ = nullptr;
+             ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr;
+  float last_gpu_call_ms_ = 0.f;
+  Status TimedLookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T);
 
   size_t max_keys_ = 0;           // max_batch * sum(maxnum_catfeature)
   int64_t* h_keys_pinned_ = nullptr;

@@ -77,7 +77,9 @@ typedef struct hps_lookup_stats {
   int32_t async_insert;    /* 1: answered in async-insert mode (missed keys returned the default vector) */
   float probe_gather_ms;   /* HIP-event time of the probe+gather kernel (option "timing"=1), else 0 */
   float phase_ms[4];       /* host wall clock of the last call: [0] until miss counts are known,
-                              [1] host parameter-server gather, [2] H2D + scatter + insert, [3] whole call */
+                              [1] host parameter-server gather (ps_direct_access: HIP-event time of the fetch kernel),
+                              [2] H2D + scatter + insert, [3] whole call */
+  float gpu_call_ms;       /* HIP-event span of the call on the session's stream, first kernel to last (option "timing"=1) */
 } hps_lookup_stats_t;
 
 const char* hps_last_error(void);
