@@ -57,3 +57,21 @@ def test_engine_fails_loudly_without_a_gpu_for_cache_models():
     with pytest.raises(hps.HpsError) as e:
         ps.create_embedding_cache_per_model("m")
     assert e.value.code == hps.ERR_UNAVAILABLE and "no CPU fallback" in e.value.msg
+
+
+def test_dense_step_and_direct_tier_fail_loudly_without_a_gpu():
+    import numpy as np
+    import pytest
+    from hugectr_backend_amd import hps
+    from hugectr_backend_amd.dense import DenseInteraction
+    from tests.conftest import ps_config
+    if hps.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(hps.HpsError) as e:
+        DenseInteraction([np.zeros((13, 128), np.float32)], [np.zeros(128, np.float32)], 26, 128)
+    assert e.value.code == hps.ERR_UNAVAILABLE and "no CPU fallback" in e.value.msg
+    tabs = [(np.arange(4, dtype=np.int64), np.zeros((4, 4), np.float32))]
+    with pytest.raises(hps.HpsError) as e:
+        hps.HierParameterServer.create_from_dict(ps_config("m", tabs, gpucache=True, extra={"ps_direct_access": True}),
+                                                 load_tables=False)
+    assert e.value.code == hps.ERR_UNAVAILABLE and "ps_direct_access needs a GPU" in e.value.msg
