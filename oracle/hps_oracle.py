@@ -131,6 +131,7 @@ def np_insert_modes(keys, num_keys, resident, hit_rate_threshold) -> list:
     rate" of the table's lookup.  Restated here over the table's keys as sent (duplicates count); tables without
     misses or without keys are synchronous by definition."""
     keys = np.asarray(keys, dtype=np.int64).ravel()
+    thr = float(np.float32(hit_rate_threshold))   # the configuration carries the threshold as a float (backend.cpp:372)
     modes, off = [], 0
     for t, n in enumerate(num_keys):
         q = keys[off:off + n]
@@ -139,7 +140,7 @@ def np_insert_modes(keys, num_keys, resident, hit_rate_threshold) -> list:
             modes.append(False)
             continue
         misses = int((~np.isin(q, np.asarray(resident[t], dtype=np.int64))).sum())
-        modes.append(misses > 0 and 1.0 - misses / n >= hit_rate_threshold)
+        modes.append(misses > 0 and 1.0 - misses / n >= thr)
     return modes
 
 
