@@ -415,6 +415,16 @@ def main():
                                "output [batch, %d] f16" % (D, ops[0].out_dim)})
             extra["c5_lookup_plus_dense"] = c5
             del fresh5
+        # (4) the miss path arranged as in the reference (host threads gather the missed rows, hipMemcpyAsync ships
+        #     them) on the very same cache and tables: session option "host_gather"
+        if a.direct and a.mode == "sync":
+            fresh6 = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
+            for s in sessions:
+                s.set_option("host_gather", 1)
+            extra["host_gather_tier_same_cache"] = leg(fresh6, 24, sessions)
+            for s in sessions:
+                s.set_option("host_gather", 0)
+            del fresh6
         del cdf_d, resident_d, hot_batches, fresh
 
     # ---- untimed parity check of the last step of session 0 against the CPU oracle (tables 0..1) ----
@@ -541,6 +551,9 @@ def main():
                 # session's PCIe fetch / dedup / insert kernels; the same kernel with nothing underneath
                 # (all-hit leg, one session) is reported next to it
                 "frac_kernel_alone": (extra.get("all_hit_one_session") or {}).get("kernel_frac_of_hbm_peak"),
+                # the same kernel, same cache, same workload and session count with the miss path arranged as in
+                # the reference (host gather + hipMemcpyAsync: the DMA engine does not disturb it; the job is slower)
+                "frac_with_host_gather_tier": (extra.get("host_gather_tier_same_cache") or {}).get("kernel_frac_of_hbm_peak"),
                 # the read side alone, and both against the measured copy ceiling of the part
                 "read_only_frac": N * (8 + 4 * D) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
                 "frac_of_copy_ceiling_6290": achieved / 6290.0,

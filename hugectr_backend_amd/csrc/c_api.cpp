@@ -329,6 +329,8 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       s->s->set_probe_unroll(value);
     } else if (n == "probe_balanced") {
       s->s->set_probe_balanced(value != 0);
+    } else if (n == "host_gather") {
+      s->s->set_force_host_gather(value != 0);
     } else if (n == "hit_rate_threshold_permille") {
       if (value < 0) return Error(Code::kInvalidArg, "hit_rate_threshold_permille must be >= 0");
       s->s->set_hit_rate_threshold((float)value / 1000.0f);

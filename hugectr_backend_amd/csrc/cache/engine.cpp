@@ -745,7 +745,10 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     cache_->counters_.misses += misses;
     cache_->counters_.unique_misses += uniq;
   };
-  if (cache_->direct() && params_.hit_rate_threshold >= 1.0f && last_misses_ > 0) {
+  // (option "host_gather": serve this session's misses the reference's way — host threads + H2D copy — although the
+  //  cache is in ps_direct_access mode; the pinned tables serve both paths)
+  const bool use_direct = cache_->direct() && !force_host_gather_;
+  if (use_direct && params_.hit_rate_threshold >= 1.0f && last_misses_ > 0) {
     // Device-driven miss path with the insertion policy fixed to "synchronous": nothing on the host depends
     // on the miss counts, so the whole call is enqueued without a round trip and the counts come back at the end.
     // (Only while the previous call of this session missed something: a fully resident working set is served
@@ -795,7 +798,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     e = LaunchMissFillDefault(d_call_, cache_->device_tables(), N, d_slot_, d_mode, cu, stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "default fill launch failed: ", hipGetErrorString(e));
     // hand the async tables' unique missed keys to the background inserter (best effort)
-    if (cache_->direct()) {
+    if (use_direct) {
       // device-driven tier: the keys never leave the GPU; fetch + insert run on the cache's own stream
       uint64_t uniq = 0, floats = 0;
       uint32_t* job_counts = h_mode_ + kMaxTables;   // [0] any misses, [1 + t] unique misses of the async tables
@@ -829,7 +832,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
       return Status::Ok();
     }
   }
-  const Status st = cache_->direct() ? HandleMissesDirect(N, epoch, /*counts_known=*/true, d_mode) : HandleMisses(N, epoch);
+  const Status st = use_direct ? HandleMissesDirect(N, epoch, /*counts_known=*/true, d_mode) : HandleMisses(N, epoch);
   phase_ms_[3] = ms_since(tc0);
   phase_ms_[2] = phase_ms_[3] - phase_ms_[0] - phase_ms_[1];
   return st;

@@ -198,6 +198,7 @@ class LookupSession {
   const float* last_phase_ms() const { return phase_ms_; }
   void set_probe_unroll(int u) { probe_unroll_ = u; }
   void set_probe_balanced(bool b) { probe_balanced_ = b; }
+  void set_force_host_gather(bool b) { force_host_gather_ = b; }
   void set_timing(bool on) { timing_ = on; }
   // per-session override of the model's hit_rate_threshold (sync vs async insertion, docs/architecture.md:65-67)
   void set_hit_rate_threshold(float v) { params_.hit_rate_threshold = v; }
@@ -257,6 +258,7 @@ class LookupSession {
   float last_gpu_ms_ = 0.f;
   float phase_ms_[4] = {0, 0, 0, 0};
   int probe_unroll_ = 1102;  // U=2, rolled key-group loop (8 waves/SIMD), LRU stamp on 1/4 of the hits (tools/kbench.py)
+  bool force_host_gather_ = false;  // option "host_gather": host-thread gather + H2D even on a ps_direct_access cache
   bool probe_balanced_ = false;  // equal chunks per wave costs more in occupancy than the tail it removes (kbench A/B)
   bool timing_ = false;
 };

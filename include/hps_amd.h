@@ -160,7 +160,9 @@ int hps_session_lookup_device(hps_session_t* session, const int64_t* d_keys_flat
                               const size_t* num_keys_per_table, size_t num_tables);
 int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
 /* options: "timing" (0/1), "probe_unroll" (1,2,4,8), "hit_rate_threshold_permille" (per-session override of
- * the model's hit_rate_threshold: 1000 = always synchronous insertion, 0 = always asynchronous) */
+ * the model's hit_rate_threshold: 1000 = always synchronous insertion, 0 = always asynchronous), "probe_balanced"
+ * (0/1), "host_gather" (0/1: on a ps_direct_access cache, serve this session's misses the reference's way — host
+ * threads gather, hipMemcpyAsync ships — e.g. to compare the two tiers on one deployment) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 /* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------

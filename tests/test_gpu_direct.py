@@ -198,3 +198,24 @@ def test_direct_async_mode_uses_background_inserter():
     assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, [q.size], [7.0], resident=[resident0])))
     cache.wait_async()
     assert (cache.query(0, cold) >= 0).all()
+
+
+def test_host_gather_option_on_a_direct_cache():
+    """Session option "host_gather": one session serves its misses the reference's way (host threads + H2D) while
+    another uses the device-driven fetch, on the same ps_direct_access cache and pinned tables; both exact."""
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(61)
+    tables = make_tables([(9000, 128), (5000, 20), (300, 1)])
+    ps, cache, s_dev = _mk("dmixed_tiers", tables, maxcat=[1, 1, 1], gpucacheper=0.1, max_batch=4096, extra=DIRECT)
+    s_host = hps.LookupSession.create(ps, "dmixed_tiers", cache)
+    s_host.set_option("host_gather", 1)
+    co = O.COracle()
+    for k, r in tables:
+        co.add_table_arrays(k, r)
+    for it in range(4):
+        nk = [4096, 3000, 200]
+        q = _queries(rng, tables, nk, miss_frac=0.05)
+        for sess in (s_host, s_dev):
+            out = sess.lookup(q, nk).cpu().numpy()
+            assert np.array_equal(_bits(out), _bits(co.lookup(q, nk, [0.0] * 3))), (it, sess is s_host)
