@@ -285,6 +285,7 @@ def main():
     lat_ms, kern_ms, miss_ct, phases, uniq_ct, gpu_ms = [], [], [], [], [], []
     lock = threading.Lock()
     post_hooks = []   # per session: work appended to every step (the config-5 leg runs the dense step here)
+    step_hooks = []   # per session: replaces the step
 
     def run_steps(count, record, first=0):
         nxt = [0]
@@ -298,7 +299,10 @@ def main():
                         return
                     nxt[0] += 1
                 t0 = time.perf_counter()
-                s.lookup_device(batches_d[(first + i) % len(batches_d)], nk, out=outs[si])
+                if step_hooks:     # a leg that replaces the whole step (the fused lookup+interaction call)
+                    step_hooks[si](si, batches_d[(first + i) % len(batches_d)])
+                else:
+                    s.lookup_device(batches_d[(first + i) % len(batches_d)], nk, out=outs[si])
                 if post_hooks:
                     post_hooks[si](si)
                 dt = (time.perf_counter() - t0) * 1e3
@@ -415,6 +419,19 @@ def main():
                                "output [batch, %d] f16" % (D, ops[0].out_dim)})
             extra["c5_lookup_plus_dense"] = c5
             del fresh5
+            # (3b) the same step with the lookup fused into the interaction: probe only, rows read from the cache
+            #      slots / miss staging by the interaction kernel, OUTPUT0 never written (device-driven tier only)
+            if a.direct and a.mode == "sync":
+                fresh5b = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
+                step_hooks[:] = [lambda si, keys: ops[si].lookup_interact(sessions[si], keys, B, xd, out=outd[si]) for _ in sessions]
+                c5f = leg(fresh5b, 24, sessions)
+                step_hooks[:] = []
+                c5f["probe_only_kernel_ms"] = c5f.pop("avg_kernel_ms")   # the probe moves no rows here:
+                c5f.pop("kernel_frac_of_hbm_peak")                        # the gather roofline does not apply to it
+                c5f.update({"samples_per_s": c5f["lookups_per_s"] / T,
+                            "note": "one call per step: probe, miss fetch, bottom MLP, interaction reading cache slots / staging, insert"})
+                extra["c5_fused_lookup_interact"] = c5f
+                del fresh5b
         # (4) the miss path arranged as in the reference (host threads gather the missed rows, hipMemcpyAsync ships
         #     them) on the very same cache and tables: session option "host_gather"
         if a.direct and a.mode == "sync":

@@ -39,6 +39,7 @@ ENGINE_SRCS = [
     "cache/engine.cpp",
     "cache/parameter_server.cpp",
     "dense/dense_kernels.hip",
+    "dense/fused_kernels.hip",
     "dense/dense.cpp",
 ]
 CAPI_SRCS = ["c_api.cpp"]

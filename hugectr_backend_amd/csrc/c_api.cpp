@@ -383,6 +383,14 @@ uint32_t hps_dense_out_dim(const hps_dense_t* dense) { return dense ? dense->d->
 
 uint32_t hps_dense_out_stride(const hps_dense_t* dense) { return dense ? dense->d->out_stride() : 0; }
 
+int hps_session_lookup_interact_device(hps_session_t* s, hps_dense_t* dense, const int64_t* d_keys_flat, uint64_t batch,
+                                       const float* d_dense, void* d_out_f16) {
+  return Guard([&]() -> Status {
+    if (!s || !dense) return Error(Code::kInvalidArg, "null argument");
+    return s->s->lookup_interact(dense->d.get(), d_keys_flat, batch, d_dense, d_out_f16);
+  });
+}
+
 int hps_dense_forward(hps_dense_t* dense, const float* d_dense, const float* d_embeddings, uint64_t batch, void* d_out_f16,
                       void* stream) {
   return Guard([&]() -> Status {

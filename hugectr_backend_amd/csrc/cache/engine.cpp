@@ -122,6 +122,16 @@ void EmbeddingCache::EndRead(hipStream_t stream, hipEvent_t reader_done) {
   last_reader_stream_ = stream;
   order_mu_.unlock();
 }
+// Fused lookup+interaction: the probe was followed, under the same lock, by kernels that still read the slots it
+// found.  Writers must wait for the last of them (reader_done, recorded here); other sessions' probes only chain
+// behind the probe itself (probe_done, recorded by the caller right after it).
+void EmbeddingCache::EndReadFused(hipStream_t stream, hipEvent_t probe_done, hipEvent_t reader_done) {
+  (void)hipEventRecord(reader_done, stream);
+  if (std::find(readers_.begin(), readers_.end(), reader_done) == readers_.end()) readers_.push_back(reader_done);
+  last_reader_ = probe_done;
+  last_reader_stream_ = stream;
+  order_mu_.unlock();
+}
 void EmbeddingCache::ForgetReader(hipEvent_t reader_done) {
   std::lock_guard<std::mutex> lk(order_mu_);
   readers_.erase(std::remove(readers_.begin(), readers_.end(), reader_done), readers_.end());
@@ -500,6 +510,7 @@ void LookupSession::Release() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   cache_->ForgetReader(ev_read_);  // our reader event may still be registered with the cache
+  cache_->ForgetReader(ev_probe_);
   cache_->ForgetFetch(ev_fetch_);
   auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
   auto dfree = [](void* p) { if (p) (void)hipFree(p); };
@@ -514,6 +525,7 @@ void LookupSession::Release() {
   if (ev_f0_) (void)hipEventDestroy(ev_f0_);
   if (ev_f1_) (void)hipEventDestroy(ev_f1_);
   if (ev_c1_) (void)hipEventDestroy(ev_c1_);
+  if (ev_probe_) (void)hipEventDestroy(ev_probe_);
   if (ev_copy_) (void)hipEventDestroy(ev_copy_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -549,6 +561,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HIP_TRY(hipEventCreate(&ev_f0_));
   HIP_TRY(hipEventCreate(&ev_f1_));
   HIP_TRY(hipEventCreate(&ev_c1_));
+  HIP_TRY(hipEventCreateWithFlags(&ev_probe_, hipEventDisableTiming));
 
   HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_keys_, max_keys_));
@@ -836,6 +849,113 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   phase_ms_[3] = ms_since(tc0);
   phase_ms_[2] = phase_ms_[3] - phase_ms_[0] - phase_ms_[1];
   return st;
+}
+
+// BASELINE config 5, fused arrangement: probe only (no OUTPUT0), unique misses fetched by the device-driven tier,
+// then the dot interaction reads every row from where it is — cache slot or miss staging — and only afterwards are
+// the missed rows inserted.  The cache stays read-locked (reader event) from the probe to the interaction, so no
+// other session's insert can recycle a slot this call still has to read; probes of other sessions chain behind OUR
+// probe only (its own event), not behind the whole call.
+Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_keys_flat, uint64_t batch, const float* d_dense_features,
+                                      void* d_out_f16) {
+  if (!cache_ || !cache_->direct())
+    return Error(Code::kUnsupported, "lookup_interact needs a GPU-cache session of a ps_direct_access model");
+  if (!dense || !d_keys_flat || !d_dense_features || !d_out_f16) return Error(Code::kInvalidArg, "lookup_interact: null argument");
+  const size_t T = tables_.size();
+  if (params_.hit_rate_threshold < 1.0f)
+    return Error(Code::kUnsupported, "lookup_interact serves exact rows only (hit_rate_threshold must be 1.0; it is ",
+                 params_.hit_rate_threshold, ")");
+  if (dense->num_tables() != T || dense->device() != device_)
+    return Error(Code::kInvalidArg, "lookup_interact: the dense step was built for ", dense->num_tables(), " tables on device ",
+                 dense->device(), ", the model has ", T, " on device ", device_);
+  for (size_t t = 0; t < T; ++t)
+    if (tables_[t]->dim() != dense->emb_dim())
+      return Error(Code::kInvalidArg, "lookup_interact: table ", t, " is ", tables_[t]->dim(), " wide, the dense step expects ", dense->emb_dim());
+  const uint64_t N = batch * T;
+  if (N > max_keys_) return Error(Code::kInvalidArg, "lookup_interact: ", N, " keys exceed the session capacity of ", max_keys_);
+  if ((uint64_t)T * (dense->emb_dim() / 4) > 1024) return Error(Code::kUnsupported, "lookup_interact: more than 4096 floats per sample");
+  if (batch == 0) return Status::Ok();
+  HIP_TRY(hipSetDevice(device_));
+  std::shared_lock<std::shared_mutex> direct_lock;
+  while (cache_->direct_writers().load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  direct_lock = std::shared_lock<std::shared_mutex>(cache_->direct_mutex());
+
+  CallDesc& c = *h_call_;
+  c.num_tables = (uint32_t)T;
+  c.keys = d_keys_flat;
+  for (size_t t = 0; t < T; ++t) {
+    c.key_start[t] = (uint64_t)t * batch;
+    c.out[t] = nullptr;   // probe only
+    c.vec_ok[t] = 0;
+  }
+  c.key_start[T] = N;
+  c.total_keys = N;
+  const uint32_t epoch = cache_->NextEpoch();
+  c.epoch = epoch;
+  HIP_TRY(hipMemcpyAsync(d_call_, h_call_, sizeof(CallDesc), hipMemcpyHostToDevice, stream_));
+  const int cu = cache_->cu_count();
+  const uint32_t probe_blocks = ProbeGridBlocks(N, cu, probe_balanced_);
+  // bottom MLP first: it needs nothing from the lookup and leaves the stream before the cache is read-locked
+  const void* d_bottom = nullptr;
+  HPS_RETURN_IF_ERROR(dense->BottomMlp(d_dense_features, batch, stream_, &d_bottom));
+
+  cache_->BeginRead(stream_);   // ---- read lock: held (order mutex + reader event) until the interaction is enqueued ----
+  if (timing_) (void)hipEventRecord(ev_t0_, stream_);
+  hipError_t e = LaunchProbeGather(d_call_, cache_->device_tables(), (uint32_t)T, N, d_slot_, d_block_miss_, probe_blocks,
+                                   probe_unroll_, stream_);
+  if (timing_) (void)hipEventRecord(ev_t1_, stream_);
+  (void)hipEventRecord(ev_probe_, stream_);
+  if (e == hipSuccess)
+    e = LaunchMissDedup(d_call_, c.key_start, (uint32_t)T, probe_blocks, d_slot_, d_block_miss_, d_set_, set_cap_, d_counts_,
+                        d_uniq_keys_, h_uniq_keys_devptr_, cu, stream_);
+  if (e == hipSuccess)
+    e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, d_counts_ + kMaxTables + 1, nullptr, stream_);
+  if (e == hipSuccess) {
+    cache_->BeginFetch(stream_);
+    if (timing_) (void)hipEventRecord(ev_f0_, stream_);
+    e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, d_uniq_keys_, d_staging_, d_found_, N, cu,
+                            stream_);
+    if (timing_) (void)hipEventRecord(ev_f1_, stream_);
+    cache_->EndFetch(stream_, ev_fetch_);
+  }
+  if (e == hipSuccess)
+    e = LaunchLookupInteract(cache_->device_tables(), d_md_, d_slot_, d_staging_, d_bottom, batch, (uint32_t)T, dense->emb_dim(),
+                             dense->out_stride(), d_out_f16, cu, stream_);
+  cache_->EndReadFused(stream_, ev_probe_, ev_read_);   // ---- read lock released (enqueue side) ----
+  if (e != hipSuccess) return Error(Code::kInternal, "lookup_interact launch failed: ", hipGetErrorString(e));
+  last_async_ = false;
+  table_async_.assign(T, 0);
+  // insert the missed rows (writer window = the insert kernel alone, as in HandleMissesDirect)
+  {
+    const uint64_t est_bytes = (uint64_t)last_unique_ * dense->emb_dim() * sizeof(float);
+    if (est_bytes > (2u << 20)) HIP_TRY(hipStreamSynchronize(stream_));
+  }
+  cache_->BeginWrite(stream_);
+  e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, N, d_call_->key_start, d_uniq_keys_, d_staging_, d_found_, epoch,
+                        d_counts_ + kMaxTables + 1, cu, stream_);
+  cache_->EndWrite(stream_);
+  if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
+  if (timing_) (void)hipEventRecord(ev_c1_, stream_);
+  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kMaxTables + 5) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipStreamSynchronize(stream_));
+  if (timing_) {
+    (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
+    (void)hipEventElapsedTime(&phase_ms_[1], ev_f0_, ev_f1_);
+    (void)hipEventElapsedTime(&last_gpu_call_ms_, ev_t0_, ev_c1_);
+  }
+  uint64_t uniq = 0;
+  for (size_t t = 0; t < T; ++t) uniq += h_counts_[1 + t];
+  last_misses_ = h_counts_[0];
+  last_unique_ = uniq;
+  std::lock_guard<std::mutex> lk(cache_->stat_mu_);
+  cache_->counters_.lookups += 1;
+  cache_->counters_.keys += N;
+  cache_->counters_.misses += last_misses_;
+  cache_->counters_.unique_misses += uniq;
+  cache_->counters_.dropped += h_counts_[kMaxTables + 1];
+  cache_->counters_.inserted += h_counts_[kMaxTables + 2];
+  cache_->counters_.refreshed += h_counts_[kMaxTables + 3];
+  return Status::Ok();
 }
 
 // Synchronous miss path, device-driven ("ps_direct_access"): the GPU resolves the unique missed keys through the

@@ -25,6 +25,7 @@
 #include "../common/status.h"
 #include "../ps/host_table.h"
 #include "../ps/thread_pool.h"
+#include "../dense/dense.h"
 #include "device_types.h"
 #include "direct_kernels.h"
 
@@ -94,6 +95,7 @@ class EmbeddingCache {
   // held while stream-waits and the kernel launch are enqueued, never while the GPU runs.
   void BeginRead(hipStream_t stream);                       // stream waits for the last writer
   void EndRead(hipStream_t stream, hipEvent_t reader_done); // records + registers the reader event
+  void EndReadFused(hipStream_t stream, hipEvent_t probe_done, hipEvent_t reader_done);
   void BeginWrite(hipStream_t stream);                      // stream waits for last writer + all readers
   void EndWrite(hipStream_t stream);                        // records the writer event
   void ForgetReader(hipEvent_t reader_done);                // a session is going away: drop its event
@@ -184,6 +186,10 @@ class LookupSession {
   // in which case the hit path is enqueued and the call returns after the miss path completed.
   Status lookup_from_device(const int64_t* d_keys_flat, float* const* d_vectors_per_table,
                             const size_t* num_keys_per_table, size_t num_tables);
+  // BASELINE config 5 fused: `batch` samples, one key per table per sample (d_keys_flat table-major, T*batch keys);
+  // result = the dense step's output [batch][out_stride] f16, no OUTPUT0.  ps_direct_access models, threshold 1.0.
+  Status lookup_interact(DenseInteraction* dense, const int64_t* d_keys_flat, uint64_t batch, const float* d_dense_features,
+                         void* d_out_f16);
 
   const InferenceParams& params() const { return params_; }
   bool uses_gpu_cache() const { return cache_ != nullptr; }
@@ -226,7 +232,7 @@ class LookupSession {
   hipStream_t copy_stream_ = nullptr;  // second H2D queue for the missed-row pieces
   hipEvent_t ev_copy_ = nullptr;
   hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr,
-             ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr;
+             ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr, ev_probe_ = nullptr;
   float last_gpu_call_ms_ = 0.f;
   Status TimedLookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T);
 

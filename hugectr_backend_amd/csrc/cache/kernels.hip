@@ -199,7 +199,8 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_gather_kernel(
             const uint64_t gi = chunk * 64 + (uint64_t)src;
             const float* row = d.rows + (uint64_t)(uint32_t)s[u] * D;
             float* dst = d.out + (gi - d.key_start) * D;
-            copy_row<true>(row, dst, D, lig, (d.flags & 2u) != 0);
+            // out == nullptr: probe-only call (the fused lookup+interaction path reads the rows from the slots itself)
+            if (d.out != nullptr) copy_row<true>(row, dst, D, lig, (d.flags & 2u) != 0);
             if (lig == 0 && !(d.flags & 1u)) {
               bool touch = true;
               if (kStampShift > 0)

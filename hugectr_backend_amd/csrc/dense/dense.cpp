@@ -94,6 +94,14 @@ Status DenseInteraction::Create(int device, uint32_t num_dense, const std::vecto
 Status DenseInteraction::Forward(const float* d_dense, const float* d_emb, uint64_t batch, void* d_out, hipStream_t stream) {
   if (batch == 0) return Status::Ok();
   if (!d_dense || !d_emb || !d_out) return Error(Code::kInvalidArg, "dense forward: null device pointer");
+  const void* bottom = nullptr;
+  HPS_RETURN_IF_ERROR(BottomMlp(d_dense, batch, stream, &bottom));
+  HIP_TRY(LaunchDenseInteract(d_emb, bottom, batch, num_tables_, emb_dim_, out_stride(), d_out, cu_count_, stream));
+  return Status::Ok();
+}
+
+Status DenseInteraction::BottomMlp(const float* d_dense, uint64_t batch, hipStream_t stream, const void** d_bottom) {
+  if (!d_dense || !d_bottom) return Error(Code::kInvalidArg, "bottom MLP: null pointer");
   HIP_TRY(hipSetDevice(device_));
   if (batch > bottom_capacity_) {
     HIP_TRY(hipStreamSynchronize(stream));
@@ -104,7 +112,7 @@ Status DenseInteraction::Forward(const float* d_dense, const float* d_emb, uint6
     bottom_capacity_ = batch;
   }
   HIP_TRY(LaunchDenseMlp(mlp_, d_dense, batch, d_bottom_, cu_count_, stream));
-  HIP_TRY(LaunchDenseInteract(d_emb, d_bottom_, batch, num_tables_, emb_dim_, out_stride(), d_out, cu_count_, stream));
+  *d_bottom = d_bottom_;
   return Status::Ok();
 }
 

@@ -6,6 +6,7 @@
 
 #include <vector>
 
+#include "../cache/device_types.h"
 #include "../common/status.h"
 
 namespace hps {
@@ -29,6 +30,11 @@ hipError_t LaunchDenseMlp(const DenseMlpDesc& d, const float* d_x, uint64_t batc
 hipError_t LaunchDenseInteract(const float* d_emb, const void* d_bottom_f16, uint64_t batch, uint32_t T, uint32_t D,
                                uint32_t out_stride, void* d_out_f16, int cu_count, hipStream_t stream);
 
+// fused_kernels.hip: the interaction reading its rows from cache slots / miss staging (no OUTPUT0); T*D/4 <= 1024 chunks
+hipError_t LaunchLookupInteract(const TableCacheDev* d_tables, const MissDesc* d_md, const int32_t* d_slot, const float* d_staging,
+                                const void* d_bottom_f16, uint64_t batch, uint32_t T, uint32_t D, uint32_t out_stride, void* d_out_f16,
+                                int cu_count, hipStream_t stream);
+
 // Owns the f16 weights on one device.  Thread-compatible (one forward at a time per object).
 class DenseInteraction {
  public:
@@ -45,6 +51,10 @@ class DenseInteraction {
   // d_dense: [batch][num_dense] fp32; d_emb: the lookup's OUTPUT0, table-major [num_tables][batch][emb_dim] fp32;
   // d_out: [batch][out_stride] f16.  Enqueues on `stream`; returns without synchronising.
   Status Forward(const float* d_dense, const float* d_emb, uint64_t batch, void* d_out, hipStream_t stream);
+  // First half only: the bottom MLP into the object's scratch, [batch][emb_dim] f16 (used by the fused lookup path)
+  Status BottomMlp(const float* d_dense, uint64_t batch, hipStream_t stream, const void** d_bottom);
+  int device() const { return device_; }
+  int cu_count() const { return cu_count_; }
 
  private:
   DenseInteraction() = default;

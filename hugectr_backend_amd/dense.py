@@ -54,6 +54,20 @@ class DenseInteraction:
                                              C.c_void_p(stream)))
         return out
 
+    def lookup_interact(self, session, keys, batch: int, dense, out=None):
+        """Fused arrangement: `keys` CUDA int64 [num_tables * batch] (table-major, one key per table per sample)
+        looked up through `session` (a LookupSession of a ps_direct_access model) and fed to the interaction from
+        the cache slots / miss staging directly — no OUTPUT0.  Returns the same tensor as forward().  Blocking."""
+        import torch
+        assert keys.is_cuda and keys.dtype == torch.int64 and keys.is_contiguous() and keys.numel() == self.num_tables * batch
+        assert dense.is_cuda and dense.dtype == torch.float32 and dense.is_contiguous() and dense.numel() == batch * self.num_dense
+        if out is None:
+            out = torch.empty((batch, self.out_stride), dtype=torch.float16, device=keys.device)
+        torch.cuda.current_stream(keys.device).synchronize()      # the session works on its own stream
+        hps._check(hps.LIB.hps_session_lookup_interact_device(session._h, self._h, keys.data_ptr(), batch, dense.data_ptr(),
+                                                              out.data_ptr()))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             hps.LIB.hps_dense_destroy(self._h)

@@ -114,6 +114,7 @@ def _load() -> C.CDLL:
         "hps_dense_out_dim": (u32, [P]),
         "hps_dense_out_stride": (u32, [P]),
         "hps_dense_forward": (C.c_int, [P, P, P, u64, P, P]),
+        "hps_session_lookup_interact_device": (C.c_int, [P, P, P, u64, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = symbol missing from the library
@@ -133,7 +134,7 @@ EXPORTED_SYMBOLS = [
     "hps_session_destroy", "hps_session_lookup", "hps_session_lookup_device", "hps_session_last_stats",
     "hps_session_set_option", "hps_shard_owner", "hps_shard_bucket_workspace_bytes", "hps_shard_bucket_device",
     "hps_shard_unpermute_device", "hps_dense_create", "hps_dense_destroy", "hps_dense_out_dim", "hps_dense_out_stride",
-    "hps_dense_forward",
+    "hps_dense_forward", "hps_session_lookup_interact_device",
 ]
 
 

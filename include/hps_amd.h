@@ -197,6 +197,13 @@ uint32_t hps_dense_out_stride(const hps_dense_t* dense);  /* out_dim rounded up 
  * d_out_f16: [batch][out_stride] f16.  All device pointers; enqueued on `stream` (a hipStream_t), not synchronised. */
 int hps_dense_forward(hps_dense_t* dense, const float* d_dense, const float* d_embeddings, uint64_t batch,
                       void* d_out_f16, void* stream);
+/* Lookup fused into the dense step: `batch` samples, one key per table per sample (d_keys_flat: table-major,
+ * T*batch int64 on the device); the interaction reads each embedding row from the cache slot the probe found or
+ * from the miss staging, OUTPUT0 is never materialised; the missed rows are inserted before the call returns.
+ * Same output as hps_session_lookup_device + hps_dense_forward.  Needs a ps_direct_access model with
+ * hit_rate_threshold 1.0 whose tables are all as wide as the dense step's embeddings.  Blocking. */
+int hps_session_lookup_interact_device(hps_session_t* session, hps_dense_t* dense, const int64_t* d_keys_flat, uint64_t batch,
+                                       const float* d_dense, void* d_out_f16);
 
 #ifdef __cplusplus
 }

@@ -101,3 +101,91 @@ def test_dense_rejects_unsupported_shapes():
         DenseInteraction([w(13, 128)], [b(128)], 32, 128)          # 33 vectors do not fit the 32x32 tile
     with pytest.raises(hps.HpsError):
         DenseInteraction([w(13, 64)], [b(64)], 26, 128)            # last layer != embedding width
+
+
+def _fused_setup(name, T, R, D, B, cachefrac, seed):
+    import torch
+    from hugectr_backend_amd.dense import DenseInteraction
+    from tests.conftest import make_tables
+    from tests.test_gpu_lookup import _mk
+    tables = make_tables([(R, D)] * T, seed=seed)
+    ps, cache, s = _mk(name, tables, maxcat=[1] * T, gpucacheper=cachefrac, max_batch=B, extra={"ps_direct_access": True})
+    ws, bs, x, _ = _make(torch, 13, [64, D], T, D, B, seed=seed)
+    op = DenseInteraction([w.cpu().numpy() for w in ws], [b.cpu().numpy() for b in bs], T, D)
+    return tables, ps, cache, s, op, ws, bs, x
+
+
+@pytest.mark.parametrize("T,D,B", [(26, 128, 512), (3, 32, 333), (31, 64, 64), (8, 256, 100)])
+def test_fused_lookup_interact_matches_unfused(T, D, B):
+    """lookup fused into the interaction (rows read from cache slots / miss staging, no OUTPUT0) against the same
+    library's lookup + dense forward, and against the oracle rows through the torch operator; cold and warm calls,
+    absent keys (default rows) included."""
+    import torch
+    from oracle import hps_oracle as O
+    from hugectr_backend_amd import hps
+    tables, ps, cache, s, op, ws, bs, x = _fused_setup(f"fz{T}_{D}", T, 2000, D, B, 0.2, seed=T * 7 + D)
+    s2 = hps.LookupSession.create(ps, f"fz{T}_{D}", cache)
+    rng = np.random.default_rng(T + D)
+    for it in range(3):
+        parts = []
+        for k, _ in tables:
+            qq = rng.choice(k, B)
+            qq = np.where(rng.random(B) < 0.1, -5 - rng.integers(0, 1 << 40, B), qq)   # 10 % absent -> default row
+            parts.append(qq.astype(np.int64))
+        q = np.concatenate(parts)
+        dq = torch.from_numpy(q).cuda()
+        got = op.lookup_interact(s, dq, B, x)[:, : op.out_dim].float()
+        st = s.last_stats()
+        assert st.misses > 0 and st.unique_misses <= st.misses
+        rows = torch.from_numpy(O.np_lookup(tables, q, [B] * T, [0.0] * T)).cuda()
+        ref = _reference(torch, x, rows, ws, bs, T, B, D, half_points=True)
+        err = ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+        assert err <= 2e-3, (it, err)
+        # the unfused path of the same library on another session of the same cache: bit-identical f16 output
+        out0 = s2.lookup_device(dq, [B] * T)
+        unf = op.forward(x, out0, B)
+        torch.cuda.synchronize()
+        assert torch.equal(unf[:, : op.out_dim], op.lookup_interact(s, dq, B, x)[:, : op.out_dim])
+    assert cache.counters()["inserted"] > 0
+
+
+def test_fused_lookup_interact_two_sessions_and_guards():
+    import threading
+    import torch
+    from oracle import hps_oracle as O
+    from hugectr_backend_amd import hps
+    from hugectr_backend_amd.dense import DenseInteraction
+    T, D, B = 6, 64, 256
+    tables, ps, cache, s0, op0, ws, bs, x = _fused_setup("fz2s", T, 5000, D, B, 0.05, seed=3)
+    s1 = hps.LookupSession.create(ps, "fz2s", cache)
+    op1 = DenseInteraction([w.cpu().numpy() for w in ws], [b.cpu().numpy() for b in bs], T, D)
+    errs = []
+
+    def worker(sess, op, seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for _ in range(10):
+                q = np.concatenate([rng.choice(k, B) for k, _ in tables]).astype(np.int64)
+                got = op.lookup_interact(sess, torch.from_numpy(q).cuda(), B, x)[:, : op.out_dim].float()
+                rows = torch.from_numpy(O.np_lookup(tables, q, [B] * T, [0.0] * T)).cuda()
+                ref = _reference(torch, x, rows, ws, bs, T, B, D, half_points=True)
+                if ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item() > 2e-3:
+                    errs.append("mismatch")
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(s0, op0, 1)), threading.Thread(target=worker, args=(s1, op1, 2))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[:3]
+    # guards: host-gather models and async thresholds are refused, not silently served another way
+    from tests.conftest import make_tables
+    from tests.test_gpu_lookup import _mk
+    tb = make_tables([(500, D)] * T)
+    _, _, sh = _mk("fz_host", tb, maxcat=[1] * T, gpucacheper=0.5, max_batch=B)
+    with pytest.raises(hps.HpsError):
+        op0.lookup_interact(sh, torch.zeros(T * B, dtype=torch.int64, device="cuda"), B, x)
+    _, _, sa = _mk("fz_async", tb, maxcat=[1] * T, gpucacheper=0.5, max_batch=B, hit_rate_threshold=0.5,
+                   extra={"ps_direct_access": True})
+    with pytest.raises(hps.HpsError):
+        op0.lookup_interact(sa, torch.zeros(T * B, dtype=torch.int64, device="cuda"), B, x)
