@@ -26,6 +26,6 @@ hipError_t LaunchMissDescBuild(const TableCacheDev* d_tables, uint32_t T, const 
                                hipStream_t stream);
 hipError_t LaunchPsFetchDirect(const PsIndexDev* d_index, uint32_t T, const MissDesc* d_md, const uint64_t* d_key_start,
                                const int64_t* d_uniq_keys, float* d_staging, uint8_t* d_found, uint64_t max_unique,
-                               int cu_count, hipStream_t stream);
+                               int grid_blocks /*0: default*/, hipStream_t stream);
 
 }  // namespace hps

@@ -159,7 +159,7 @@ hipError_t LaunchMissDescBuild(const TableCacheDev* d_tables, uint32_t T, const 
 
 hipError_t LaunchPsFetchDirect(const PsIndexDev* d_index, uint32_t T, const MissDesc* d_md, const uint64_t* d_key_start,
                                const int64_t* d_uniq_keys, float* d_staging, uint8_t* d_found, uint64_t max_unique,
-                               int cu_count, hipStream_t stream) {
+                               int grid_blocks, hipStream_t stream) {
   if (max_unique == 0) return hipSuccess;
   uint64_t want = (max_unique + 15) / 16;
   // Grid = rows in flight over PCIe (16 per block), not chip occupancy: ~512 rows in flight saturate the link
@@ -170,8 +170,9 @@ hipError_t LaunchPsFetchDirect(const PsIndexDev* d_index, uint32_t T, const Miss
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 128;
   }();
-  (void)cu_count;
-  const uint64_t cap = (uint64_t)max_blocks;
+  // grid_blocks > 0: the caller's own bound (the background inserter runs a small grid: it is in no hurry, and
+  // fewer PCIe reads in flight disturb the probe kernels of the foreground lookups less)
+  const uint64_t cap = (uint64_t)(grid_blocks > 0 ? grid_blocks : max_blocks);
   if (want > cap) want = cap;
   hipLaunchKernelGGL(hps_ps_fetch_direct_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_index, T, d_md, d_key_start,
                      d_uniq_keys, d_staging, d_found);

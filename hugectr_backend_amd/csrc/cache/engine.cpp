@@ -450,12 +450,10 @@ Status EmbeddingCache::FinishDirectInsert() {
   HIP_TRY(hipStreamWaitEvent(I.stream, I.ev_copied, 0));
   const uint32_t epoch = NextEpoch();
   hipError_t e = LaunchMissDescBuild(d_tables_, (uint32_t)T, I.d_counts, I.d_md, I.d_counts + kMaxTables + 1, nullptr, I.stream);
-  if (e == hipSuccess) {
-    BeginFetch(I.stream);
-    e = LaunchPsFetchDirect(d_index_, (uint32_t)T, I.d_md, I.d_key_start, I.d_keys, I.d_staging, I.d_found, I.unique_total, cu_count_,
-                            I.stream);
-    EndFetch(I.stream, I.ev_fetch);
-  }
+  // not part of the foreground fetch chain: a small grid that takes its time must not hold up a lookup's fetch
+  if (e == hipSuccess)
+    e = LaunchPsFetchDirect(d_index_, (uint32_t)T, I.d_md, I.d_key_start, I.d_keys, I.d_staging, I.d_found, I.unique_total,
+                            /*grid_blocks=*/32, I.stream);
   if (e != hipSuccess) return Error(Code::kInternal, "direct background fetch launch failed: ", hipGetErrorString(e));
   HIP_TRY(hipStreamSynchronize(I.stream));
   BeginWrite(I.stream);
@@ -913,7 +911,7 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
   if (e == hipSuccess) {
     cache_->BeginFetch(stream_);
     if (timing_) (void)hipEventRecord(ev_f0_, stream_);
-    e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, d_uniq_keys_, d_staging_, d_found_, N, cu,
+    e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, d_uniq_keys_, d_staging_, d_found_, N, 0,
                             stream_);
     if (timing_) (void)hipEventRecord(ev_f1_, stream_);
     cache_->EndFetch(stream_, ev_fetch_);
@@ -970,7 +968,7 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
     cache_->BeginFetch(stream_);
     if (timing_) (void)hipEventRecord(ev_f0_, stream_);
     e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, d_uniq_keys_, d_staging_,
-                            d_found_, max_unique, cu, stream_);
+                            d_found_, max_unique, 0, stream_);
     if (timing_) (void)hipEventRecord(ev_f1_, stream_);
     cache_->EndFetch(stream_, ev_fetch_);
   }
