@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Side benchmarks for the BASELINE configs that are not the headline (bench.py = config 2):
 
-    python tools/bench_configs.py c1     # 1 table 1,048,576 x 16, 4,096-key batch, CPU parameter server only
-    python tools/bench_configs.py c4     # two W&D models (D=[1,16], keys/sample [2,26], batch 1,024) sharing one GPU
+    python tests/tools/bench_configs.py c1     # 1 table 1,048,576 x 16, 4,096-key batch, CPU parameter server only
+    python tests/tools/bench_configs.py c4     # two W&D models (D=[1,16], keys/sample [2,26], batch 1,024) sharing one GPU
 
 Both go through the Triton plugin ABI (TRITONBACKEND_ModelInstanceExecute of libtriton_hps.so) driven by the mock
 Triton core, i.e. what perf_analyzer would exercise against the reference (.gitlab-ci.yml:70).  Prints one JSON line.
@@ -16,7 +16,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from tests import triton_mock as tm  # noqa: E402
 from tests.conftest import ps_config  # noqa: E402

@@ -2,7 +2,7 @@
 refreshing the cache and reloading the host tables (same content), for a fixed time.  Every answer is checked bit for bit
 (tables use keys 0..R-1, so the expected row of key k is rows[k]; absent keys must come back as the default).
 
-    python tools/soak.py [seconds=60] [direct=1] [sessions=3] [threshold=1.0]
+    python tests/tools/soak.py [seconds=60] [direct=1] [sessions=3] [threshold=1.0]
 """
 import sys
 import threading
@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 
 
 def main():
