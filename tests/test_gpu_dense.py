@@ -164,7 +164,7 @@ def test_fused_lookup_interact_two_sessions_and_guards():
     def worker(sess, op, seed):
         rng = np.random.default_rng(seed)
         try:
-            for _ in range(10):
+            for _ in range(60):
                 q = np.concatenate([rng.choice(k, B) for k, _ in tables]).astype(np.int64)
                 got = op.lookup_interact(sess, torch.from_numpy(q).cuda(), B, x)[:, : op.out_dim].float()
                 rows = torch.from_numpy(O.np_lookup(tables, q, [B] * T, [0.0] * T)).cuda()
