@@ -9,7 +9,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/bench.py --steps 100 --warmup 10 \
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/bench.py --steps 100 --warmup 10 --no-extra-legs --no-cpu-baseline \
     > $O/bench_under_rocprof.json 2> $O/kt.log
 rm -f $O/kt/kt_kernel_trace.csv
 for C in FETCH_SIZE WRITE_SIZE; do
