@@ -277,6 +277,7 @@ hipError_t LaunchDenseInteract(const float* d_emb, const void* d_bottom_f16, uin
   };
   if (per_lane <= 4) return go(hps_dense_interact_kernel<4>);
   if (per_lane <= 8) return go(hps_dense_interact_kernel<8>);
+  if (per_lane <= 13) return go(hps_dense_interact_kernel<13>);   // T = 26, D = 128: 13 chunks exactly (fewer registers than <16>)
   if (per_lane <= 16) return go(hps_dense_interact_kernel<16>);
   return go(hps_dense_interact_kernel<0>);
 }

@@ -127,6 +127,7 @@ hipError_t LaunchLookupInteract(const TableCacheDev* d_tables, const MissDesc* d
   };
   if (per_lane <= 4) return go(hps_lookup_interact_kernel<4>);
   if (per_lane <= 8) return go(hps_lookup_interact_kernel<8>);
+  if (per_lane <= 13) return go(hps_lookup_interact_kernel<13>);   // T = 26, D = 128: 13 chunks exactly (fewer registers than <16>)
   return go(hps_lookup_interact_kernel<16>);
 }
 
