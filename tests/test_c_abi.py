@@ -75,3 +75,16 @@ def test_dense_step_and_direct_tier_fail_loudly_without_a_gpu():
         hps.HierParameterServer.create_from_dict(ps_config("m", tabs, gpucache=True, extra={"ps_direct_access": True}),
                                                  load_tables=False)
     assert e.value.code == hps.ERR_UNAVAILABLE and "ps_direct_access needs a GPU" in e.value.msg
+
+
+def test_bench_and_entry_scripts_parse_and_show_help():
+    """bench.py / __graft_entry__.py are what the driver runs: they must at least parse, and bench.py must accept the
+    contract's flags (--gpus/--steps/--warmup) without touching a GPU."""
+    import ast
+    import sys
+    for f in ("bench.py", "__graft_entry__.py", "tests/tools/soak.py", "tests/tools/bench_configs.py", "tools/dense_bench.py"):
+        ast.parse((ROOT / f).read_text())
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--direct", "--no-sharded-leg"):
+        assert flag in out.stdout
