@@ -331,3 +331,27 @@ def test_insertion_policy_is_decided_per_table(direct):
     out2 = s.lookup(q, nk).cpu().numpy()
     ref2 = O.np_lookup(tables, q, nk, [7.0, -3.0, 0.5], resident=[res2[t] if modes2[t] else None for t in range(3)])
     assert np.array_equal(_bits(out2), _bits(ref2))
+
+
+@pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
+def test_cold_batch_larger_than_one_staging_chunk(direct):
+    """600 K distinct missed rows of 512 B = 307 MB: more than the 256-MB staging chunk of the host-gather path, so its
+    miss loop runs twice (the device-driven tier stages the whole call at once); rows exact either way."""
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    R, D, n = 700_000, 128, 600_000
+    keys = np.arange(R, dtype=np.int64)
+    rows = O.c_synth_rows(O.SEED, 0, 0, R, D)
+    cfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8},
+           "models": [{"model": "cold", "sparse_files": ["x"], "num_of_worker_buffer_in_pool": 1,
+                       "embedding_vecsize_per_table": [D], "maxnum_catfeature_query_per_table_per_sample": [1],
+                       "default_value_for_each_table": [0.0], "deployed_device_list": [0], "max_batch_size": n,
+                       "gpucache": True, "gpucacheper": 0.01, "hit_rate_threshold": 1.0, "ps_direct_access": direct}]}
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    ps.load_table_arrays("cold", 0, keys, rows)
+    ps.create_embedding_cache_per_model("cold")
+    s = hps.LookupSession.create(ps, "cold", ps.get_embedding_cache("cold", 0))
+    q = np.random.default_rng(4).permutation(R)[:n].astype(np.int64)
+    out = s.lookup(q, [n]).cpu().numpy().reshape(n, D)
+    assert s.last_stats().unique_misses > 590_000
+    assert np.array_equal(out.view(np.uint32), rows[q].view(np.uint32))
