@@ -1,0 +1,183 @@
+// Sanitizer driver for the host side of the engine (the reference has no sanitizer or race-detection
+// jobs; this build runs its CPU tier under ASan+UBSan and under TSan).  Built by tests/test_sanitizers.py with g++
+// from the product sources csrc/common/{json,config}.cpp, csrc/ps/{thread_pool,host_table}.cpp — no GPU needed.
+//
+//   driver parse     configuration parser on valid / truncated / hostile inputs
+//   driver table     load, duplicates, sentinel key, synthetic + sharded generation, lookups checked against a std::map
+//   driver threads   concurrent Fetch from several threads while another thread upserts and reloads; pool stress
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common/config.h"
+#include "common/hps_hash.h"
+#include "ps/host_table.h"
+#include "ps/thread_pool.h"
+
+using namespace hps;
+
+#define CHECK(c)                                                            \
+  do {                                                                      \
+    if (!(c)) { fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #c, __FILE__, __LINE__); return 1; } \
+  } while (0)
+
+static const char* kGoodJson = R"({"supportlonglong": true,
+  "volatile_db": {"type": "hash_map", "num_partitions": 4},
+  "models": [{"model": "m", "sparse_files": ["/a", "/b"], "num_of_worker_buffer_in_pool": 2,
+              "embedding_vecsize_per_table": [1, 16], "maxnum_catfeature_query_per_table_per_sample": [2, 26],
+              "default_value_for_each_table": [0.0, 1.5], "deployed_device_list": [0], "max_batch_size": 64,
+              "gpucache": true, "hit_rate_threshold": 0.9, "gpucacheper": 0.5, "ps_direct_access": false}]})";
+
+static int run_parse() {
+  ParameterServerConfig cfg;
+  CHECK(ParseParameterServerText(kGoodJson, &cfg).ok());
+  CHECK(cfg.models.at("m").num_tables() == 2);
+  const std::string good(kGoodJson);
+  // every prefix of a valid document, and every single-byte corruption of it, must be rejected or accepted cleanly
+  for (size_t n = 0; n < good.size(); n += 3) {
+    ParameterServerConfig c;
+    (void)ParseParameterServerText(good.substr(0, n), &c);
+  }
+  std::mt19937 rng(7);
+  for (int it = 0; it < 400; ++it) {
+    std::string s = good;
+    s[rng() % s.size()] = (char)(rng() % 256);
+    ParameterServerConfig c;
+    (void)ParseParameterServerText(s, &c);
+  }
+  const char* hostile[] = {"", "{", "[[[[[[[[[[[[[[[[[[[[[[[[[[[[[[[[", "{\"models\": 3}", "{\"supportlonglong\": true, \"models\": [{}]}",
+                           "{\"supportlonglong\": true, \"models\": [{\"model\": \"x\", \"sparse_files\": []}]}",
+                           "\"\\u00", "{\"a\": 1e999999}", "nul", "{\"supportlonglong\": \"maybe\"}"};
+  for (const char* h : hostile) {
+    ParameterServerConfig c;
+    (void)ParseParameterServerText(h, &c);
+  }
+  return 0;
+}
+
+static int check_against_map(const HostTable& tb, const std::map<int64_t, size_t>& ref, const std::vector<float>& rows, uint32_t D,
+                             const std::vector<int64_t>& q) {
+  std::vector<float> out(q.size() * D);
+  std::vector<uint8_t> found(q.size());
+  tb.Fetch(q.data(), q.size(), out.data(), D, -7.f, found.data());
+  for (size_t i = 0; i < q.size(); ++i) {
+    auto it = ref.find(q[i]);
+    CHECK((it != ref.end()) == (found[i] != 0));
+    for (uint32_t j = 0; j < D; ++j) {
+      const float want = it != ref.end() ? rows[it->second * D + j] : -7.f;
+      CHECK(memcmp(&want, &out[i * D + j], 4) == 0);
+    }
+  }
+  return 0;
+}
+
+static int run_table() {
+  ThreadPool pool(3);
+  for (uint32_t D : {1u, 3u, 16u, 128u}) {
+    const size_t R = 20000;
+    std::vector<int64_t> keys(R);
+    std::vector<float> rows(R * D);
+    std::mt19937_64 rng(D);
+    for (size_t r = 0; r < R; ++r) keys[r] = (int64_t)(rng() % (R * 3)) - (int64_t)R;   // duplicates on purpose
+    keys[17] = HPS_EMPTY_KEY;                                                            // the sentinel is a legal key
+    for (auto& v : rows) v = (float)(rng() % 100000) * 0.25f;
+    std::map<int64_t, size_t> ref;
+    for (size_t r = 0; r < R; ++r) ref[keys[r]] = r;                                    // last duplicate wins
+    HostTable tb("t", D, 8);
+    CHECK(tb.LoadFromArrays(keys.data(), rows.data(), R, false, &pool).ok());
+    CHECK(tb.size() == R && tb.has_duplicate_keys());
+    std::vector<int64_t> q;
+    for (int i = 0; i < 5000; ++i) q.push_back((int64_t)(rng() % (R * 4)) - (int64_t)R);
+    q.push_back(HPS_EMPTY_KEY);
+    q.push_back(INT64_MAX);
+    if (check_against_map(tb, ref, rows, D, q)) return 1;
+    // upserts: new keys and overwrites
+    std::vector<int64_t> uk;
+    std::vector<float> ur;
+    for (int i = 0; i < 3000; ++i) {
+      uk.push_back((int64_t)(rng() % (R * 6)));
+      for (uint32_t j = 0; j < D; ++j) ur.push_back((float)i + (float)j * 0.5f);
+    }
+    CHECK(tb.Upsert(uk.data(), ur.data(), uk.size()).ok());
+    for (size_t i = 0; i < uk.size(); ++i) {
+      const int64_t row = tb.Find(uk[i]);
+      CHECK(row >= 0);
+    }
+  }
+  // synthetic generation, whole and sharded: the shards partition the table
+  const size_t R = 30011;
+  HostTable whole("w", 20, 8);
+  CHECK(whole.LoadSynthetic(5, 1, 100, R, &pool).ok());
+  size_t total = 0;
+  for (uint32_t s = 0; s < 3; ++s) {
+    HostTable part("p", 20, 8);
+    CHECK(part.LoadSynthetic(5, 1, 100, R, &pool, s, 3).ok());
+    total += part.size();
+    for (size_t r = 0; r < part.size(); r += 97) {
+      const int64_t k = part.key_at(r);
+      CHECK(hps_mix64((uint64_t)k) % 3 == s);
+      const int64_t wr = whole.Find(k);
+      CHECK(wr >= 0 && memcmp(whole.row_at((size_t)wr), part.row_at(r), 20 * 4) == 0);
+    }
+  }
+  CHECK(total == R);
+  CHECK(!HostTable("bad", 4, 8).LoadSynthetic(1, 0, 0, 10, &pool, 5, 3).ok());
+  return 0;
+}
+
+static int run_threads() {
+  ThreadPool pool(4, 50);
+  const uint32_t D = 32;
+  const size_t R = 50000;
+  HostTable tb("t", D, 8);
+  CHECK(tb.LoadSynthetic(9, 0, 0, R, &pool).ok());
+  std::atomic<bool> stop{false};
+  std::atomic<int> bad{0};
+  auto reader = [&](int seed) {
+    std::mt19937_64 rng(seed);
+    std::vector<int64_t> q(512);
+    std::vector<float> out(q.size() * D);
+    std::vector<uint8_t> found(q.size());
+    while (!stop.load()) {
+      for (auto& k : q) k = (int64_t)(rng() % (R + R / 10));
+      tb.Fetch(q.data(), q.size(), out.data(), D, 0.f, found.data());
+      for (size_t i = 0; i < q.size(); ++i)
+        if ((q[i] < (int64_t)R) != (found[i] != 0) && q[i] < (int64_t)R) bad.fetch_add(1);   // original keys never disappear
+    }
+  };
+  std::vector<std::thread> th;
+  for (int i = 0; i < 3; ++i) th.emplace_back(reader, 100 + i);
+  std::mt19937_64 rng(1);
+  for (int round = 0; round < 30; ++round) {
+    std::vector<int64_t> uk(256);
+    std::vector<float> ur(uk.size() * D, (float)round);
+    for (auto& k : uk) k = (int64_t)(R + rng() % (R / 10));    // new keys only: readers' expectations stay valid
+    CHECK(tb.Upsert(uk.data(), ur.data(), uk.size()).ok());
+    if (round % 10 == 9) CHECK(tb.LoadSynthetic(9, 0, 0, R, &pool).ok());   // full reload under the readers
+    std::atomic<size_t> sum{0};
+    pool.ParallelFor(1000, [&](size_t i) { sum.fetch_add(i); });
+    CHECK(sum.load() == 999 * 1000 / 2);
+    std::atomic<int> fired{0};
+    for (int i = 0; i < 16; ++i) pool.Submit([&fired] { fired.fetch_add(1); });
+    while (fired.load() < 16) std::this_thread::yield();
+  }
+  stop.store(true);
+  for (auto& t : th) t.join();
+  CHECK(bad.load() == 0);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const std::string what = argc > 1 ? argv[1] : "all";
+  int rc = 0;
+  if (what == "parse" || what == "all") rc |= run_parse();
+  if (what == "table" || what == "all") rc |= run_table();
+  if (what == "threads" || what == "all") rc |= run_threads();
+  printf("%s: %s\n", what.c_str(), rc ? "FAILED" : "ok");
+  return rc;
+}
