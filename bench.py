@@ -140,6 +140,8 @@ def main():
         # share the host cores between the ranks' parameter-server pools
         os.environ.setdefault("HCTR_DEFAULT_CONCURRENCY", str(max(2, effective_cpus() // world)))
 
+    from hugectr_backend_amd.gpu_wait import wait_for_gpu
+    wait_for_gpu(30.0)   # a device that another process has just released can be invisible for a moment
     import torch
     import torch.distributed as dist
     from hugectr_backend_amd import build as hb
