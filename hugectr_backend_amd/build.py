@@ -19,14 +19,17 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-LIB = PKG / "lib"
-OBJ = PKG / "build"
 ROOT = PKG.parent
+# HPS_AMD_LIB_DIR / HPS_AMD_EXTRA_FLAGS: an instrumented variant of the libraries next to the product build
+# (tests/test_sanitizers.py builds the shell with -fsanitize=address into a scratch directory this way)
+_ALT = os.environ.get("HPS_AMD_LIB_DIR")
+LIB = Path(_ALT) if _ALT else PKG / "lib"
+OBJ = Path(_ALT) / "obj" if _ALT else PKG / "build"
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-pthread",
-            f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+            f"-I{ROOT / 'include'}", f"-I{CSRC}", *os.environ.get("HPS_AMD_EXTRA_FLAGS", "").split()]
 
 ENGINE_SRCS = [
     "common/json.cpp",
@@ -89,7 +92,8 @@ def _compile(rel: str, force: bool) -> Path:
 
 def _link(out: Path, objs, extra=()):
     out.parent.mkdir(parents=True, exist_ok=True)
-    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(out), *map(str, objs), "-pthread", *extra])
+    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(out), *map(str, objs), "-pthread", *extra,
+          *os.environ.get("HPS_AMD_EXTRA_LDFLAGS", "").split()])
 
 
 def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> dict:

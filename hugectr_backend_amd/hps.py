@@ -18,7 +18,9 @@ from typing import Sequence
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-_LIBPATH = _PKG / "lib" / "libhps_amd.so"
+import os as _os  # noqa: E402
+# HPS_AMD_LIB_DIR: an instrumented build of the same sources (sanitizer job), see hugectr_backend_amd/build.py
+_LIBPATH = (Path(_os.environ["HPS_AMD_LIB_DIR"]) if _os.environ.get("HPS_AMD_LIB_DIR") else _PKG / "lib") / "libhps_amd.so"
 
 
 class HpsError(RuntimeError):

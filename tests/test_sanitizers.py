@@ -56,3 +56,29 @@ def test_host_side_under_asan_ubsan(binaries, what):
 
 def test_host_side_under_tsan(binaries):
     _run(binaries["tsan"], "threads", {"TSAN_OPTIONS": "halt_on_error=0:report_signal_unsafe=0"})
+
+
+def test_triton_shell_and_engine_host_code_under_asan(tmp_path):
+    """The three product libraries rebuilt with -fsanitize=address (host code; device code untouched) into a scratch
+    directory, and the CPU-runnable suites of the Triton shell, the host tier and the configuration parser run against
+    them with the ASan runtime preloaded: every request/response/error path the mock core drives, under ASan."""
+    import sys
+    clang = Path("/opt/rocm/lib/llvm/bin/clang")
+    if not clang.exists():
+        pytest.skip("ROCm clang not available")
+    rt = subprocess.run([str(clang), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not rt or not Path(rt).exists():
+        pytest.skip("clang ASan runtime not available")
+    env = dict(os.environ, HPS_AMD_LIB_DIR=str(tmp_path),
+               HPS_AMD_EXTRA_FLAGS="-fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer -g -shared-libsan",
+               HPS_AMD_EXTRA_LDFLAGS="-fsanitize=address -shared-libsan")
+    b = subprocess.run([sys.executable, "-m", "hugectr_backend_amd.build"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert b.returncode == 0, (b.stdout + b.stderr)[-2000:]
+    syms = subprocess.run(["nm", "-D", str(tmp_path / "libtriton_hps.so")], capture_output=True, text=True).stdout
+    assert "__asan" in syms, "the scratch build is not instrumented"
+    env.update(LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0:verify_asan_link_order=0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_triton_backend_cpu.py", "tests/test_host_tier.py",
+                        "tests/test_config.py", "-x", "-q", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    report = r.stdout + r.stderr
+    assert r.returncode == 0 and "ERROR: AddressSanitizer" not in report, report[-3000:]

@@ -13,7 +13,8 @@ from pathlib import Path
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
-LIBDIR = ROOT / "hugectr_backend_amd" / "lib"
+import os as _os  # noqa: E402
+LIBDIR = Path(_os.environ["HPS_AMD_LIB_DIR"]) if _os.environ.get("HPS_AMD_LIB_DIR") else ROOT / "hugectr_backend_amd" / "lib"
 BACKEND_LIB = LIBDIR / "libtriton_hps.so"
 MOCK_LIB = LIBDIR / "libtriton_mock_core.so"
 
