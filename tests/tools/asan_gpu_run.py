@@ -1,0 +1,109 @@
+"""Torch-free exercise of the GPU lookup paths, for runs with the ASan runtime preloaded (torch's CUDA initialisation does
+not survive LD_PRELOAD=libclang_rt.asan).  Device buffers come from hipMalloc through ctypes; everything else is the
+product's C ABI.  Both parameter-server tiers, synchronous / mixed / async policy, two sessions on two threads, a table
+reload and a cache refresh in between; every row compared with the oracle.
+
+    HPS_AMD_LIB_DIR=<asan build> LD_PRELOAD=<libclang_rt.asan-x86_64.so> python tests/tools/asan_gpu_run.py
+"""
+import ctypes as C
+import sys
+import threading
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+
+HIP = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+HIP.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+HIP.hipFree.argtypes = [C.c_void_p]
+
+
+def dmalloc(nbytes):
+    p = C.c_void_p()
+    assert HIP.hipMalloc(C.byref(p), max(nbytes, 16)) == 0
+    return p
+
+
+def main():
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    from tests.conftest import make_tables, ps_config
+    assert hps.device_count() > 0
+    shapes = [(6000, 128), (4000, 16), (900, 3)]
+    tables = make_tables(shapes)
+    T = len(tables)
+    dims = [d for _, d in shapes]
+    failures = []
+    for direct in (False, True):
+        for thr in (1.0, 0.8):
+            name = f"asan_{int(direct)}_{int(thr * 10)}"
+            cfg = ps_config(name, tables, maxcat=[1] * T, defaults=[0.5, -1.0, 2.0], gpucacheper=0.2, max_batch=4096,
+                            hit_rate_threshold=thr, extra={"ps_direct_access": direct})
+            ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+            for t, (k, r) in enumerate(tables):
+                ps.load_table_arrays(name, t, k, r)
+            ps.create_embedding_cache_per_model(name)
+            cache = ps.get_embedding_cache(name, 0)
+            sessions = [hps.LookupSession.create(ps, name, cache) for _ in range(2)]
+
+            def worker(si, seed):
+                rng = np.random.default_rng(seed)
+                s = sessions[si]
+                try:
+                    for it in range(12):
+                        nk = [int(rng.integers(0, 4097)) for _ in range(T)]
+                        parts = []
+                        for (keys, _), n in zip(tables, nk):
+                            q = rng.choice(keys[: keys.size // 3], n) if it % 2 else rng.choice(keys, n)
+                            q = np.where(rng.random(n) < 0.05, -1 - rng.integers(0, 1 << 40, n), q)
+                            parts.append(q.astype(np.int64))
+                        q = np.concatenate(parts)
+                        n_out = sum(n * d for n, d in zip(nk, dims))
+                        d_out = dmalloc(n_out * 4)
+                        offs, ptrs, off = [], [], 0
+                        for n, d in zip(nk, dims):
+                            ptrs.append((d_out.value or 0) + off * 4)
+                            off += n * d
+                        kptrs, koff = [], 0
+                        for n in nk:
+                            kptrs.append(q.ctypes.data + koff * 8)
+                            koff += n
+                        kp = (C.c_void_p * T)(*kptrs)
+                        vp = (C.c_void_p * T)(*ptrs)
+                        nkc = (C.c_size_t * T)(*nk)
+                        hps._check(hps.LIB.hps_session_lookup(s._h, kp, vp, nkc, T))
+                        out = np.empty(n_out, np.float32)
+                        if n_out:
+                            assert HIP.hipMemcpy(out.ctypes.data, d_out, n_out * 4, 2) == 0
+                        HIP.hipFree(d_out)
+                        ref_sync = O.np_lookup(tables, q, nk, [0.5, -1.0, 2.0])
+                        same = out.view(np.uint32) == ref_sync.view(np.uint32)
+                        if thr < 1.0:   # async tables may answer the default for keys not resident yet
+                            dflt = np.concatenate([np.full(n * d, v, np.float32) for n, d, v in zip(nk, dims, [0.5, -1.0, 2.0])])
+                            same |= out.view(np.uint32) == dflt.view(np.uint32)
+                        if not same.all():
+                            failures.append((name, si, it, int((~same).sum())))
+                            return
+                        if si == 0 and it == 5:
+                            ps.load_table_arrays(name, 1, *tables[1])      # reload under the other session
+                            ps.refresh_embedding_cache(name, 0)
+                except Exception as e:  # noqa: BLE001
+                    failures.append((name, si, repr(e)))
+
+            th = [threading.Thread(target=worker, args=(i, 10 * i + int(direct))) for i in range(2)]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            cache.wait_async()
+            for s in sessions:
+                s.close()
+            print(f"{name}: direct={direct} threshold={thr}: {cache.counters()}")
+            cache.release()
+            ps.close()
+    print("asan_gpu_run:", "FAILED " + repr(failures[:3]) if failures else "ok")
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
