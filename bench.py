@@ -56,9 +56,14 @@ def parse_args():
     ap.add_argument("--distinct-batches", type=int, default=0,
                     help="0: one fresh batch per step (warmup+steps distinct batches)")
     ap.add_argument("--unroll", type=int, default=1102, help="probe+gather kernel variant (tools/kbench.py)")
-    ap.add_argument("--direct", type=int, default=1,
-                    help="1: ps_direct_access (the GPU resolves misses itself out of pinned host memory); "
-                         "0: host threads gather the missed rows (the reference's arrangement)")
+    ap.add_argument("--direct", type=int, default=-1,
+                    help="parameter-server tier of the miss path.  0: host threads gather the missed rows and "
+                         "hipMemcpyAsync ships them (the reference's arrangement); 1: ps_direct_access (the GPU resolves "
+                         "misses itself out of pinned host memory, no host threads); -1 (default): host gather when this "
+                         "rank has at least 12 CPUs to itself, else device-driven — on one GPU the other tier is measured "
+                         "right after the headline and reported under extra_legs")
+    ap.add_argument("--no-direct-leg", action="store_true",
+                    help="one GPU, host-gather headline: skip the device-driven-tier leg measured afterwards")
     ap.add_argument("--no-sharded-leg", action="store_true",
                     help="N>1: skip the BASELINE config 3 leg (one table sharded over the ranks, RCCL all-to-all)")
     ap.add_argument("--shard-rows", type=int, default=1 << 28,
@@ -139,7 +144,16 @@ def main():
     if world > 1:
         # share the host cores between the ranks' parameter-server pools
         os.environ.setdefault("HCTR_DEFAULT_CONCURRENCY", str(max(2, effective_cpus() // world)))
+    tier_auto = a.direct < 0
+    if tier_auto:
+        # the host-gather tier needs host cores (its gather runs on ~14 threads per GPU); with fewer, or with several
+        # replicas sharing one host, the device-driven tier, which needs none, is the one to run
+        a.direct = 0 if (world == 1 and effective_cpus() >= 12) else 1
 
+    # HIP spreads a process's streams over 4 hardware queues by default; two lookup sessions whose streams land on the
+    # same queue run strictly one after the other (measured: 1.30 instead of 1.85 G lookups/s for the device-driven tier
+    # after an earlier phase of the process had created other streams).  Must be in the environment before HIP starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     from hugectr_backend_amd.gpu_wait import wait_for_gpu
     wait_for_gpu(30.0)   # a device that another process has just released can be invisible for a moment
     import torch
@@ -623,6 +637,25 @@ def main():
     for s in sessions:
         s.close()
 
+    # ---- one GPU, headline measured on the host-gather tier: the device-driven tier (ps_direct_access) on the same
+    #      workload right after, with the headline's resources released first (its tables are page-locked: a second
+    #      133 GB next to the first would not fit the box) ----
+    if world == 1 and not a.direct and not a.no_extra_legs and not a.no_direct_leg:
+        import gc
+        del sessions, cache, ps, made
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            dleg = direct_tier_leg(a, torch, hps, T, R, D, B, N, dev, outs, cfg)
+        except Exception as e:  # noqa: BLE001
+            dleg = {"error": repr(e)[:300]}
+            sys.stderr.write(f"[bench] device-driven tier leg stopped: {e!r}\n")
+        fused = dleg.pop("c5_fused_lookup_interact", None) if isinstance(dleg, dict) else None
+        res["extra_legs"] = dict(res["extra_legs"] or {}, device_driven_tier=dleg)
+        if fused:
+            res["extra_legs"]["c5_fused_lookup_interact"] = fused
+        res["roofline"]["frac_under_device_driven_tier"] = dleg.get("kernel_frac_of_hbm_peak")
+
     # ---- BASELINE config 3 leg (N > 1 only): ONE table sharded over the ranks, RCCL all-to-all of keys and rows ----
     # Runs after the headline measurement is complete and its resources are released; a watchdog prints the headline
     # line and ends every rank if the leg does not finish (a collective that hangs cannot be caught any other way).
@@ -654,6 +687,114 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def direct_tier_leg(a, torch, hps, T, R, D, B, N, dev, outs, cfg):
+    """The headline workload on a ps_direct_access deployment of the same model (own server: page-locked tables, device
+    index): two sessions, fresh batches, exact rows; then the fused lookup+interaction call of config 5."""
+    model = cfg["models"][0]["model"]
+    cfg = json.loads(json.dumps(cfg))
+    cfg["models"][0]["ps_direct_access"] = True
+    t0 = time.time()
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    for t in range(T):
+        ps.load_table_synthetic(model, t, SEED, 0, R)
+    ps.create_embedding_cache_per_model(model)
+    cache = ps.get_embedding_cache(model, dev)
+    t_setup = time.time() - t0
+    sessions = [hps.LookupSession.create(ps, model, cache) for _ in range(a.sessions)]
+    for s in sessions:
+        s.set_option("timing", 1)
+        s.set_option("probe_unroll", a.unroll)
+    C = int(np.ceil(a.cache_frac * R))
+    resident = []
+    for t in range(T):
+        k = np.arange(C, dtype=np.int64)
+        resident.append(k[cache.query(t, k) >= 0])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(SEED + 555)
+    cdf_d = torch.from_numpy(zipf_cdf(C, a.zipf)).cuda()
+    resident_d = [torch.from_numpy(r).cuda() for r in resident]
+    nk = [B] * T
+    lock = threading.Lock()
+
+    def run(batches, count, first, record, step=None):
+        nxt = [0]
+        lat, kern, fetch, miss, uniq, gpu = [], [], [], [], [], []
+
+        def worker(si):
+            s = sessions[si]
+            while True:
+                with lock:
+                    i = nxt[0]
+                    if i >= count:
+                        return
+                    nxt[0] += 1
+                keys = batches[(first + i) % len(batches)]
+                ts = time.perf_counter()
+                if step:
+                    step(si, keys)
+                else:
+                    s.lookup_device(keys, nk, out=outs[si])
+                dt = (time.perf_counter() - ts) * 1e3
+                st = s.last_stats()
+                if record:
+                    with lock:
+                        lat.append(dt); kern.append(st.probe_gather_ms); fetch.append(st.phase_ms[1])
+                        miss.append(st.misses); uniq.append(st.unique_misses); gpu.append(st.gpu_call_ms)
+
+        th = [threading.Thread(target=worker, args=(si,)) for si in range(len(sessions))]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        [x.start() for x in th]
+        [x.join() for x in th]
+        torch.cuda.synchronize()
+        return time.perf_counter() - t1, lat, kern, fetch, miss, uniq, gpu
+
+    steps = 40
+    batches = make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, a.hit, steps + 8)
+    run(batches, 8, 0, False)
+    dt, lat, kern, fetch, miss, uniq, gpu = run(batches, steps, 8, True)
+    k_ms, f_ms = float(np.mean(kern)), float(np.mean(fetch))
+    out = {
+        "lookups_per_s": steps * N / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "sessions": len(sessions),
+        "p50_batch_latency_ms": float(np.percentile(lat, 50)), "p99_batch_latency_ms": float(np.percentile(lat, 99)),
+        "p50_batch_gpu_ms": float(np.percentile(gpu, 50)),
+        "measured_hit_rate": 1.0 - float(np.mean(miss)) / N,
+        "avg_kernel_ms": k_ms, "kernel_frac_of_hbm_peak": N * (8 + 8 * D) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "roofline_pcie": {"bound": "pcie", "kernel": "hps_ps_fetch_direct_kernel", "avg_kernel_ms": f_ms,
+                          "achieved": float(np.mean(uniq)) * 4 * D / (f_ms * 1e-3) / 1e9 if f_ms > 0 else None,
+                          "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                          "frac": float(np.mean(uniq)) * 4 * D / (f_ms * 1e-3) / 1e9 / PCIE_PEAK_GBS if f_ms > 0 else None},
+        "setup_seconds": t_setup,
+        "note": "same workload, two sessions, exact rows; the GPU resolves the misses through a device index of the page-locked "
+                "host tables and reads the rows over PCIe itself (no host threads on the path)",
+    }
+    del batches
+    if D % 32 == 0 and D <= 512 and T <= 31 and a.mode == "sync":
+        from hugectr_backend_amd.dense import DenseInteraction
+        rngw = np.random.default_rng(SEED)
+        dims, k = [512, 256, D], 13
+        ws, bs = [], []
+        for n in dims:
+            ws.append(((rngw.random((k, n), dtype=np.float32) * 2 - 1) * (1.5 / np.sqrt(k))).astype(np.float32))
+            bs.append(((rngw.random(n, dtype=np.float32) - 0.3) * 0.2).astype(np.float32))
+            k = n
+        ops = [DenseInteraction(ws, bs, T, D, device=dev) for _ in sessions]
+        xd = torch.randn(B, 13, device="cuda")
+        outd = [torch.empty((B, ops[0].out_stride), dtype=torch.float16, device="cuda") for _ in sessions]
+        fb = make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, a.hit, 28)
+        step = lambda si, keys: ops[si].lookup_interact(sessions[si], keys, B, xd, out=outd[si])  # noqa: E731
+        run(fb, 4, 0, False, step)
+        dtf, latf, kernf, _, missf, _, _ = run(fb, 24, 4, True, step)
+        out["c5_fused_lookup_interact"] = {
+            "lookups_per_s": 24 * N / dtf, "ms_per_step": dtf / 24 * 1e3, "samples_per_s": 24 * B / dtf,
+            "measured_hit_rate": 1.0 - float(np.mean(missf)) / N, "probe_only_kernel_ms": float(np.mean(kernf)),
+            "note": "one call per step: probe, miss fetch, bottom MLP, interaction reading cache slots / staging, insert",
+        }
+    for s in sessions:
+        s.close()
+    return out
 
 
 def sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev):

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -21,6 +22,10 @@ struct hps_session { std::shared_ptr<HierParameterServer> ps; std::unique_ptr<Lo
 struct hps_dense { std::unique_ptr<DenseInteraction> d; };
 
 namespace {
+// Runs when the library is loaded.  HIP maps a process's streams onto 4 hardware queues unless told otherwise; lookup
+// sessions whose streams share a queue execute one after the other.  Only a hint: it has no effect if the hosting
+// process initialised HIP earlier or set the variable itself (Triton deployments: export GPU_MAX_HW_QUEUES=8).
+const int g_hw_queue_hint = (setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0), 0);
 thread_local std::string g_err;
 
 int Fail(const Status& st) {

@@ -83,11 +83,9 @@ ThreadPool::ThreadPool(size_t num_workers, unsigned spin_us) : spin_us_(spin_us)
 }
 
 ThreadPool::~ThreadPool() {
-  {
-    std::lock_guard<std::mutex> lk(mu_);
-    stop_ = true;
-    seq_.fetch_add(1, std::memory_order_release);
-  }
+  stop_.store(true, std::memory_order_release);
+  seq_.fetch_add(1, std::memory_order_release);
+  { std::lock_guard<std::mutex> lk(mu_); }   // a worker between its predicate check and its wait sees the new seq_
   cv_.notify_all();
   for (auto& t : workers_) t.join();
 }
@@ -115,14 +113,47 @@ static inline void CpuRelax() {
 #endif
 }
 
+uint32_t ThreadPool::RunFast(FastLoop& L, uint32_t gen) {
+  uint32_t ran = 0;
+  for (;;) {
+    uint64_t cur = L.next.load(std::memory_order_acquire);
+    if ((uint32_t)(cur >> 32) != gen) break;                 // the slot moved on to another loop
+    const uint32_t idx = (uint32_t)cur;
+    const uint32_t n = L.n.load(std::memory_order_relaxed);
+    if (idx >= n) break;                                     // everything claimed
+    const uint32_t g = L.grain.load(std::memory_order_relaxed);
+    const uint32_t end = idx + g < n ? idx + g : n;
+    // the generation in the word makes the claim fail if the parameters just read belong to an older loop
+    if (!L.next.compare_exchange_weak(cur, ((uint64_t)gen << 32) | end, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
+    const std::function<void(size_t)>* fn = L.fn.load(std::memory_order_relaxed);
+    for (uint32_t i = idx; i < end; ++i) (*fn)(i);
+    ran += end - idx;
+    L.done.fetch_add(end - idx, std::memory_order_acq_rel);   // the owner returns (and fn dies) only after this
+  }
+  return ran;
+}
+
+bool ThreadPool::HelpFastLoops() {
+  bool any = false;
+  for (FastLoop& L : fast_) {
+    if (L.state.load(std::memory_order_acquire) != 1) continue;
+    const uint32_t gen = (uint32_t)(L.next.load(std::memory_order_acquire) >> 32);
+    any |= RunFast(L, gen) > 0;
+  }
+  return any;
+}
+
 void ThreadPool::WorkerMain() {
   uint64_t seen = 0;
   for (;;) {
     std::shared_ptr<Loop> loop;
     std::function<void()> task;
+    // read the enqueue counter BEFORE looking for work: anything published after this read changes it, so the idle
+    // wait below cannot sleep through a loop this pass did not see
+    seen = seq_.load(std::memory_order_acquire);
+    if (spin_us_ && HelpFastLoops()) continue;
     {
-      std::unique_lock<std::mutex> lk(mu_);
-      seen = seq_.load(std::memory_order_acquire);
+      std::lock_guard<SpinLock> lk(qlock_);
       // drop loops whose tasks are all claimed
       while (!loops_.empty() && loops_.front()->next.load(std::memory_order_relaxed) >= loops_.front()->n)
         loops_.pop_front();
@@ -135,7 +166,7 @@ void ThreadPool::WorkerMain() {
         }
       }
       if (!loop && !tasks_.empty()) { task = std::move(tasks_.front()); tasks_.pop_front(); }
-      if (!loop && !task && stop_) return;
+      if (!loop && !task && stop_.load(std::memory_order_acquire)) return;
     }
     if (loop) { RunLoop(loop.get()); continue; }
     if (task) { task(); continue; }
@@ -151,8 +182,14 @@ void ThreadPool::WorkerMain() {
       }
       if (woke) continue;
     }
-    std::unique_lock<std::mutex> lk(mu_);
-    cv_.wait(lk, [&] { return stop_ || seq_.load(std::memory_order_acquire) != seen; });
+    // park.  sleepers_ is raised BEFORE the predicate is evaluated and producers read it AFTER bumping seq_ (both
+    // sequentially consistent): either the producer sees a sleeper and wakes it, or the sleeper sees the new seq_.
+    sleepers_.fetch_add(1);
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return stop_.load() || seq_.load() != seen; });
+    }
+    sleepers_.fetch_sub(1);
   }
 }
 
@@ -162,6 +199,36 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
     for (size_t i = 0; i < num_tasks; ++i) fn(i);
     return;
   }
+  // ---- fast path (spinning pools): a lock-free slot, see FastLoop ----
+  if (spin_us_ && num_tasks < (1u << 31)) {
+    FastLoop* L = nullptr;
+    for (FastLoop& s : fast_) {
+      uint32_t expect = 0;
+      if (s.state.compare_exchange_strong(expect, 2, std::memory_order_acq_rel)) { L = &s; break; }
+    }
+    if (L) {
+      size_t threads = workers_.size() + 1;
+      if (max_parallel && max_parallel < threads) threads = max_parallel;
+      // grains: one claim per thread when the caller asked for a cap, else task by task (callers size their tasks)
+      const uint32_t grain = max_parallel ? (uint32_t)((num_tasks + threads - 1) / threads) : 1u;
+      const uint32_t gen = ++L->gen;
+      L->fn.store(&fn, std::memory_order_relaxed);
+      L->n.store((uint32_t)num_tasks, std::memory_order_relaxed);
+      L->grain.store(grain ? grain : 1u, std::memory_order_relaxed);
+      L->done.store(0, std::memory_order_relaxed);
+      L->next.store((uint64_t)gen << 32, std::memory_order_release);
+      L->state.store(1, std::memory_order_release);
+      seq_.fetch_add(1);
+      if (sleepers_.load() > 0) {
+        { std::lock_guard<std::mutex> lk(mu_); }
+        cv_.notify_all();
+      }
+      RunFast(*L, gen);
+      while (L->done.load(std::memory_order_acquire) != (uint32_t)num_tasks) CpuRelax();
+      L->state.store(0, std::memory_order_release);
+      return;
+    }
+  }
   auto loop = std::make_shared<Loop>();
   loop->fn = &fn;
   loop->n = num_tasks;
@@ -170,12 +237,17 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
   if (num_tasks - 1 < helpers) helpers = num_tasks - 1;
   loop->max_helpers = helpers;
   {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<SpinLock> lk(qlock_);
     loops_.push_back(loop);
-    seq_.fetch_add(1, std::memory_order_release);
+    seq_.fetch_add(1);
   }
-  if (helpers >= workers_.size() / 2) cv_.notify_all();
-  else for (size_t i = 0; i < helpers; ++i) cv_.notify_one();
+  // parked workers: an empty critical section on mu_ orders the seq_ bump against a worker that has checked its
+  // predicate but not yet gone to sleep, then the wake-up (spinning workers have seen seq_ already)
+  if (sleepers_.load() > 0) {
+    { std::lock_guard<std::mutex> lk(mu_); }
+    if (helpers >= workers_.size() / 2) cv_.notify_all();
+    else for (size_t i = 0; i < helpers; ++i) cv_.notify_one();
+  }
   RunLoop(loop.get());
   // the stragglers usually finish within microseconds: poll before paying for a futex sleep + wake
   for (int it = 0; it < 20000; ++it) {
@@ -188,10 +260,11 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
 
 void ThreadPool::Submit(std::function<void()> fn) {
   {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<SpinLock> lk(qlock_);
     tasks_.push_back(std::move(fn));
-    seq_.fetch_add(1, std::memory_order_release);
+    seq_.fetch_add(1);
   }
+  { std::lock_guard<std::mutex> lk(mu_); }
   cv_.notify_one();
 }
 

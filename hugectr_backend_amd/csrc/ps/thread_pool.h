@@ -57,14 +57,49 @@ class ThreadPool {
   void WorkerMain();
   static void RunLoop(Loop* l);
 
+  // Fast path of ParallelFor in a spinning (serving) pool: a few loop slots that live as long as the pool, found by
+  // the workers with plain loads (no lock) and claimed in grains with ONE compare-and-swap on a word that carries the
+  // slot's generation — a worker that read the parameters of an older generation fails its CAS and runs nothing.
+  // Measured on the MI355X box (14 threads spread over two sockets): 14 empty tasks through the locked queue 13.7 us,
+  // the hardware floor of a flag + a counter 2.9 us (tools/micro/forkjoin_min.bin).
+  struct alignas(64) FastLoop {
+    std::atomic<uint64_t> next{0};                                     // (generation << 32) | next task index
+    alignas(64) std::atomic<uint32_t> done{0};                         // tasks finished
+    alignas(64) std::atomic<uint32_t> state{0};                        // 0 free, 1 published, 2 being set up / torn down
+    std::atomic<const std::function<void(size_t)>*> fn{nullptr};
+    std::atomic<uint32_t> n{0}, grain{1};
+    uint32_t gen = 0;                                                  // owner only
+  };
+  static constexpr int kFastSlots = 4;
+  FastLoop fast_[kFastSlots];
+  // claims and runs grains of slot `L` while its generation is `gen`; returns the number of tasks this thread ran
+  static uint32_t RunFast(FastLoop& L, uint32_t gen);
+  bool HelpFastLoops();   // worker side: one pass over the published slots
+
+  // The queues are guarded by a spin lock, not by mu_: when a loop is published, every spinning worker comes for it at
+  // once, and a dozen threads handing a std::mutex to each other through the futex cost ~20 us per request (the whole
+  // gather of a 4,096-key request is 7 us on 14 threads).  mu_/cv_ only park and wake idle workers.
+  struct SpinLock {
+    std::atomic_flag f = ATOMIC_FLAG_INIT;
+    void lock() {
+      while (f.test_and_set(std::memory_order_acquire)) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+      }
+    }
+    void unlock() { f.clear(std::memory_order_release); }
+  };
   std::vector<std::thread> workers_;
+  SpinLock qlock_;
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<std::shared_ptr<Loop>> loops_;
   std::deque<std::function<void()>> tasks_;
   std::atomic<uint64_t> seq_{0};  // bumped on every enqueue; spinning workers poll it
+  std::atomic<int> sleepers_{0};   // workers parked on cv_ (or about to be)
   unsigned spin_us_ = 0;
-  bool stop_ = false;
+  std::atomic<bool> stop_{false};
 };
 
 }  // namespace hps

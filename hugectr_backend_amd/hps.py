@@ -19,6 +19,9 @@ import numpy as np
 
 _PKG = Path(__file__).resolve().parent
 import os as _os  # noqa: E402
+# more hardware queues than HIP's default of 4, so that concurrent lookup sessions do not share one;
+# only effective if HIP has not been initialised in this process yet
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # HPS_AMD_LIB_DIR: an instrumented build of the same sources (sanitizer job), see hugectr_backend_amd/build.py
 _LIBPATH = (Path(_os.environ["HPS_AMD_LIB_DIR"]) if _os.environ.get("HPS_AMD_LIB_DIR") else _PKG / "lib") / "libhps_amd.so"
 
