@@ -13,6 +13,7 @@
 //   * no C++ exception crosses the C ABI (CK_CUDA_THROW_ at hps.cc:677-685 does).
 #include <hip/hip_runtime_api.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -28,6 +29,11 @@ using namespace hps;
 using namespace hps::triton;
 
 namespace {
+
+// Load-time hint, see c_api.cpp: more HIP hardware queues than the default 4, so that the streams of two model instances do
+// not share one and serialise.  No effect when tritonserver has initialised HIP before loading the backend: export
+// GPU_MAX_HW_QUEUES in the launch environment then.
+const int g_hw_queue_hint = (setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0), 0);
 
 // Gather one input into a contiguous buffer the lookup can consume.
 //   *data / *on_device describe the result; staging (host) is used when the input arrives in several
