@@ -36,6 +36,7 @@ ENGINE_SRCS = [
     "common/config.cpp",
     "ps/thread_pool.cpp",
     "ps/host_table.cpp",
+    "ps/volatile_tier.cpp",
     "cache/kernels.hip",
     "cache/shard_kernels.hip",
     "cache/direct_kernels.hip",

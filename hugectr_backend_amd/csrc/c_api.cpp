@@ -240,6 +240,48 @@ int hps_server_fetch(hps_server_t* sv, const char* model, uint32_t table, const 
   });
 }
 
+int hps_server_upsert(hps_server_t* sv, const char* model, uint32_t table, const int64_t* keys, const float* rows,
+                      uint64_t n) {
+  return Guard([&]() -> Status {
+    const InferenceParams* p = nullptr;
+    HPS_RETURN_IF_ERROR(FindModel(sv, model, &p));
+    if (n && (!keys || !rows)) return Error(Code::kInvalidArg, "null argument");
+    return sv->ps->upsert_table(model, table, keys, rows, n);
+  });
+}
+
+int hps_server_host_tier_stats(hps_server_t* sv, const char* model, uint32_t table, hps_host_tier_stats_t* out) {
+  return Guard([&]() -> Status {
+    const InferenceParams* p = nullptr;
+    HPS_RETURN_IF_ERROR(FindModel(sv, model, &p));
+    auto tabs = sv->ps->tables_of(model);
+    if (table >= tabs.size() || !out) return Error(Code::kInvalidArg, "bad table / null argument");
+    const HostTierStats s = tabs[table]->tier_stats();
+    *out = hps_host_tier_stats_t{};
+    out->tiered = tabs[table]->tiered() ? 1 : 0;
+    out->persistent_rows = s.persistent_rows;
+    out->entries = s.vdb.entries; out->capacity = s.vdb.capacity; out->max_partition_entries = s.vdb.max_partition_entries;
+    out->lookups = s.vdb.lookups; out->hits = s.vdb.hits;
+    out->persistent_hits = s.persistent_hits; out->not_found = s.not_found;
+    out->inserts = s.vdb.inserts; out->evictions = s.vdb.evictions; out->overflows = s.vdb.overflows;
+    return Status::Ok();
+  });
+}
+
+int hps_server_host_tier_keys(hps_server_t* sv, const char* model, uint32_t table, int64_t* out, uint64_t cap, uint64_t* n) {
+  return Guard([&]() -> Status {
+    const InferenceParams* p = nullptr;
+    HPS_RETURN_IF_ERROR(FindModel(sv, model, &p));
+    auto tabs = sv->ps->tables_of(model);
+    if (table >= tabs.size() || !n) return Error(Code::kInvalidArg, "bad table / null argument");
+    std::vector<int64_t> keys;
+    tabs[table]->DumpVolatileKeys(&keys);
+    *n = keys.size();
+    if (out && cap >= keys.size() && !keys.empty()) memcpy(out, keys.data(), keys.size() * sizeof(int64_t));
+    return Status::Ok();
+  });
+}
+
 int hps_cache_num_tables(hps_cache_t* c) { return c ? (int)c->cache->num_tables() : 0; }
 
 int hps_cache_table_info(hps_cache_t* c, uint32_t table, hps_cache_table_info_t* out) {

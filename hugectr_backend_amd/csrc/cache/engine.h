@@ -299,6 +299,8 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
                                std::unique_ptr<LookupSession>* out);
 
   // table injection without files
+  // online update hook: insert-or-overwrite rows of one table (fences ps_direct_access caches like a reload)
+  Status upsert_table(const std::string& model, size_t table, const int64_t* keys, const float* rows, size_t n);
   Status load_table_from_arrays(const std::string& model, size_t table, const int64_t* keys, const float* rows,
                                 size_t R, bool borrow);
   Status load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0, size_t R,

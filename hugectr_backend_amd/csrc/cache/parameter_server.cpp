@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <filesystem>
 #include <cstring>
 
 #include "engine.h"
@@ -174,18 +175,33 @@ Status HierParameterServer::create_from_config(const ParameterServerConfig& cfg,
   if (cfg.volatile_db.type == DatabaseType::Disabled || cfg.volatile_db.type == DatabaseType::RocksDB)
     return Error(Code::kUnsupported, "volatile_db.type = ", ToString(cfg.volatile_db.type),
                  ": the in-process host tier (hash_map / parallel_hash_map) is the only volatile database of this build");
-  if (cfg.persistent_db.type != DatabaseType::Disabled)
+  // persistent_db.type = rocks_db selects this build's persistent tier: a memory-mapped row store under
+  // persistent_db.path (csrc/ps/host_table.h); RocksDB's own file format is neither read nor written.
+  if (cfg.persistent_db.type != DatabaseType::Disabled && cfg.persistent_db.type != DatabaseType::RocksDB)
     return Error(Code::kUnsupported, "persistent_db.type = ", ToString(cfg.persistent_db.type),
-                 " is not implemented in this build; every table is held completely by the host tier "
-                 "(set persistent_db.type to 'disabled')");
+                 " is not a persistent database (available: disabled, rocks_db)");
   if (cfg.update_source.type != UpdateSourceType::Null)
     return Error(Code::kUnsupported, "update_source.type = ", ToString(cfg.update_source.type),
                  " (Kafka online updates) is not implemented in this build");
-  if (cfg.volatile_db.initial_cache_rate < 1.0)
-    return Error(Code::kUnsupported, "volatile_db.initial_cache_rate = ", cfg.volatile_db.initial_cache_rate,
-                 " < 1 needs a persistent database behind the host tier, which this build does not have");
+  if (!(cfg.volatile_db.initial_cache_rate >= 0.0) || cfg.volatile_db.initial_cache_rate > 1.0)
+    return Error(Code::kInvalidArg, "volatile_db.initial_cache_rate = ", cfg.volatile_db.initial_cache_rate, " is outside [0, 1]");
+  if (cfg.volatile_db.overflow_margin == 0) return Error(Code::kInvalidArg, "volatile_db.overflow_margin must be > 0");
   HPS_RETURN_IF_ERROR(ps->Build(load_tables));
   *out = std::move(ps);
+  return Status::Ok();
+}
+
+// Copies a table's two files into the persistent store directory (created if needed).
+static Status MaterializeStore(const std::string& src, const std::string& dst) {
+  std::error_code ec;
+  std::filesystem::create_directories(dst, ec);
+  if (ec) return Error(Code::kInternal, "persistent_db: cannot create '", dst, "': ", ec.message());
+  for (const char* f : {"key", "emb_vector"}) {
+    std::filesystem::copy_file(src + "/" + f, dst + "/" + f, std::filesystem::copy_options::overwrite_existing, ec);
+    if (ec) return Error(Code::kNotFound, "persistent_db: cannot copy '", src, "/", f, "' to '", dst, "': ", ec.message());
+    std::filesystem::permissions(dst + "/" + f, std::filesystem::perms::owner_read | std::filesystem::perms::owner_write,
+                                 std::filesystem::perm_options::add, ec);
+  }
   return Status::Ok();
 }
 
@@ -205,6 +221,15 @@ Status HierParameterServer::EnsureTables(const InferenceParams& p, bool load) {
     if (!pinned) return Error(Code::kUnavailable, "model '", p.model_name, "': ps_direct_access needs a GPU");
     (void)hipSetDevice(p.deployed_devices.empty() ? p.device_id : p.deployed_devices[0]);
   }
+  // Host tier smaller than the table: a bounded volatile tier and/or a persistent row store behind it (host_table.h)
+  HostTierOptions tier;
+  tier.persistent = p.persistent_db.type != DatabaseType::Disabled;
+  tier.store_writable = tier.persistent && !p.persistent_db.read_only;
+  tier.vdb = p.volatile_db;
+  tier.tiered = p.volatile_db.overflow_margin != SIZE_MAX || p.volatile_db.initial_cache_rate < 1.0;
+  if (tier.tiered && pinned)
+    return Error(Code::kUnsupported, "model '", p.model_name, "': ps_direct_access reads the host tier from the GPU and needs "
+                 "the whole table in RAM (volatile_db.overflow_margin unlimited, initial_cache_rate 1.0)");
   const bool fresh = tabs.size() != T || (T && tabs[0]->pinned() != pinned);
   if (fresh) {
     tabs.clear();
@@ -215,7 +240,19 @@ Status HierParameterServer::EnsureTables(const InferenceParams& p, bool load) {
   }
   if (load) {
     HPS_RETURN_IF_ERROR(MutateTables(p.model_name, [&]() -> Status {
-      for (size_t t = 0; t < T; ++t) HPS_RETURN_IF_ERROR(tabs[t]->LoadFromDir(p.sparse_model_files[t], pool_));
+      for (size_t t = 0; t < T; ++t) {
+        std::string dir = p.sparse_model_files[t];
+        if (tier.persistent) {
+          // the persistent database holds a full copy of every table (docs/hierarchical_parameter_server.md:520-569):
+          // <path>/<model>/<table>/{key,emb_vector}, (re)written from the model files unless read_only
+          const std::string base = p.persistent_db.path.empty() ? std::string("/tmp/rocksdb") : p.persistent_db.path;
+          const std::string store = base + "/" + p.model_name + "/" + p.embedding_table_names[t];
+          if (tier.store_writable) HPS_RETURN_IF_ERROR(MaterializeStore(dir, store));
+          dir = store;
+        }
+        tabs[t]->SetTierOptions(tier);
+        HPS_RETURN_IF_ERROR(tabs[t]->LoadFromDir(dir, pool_));
+      }
       return Status::Ok();
     }));
   }
@@ -391,6 +428,13 @@ Status HierParameterServer::load_table_from_arrays(const std::string& model, siz
   auto tabs = tables_of(model);
   if (table >= tabs.size()) return Error(Code::kNotFound, "model '", model, "' has no table ", table);
   return MutateTables(model, [&]() { return tabs[table]->LoadFromArrays(keys, rows, R, borrow, pool_); });
+}
+
+Status HierParameterServer::upsert_table(const std::string& model, size_t table, const int64_t* keys, const float* rows,
+                                         size_t n) {
+  auto tabs = tables_of(model);
+  if (table >= tabs.size()) return Error(Code::kNotFound, "model '", model, "' has no table ", table);
+  return MutateTables(model, [&]() { return tabs[table]->Upsert(keys, rows, n); });
 }
 
 Status HierParameterServer::load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0,

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -93,6 +94,9 @@ void HostTable::FreeAll() {
   for (auto& p : parts_) { free(p->slots); p->slots = nullptr; p->mask = 0; p->used.store(0); }
   if (owns_keys_) DataFree(keys_);
   if (owns_rows_) DataFree(rows_);
+  if (map_bytes_) munmap(rows_, map_bytes_);
+  map_bytes_ = 0; map_dir_.clear(); rows_writable_ = true;
+  vt_.reset();
   keys_ = nullptr; rows_ = nullptr; num_rows_ = cap_rows_ = 0;
   owns_keys_ = owns_rows_ = false;
   has_sentinel_ = false; sentinel_row_ = -1; has_dups_ = false;
@@ -207,8 +211,29 @@ Status HostTable::LoadFromDir(const std::string& dir, ThreadPool* pool) {
   if (vb != R * (size_t)dim_ * sizeof(float))
     return Error(Code::kInvalidArg, "'", dir, "/emb_vector': size ", vb, " != rows(", R, ") x embedding_vecsize(",
                  dim_, ") x 4; check embedding_vecsize_per_table");
-  std::unique_lock<std::shared_mutex> lk(mu_);
+  WriteLock lk(*this);
   FreeAll();
+  if (tier_opt_.tiered) {
+    if (pinned_) return Error(Code::kUnsupported, "host table '", name_, "': ps_direct_access needs the whole table in RAM");
+    // rows stay on disk: map the row store, keep only the keys (and their index) in RAM
+    keys_ = (int64_t*)DataAlloc(kb);
+    owns_keys_ = true;
+    if (!keys_) return Error(Code::kInternal, "host table '", name_, "': out of memory (", kb, " bytes)");
+    HPS_RETURN_IF_ERROR(ReadFileParallel(dir + "/key", keys_, kb, pool));
+    const bool writable = tier_opt_.persistent && tier_opt_.store_writable;
+    const int fd = open((dir + "/emb_vector").c_str(), writable ? O_RDWR : O_RDONLY);
+    if (fd < 0) return Error(Code::kNotFound, "cannot open '", dir, "/emb_vector': ", strerror(errno));
+    void* m = vb ? mmap(nullptr, vb, writable ? PROT_READ | PROT_WRITE : PROT_READ, MAP_SHARED, fd, 0) : nullptr;
+    close(fd);
+    if (vb && m == MAP_FAILED) return Error(Code::kInternal, "cannot map '", dir, "/emb_vector': ", strerror(errno));
+    if (vb) madvise(m, vb, MADV_RANDOM);
+    rows_ = (float*)m;
+    map_bytes_ = vb;
+    map_dir_ = dir;
+    rows_writable_ = writable;
+    num_rows_ = cap_rows_ = R;
+    return FinishLoad(pool);
+  }
   keys_ = (int64_t*)DataAlloc(kb);
   rows_ = (float*)DataAlloc(vb);
   owns_keys_ = owns_rows_ = true;
@@ -216,11 +241,100 @@ Status HostTable::LoadFromDir(const std::string& dir, ThreadPool* pool) {
   num_rows_ = cap_rows_ = R;
   HPS_RETURN_IF_ERROR(ReadFileParallel(dir + "/key", keys_, kb, pool));
   HPS_RETURN_IF_ERROR(ReadFileParallel(dir + "/emb_vector", rows_, vb, pool));
-  return BuildIndex(pool);
+  return FinishLoad(pool);
+}
+
+Status HostTable::FinishLoad(ThreadPool* pool) {
+  HPS_RETURN_IF_ERROR(BuildIndex(pool));
+  SetupTier();
+  return Status::Ok();
+}
+
+// Builds the volatile tier over the freshly indexed row store and caches the first initial_cache_rate * R rows in
+// file order (docs/hierarchical_parameter_server.md:491-495; the same convention as the GPU cache's warm-up).
+void HostTable::SetupTier() {
+  vt_.reset();
+  if (!tier_opt_.tiered) return;
+  std::vector<size_t> per_part(parts_.size());
+  for (size_t p = 0; p < parts_.size(); ++p) per_part[p] = parts_[p]->used.load();
+  if (has_sentinel_) ++per_part[PartitionOf(HPS_EMPTY_KEY)];
+  vt_.reset(new VolatileTier(dim_, per_part, tier_opt_.vdb));
+  double rate = tier_opt_.vdb.initial_cache_rate;
+  if (!(rate >= 0.0)) rate = 0.0;
+  if (rate > 1.0) rate = 1.0;
+  const size_t first = (size_t)std::ceil(rate * (double)num_rows_);
+  for (size_t r = 0; r < first && r < num_rows_; ++r) {
+    if (FindUnlocked(keys_[r]) != (int64_t)r) continue;   // an older duplicate of a key: not the live row
+    vt_->Insert(PartitionOf(keys_[r]), keys_[r], rows_ + r * dim_, 0);
+  }
+  clock_.store(0);
+  persistent_hits_.store(0);
+  not_found_.store(0);
+}
+
+HostTierStats HostTable::tier_stats() const {
+  ReadLock lk(*this);
+  HostTierStats s;
+  s.persistent_rows = num_rows_;
+  if (vt_) {
+    std::shared_lock<std::shared_mutex> tl(tier_mu_);
+    s.vdb = vt_->stats();
+  }
+  s.persistent_hits = persistent_hits_.load();
+  s.not_found = not_found_.load();
+  return s;
+}
+
+void HostTable::DumpVolatileKeys(std::vector<int64_t>* out) const {
+  ReadLock lk(*this);
+  out->clear();
+  if (!vt_) return;
+  std::shared_lock<std::shared_mutex> tl(tier_mu_);
+  vt_->DumpKeys(out);
+}
+
+size_t HostTable::FetchTiered(const int64_t* keys, size_t n, float* out, size_t stride, float default_value,
+                              uint8_t* found) const {
+  const uint32_t D = dim_;
+  const uint64_t now = clock_.fetch_add(1, std::memory_order_relaxed) + 1;
+  const bool cache_missed = tier_opt_.vdb.cache_missed_embeddings;
+  std::vector<std::pair<int64_t, int64_t>> missed;   // (key, row in the store) served from behind the volatile tier
+  size_t nfound = 0, from_store = 0, absent = 0;
+  {
+    std::shared_lock<std::shared_mutex> tl(tier_mu_);
+    for (size_t i = 0; i < n; ++i) {
+      const int64_t key = keys[i];
+      float* dst = out + i * stride;
+      bool ok = vt_->Lookup(PartitionOf(key), key, dst, now);
+      if (!ok && tier_opt_.persistent) {
+        const int64_t r = FindUnlocked(key);
+        if (r >= 0) {
+          memcpy(dst, rows_ + (size_t)r * D, (size_t)D * sizeof(float));
+          ok = true;
+          ++from_store;
+          if (cache_missed) missed.emplace_back(key, r);
+        }
+      }
+      if (!ok) {
+        for (uint32_t c = 0; c < D; ++c) dst[c] = default_value;
+        ++absent;
+      }
+      nfound += ok;
+      if (found) found[i] = ok ? 1 : 0;
+    }
+  }
+  if (from_store) persistent_hits_.fetch_add(from_store, std::memory_order_relaxed);
+  if (absent) not_found_.fetch_add(absent, std::memory_order_relaxed);
+  if (!missed.empty()) {
+    std::unique_lock<std::shared_mutex> tl(tier_mu_);
+    for (const auto& kr : missed)
+      vt_->Insert(PartitionOf(kr.first), kr.first, rows_ + (size_t)kr.second * D, now);
+  }
+  return nfound;
 }
 
 Status HostTable::LoadFromArrays(const int64_t* keys, const float* rows, size_t R, bool borrow, ThreadPool* pool) {
-  std::unique_lock<std::shared_mutex> lk(mu_);
+  WriteLock lk(*this);
   FreeAll();
   if (borrow && !pinned_) {  // a pinned table always owns its (device-mapped) storage
     keys_ = const_cast<int64_t*>(keys);
@@ -234,7 +348,7 @@ Status HostTable::LoadFromArrays(const int64_t* keys, const float* rows, size_t 
     memcpy(rows_, rows, R * (size_t)dim_ * sizeof(float));
   }
   num_rows_ = cap_rows_ = R;
-  return BuildIndex(pool);
+  return FinishLoad(pool);
 }
 
 // Synthetic rows, 8 splitmix64 lanes at a time (the generator is the setup cost of the benchmark: 33 G
@@ -266,7 +380,7 @@ Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, 
     // One shard of the table key0..key0+R-1: the keys whose owner (mix64(key) mod num_shards, the function the
     // sharded lookup routes with) is `shard`, in key order.  Pass 1 counts per chunk, pass 2 fills.
     if (shard >= num_shards) return Error(Code::kInvalidArg, "shard ", shard, " of ", num_shards);
-    std::unique_lock<std::shared_mutex> lk(mu_);
+    WriteLock lk(*this);
     FreeAll();
     const size_t chunk = 1u << 16;
     const size_t ntasks = (R + chunk - 1) / chunk;
@@ -304,9 +418,9 @@ Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, 
       }
     };
     if (pool) pool->ParallelFor(ntasks, fill); else for (size_t i = 0; i < ntasks; ++i) fill(i);
-    return BuildIndex(pool);
+    return FinishLoad(pool);
   }
-  std::unique_lock<std::shared_mutex> lk(mu_);
+  WriteLock lk(*this);
   FreeAll();
   keys_ = (int64_t*)DataAlloc(R * sizeof(int64_t));
   rows_ = (float*)DataAlloc(R * (size_t)dim_ * sizeof(float));
@@ -336,7 +450,7 @@ Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, 
     }
   };
   if (pool) pool->ParallelFor(ntasks, body); else for (size_t i = 0; i < ntasks; ++i) body(i);
-  return BuildIndex(pool);
+  return FinishLoad(pool);
 }
 
 int64_t HostTable::FindUnlocked(int64_t key) const {
@@ -353,13 +467,14 @@ int64_t HostTable::FindUnlocked(int64_t key) const {
 }
 
 int64_t HostTable::Find(int64_t key) const {
-  std::shared_lock<std::shared_mutex> lk(mu_);
+  ReadLock lk(*this);
   return FindUnlocked(key);
 }
 
 size_t HostTable::Fetch(const int64_t* keys, size_t n, float* out, size_t stride, float default_value,
                         uint8_t* found) const {
-  std::shared_lock<std::shared_mutex> lk(mu_);
+  ReadLock lk(*this);
+  if (vt_) return FetchTiered(keys, n, out, stride, default_value, found);
   const uint32_t D = dim_;
   const size_t row_bytes = (size_t)D * sizeof(float);
   size_t nfound = 0;
@@ -420,7 +535,8 @@ size_t HostTable::Fetch(const int64_t* keys, size_t n, float* out, size_t stride
 }
 
 Status HostTable::Upsert(const int64_t* keys, const float* rows, size_t n) {
-  std::unique_lock<std::shared_mutex> lk(mu_);
+  WriteLock lk(*this);
+  if (vt_) return UpsertTiered(keys, rows, n);
   const uint32_t D = dim_;
   // overwrite existing, collect new
   std::vector<size_t> fresh;
@@ -430,8 +546,49 @@ Status HostTable::Upsert(const int64_t* keys, const float* rows, size_t n) {
     else fresh.push_back(i);
   }
   if (fresh.empty()) return Status::Ok();
-  // grow slab (always into owned memory) and rebuild the index; updates are rare relative to lookups
+  return AppendRows(keys, rows, fresh);
+}
+
+// Appends the rows keys[i], i in fresh, to the row store and re-indexes (updates are rare relative to lookups).
+Status HostTable::AppendRows(const int64_t* keys, const float* rows, const std::vector<size_t>& fresh) {
+  const uint32_t D = dim_;
   const size_t newR = num_rows_ + fresh.size();
+  if (map_bytes_ || !map_dir_.empty()) {
+    // mapped row store: append to its two files, map the longer file
+    const size_t row_bytes = (size_t)D * sizeof(float);
+    const int kfd = open((map_dir_ + "/key").c_str(), O_WRONLY);
+    const int vfd = open((map_dir_ + "/emb_vector").c_str(), O_RDWR);
+    if (kfd < 0 || vfd < 0) {
+      if (kfd >= 0) close(kfd);
+      if (vfd >= 0) close(vfd);
+      return Error(Code::kInternal, "cannot open the row store under '", map_dir_, "' for appending: ", strerror(errno));
+    }
+    bool ok = true;
+    size_t w = num_rows_;
+    for (size_t i : fresh) {
+      ok &= pwrite(kfd, keys + i, sizeof(int64_t), (off_t)(w * sizeof(int64_t))) == (ssize_t)sizeof(int64_t);
+      ok &= pwrite(vfd, rows + i * D, row_bytes, (off_t)(w * row_bytes)) == (ssize_t)row_bytes;
+      ++w;
+    }
+    close(kfd);
+    if (!ok) { close(vfd); return Error(Code::kInternal, "short write to the row store under '", map_dir_, "'"); }
+    if (map_bytes_) munmap(rows_, map_bytes_);
+    void* m = mmap(nullptr, newR * row_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, vfd, 0);
+    close(vfd);
+    if (m == MAP_FAILED) { rows_ = nullptr; map_bytes_ = 0; return Error(Code::kInternal, "cannot re-map the row store: ", strerror(errno)); }
+    madvise(m, newR * row_bytes, MADV_RANDOM);
+    rows_ = (float*)m;
+    map_bytes_ = newR * row_bytes;
+    int64_t* nk = (int64_t*)DataAlloc(newR * sizeof(int64_t));
+    if (!nk) return Error(Code::kInternal, "host table '", name_, "': out of memory");
+    memcpy(nk, keys_, num_rows_ * sizeof(int64_t));
+    if (owns_keys_) DataFree(keys_);
+    keys_ = nk; owns_keys_ = true;
+    for (size_t i : fresh) keys_[num_rows_++] = keys[i];
+    cap_rows_ = num_rows_;
+    return BuildIndex(nullptr);
+  }
+  // grow slab (always into owned memory) and rebuild the index
   if (newR > cap_rows_ || !owns_keys_ || !owns_rows_) {
     const size_t cap = std::max(newR, cap_rows_ + cap_rows_ / 2);
     int64_t* nk = (int64_t*)DataAlloc(cap * sizeof(int64_t));
@@ -454,4 +611,27 @@ Status HostTable::Upsert(const int64_t* keys, const float* rows, size_t n) {
   return BuildIndex(nullptr);
 }
 
+// Online update with a bounded volatile tier.  With a persistent database behind it the row store is the database of
+// record (written through unless read_only) and a cached copy is refreshed in place; without one the volatile tier IS
+// the database and takes the rows, pruning by its overflow policy like any other insert.
+Status HostTable::UpsertTiered(const int64_t* keys, const float* rows, size_t n) {
+  const uint32_t D = dim_;
+  const uint64_t now = clock_.fetch_add(1, std::memory_order_relaxed) + 1;
+  std::vector<size_t> fresh;
+  std::unique_lock<std::shared_mutex> tl(tier_mu_);
+  for (size_t i = 0; i < n; ++i) {
+    const int64_t r = FindUnlocked(keys[i]);
+    if (r >= 0 && rows_writable_ && tier_opt_.persistent) memcpy(rows_ + (size_t)r * D, rows + i * D, (size_t)D * sizeof(float));
+    if (r < 0) fresh.push_back(i);
+    const size_t p = PartitionOf(keys[i]);
+    if (tier_opt_.persistent) vt_->Overwrite(p, keys[i], rows + i * D);
+    else vt_->Insert(p, keys[i], rows + i * D, now);
+  }
+  if (fresh.empty() || !tier_opt_.persistent) return Status::Ok();
+  if (!rows_writable_)
+    return Error(Code::kUnsupported, "host table '", name_, "': the persistent database is read_only, new keys cannot be added");
+  return AppendRows(keys, rows, fresh);
+}
+
 }  // namespace hps
+

@@ -14,13 +14,38 @@
 #include <string>
 #include <vector>
 
+#include "../common/config.h"
 #include "../common/status.h"
 #include "thread_pool.h"
+#include "volatile_tier.h"
 
 namespace hps {
 
+// Host tier smaller than the table (docs/hierarchical_parameter_server.md:460-507, 520-569): the rows stay in a
+// memory-mapped row store on disk, the key index stays in RAM (16 B per row against 4*D B per row), and a bounded
+// volatile tier (volatile_tier.h) holds the rows that are served from RAM.
+struct HostTierOptions {
+  bool tiered = false;          // false: the whole table in RAM (the fast path, BASELINE configs 1-5)
+  bool persistent = false;      // a persistent database stands behind the volatile tier: its misses are read from the
+                                // row store; false: what the volatile tier does not hold is not found (default vector)
+  bool store_writable = false;  // online updates are written through to the row store (persistent_db.read_only=false)
+  VolatileDatabaseParams vdb;   // overflow_margin, overflow_policy, overflow_resolution_target, initial_cache_rate,
+                                // cache_missed_embeddings
+};
+
+struct HostTierStats {
+  VolatileTierStats vdb;
+  uint64_t persistent_hits = 0, not_found = 0, persistent_rows = 0;
+};
+
 class HostTable {
  public:
+  // Takes effect at the next load.
+  void SetTierOptions(const HostTierOptions& o) { tier_opt_ = o; }
+  bool tiered() const { return vt_ != nullptr; }
+  HostTierStats tier_stats() const;
+  void DumpVolatileKeys(std::vector<int64_t>* out) const;
+
   // pinned: keys and rows live in page-locked, device-mapped host memory (hipHostMalloc) so that the GPU can
   // read them in place over PCIe ("ps_direct_access": the miss path then needs no host threads at all).
   HostTable(std::string name, uint32_t dim, size_t num_partitions, bool pinned = false);
@@ -71,6 +96,11 @@ class HostTable {
     std::atomic<size_t> used{0};
   };
   void FreeAll();
+  void SetupTier();
+  Status FinishLoad(ThreadPool* pool);
+  size_t FetchTiered(const int64_t* keys, size_t n, float* out, size_t stride, float default_value, uint8_t* found) const;
+  Status UpsertTiered(const int64_t* keys, const float* rows, size_t n);
+  Status AppendRows(const int64_t* keys, const float* rows, const std::vector<size_t>& fresh);
   void* DataAlloc(size_t bytes);
   void DataFree(void* p);
   bool pinned_ = false;
@@ -95,6 +125,37 @@ class HostTable {
   bool has_sentinel_ = false;  // HPS_EMPTY_KEY itself stored as a legal key
   int64_t sentinel_row_ = -1;
   mutable std::shared_mutex mu_;
+  // glibc's rwlock prefers readers: a reload or an online update would wait for as long as lookups keep overlapping.
+  // Readers therefore stand aside while a writer is waiting or working.
+  mutable std::atomic<int> writers_{0};
+  struct ReadLock {
+    explicit ReadLock(const HostTable& t) : t_(t) {
+      while (t.writers_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      t.mu_.lock_shared();
+    }
+    ~ReadLock() { t_.mu_.unlock_shared(); }
+    const HostTable& t_;
+  };
+  struct WriteLock {
+    explicit WriteLock(HostTable& t) : t_(t) {
+      t.writers_.fetch_add(1, std::memory_order_acq_rel);
+      t.mu_.lock();
+    }
+    ~WriteLock() {
+      t_.mu_.unlock();
+      t_.writers_.fetch_sub(1, std::memory_order_acq_rel);
+    }
+    HostTable& t_;
+  };
+  // tiered mode
+  HostTierOptions tier_opt_;
+  std::unique_ptr<VolatileTier> vt_;
+  mutable std::shared_mutex tier_mu_;          // shared: lookups of the volatile tier; exclusive: its inserts / prunes
+  mutable std::atomic<uint64_t> clock_{0};     // one tick per fetch call: the access stamp of evict_oldest
+  mutable std::atomic<uint64_t> persistent_hits_{0}, not_found_{0};
+  std::string map_dir_;                        // row store directory when rows_ is a file mapping
+  size_t map_bytes_ = 0;
+  bool rows_writable_ = true;
 };
 
 }  // namespace hps

@@ -53,6 +53,12 @@ class TableInfo(C.Structure):
                 ("rows_loaded", C.c_uint64)]
 
 
+class HostTierStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("tiered", "persistent_rows", "entries", "capacity", "max_partition_entries",
+                                          "lookups", "hits", "persistent_hits", "not_found", "inserts", "evictions",
+                                          "overflows")]
+
+
 class CacheTableInfo(C.Structure):
     _fields_ = [("embedding_vecsize", C.c_uint32), ("num_buckets", C.c_uint64), ("capacity_rows", C.c_uint64)]
 
@@ -98,6 +104,9 @@ def _load() -> C.CDLL:
         "hps_server_load_table_synthetic": (C.c_int, [P, cp, u32, u64, i64, u64]),
         "hps_server_load_table_synthetic_shard": (C.c_int, [P, cp, u32, u64, i64, u64, u32, u32]),
         "hps_server_fetch": (C.c_int, [P, cp, u32, P, u64, P, P]),
+        "hps_server_upsert": (C.c_int, [P, cp, u32, P, P, u64]),
+        "hps_server_host_tier_stats": (C.c_int, [P, cp, u32, C.POINTER(HostTierStats)]),
+        "hps_server_host_tier_keys": (C.c_int, [P, cp, u32, P, u64, C.POINTER(u64)]),
         "hps_cache_num_tables": (C.c_int, [P]),
         "hps_cache_table_info": (C.c_int, [P, u32, C.POINTER(CacheTableInfo)]),
         "hps_cache_counters": (C.c_int, [P, C.POINTER(CacheCounters)]),
@@ -134,7 +143,8 @@ EXPORTED_SYMBOLS = [
     "hps_server_deployed_device", "hps_server_parse_config", "hps_server_update_database_per_model",
     "hps_server_create_embedding_cache_per_model", "hps_server_destroy_embedding_cache_per_model",
     "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
-    "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_cache_num_tables", "hps_cache_table_info",
+    "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
+    "hps_server_host_tier_stats", "hps_server_host_tier_keys", "hps_cache_num_tables", "hps_cache_table_info",
     "hps_cache_counters", "hps_cache_query", "hps_cache_wait_async", "hps_cache_release", "hps_session_create",
     "hps_session_destroy", "hps_session_lookup", "hps_session_lookup_device", "hps_session_last_stats",
     "hps_session_set_option", "hps_shard_owner", "hps_shard_bucket_workspace_bytes", "hps_shard_bucket_device",
@@ -273,6 +283,27 @@ class HierParameterServer:
         _check(LIB.hps_server_fetch(self._h, model.encode(), table, keys.ctypes.data, keys.size, out.ctypes.data,
                                     found.ctypes.data if return_found else None))
         return (out, found) if return_found else out
+
+    def upsert(self, model: str, table: int, keys, rows):
+        """Online update of the host tier: insert-or-overwrite rows."""
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        assert rows.size == keys.size * self.table_info(model, table).embedding_vecsize
+        _check(LIB.hps_server_upsert(self._h, model.encode(), table, keys.ctypes.data, rows.ctypes.data, keys.size))
+
+    def host_tier_stats(self, model: str, table: int) -> dict:
+        st = HostTierStats()
+        _check(LIB.hps_server_host_tier_stats(self._h, model.encode(), table, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in HostTierStats._fields_}
+
+    def host_tier_keys(self, model: str, table: int):
+        """Keys the bounded volatile tier of the table holds now, ascending."""
+        n = C.c_uint64(0)
+        _check(LIB.hps_server_host_tier_keys(self._h, model.encode(), table, None, 0, C.byref(n)))
+        out = np.empty(int(n.value), dtype=np.int64)
+        _check(LIB.hps_server_host_tier_keys(self._h, model.encode(), table, out.ctypes.data, out.size, C.byref(n)))
+        assert int(n.value) == out.size
+        return out
 
     def close(self):
         if self._h:

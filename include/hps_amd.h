@@ -131,6 +131,30 @@ int hps_server_load_table_synthetic_shard(hps_server_t* server, const char* mode
 int hps_server_fetch(hps_server_t* server, const char* model, uint32_t table, const int64_t* keys, uint64_t n,
                      float* out, uint8_t* found);
 
+/* Online update of the host tier: insert-or-overwrite rows (duplicate keys: last wins).  The entry point a consumer of
+ * the reference's update source would call per message batch (docs/architecture.md:104-180); GPU caches pick the
+ * new rows up at their next refresh.  With a persistent database the rows are written through to the row store
+ * unless persistent_db.read_only. */
+int hps_server_upsert(hps_server_t* server, const char* model, uint32_t table, const int64_t* keys, const float* rows,
+                      uint64_t n);
+
+/* Host tier smaller than the table (volatile_db.overflow_margin / overflow_policy / overflow_resolution_target /
+ * initial_cache_rate / cache_missed_embeddings, persistent_db.*;  docs/hierarchical_parameter_server.md:460-569). */
+typedef struct hps_host_tier_stats {
+  uint64_t tiered;                 /* 0: whole table in RAM (every other field except persistent_rows is 0) */
+  uint64_t persistent_rows;        /* rows of the row store behind the volatile tier */
+  uint64_t entries, capacity;      /* volatile tier: embeddings held now / at most (sum over partitions) */
+  uint64_t max_partition_entries;  /* largest partition now (never above overflow_margin) */
+  uint64_t lookups, hits;          /* volatile tier */
+  uint64_t persistent_hits;        /* served from the persistent database behind it */
+  uint64_t not_found;              /* answered with the default vector */
+  uint64_t inserts, evictions, overflows;
+} hps_host_tier_stats_t;
+int hps_server_host_tier_stats(hps_server_t* server, const char* model, uint32_t table, hps_host_tier_stats_t* out);
+/* Keys the volatile tier holds, ascending; *n = their number (also when cap is too small: then nothing is written). */
+int hps_server_host_tier_keys(hps_server_t* server, const char* model, uint32_t table, int64_t* out, uint64_t cap,
+                              uint64_t* n);
+
 /* ---- EmbeddingCacheBase ----------------------------------------------------------------------- */
 /* get_cache_config().num_emb_table_                                src/model_instance_state.cpp:107-109,169 */
 int hps_cache_num_tables(hps_cache_t* cache);

@@ -144,6 +144,88 @@ def np_insert_modes(keys, num_keys, resident, hit_rate_threshold) -> list:
     return modes
 
 
+class VolatileDbModel:
+    """Bounded CPU-memory database in front of a persistent one — the host tier when RAM < table
+    (docs/hierarchical_parameter_server.md:460-507): at most `overflow_margin` embeddings per partition (partition =
+    key mod num_partitions, docs/architecture.md:131); inserting one more prunes the partition to
+    `overflow_margin * overflow_resolution_target` by `overflow_policy`; `initial_cache_rate` of the table (first rows
+    in file order) is cached at start-up; `cache_missed_embeddings` inserts what had to be read from behind the tier.
+    Pure-Python, single-threaded, small cases only.  Where the documentation is silent this model decides, and the
+    product follows it (csrc/ps/volatile_tier.h): keep = max(1, floor(margin * target)); evict_oldest orders by
+    (last access, key), evict_least_used by (access count, last access, key), smallest evicted first; one access
+    stamp per fetch call; an insert counts as one access.  evict_random is not modelled beyond its sizes."""
+
+    def __init__(self, table_keys, num_partitions=8, overflow_margin=None, overflow_policy="evict_random",
+                 overflow_resolution_target=0.8, initial_cache_rate=1.0, cache_missed_embeddings=False, persistent=True):
+        keys = np.asarray(table_keys, dtype=np.int64)
+        self.P = int(num_partitions)
+        self.policy = overflow_policy
+        self.cache_missed = bool(cache_missed_embeddings)
+        self.persistent = bool(persistent)
+        self.live = {}                       # key -> row number of its last occurrence (duplicate keys: last wins)
+        for r, k in enumerate(keys.tolist()):
+            self.live[k] = r
+        per_part = [0] * self.P
+        for k in self.live:
+            per_part[self._p(k)] += 1
+        margin = overflow_margin if overflow_margin is not None else max(per_part + [1])
+        self.cap = [max(1, min(margin, c)) for c in per_part]
+        t = overflow_resolution_target if 0.0 < overflow_resolution_target < 1.0 else 0.8
+        self.keep = [c if margin >= n else max(1, int(np.floor(c * t))) for c, n in zip(self.cap, per_part)]
+        self.part = [dict() for _ in range(self.P)]      # key -> [stamp, count]
+        self.clock = 0
+        self.evictions = 0
+        first = int(np.ceil(min(max(initial_cache_rate, 0.0), 1.0) * keys.size))
+        for r in range(first):
+            k = int(keys[r])
+            if self.live[k] == r:
+                self._insert(k, 0)
+
+    def _p(self, k):
+        return (k & 0xFFFFFFFFFFFFFFFF) % self.P   # the key's bits as unsigned, like the product
+
+    def _insert(self, k, now):
+        p = self._p(k)
+        part = self.part[p]
+        if k not in part:
+            if len(part) >= self.cap[p]:
+                if self.policy == "evict_random":
+                    raise NotImplementedError("evict_random is only checked through sizes")
+                rank = (lambda kv: (kv[1][1], kv[1][0], kv[0])) if self.policy == "evict_least_used" else \
+                       (lambda kv: (kv[1][0], kv[0]))
+                victims = sorted(part.items(), key=rank)[:len(part) - self.keep[p]]
+                for v, _ in victims:
+                    del part[v]
+                self.evictions += len(victims)
+            part[k] = [now, 0]
+        part[k][0] = now
+        part[k][1] += 1
+
+    def fetch(self, keys):
+        """One fetch call: returns found[i]; updates the access statistics and (cache_missed_embeddings) the content."""
+        self.clock += 1
+        now = self.clock
+        found, missed = [], []
+        for k in np.asarray(keys, dtype=np.int64).tolist():
+            part = self.part[self._p(k)]
+            if k in part:
+                part[k][0] = now
+                part[k][1] += 1
+                found.append(True)
+            elif self.persistent and k in self.live:
+                found.append(True)
+                if self.cache_missed:
+                    missed.append(k)
+            else:
+                found.append(False)
+        for k in missed:
+            self._insert(k, now)
+        return np.array(found, dtype=bool)
+
+    def resident(self) -> np.ndarray:
+        return np.array(sorted(k for part in self.part for k in part), dtype=np.int64)
+
+
 # --------------------------------------------------------------------------------------------------
 # C oracle binding
 # --------------------------------------------------------------------------------------------------

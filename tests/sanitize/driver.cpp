@@ -172,9 +172,69 @@ static int run_threads() {
   return 0;
 }
 
+// Bounded volatile tier in front of the row store: readers (shared side, statistics by relaxed atomics) against the
+// inserts and prunes their own misses cause (exclusive side), plus online updates and a reload underneath.
+static int run_tiered() {
+  ThreadPool pool(4, 50);
+  const uint32_t D = 8;
+  const size_t R = 20000;
+  HostTable tb("t", D, 4);
+  HostTierOptions opt;
+  opt.tiered = true;
+  opt.persistent = true;
+  opt.store_writable = true;
+  opt.vdb.overflow_margin = 300;
+  opt.vdb.overflow_policy = DatabaseOverflowPolicy::EvictLeastUsed;
+  opt.vdb.overflow_resolution_target = 0.6;
+  opt.vdb.initial_cache_rate = 0.02;
+  opt.vdb.cache_missed_embeddings = true;
+  tb.SetTierOptions(opt);
+  CHECK(tb.LoadSynthetic(11, 0, 0, R, &pool).ok());
+  CHECK(tb.tiered());
+  HostTable plain("p", D, 4);
+  CHECK(plain.LoadSynthetic(11, 0, 0, R, &pool).ok());
+  std::atomic<bool> stop{false};
+  std::atomic<int> bad{0};
+  std::atomic<size_t> fetches{0};
+  auto reader = [&](int seed) {
+    std::mt19937_64 rng(seed);
+    std::vector<int64_t> q(256);
+    std::vector<float> out(q.size() * D), ref(q.size() * D);
+    while (!stop.load()) {
+      for (auto& k : q) k = (int64_t)(rng() % (R + R / 20));
+      fetches.fetch_add(1);
+      tb.Fetch(q.data(), q.size(), out.data(), D, -1.f, nullptr);
+      plain.Fetch(q.data(), q.size(), ref.data(), D, -1.f, nullptr);
+      for (size_t i = 0; i < q.size(); ++i)
+        if (q[i] < (int64_t)R / 2 && memcmp(&out[i * D], &ref[i * D], D * 4) != 0) bad.fetch_add(1);   // upper half is updated below
+    }
+  };
+  std::vector<std::thread> th;
+  for (int i = 0; i < 3; ++i) th.emplace_back(reader, 200 + i);
+  std::mt19937_64 rng(2);
+  for (int round = 0; round < 40 || fetches.load() < 900; ++round) {
+    std::vector<int64_t> uk(64);
+    std::vector<float> ur(uk.size() * D, (float)round);
+    for (auto& k : uk) k = (int64_t)(R / 2 + rng() % (R / 2 + 100));     // overwrites of the upper half and a few new keys
+    CHECK(tb.Upsert(uk.data(), ur.data(), uk.size()).ok());
+    const HostTierStats st = tb.tier_stats();
+    CHECK(st.vdb.max_partition_entries <= 300);
+    std::vector<int64_t> held;
+    tb.DumpVolatileKeys(&held);
+    CHECK(held.size() <= 4 * 300);
+    if (round == 20) CHECK(tb.LoadSynthetic(11, 0, 0, R, &pool).ok());
+  }
+  stop.store(true);
+  for (auto& t : th) t.join();
+  CHECK(bad.load() == 0);
+  CHECK(tb.tier_stats().vdb.overflows > 0);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "all";
   int rc = 0;
+  if (what == "tiered" || what == "all") rc |= run_tiered();
   if (what == "parse" || what == "all") rc |= run_parse();
   if (what == "table" || what == "all") rc |= run_table();
   if (what == "threads" || what == "all") rc |= run_threads();

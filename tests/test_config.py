@@ -106,9 +106,8 @@ def test_database_type_aliases(alias):
 def test_unimplemented_tiers_are_refused_loudly():
     from hugectr_backend_amd import hps
     base = ps_config("m", _tables(), gpucache=False)
-    for patch, needle in [({"persistent_db": {"type": "rocksdb", "path": "/tmp/x"}}, "persistent_db"),
-                          ({"update_source": {"type": "kafka", "brokers": "h:9092"}}, "update_source"),
-                          ({"volatile_db": {"type": "hash_map", "initial_cache_rate": 0.5}}, "initial_cache_rate")]:
+    for patch, needle in [({"persistent_db": {"type": "hash_map", "path": "/tmp/x"}}, "persistent_db"),
+                          ({"update_source": {"type": "kafka", "brokers": "h:9092"}}, "update_source")]:
         cfg = copy.deepcopy(base)
         cfg.update(patch)
         with pytest.raises(hps.HpsError) as e:
@@ -116,6 +115,10 @@ def test_unimplemented_tiers_are_refused_loudly():
         assert e.value.code == hps.ERR_UNSUPPORTED and needle in e.value.msg
     ok = copy.deepcopy(base)
     ok["persistent_db"] = {"type": "disabled"}
+    _mk(ok)
+    # the persistent tier and the bounded volatile tier exist (tests/test_host_tier_bounded.py): accepted
+    ok["persistent_db"] = {"type": "rocksdb", "path": "/tmp/x", "read_only": True}
+    ok["volatile_db"] = {"type": "hash_map", "initial_cache_rate": 0.5, "overflow_margin": 1000}
     _mk(ok)
 
 
