@@ -276,10 +276,7 @@ HostTierStats HostTable::tier_stats() const {
   ReadLock lk(*this);
   HostTierStats s;
   s.persistent_rows = num_rows_;
-  if (vt_) {
-    std::shared_lock<std::shared_mutex> tl(tier_mu_);
-    s.vdb = vt_->stats();
-  }
+  if (vt_) s.vdb = vt_->stats();
   s.persistent_hits = persistent_hits_.load();
   s.not_found = not_found_.load();
   return s;
@@ -289,7 +286,6 @@ void HostTable::DumpVolatileKeys(std::vector<int64_t>* out) const {
   ReadLock lk(*this);
   out->clear();
   if (!vt_) return;
-  std::shared_lock<std::shared_mutex> tl(tier_mu_);
   vt_->DumpKeys(out);
 }
 
@@ -298,38 +294,53 @@ size_t HostTable::FetchTiered(const int64_t* keys, size_t n, float* out, size_t 
   const uint32_t D = dim_;
   const uint64_t now = clock_.fetch_add(1, std::memory_order_relaxed) + 1;
   const bool cache_missed = tier_opt_.vdb.cache_missed_embeddings;
+  // Bucket the request by partition (stable): one shared lock per partition for its lookups, then one exclusive lock
+  // for the rows that had to come from behind the tier.  Partitions are independent, so this is the same as "all
+  // lookups of the call, then all inserts in request order" (oracle: VolatileDbModel.fetch).
+  const size_t P = parts_.size();
+  std::vector<uint32_t> start(P + 1, 0), order(n);
+  for (size_t i = 0; i < n; ++i) ++start[PartitionOf(keys[i]) + 1];
+  for (size_t p = 0; p < P; ++p) start[p + 1] += start[p];
+  {
+    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < n; ++i) order[fill[PartitionOf(keys[i])]++] = (uint32_t)i;
+  }
   std::vector<std::pair<int64_t, int64_t>> missed;   // (key, row in the store) served from behind the volatile tier
   size_t nfound = 0, from_store = 0, absent = 0;
-  {
-    std::shared_lock<std::shared_mutex> tl(tier_mu_);
-    for (size_t i = 0; i < n; ++i) {
-      const int64_t key = keys[i];
-      float* dst = out + i * stride;
-      bool ok = vt_->Lookup(PartitionOf(key), key, dst, now);
-      if (!ok && tier_opt_.persistent) {
-        const int64_t r = FindUnlocked(key);
-        if (r >= 0) {
-          memcpy(dst, rows_ + (size_t)r * D, (size_t)D * sizeof(float));
-          ok = true;
-          ++from_store;
-          if (cache_missed) missed.emplace_back(key, r);
+  for (size_t p = 0; p < P; ++p) {
+    if (start[p] == start[p + 1]) continue;
+    {
+      std::shared_lock<std::shared_mutex> tl(vt_->mutex(p));
+      for (uint32_t o = start[p]; o < start[p + 1]; ++o) {
+        const size_t i = order[o];
+        const int64_t key = keys[i];
+        float* dst = out + i * stride;
+        bool ok = vt_->Lookup(p, key, dst, now);
+        if (!ok && tier_opt_.persistent) {
+          const int64_t r = FindUnlocked(key);
+          if (r >= 0) {
+            memcpy(dst, rows_ + (size_t)r * D, (size_t)D * sizeof(float));
+            ok = true;
+            ++from_store;
+            if (cache_missed) missed.emplace_back(key, r);
+          }
         }
+        if (!ok) {
+          for (uint32_t c = 0; c < D; ++c) dst[c] = default_value;
+          ++absent;
+        }
+        nfound += ok;
+        if (found) found[i] = ok ? 1 : 0;
       }
-      if (!ok) {
-        for (uint32_t c = 0; c < D; ++c) dst[c] = default_value;
-        ++absent;
-      }
-      nfound += ok;
-      if (found) found[i] = ok ? 1 : 0;
+    }
+    if (!missed.empty()) {
+      std::unique_lock<std::shared_mutex> tl(vt_->mutex(p));
+      for (const auto& kr : missed) vt_->Insert(p, kr.first, rows_ + (size_t)kr.second * D, now);
+      missed.clear();
     }
   }
   if (from_store) persistent_hits_.fetch_add(from_store, std::memory_order_relaxed);
   if (absent) not_found_.fetch_add(absent, std::memory_order_relaxed);
-  if (!missed.empty()) {
-    std::unique_lock<std::shared_mutex> tl(tier_mu_);
-    for (const auto& kr : missed)
-      vt_->Insert(PartitionOf(kr.first), kr.first, rows_ + (size_t)kr.second * D, now);
-  }
   return nfound;
 }
 
@@ -618,7 +629,7 @@ Status HostTable::UpsertTiered(const int64_t* keys, const float* rows, size_t n)
   const uint32_t D = dim_;
   const uint64_t now = clock_.fetch_add(1, std::memory_order_relaxed) + 1;
   std::vector<size_t> fresh;
-  std::unique_lock<std::shared_mutex> tl(tier_mu_);
+  // (the table's writer lock is held: no lookup is inside the tier, its partition locks are not needed)
   for (size_t i = 0; i < n; ++i) {
     const int64_t r = FindUnlocked(keys[i]);
     if (r >= 0 && rows_writable_ && tier_opt_.persistent) memcpy(rows_ + (size_t)r * D, rows + i * D, (size_t)D * sizeof(float));

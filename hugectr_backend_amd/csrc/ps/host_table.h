@@ -150,7 +150,6 @@ class HostTable {
   // tiered mode
   HostTierOptions tier_opt_;
   std::unique_ptr<VolatileTier> vt_;
-  mutable std::shared_mutex tier_mu_;          // shared: lookups of the volatile tier; exclusive: its inserts / prunes
   mutable std::atomic<uint64_t> clock_{0};     // one tick per fetch call: the access stamp of evict_oldest
   mutable std::atomic<uint64_t> persistent_hits_{0}, not_found_{0};
   std::string map_dir_;                        // row store directory when rows_ is a file mapping

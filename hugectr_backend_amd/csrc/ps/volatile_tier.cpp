@@ -158,14 +158,17 @@ bool VolatileTier::Overwrite(size_t partition, int64_t key, const float* row) {
 
 void VolatileTier::DumpKeys(std::vector<int64_t>* out) const {
   out->clear();
-  for (const Partition* P : parts_)
+  for (const Partition* P : parts_) {
+    std::shared_lock<std::shared_mutex> lk(P->mu);
     for (const Cell& c : P->index) if (c.slot != kNoSlot) out->push_back(c.key);
+  }
   std::sort(out->begin(), out->end());
 }
 
 VolatileTierStats VolatileTier::stats() const {
   VolatileTierStats s;
   for (const Partition* P : parts_) {
+    std::shared_lock<std::shared_mutex> lk(P->mu);
     s.entries += P->size;
     s.capacity += P->cap;
     s.max_partition_entries = std::max<uint64_t>(s.max_partition_entries, P->size);

@@ -13,6 +13,7 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <shared_mutex>
 #include <vector>
 
 #include "../common/config.h"
@@ -32,6 +33,10 @@ class VolatileTier {
   VolatileTier(const VolatileTier&) = delete;
   VolatileTier& operator=(const VolatileTier&) = delete;
 
+  // One reader/writer lock per partition, taken by the caller around the calls below (a request is bucketed by
+  // partition, so a lock is taken once per partition and request, not once per key).
+  std::shared_mutex& mutex(size_t partition) const { return parts_[partition]->mu; }
+
   // --- shared side (any number of threads, none inside the exclusive side) ---
   // Copies the row of `key` to dst and records the access; false if the key is not held.
   bool Lookup(size_t partition, int64_t key, float* dst, uint64_t now);
@@ -43,6 +48,7 @@ class VolatileTier {
   // Overwrite only if present (online update of a cached row); keeps the access statistics.
   bool Overwrite(size_t partition, int64_t key, const float* row);
 
+  // These two take the partition locks themselves (shared), one partition at a time.
   void DumpKeys(std::vector<int64_t>* out) const;
   VolatileTierStats stats() const;
   size_t num_partitions() const { return parts_.size(); }
@@ -51,6 +57,7 @@ class VolatileTier {
   static constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
   struct Cell { int64_t key; uint32_t slot; };
   struct Partition {
+    mutable std::shared_mutex mu;
     std::vector<Cell> index;        // open addressing, linear probing, backward-shift deletion; slot == kNoSlot: empty
     uint64_t mask = 0;
     size_t cap = 0;                 // slots
