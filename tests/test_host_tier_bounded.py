@@ -219,3 +219,21 @@ def test_concurrent_fetches_with_pruning_return_exact_rows(tmp_path):
     st = ps.host_tier_stats("m", 0)
     assert st["max_partition_entries"] <= 200 and st["overflows"] > 0
     assert st["hits"] + st["persistent_hits"] + st["not_found"] == 4 * 20 * 3000
+
+
+def test_documented_overflow_example(tmp_path):
+    """docs/hierarchical_parameter_server.md:487-489: "The default value is 0.8 and indicates to evict embeddings from a
+    partition until it is shrunk to 80% of its maximum size. In other words, when the partition size surpasses
+    overflow_margin embeddings, 20% of the embeddings are evicted according to the specified overflow_policy."""
+    tables = make_tables([(100, 2)])
+    k, _ = tables[0]
+    vdb = {"overflow_margin": 10, "overflow_policy": "evict_oldest", "initial_cache_rate": 0.0,
+           "cache_missed_embeddings": True}                      # overflow_resolution_target left at its default
+    ps = _server(tmp_path, tables, vdb=vdb, pdb={}, partitions=1)
+    for i in range(10):
+        ps.fetch("m", 0, k[i:i + 1])
+    assert ps.host_tier_stats("m", 0)["entries"] == 10           # at the margin: nothing evicted yet
+    ps.fetch("m", 0, k[10:11])                                   # surpasses it: 20 % go (the two oldest), the new one enters
+    st = ps.host_tier_stats("m", 0)
+    assert (st["entries"], st["evictions"], st["overflows"]) == (9, 2, 1)
+    assert np.array_equal(ps.host_tier_keys("m", 0), np.sort(k[2:11]))
