@@ -278,3 +278,33 @@ def test_two_models_two_instances_concurrently(tmp_path):
         assert not errs, errs[:3]
     finally:
         srv.shutdown()
+
+
+def test_host_tier_smaller_than_the_table_through_the_plugin(tmp_path):
+    """ps.json with the reference's overflow keys and a persistent database (docs/hierarchical_parameter_server.md:460-569):
+    the plugin serves exact rows while the bounded volatile tier prunes underneath (tests/test_host_tier_bounded.py has
+    the tier's own checks); the store directory is created under persistent_db.path."""
+    from oracle import hps_oracle as O
+    tables = make_tables([(3000, 1), (2000, 16)])
+    dirs = []
+    for t, (k, r) in enumerate(tables):
+        O.np_write_table(tmp_path / f"t{t}", k, r)
+        dirs.append(str(tmp_path / f"t{t}"))
+    cfg = ps_config("hps_wdl", tables, dirs=dirs, gpucache=False, maxcat=[2, 26], defaults=[0.0, 0.0], max_batch=1024)
+    cfg["volatile_db"].update({"overflow_margin": 40, "overflow_policy": "evict_least_used", "overflow_resolution_target": 0.5,
+                               "initial_cache_rate": 0.1, "cache_missed_embeddings": True})
+    cfg["persistent_db"] = {"type": "rocks_db", "path": str(tmp_path / "pdb"), "num_threads": 4, "read_only": False}
+    (tmp_path / "ps.json").write_text(json.dumps(cfg))
+    srv = tm.Server(tmp_path / "ps.json")
+    try:
+        inst = srv.load_model("hps_wdl", tm.model_config("hps_wdl", kind="KIND_CPU", gpus=[])).create_instance("i0", tm.KIND_CPU, 0)
+        rng = np.random.default_rng(3)
+        for i in range(30):
+            req, q, nk = _wdl_request(rng, tables, batch=int(rng.integers(1, 30)), rid=str(i))
+            inst.execute([req])
+            assert req.error_code == -1
+            assert np.array_equal(_bits(req.output_numpy()), _bits(O.np_lookup(tables, q, nk, [0.0, 0.0])))
+            req.close()
+        assert (tmp_path / "pdb" / "hps_wdl" / "sparse_embedding2" / "emb_vector").stat().st_size == tables[1][1].nbytes
+    finally:
+        srv.shutdown()
