@@ -612,6 +612,11 @@ def main():
                 # the read side alone, and both against the measured copy ceiling of the part
                 "read_only_frac": N * (8 + 4 * D) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
                 "frac_of_copy_ceiling_6290": achieved / 6290.0,
+                # SURVEY.md 8(d) prices every lookup at 8 + 4D + 4D bytes; the kernel itself moves rows only for the
+                # keys that hit (a missed key's row is written later by the scatter kernel).  Bytes the kernel really
+                # has to move = 8 per key + 8D per hit: the stricter figure, and the one to read at low hit rates
+                "frac_hit_rows_only": ((N * 8 + (N - float(np.mean(miss_ct))) * 8 * D) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                       if k_ms > 0 and miss_ct else None),
             },
             # the other leg of the synchronous path: the missed rows cross PCIe once each.  Device-driven tier:
             # HIP-event time of hps_ps_fetch_direct_kernel; bytes = unique missed rows x 4*D.
