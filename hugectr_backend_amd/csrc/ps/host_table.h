@@ -8,6 +8,7 @@
 // upserts take the table's writer lock.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <memory>
 #include <shared_mutex>
@@ -130,7 +131,11 @@ class HostTable {
   mutable std::atomic<int> writers_{0};
   struct ReadLock {
     explicit ReadLock(const HostTable& t) : t_(t) {
-      while (t.writers_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      // (a reload takes seconds and runs on the pool: waiting readers must not eat the CPU quota it needs)
+      for (unsigned spins = 0; t.writers_.load(std::memory_order_acquire) > 0; ++spins) {
+        if (spins < 64) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(100));
+      }
       t.mu_.lock_shared();
     }
     ~ReadLock() { t_.mu_.unlock_shared(); }
