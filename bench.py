@@ -62,6 +62,9 @@ def parse_args():
                          "misses itself out of pinned host memory, no host threads); -1 (default): host gather when this "
                          "rank has at least 12 CPUs to itself, else device-driven — on one GPU the other tier is measured "
                          "right after the headline and reported under extra_legs")
+    ap.add_argument("--split-probe", type=int, default=-1,
+                    help="host-gather tier: 1 = K_A probes only and the hit rows are moved by hps_gather_hits_kernel while the "
+                         "misses are fetched (DESIGN.md 3.4c); 0 = fused probe+gather; -1 = on for the host-gather tier")
     ap.add_argument("--no-direct-leg", action="store_true",
                     help="one GPU, host-gather headline: skip the device-driven-tier leg measured afterwards")
     ap.add_argument("--no-sharded-leg", action="store_true",
@@ -273,9 +276,11 @@ def main():
         made = setup()
     ps, cache, t_tables, t_cache = made
     sessions = [hps.LookupSession.create(ps, model, cache) for _ in range(a.sessions)]
+    split = (a.split_probe != 0) and not a.direct     # the device-driven tier has no split path yet
     for s in sessions:
         s.set_option("timing", 1)
         s.set_option("probe_unroll", a.unroll)
+        s.set_option("split_probe", 1 if split else 0)
 
     # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
     C = int(np.ceil(a.cache_frac * R))
@@ -298,7 +303,7 @@ def main():
     torch.cuda.synchronize()
 
     ncpu = effective_cpus()
-    lat_ms, kern_ms, miss_ct, phases, uniq_ct, gpu_ms = [], [], [], [], [], []
+    lat_ms, kern_ms, miss_ct, phases, uniq_ct, gpu_ms, gath_ms = [], [], [], [], [], [], []
     lock = threading.Lock()
     post_hooks = []   # per session: work appended to every step (the config-5 leg runs the dense step here)
     step_hooks = []   # per session: replaces the step
@@ -327,6 +332,7 @@ def main():
                     with lock:
                         lat_ms.append(dt)
                         kern_ms.append(st.probe_gather_ms)
+                        gath_ms.append(st.hit_gather_ms)
                         miss_ct.append(st.misses)
                         uniq_ct.append(st.unique_misses)
                         gpu_ms.append(st.gpu_call_ms)
@@ -359,6 +365,9 @@ def main():
     extra = {}
     main_lat, main_kern, main_miss, main_phases = list(lat_ms), list(kern_ms), list(miss_ct), list(phases)
     main_uniq = list(uniq_ct)
+    main_gath = list(gath_ms)
+    for s in sessions:   # the extra legs measure the fused kernel (their kernel times are K_A's)
+        s.set_option("split_probe", 0)
     main_gpu = list(gpu_ms)
     if not a.no_extra_legs and world == 1:  # informational legs: single-GPU run only
         def leg(batches, steps, sess_list):
@@ -459,6 +468,11 @@ def main():
                 for s in sessions:
                     s.set_option("host_gather", 0)
                 del fresh6
+            # (5) the headline ran with the split probe: the same workload with the fused probe+gather kernel
+            if split and a.mode == "sync":
+                fresh7 = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
+                extra["fused_probe_gather_same_cache"] = leg(fresh7, 24, sessions)
+                del fresh7
 
         try:   # the legs are informational: a failure in one of them must not cost the headline line
             run_legs()
@@ -558,6 +572,25 @@ def main():
         k_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
         fetch_ms = float(np.mean(np.array(phases)[:, 1])) if phases else 0.0
         alg_bytes = N * (8 + 8 * D)  # 8 B key + 4D row read + 4D row write per lookup
+        hits = N - (float(np.mean(miss_ct)) if miss_ct else 0.0)
+        g_ms = float(np.mean([g for g in main_gath if g > 0])) if any(g > 0 for g in main_gath) else 0.0
+        split_run = split and g_ms > 0
+        probe_ms = k_ms
+        roof_kernel = "hps_probe_gather_kernel"
+        if split_run:
+            # Split probe: the rows are moved by hps_gather_hits_kernel (the dominant, HBM-bound kernel of the call);
+            # K_A only probes.  Its algorithmic bytes: 4 B slot word per key + 4D read + 4D write per HIT.
+            # The pair against SURVEY 8(d)'s 1,032 B per lookup is reported next to it (frac_probe_plus_gather).
+            roof_kernel = "hps_gather_hits_kernel"
+            k_ms = g_ms
+            alg_bytes = int(N * 4 + hits * 8 * D)
+            traffic, traffic_src = None, None
+            try:   # the PMC passes of the same profile set, restricted to this kernel
+                if pj.get("workload_keys") == N and pj.get("dim") == D:
+                    traffic = pj["pmc_by_kernel"]["hps_gather_hits"]["hbm_bytes_per_launch_fetch_doubled"]
+                    traffic_src = pj.get("source")
+            except Exception:
+                pass
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         value = world * a.steps * N / elapsed
         res = {
@@ -593,7 +626,7 @@ def main():
             "resident_fraction_after_warmup": resident_frac,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "hps_probe_gather_kernel",
+                "kernel": roof_kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -610,13 +643,18 @@ def main():
                 # the reference (host gather + hipMemcpyAsync: the DMA engine does not disturb it; the job is slower)
                 "frac_with_host_gather_tier": (extra.get("host_gather_tier_same_cache") or {}).get("kernel_frac_of_hbm_peak"),
                 # the read side alone, and both against the measured copy ceiling of the part
-                "read_only_frac": N * (8 + 4 * D) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+                "read_only_frac": ((N * 4 + hits * 4 * D) if split_run else N * (8 + 4 * D)) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
                 "frac_of_copy_ceiling_6290": achieved / 6290.0,
                 # SURVEY.md 8(d) prices every lookup at 8 + 4D + 4D bytes; the kernel itself moves rows only for the
                 # keys that hit (a missed key's row is written later by the scatter kernel).  Bytes the kernel really
                 # has to move = 8 per key + 8D per hit: the stricter figure, and the one to read at low hit rates
-                "frac_hit_rows_only": ((N * 8 + (N - float(np.mean(miss_ct))) * 8 * D) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                "frac_hit_rows_only": (((N * 4 if split_run else N * 8) + hits * 8 * D) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                                        if k_ms > 0 and miss_ct else None),
+                # split probe: the probe kernel's time, the pair priced at SURVEY 8(d)'s 1,032 B per lookup over both
+                # kernels' time, and the fused kernel on the same cache and workload (leg fused_probe_gather_same_cache)
+                "probe_kernel_ms": probe_ms if split_run else None,
+                "frac_probe_plus_gather": (N * (8 + 8 * D) / ((probe_ms + g_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS if split_run else None),
+                "frac_fused_kernel": (extra.get("fused_probe_gather_same_cache") or {}).get("kernel_frac_of_hbm_peak"),
             },
             # the other leg of the synchronous path: the missed rows cross PCIe once each.  Device-driven tier:
             # HIP-event time of hps_ps_fetch_direct_kernel; bytes = unique missed rows x 4*D.

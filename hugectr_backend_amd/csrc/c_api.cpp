@@ -359,6 +359,7 @@ int hps_session_last_stats(hps_session_t* s, hps_lookup_stats_t* out) {
     out->probe_gather_ms = s->s->last_gpu_ms();
     for (int i = 0; i < 4; ++i) out->phase_ms[i] = s->s->last_phase_ms()[i];
     out->gpu_call_ms = s->s->last_gpu_call_ms();
+    out->hit_gather_ms = s->s->last_gather_ms();
     return Status::Ok();
   });
 }
@@ -378,6 +379,8 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       s->s->set_probe_balanced(value != 0);
     } else if (n == "host_gather") {
       s->s->set_force_host_gather(value != 0);
+    } else if (n == "split_probe") {
+      s->s->set_split_probe(value != 0);
     } else if (n == "hit_rate_threshold_permille") {
       if (value < 0) return Error(Code::kInvalidArg, "hit_rate_threshold_permille must be >= 0");
       s->s->set_hit_rate_threshold((float)value / 1000.0f);

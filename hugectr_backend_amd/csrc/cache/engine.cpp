@@ -512,7 +512,10 @@ void LookupSession::Release() {
   cache_->ForgetFetch(ev_fetch_);
   auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
   auto dfree = [](void* p) { if (p) (void)hipFree(p); };
-  hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_call_); dfree(d_call_); hfree(h_md_); dfree(d_md_);
+  hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_call_); dfree(d_call_); hfree(h_call_probe_); dfree(d_call_probe_);
+  if (ev_g0_) (void)hipEventDestroy(ev_g0_);
+  if (ev_g1_) (void)hipEventDestroy(ev_g1_);
+  hfree(h_md_); dfree(d_md_);
   dfree(d_slot_); dfree(d_block_miss_); dfree(d_set_); dfree(d_counts_); hfree(h_counts_); hfree(h_mode_);
   dfree(d_uniq_keys_); hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
   if (ev_done_) (void)hipEventDestroy(ev_done_);
@@ -565,6 +568,11 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HPS_RETURN_IF_ERROR(DevAlloc(&d_keys_, max_keys_));
   HPS_RETURN_IF_ERROR(PinAlloc(&h_call_, 1));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_call_, 1));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_call_probe_, 1));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_call_probe_, 1));
+  HIP_TRY(hipEventCreate(&ev_g0_));
+  HIP_TRY(hipEventCreate(&ev_g1_));
+  if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switch
   HPS_RETURN_IF_ERROR(PinAlloc(&h_md_, 1));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_md_, 1));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_slot_, max_keys_));
@@ -728,21 +736,45 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   const size_t desc_bytes = sizeof(CallDesc);
   HIP_TRY(hipMemcpyAsync(d_call_, h_call_, desc_bytes, hipMemcpyHostToDevice, stream_));
 
+  // (option "host_gather": serve this session's misses the reference's way — host threads + H2D copy — although the
+  //  cache is in ps_direct_access mode; the pinned tables serve both paths)
+  const bool use_direct = cache_->direct() && !force_host_gather_;
+  const bool fast_direct = use_direct && params_.hit_rate_threshold >= 1.0f && last_misses_ > 0;
+  // Split probe (host-gather tier, while calls keep missing): K_A only probes (75 us instead of 290), the miss counts
+  // reach the host right after the dedup, and the hit rows are gathered by K_G while the host threads gather the
+  // missed rows and the DMA engine uploads them — HBM-bound and PCIe-bound halves of one call side by side.
+  const bool split = split_probe_ && !use_direct && last_misses_ > 0 && N > 0;
+  bool all128 = true;
+  const CallDesc* d_probe_call = d_call_;
+  last_gather_ms_ = 0.f;
+  if (split) {
+    *h_call_probe_ = c;
+    for (size_t t = 0; t < T; ++t) {
+      h_call_probe_->out[t] = nullptr;
+      all128 &= tables_[t]->dim() == 128 && c.vec_ok[t];
+    }
+    HIP_TRY(hipMemcpyAsync(d_call_probe_, h_call_probe_, desc_bytes, hipMemcpyHostToDevice, stream_));
+    d_probe_call = d_call_probe_;
+  }
+
   // ---- K_A: probe + gather hits ----
   const int cu = cache_->cu_count();
   const uint32_t probe_blocks = ProbeGridBlocks(N, cu, probe_balanced_);
   cache_->BeginRead(stream_);
   if (timing_) (void)hipEventRecord(ev_t0_, stream_);
-  hipError_t e = LaunchProbeGather(d_call_, cache_->device_tables(), (uint32_t)T, N, d_slot_, d_block_miss_, probe_blocks,
+  hipError_t e = LaunchProbeGather(d_probe_call, cache_->device_tables(), (uint32_t)T, N, d_slot_, d_block_miss_, probe_blocks,
                                    probe_unroll_, stream_);
   if (timing_) (void)hipEventRecord(ev_t1_, stream_);
-  cache_->EndRead(stream_, ev_read_);
-  if (e != hipSuccess) return Error(Code::kInternal, "probe/gather launch failed: ", hipGetErrorString(e));
+  if (split) (void)hipEventRecord(ev_probe_, stream_);   // other sessions' probes chain behind the probe alone
+  else cache_->EndRead(stream_, ev_read_);
+  // (split: the cache stays read-locked until K_G has read the slots; released below on every path)
+  auto end_split_read = [&]() { if (split) cache_->EndReadFused(stream_, ev_probe_, ev_read_); };
+  if (e != hipSuccess) { end_split_read(); return Error(Code::kInternal, "probe/gather launch failed: ", hipGetErrorString(e)); }
 
   // ---- K_B: unique missed keys (all three kernels exit at once when nothing missed) ----
   e = LaunchMissDedup(d_call_, c.key_start, (uint32_t)T, probe_blocks, d_slot_, d_block_miss_, d_set_, set_cap_,
                       d_counts_, d_uniq_keys_, h_uniq_keys_devptr_, cu, stream_);
-  if (e != hipSuccess) return Error(Code::kInternal, "miss dedup launch failed: ", hipGetErrorString(e));
+  if (e != hipSuccess) { end_split_read(); return Error(Code::kInternal, "miss dedup launch failed: ", hipGetErrorString(e)); }
   last_async_ = false;
   auto account = [&]() {
     const uint64_t misses = h_counts_[0];
@@ -756,10 +788,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     cache_->counters_.misses += misses;
     cache_->counters_.unique_misses += uniq;
   };
-  // (option "host_gather": serve this session's misses the reference's way — host threads + H2D copy — although the
-  //  cache is in ps_direct_access mode; the pinned tables serve both paths)
-  const bool use_direct = cache_->direct() && !force_host_gather_;
-  if (use_direct && params_.hit_rate_threshold >= 1.0f && last_misses_ > 0) {
+  if (fast_direct) {
     // Device-driven miss path with the insertion policy fixed to "synchronous": nothing on the host depends
     // on the miss counts, so the whole call is enqueued without a round trip and the counts come back at the end.
     // (Only while the previous call of this session missed something: a fully resident working set is served
@@ -774,14 +803,29 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   }
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
   HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kTableMissBase + T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-  HIP_TRY(hipEventRecord(ev_done_, stream_));
+  (void)hipEventRecord(ev_done_, stream_);
+  if (split) {
+    // K_G behind the counts: it runs while the host reads them and works on the misses
+    if (timing_) (void)hipEventRecord(ev_g0_, stream_);
+    e = LaunchGatherHits(d_call_, cache_->device_tables(), (uint32_t)T, N, d_slot_, probe_blocks, all128, stream_);
+    if (timing_) (void)hipEventRecord(ev_g1_, stream_);
+    end_split_read();
+    if (e != hipSuccess) return Error(Code::kInternal, "hit gather launch failed: ", hipGetErrorString(e));
+  }
   HIP_TRY(hipEventSynchronize(ev_done_));
   if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
   account();
   const uint64_t misses = h_counts_[0];
   phase_ms_[0] = phase_ms_[3] = ms_since(tc0);
   table_async_.assign(T, 0);
-  if (misses == 0) return Status::Ok();
+  split_call_ = split;
+  if (misses == 0) {
+    if (split) {
+      HIP_TRY(hipStreamSynchronize(stream_));   // the hit rows are still being written
+      if (timing_) (void)hipEventElapsedTime(&last_gather_ms_, ev_g0_, ev_g1_);
+    }
+    return Status::Ok();
+  }
 
   // ---- insertion policy, decided per table as the reference's per-table lookup loop does
   //      (docs/architecture.md:65-67): a table whose hit rate in this call reaches
@@ -844,6 +888,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     }
   }
   const Status st = use_direct ? HandleMissesDirect(N, epoch, /*counts_known=*/true, d_mode) : HandleMisses(N, epoch);
+  if (split && timing_ && st.ok()) (void)hipEventElapsedTime(&last_gather_ms_, ev_g0_, ev_g1_);
   phase_ms_[3] = ms_since(tc0);
   phase_ms_[2] = phase_ms_[3] - phase_ms_[0] - phase_ms_[1];
   return st;
@@ -1058,7 +1103,8 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       // (A/B on the MI355X box: alternating the pieces between two copy streams was slower — 1.24 vs 1.06
       //  ms/step at two sessions — so every piece goes down the session's own stream.)
       constexpr bool kTwoCopyStreams = false;
-      hipStream_t cs = (kTwoCopyStreams && (piece_no++ & 1)) ? copy_stream_ : stream_;
+      // split call: the session's stream is busy with K_G, the pieces go down the copy stream
+      hipStream_t cs = (split_call_ || (kTwoCopyStreams && (piece_no++ & 1))) ? copy_stream_ : stream_;
       HIP_TRY(hipMemcpyAsync(d_staging_ + piece_begin, h_staging_ + piece_begin, (piece_end - piece_begin) * sizeof(float),
                              hipMemcpyHostToDevice, cs));
       used_copy_stream |= (cs == copy_stream_);

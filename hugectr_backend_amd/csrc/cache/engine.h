@@ -198,6 +198,8 @@ class LookupSession {
   uint64_t last_unique_miss_count() const { return last_unique_; }
   bool last_call_async() const { return last_async_; }
   float last_gpu_ms() const { return last_gpu_ms_; }      // probe+gather kernel time of the last call (HIP events)
+  float last_gather_ms() const { return last_gather_ms_; }  // hit-gather kernel of a split call (0 otherwise)
+  void set_split_probe(bool b) { split_probe_ = b; }
   float last_gpu_call_ms() const { return last_gpu_call_ms_; }  // first kernel to last of the last call (HIP events)
   // host wall-clock phases of the last call (ms): [0] enqueue -> miss counts known, [1] parameter-server
   // gather, [2] H2D + scatter + insert until the stream drained, [3] whole call
@@ -241,6 +243,12 @@ class LookupSession {
   int64_t* d_keys_ = nullptr;
   CallDesc* h_call_ = nullptr;    // pinned
   CallDesc* d_call_ = nullptr;
+  CallDesc* h_call_probe_ = nullptr;   // split probe: the same call with null output pointers (K_A probes only)
+  CallDesc* d_call_probe_ = nullptr;
+  hipEvent_t ev_g0_ = nullptr, ev_g1_ = nullptr;   // around the hit-gather kernel of a split call
+  float last_gather_ms_ = 0.f;
+  bool split_call_ = false;      // the call in progress is split (HandleMisses routes its copies accordingly)
+  bool split_probe_ = false;     // host-gather tier: probe only, start the miss path, gather the hits meanwhile
   MissDesc* h_md_ = nullptr;      // pinned
   MissDesc* d_md_ = nullptr;
   int32_t* d_slot_ = nullptr;

@@ -17,6 +17,10 @@ hipError_t LaunchMissDedup(const CallDesc* d_call, const uint64_t* h_key_start, 
                            uint32_t* d_counts, int64_t* d_uniq_keys, int64_t* uniq_keys_host_mapped, int cu_count,
                            hipStream_t stream);
 
+// K_G: hit rows cache -> output from the slot indices a probe-only K_A left (d_call carries the output pointers).
+hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
+                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, hipStream_t stream);
+
 hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tables, const MissDesc* d_md, uint64_t N,
                              const int32_t* d_slot, const float* d_staging, int cu_count, hipStream_t stream);
 

@@ -495,6 +495,77 @@ __global__ __launch_bounds__(256) void hps_miss_fill_default_kernel(const CallDe
 }
 
 // ------------------------------------------------------------------------------------------------
+// K_G: hit rows cache -> output from the slot indices of a probe-only K_A ("split probe": the miss path of the call —
+// PCIe-bound — starts right after the 75-us probe and runs while this HBM-bound kernel moves the hits).
+// Same decomposition as K_A: a wave takes 64 keys, each 16-lane group walks its 16 keys kU at a time; with the slots
+// known up front every row load is independent (no bucket -> row dependency).
+// Algorithmic bytes per key: 4 (slot) + 4D (row read) + 4D (row write) for hits, 4 for misses.
+// ------------------------------------------------------------------------------------------------
+// kFast: every table is 128 wide with 16-B aligned output (checked on the host): rows are staged in registers, 2*kU
+// independent 16-B loads per lane in flight.  Otherwise: one row at a time with copy_row.
+template <int kU, bool kFast>
+__global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(const CallDesc* __restrict__ call,
+                                                                             const TableCacheDev* __restrict__ tables,
+                                                                             const int32_t* __restrict__ slot_in) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = (int)call->num_tables;
+  TableLds* sh_tab = reinterpret_cast<TableLds*>(smem);
+  uint64_t* sh_ks = reinterpret_cast<uint64_t*>(smem + sizeof(TableLds) * (size_t)T);
+  load_tables_to_lds(sh_tab, sh_ks, call, tables, T);
+  __syncthreads();
+  const uint64_t N = call->total_keys;
+  const int lane = lane_id();
+  const int g = lane >> 4, lig = lane & 15;
+  const uint64_t waves_total = (uint64_t)gridDim.x * (kProbeBlockThreads / 64);
+  const uint64_t wave_global = (uint64_t)blockIdx.x * (kProbeBlockThreads / 64) + (threadIdx.x >> 6);
+  const uint64_t chunks = (N + 63) / 64;
+  for (uint64_t chunk = wave_global; chunk < chunks; chunk += waves_total) {
+    const uint64_t i = chunk * 64 + (uint64_t)lane;
+    const int32_t s = i < N ? slot_in[i] : -1;
+    int t = (int)uniform_u32((uint32_t)find_table(sh_ks, T, chunk * 64));
+    if (i < N) { while (i >= sh_ks[t + 1]) ++t; }
+#pragma unroll 1
+    for (int j0 = 0; j0 < 16; j0 += kU) {
+      if (kFast) {
+        f4 v[kU][2];
+        float* dst[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int src = g * 16 + j0 + u;
+          const int32_t ss = __shfl(s, src, 64);
+          const int tt = __shfl(t, src, 64);
+          dst[u] = nullptr;
+          if (ss >= 0) {
+            const float* row = sh_tab[tt].rows + (uint64_t)(uint32_t)ss * 128u;
+            dst[u] = sh_tab[tt].out + (chunk * 64 + (uint64_t)src - sh_tab[tt].key_start) * 128u;
+            v[u][0] = *reinterpret_cast<const f4*>(row + lig * 4);
+            v[u][1] = *reinterpret_cast<const f4*>(row + 64 + lig * 4);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (dst[u]) {
+            __builtin_nontemporal_store(v[u][0], reinterpret_cast<f4*>(dst[u] + lig * 4));
+            __builtin_nontemporal_store(v[u][1], reinterpret_cast<f4*>(dst[u] + 64 + lig * 4));
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int u = 0; u < kU; ++u) {
+          const int src = g * 16 + j0 + u;
+          const int32_t ss = __shfl(s, src, 64);
+          const int tt = __shfl(t, src, 64);
+          if (ss < 0) continue;
+          const TableLds& tb = sh_tab[tt];
+          copy_row<true>(tb.rows + (uint64_t)(uint32_t)ss * tb.dim, tb.out + (chunk * 64 + (uint64_t)src - tb.key_start) * tb.dim,
+                         tb.dim, lig, (tb.flags & 2u) != 0);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K_C2: insert unique missed (key,row) pairs.  One 16-lane group per key.  The group loads the
 // bucket's keys and LRU stamps; if the key is already resident the row is refreshed in place;
 // otherwise the victim is the slot with the smallest stamp that was not used in this epoch (empty
@@ -705,6 +776,17 @@ hipError_t LaunchMissDedup(const CallDesc* d_call, const uint64_t* h_key_start, 
                      d_counts, d_uniq_keys, uniq_keys_host_mapped);
   hipLaunchKernelGGL(hps_miss_resolve_kernel, dim3(nb), dim3(kDedupBlock), 0, stream, d_call, d_slot,
                      (const int32_t*)d_set, set_cap, (const uint32_t*)d_counts);
+  return hipGetLastError();
+}
+
+hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
+                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, hipStream_t stream) {
+  if (N == 0) return hipSuccess;
+  const size_t lds = sizeof(TableLds) * num_tables + sizeof(uint64_t) * (num_tables + 1);
+  if (all_128_aligned)
+    hipLaunchKernelGGL((hps_gather_hits_kernel<4, true>), dim3(grid), dim3(kProbeBlockThreads), lds, stream, d_call, d_tables, d_slot);
+  else
+    hipLaunchKernelGGL((hps_gather_hits_kernel<4, false>), dim3(grid), dim3(kProbeBlockThreads), lds, stream, d_call, d_tables, d_slot);
   return hipGetLastError();
 }
 

@@ -80,6 +80,8 @@ typedef struct hps_lookup_stats {
                               [1] host parameter-server gather (ps_direct_access: HIP-event time of the fetch kernel),
                               [2] H2D + scatter + insert, [3] whole call */
   float gpu_call_ms;       /* HIP-event span of the call on the session's stream, first kernel to last (option "timing"=1) */
+  float hit_gather_ms;     /* option "split_probe"=1: HIP-event time of the hit-gather kernel of a split call (probe_gather_ms
+                              is then the probe alone); 0 for a fused call */
 } hps_lookup_stats_t;
 
 const char* hps_last_error(void);

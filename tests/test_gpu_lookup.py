@@ -355,3 +355,47 @@ def test_cold_batch_larger_than_one_staging_chunk(direct):
     out = s.lookup(q, [n]).cpu().numpy().reshape(n, D)
     assert s.last_stats().unique_misses > 590_000
     assert np.array_equal(out.view(np.uint32), rows[q].view(np.uint32))
+
+
+@pytest.mark.parametrize("dims", [[128, 128, 128], [16, 128, 1, 8]], ids=["all_128", "mixed_widths"])
+def test_split_probe_returns_the_same_rows(dims):
+    """Option split_probe (host-gather tier): K_A probes only, the hit rows are moved by K_G while the misses are fetched.
+    Same rows and counts as the fused call, through ragged requests with duplicates, absent keys, empty tables, an
+    all-hit call (falls back to the fused kernel once nothing missed) and the async-insert policy."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(len(dims))
+    tables = make_tables([(30000 + 1000 * t, d) for t, d in enumerate(dims)])
+    defaults = [0.25 * (t + 1) for t in range(len(dims))]
+    ps, cache, s = _mk("split" + str(len(dims)), tables, maxcat=[1] * len(dims), defaults=defaults, gpucacheper=0.1, max_batch=20000)
+    s.set_option("split_probe", 1)
+    s.set_option("timing", 1)
+    saw_split = 0
+    for it in range(14):
+        nk = [int(rng.integers(0, 15000)) for _ in dims]
+        if it == 5:
+            nk[1] = 0
+        q = _queries(rng, tables, nk, miss_frac=0.1)
+        if it in (8, 9):   # resident keys only -> no misses -> the next call goes back to the fused kernel
+            q = np.concatenate([rng.choice(tk[cache.query(t, tk) >= 0], n) for t, ((tk, _), n) in enumerate(zip(tables, nk))]).astype(np.int64)
+        misses = uniq = off = 0
+        for t, n in enumerate(nk):
+            qt = q[off:off + n]
+            off += n
+            m = qt[cache.query(t, qt) < 0] if n else qt
+            misses += m.size
+            uniq += np.unique(m).size
+        out = s.lookup(q, nk).cpu().numpy()
+        assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, nk, defaults))), it
+        st = s.last_stats()
+        assert (st.misses, st.unique_misses) == (misses, uniq), it
+        saw_split += st.hit_gather_ms > 0
+    assert saw_split >= 8
+    # async-insert policy on top of a split call: defaults for the missed keys of the async tables
+    s.set_option("hit_rate_threshold_permille", 500)
+    nk = [8000] * len(dims)
+    q = _queries(rng, tables, nk, miss_frac=0.05)
+    res = [tk[cache.query(t, tk) >= 0] for t, (tk, _) in enumerate(tables)]
+    modes = O.np_insert_modes(q, nk, res, 0.5)
+    out = s.lookup(q, nk).cpu().numpy()
+    ref = O.np_lookup(tables, q, nk, defaults, resident=[res[t] if modes[t] else None for t in range(len(dims))])
+    assert np.array_equal(_bits(out), _bits(ref))

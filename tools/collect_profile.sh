@@ -13,7 +13,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt 
     > $O/bench_under_rocprof.json 2> $O/kt.log
 rm -f $O/kt/kt_kernel_trace.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "hps_probe_gather" --output-format csv -d $O/pmc_$C -o pmc -- \
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "hps_probe_gather|hps_gather_hits" --output-format csv -d $O/pmc_$C -o pmc -- \
       python $R/bench.py --steps 12 --warmup 4 --sessions 1 --no-cpu-baseline --no-extra-legs > $O/pmc_$C.json 2> $O/pmc_$C.log
   rm -f $O/pmc_$C/pmc_kernel_trace.csv
 done

@@ -28,21 +28,28 @@ def main(d, out):
                 res["kernel_stats"].append({"kernel": short(r["Name"]), "calls": int(r["Calls"]),
                                             "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
                                             "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])})
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        vals = []
-        for f in glob.glob(f"{d}/pmc_{c}/*counter_collection.csv"):
-            for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] == c and "hps_probe_gather" in r["Kernel_Name"]:
-                    vals.append(float(r["Counter_Value"]))
-        if vals:
-            res["pmc"][c] = {"launches": len(vals), "mean_KiB": sum(vals) / len(vals), "min_KiB": min(vals), "max_KiB": max(vals)}
-    if "FETCH_SIZE" in res["pmc"] and "WRITE_SIZE" in res["pmc"]:
-        f, w = res["pmc"]["FETCH_SIZE"]["mean_KiB"] * 1024, res["pmc"]["WRITE_SIZE"]["mean_KiB"] * 1024
-        res["pmc"]["hbm_bytes_per_launch_raw"] = f + w
-        res["pmc"]["hbm_bytes_per_launch_fetch_doubled"] = 2 * f + w
-        res["pmc"]["note"] = ("probe+gather kernel only, one session; FETCH_SIZE and WRITE_SIZE from separate --pmc passes; "
-                              "reads are 16 B/lane coalesced (rows) and 8 B/lane (bucket lines), so the gfx950 x2 correction "
-                              "applies to the bulk of FETCH_SIZE")
+    def pmc_of(kernel_pat):
+        got = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals = []
+            for f in glob.glob(f"{d}/pmc_{c}/*counter_collection.csv"):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == c and kernel_pat in r["Kernel_Name"]:
+                        vals.append(float(r["Counter_Value"]))
+            if vals:
+                got[c] = {"launches": len(vals), "mean_KiB": sum(vals) / len(vals), "min_KiB": min(vals), "max_KiB": max(vals)}
+        if "FETCH_SIZE" in got and "WRITE_SIZE" in got:
+            f, w = got["FETCH_SIZE"]["mean_KiB"] * 1024, got["WRITE_SIZE"]["mean_KiB"] * 1024
+            got["hbm_bytes_per_launch_raw"] = f + w
+            got["hbm_bytes_per_launch_fetch_doubled"] = 2 * f + w
+        return got
+
+    res["pmc"] = pmc_of("hps_probe_gather")
+    if res["pmc"]:
+        res["pmc"]["note"] = ("probe+gather kernel only (a probe-only launch when the run used the split probe), one session; "
+                              "FETCH_SIZE and WRITE_SIZE from separate --pmc passes; reads are 16 B/lane coalesced (rows) and "
+                              "8 B/lane (bucket lines), so the gfx950 x2 correction applies to the bulk of FETCH_SIZE")
+    res["pmc_by_kernel"] = {k: v for k, v in (("hps_probe_gather", res["pmc"]), ("hps_gather_hits", pmc_of("hps_gather_hits"))) if v}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res)[:1500])
 
