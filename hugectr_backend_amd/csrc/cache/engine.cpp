@@ -743,6 +743,9 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   // Split probe (host-gather tier, while calls keep missing): K_A only probes (75 us instead of 290), the miss counts
   // reach the host right after the dedup, and the hit rows are gathered by K_G while the host threads gather the
   // missed rows and the DMA engine uploads them — HBM-bound and PCIe-bound halves of one call side by side.
+  // (device-driven tier: measured and left fused.  With K_G on the session's stream and the staging layout + fetch kernel
+  //  on the second one, config 2 dropped from 1.85 to 1.70 G lookups/s: the fetch kernel then shares the memory system with
+  //  its own session's K_G as well as the other session's kernels, and falls from 0.78 to 0.70 of the PCIe peak.)
   const bool split = split_probe_ && !use_direct && last_misses_ > 0 && N > 0;
   bool all128 = true;
   const CallDesc* d_probe_call = d_call_;
@@ -974,6 +977,7 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
     if (est_bytes > (2u << 20)) HIP_TRY(hipStreamSynchronize(stream_));
   }
   cache_->BeginWrite(stream_);
+
   e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, N, d_call_->key_start, d_uniq_keys_, d_staging_, d_found_, epoch,
                         d_counts_ + kMaxTables + 1, cu, stream_);
   cache_->EndWrite(stream_);
@@ -1007,15 +1011,16 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   const size_t T = tables_.size();
   const int cu = cache_->cu_count();
   const uint64_t max_unique = counts_known ? (uint64_t)last_unique_ : N;
+  hipStream_t fs = stream_;
   hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, d_counts_ + kMaxTables + 1,
-                                     d_table_mode, stream_);
+                                     d_table_mode, fs);
   if (e == hipSuccess) {
-    cache_->BeginFetch(stream_);
-    if (timing_) (void)hipEventRecord(ev_f0_, stream_);
+    cache_->BeginFetch(fs);
+    if (timing_) (void)hipEventRecord(ev_f0_, fs);
     e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, d_uniq_keys_, d_staging_,
-                            d_found_, max_unique, 0, stream_);
-    if (timing_) (void)hipEventRecord(ev_f1_, stream_);
-    cache_->EndFetch(stream_, ev_fetch_);
+                            d_found_, max_unique, 0, fs);
+    if (timing_) (void)hipEventRecord(ev_f1_, fs);
+    cache_->EndFetch(fs, ev_fetch_);
   }
   if (e == hipSuccess) e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, N, d_slot_, d_staging_, cu, stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "direct miss path launch failed: ", hipGetErrorString(e));

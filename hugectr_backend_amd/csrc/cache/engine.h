@@ -248,7 +248,8 @@ class LookupSession {
   hipEvent_t ev_g0_ = nullptr, ev_g1_ = nullptr;   // around the hit-gather kernel of a split call
   float last_gather_ms_ = 0.f;
   bool split_call_ = false;      // the call in progress is split (HandleMisses routes its copies accordingly)
-  bool split_probe_ = false;     // host-gather tier: probe only, start the miss path, gather the hits meanwhile
+  bool split_probe_ = true;      // host-gather tier: probe only, start the miss path, gather the hits meanwhile (§3.4c);
+                                 // HPS_SPLIT_PROBE=0 / session option split_probe=0 keep the fused kernel
   MissDesc* h_md_ = nullptr;      // pinned
   MissDesc* d_md_ = nullptr;
   int32_t* d_slot_ = nullptr;

@@ -357,8 +357,9 @@ def test_cold_batch_larger_than_one_staging_chunk(direct):
     assert np.array_equal(out.view(np.uint32), rows[q].view(np.uint32))
 
 
+@pytest.mark.parametrize("direct", [False], ids=["host_gather"])   # the device-driven tier keeps the fused kernel
 @pytest.mark.parametrize("dims", [[128, 128, 128], [16, 128, 1, 8]], ids=["all_128", "mixed_widths"])
-def test_split_probe_returns_the_same_rows(dims):
+def test_split_probe_returns_the_same_rows(dims, direct):
     """Option split_probe (host-gather tier): K_A probes only, the hit rows are moved by K_G while the misses are fetched.
     Same rows and counts as the fused call, through ragged requests with duplicates, absent keys, empty tables, an
     all-hit call (falls back to the fused kernel once nothing missed) and the async-insert policy."""
@@ -366,7 +367,8 @@ def test_split_probe_returns_the_same_rows(dims):
     rng = np.random.default_rng(len(dims))
     tables = make_tables([(30000 + 1000 * t, d) for t, d in enumerate(dims)])
     defaults = [0.25 * (t + 1) for t in range(len(dims))]
-    ps, cache, s = _mk("split" + str(len(dims)), tables, maxcat=[1] * len(dims), defaults=defaults, gpucacheper=0.1, max_batch=20000)
+    ps, cache, s = _mk(f"split{len(dims)}{int(direct)}", tables, maxcat=[1] * len(dims), defaults=defaults, gpucacheper=0.1,
+                       max_batch=20000, extra={"ps_direct_access": direct})
     s.set_option("split_probe", 1)
     s.set_option("timing", 1)
     saw_split = 0
