@@ -73,7 +73,14 @@ ThreadPool& ThreadPool::Serving() {
     // leave two CPUs of the budget to the callers (session threads, HIP runtime threads)
     const size_t c = DefaultConcurrency();
     return std::max<size_t>(1, std::min<size_t>(64, c > 4 ? c - 3 : c / 2));
-  }(), 100);
+  }(), [] {
+    // idle spin of the workers after a job, microseconds (HPS_SERVING_SPIN_US; 0 would turn the lock-free loop slots off)
+    if (const char* e = std::getenv("HPS_SERVING_SPIN_US")) {
+      const long v = std::strtol(e, nullptr, 10);
+      if (v >= 1 && v <= 10000) return (unsigned)v;
+    }
+    return 100u;
+  }());
   return pool;
 }
 
