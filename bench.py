@@ -4,9 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One "step" = one pass of the lookup hot path over one batch of synthetic keys that already sit in HBM
-(26 tables x 65,536 keys): cache probe + hit gather (HIP), unique-miss extraction (HIP), parameter-server
-fetch of the missed rows (default: the device-driven tier, a HIP kernel reading them out of pinned host
-memory; --direct 0: host-thread gather + H2D copy), scatter + cache insert (HIP).
+(26 tables x 65,536 keys): cache probe (HIP), unique-miss extraction (HIP), hit-row gather (HIP) running
+while the parameter server fetches the missed rows (one GPU, >= 12 CPUs: host threads gather them and
+hipMemcpyAsync ships them, as in the reference; otherwise / --direct 1: the device-driven tier, a HIP kernel
+reading them out of pinned host memory, with the fused probe+gather kernel), scatter + cache insert (HIP).
+The other tier and the fused kernel are measured after the timed region and reported under extra_legs.
 Results are the exact fp32 rows (sync-insert mode, hit_rate_threshold=1.0), checked against the CPU
 oracle on a slice of every run.
 
