@@ -96,6 +96,16 @@ def effective_cpus() -> int:
     return n
 
 
+def cpu_throttle_stat():
+    """(nr_throttled, throttled_usec) of this container's cgroup, or None: a run whose timed region was throttled by the
+    CPU quota shows multi-millisecond stalls in its p99 that have nothing to do with the GPU path."""
+    try:
+        kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv["nr_throttled"]), int(kv["throttled_usec"])
+    except Exception:
+        return None
+
+
 def host_memory_budget() -> int:
     """Bytes of host RAM this container may still take: MemAvailable clipped by the cgroup limit."""
     avail = 1 << 62
@@ -351,6 +361,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    thr0 = cpu_throttle_stat()
     t0 = time.perf_counter()
     run_steps(a.steps, True, first=a.warmup)
     torch.cuda.synchronize()
@@ -358,6 +369,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    thr1 = cpu_throttle_stat()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -625,6 +637,10 @@ def main():
             "p50_batch_gpu_ms": float(np.percentile(main_gpu, 50)) if main_gpu else None,
             "p99_batch_gpu_ms": float(np.percentile(main_gpu, 99)) if main_gpu else None,
             "measured_hit_rate": 1.0 - float(np.mean(miss_ct)) / N if miss_ct else None,
+            # host side of the timed region: CPUs this process may use, and how often the cgroup's CPU quota stopped it
+            "host": {"cpus": ncpu,
+                     "cpu_quota_throttled_periods_in_timed_region": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
+                     "cpu_quota_throttled_ms_in_timed_region": (thr1[1] - thr0[1]) / 1e3 if thr0 and thr1 else None},
             "resident_fraction_after_warmup": resident_frac,
             "roofline": {
                 "bound": "hbm",

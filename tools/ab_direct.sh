@@ -12,7 +12,7 @@ name = sys.argv[1]
 try:
     d = json.loads(open(f"gpurun_out/ab_direct/{name}.json").read().strip().splitlines()[-1])
     print(f"{name:28s} {d['value']/1e9:6.3f} G/s  {d['ms_per_step']:.3f} ms/step  p50 {d['p50_batch_latency_ms']:.2f}  "
-          f"p99 {d['p99_batch_latency_ms']:.2f}  K_A {d['roofline']['avg_kernel_ms']*1e3:.0f} us  parity {d['parity_vs_oracle_bit_exact']}")
+          f"p99 {d['p99_batch_latency_ms']:.2f}  thr {(d.get('host') or {}).get('cpu_quota_throttled_periods_in_timed_region')}  K_A {d['roofline']['avg_kernel_ms']*1e3:.0f} us  parity {d['parity_vs_oracle_bit_exact']}")
 except Exception as e:
     print(name, "FAILED", e)
 EOF
