@@ -29,7 +29,10 @@ void* SlabAlloc(size_t bytes) {
   const size_t rounded = (bytes + align - 1) / align * align;
   if (posix_memalign(&p, align, rounded) != 0) return nullptr;
 #ifdef MADV_HUGEPAGE
-  if (rounded >= kHuge) madvise(p, rounded, MADV_HUGEPAGE);
+  // HPS_HOST_THP=0: leave the slab to the system's default page policy (experiment: background huge-page collapse
+  // takes the process's mmap lock)
+  static const bool thp = [] { const char* e = std::getenv("HPS_HOST_THP"); return !(e && e[0] == '0'); }();
+  if (rounded >= kHuge && thp) madvise(p, rounded, MADV_HUGEPAGE);
 #endif
   return p;
 }
