@@ -637,6 +637,11 @@ def main():
             "p50_batch_gpu_ms": float(np.percentile(main_gpu, 50)) if main_gpu else None,
             "p99_batch_gpu_ms": float(np.percentile(main_gpu, 99)) if main_gpu else None,
             "measured_hit_rate": 1.0 - float(np.mean(miss_ct)) / N if miss_ct else None,
+            # the five slowest calls of the timed region: [end-to-end ms, ms until the miss counts are on the host,
+            # ms inside the host gather calls, ms of upload tail + scatter + insert, ms of the whole call inside the engine]
+            # -- says which wait a multi-millisecond stall sat in
+            "slowest_calls_ms": [[round(l, 3)] + [round(x, 3) for x in ph]
+                                 for l, ph in sorted(zip(lat_ms, phases), key=lambda t: -t[0])[:5]] if lat_ms and phases else None,
             # host side of the timed region: CPUs this process may use, and how often the cgroup's CPU quota stopped it
             "host": {"cpus": ncpu,
                      "cpu_quota_throttled_periods_in_timed_region": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
