@@ -57,7 +57,7 @@ def parse_args():
                     help="sync: exact rows (threshold 1.0); async: misses return default, inserted in background")
     ap.add_argument("--distinct-batches", type=int, default=0,
                     help="0: one fresh batch per step (warmup+steps distinct batches)")
-    ap.add_argument("--unroll", type=int, default=1102, help="probe+gather kernel variant (tools/kbench.py)")
+    ap.add_argument("--unroll", type=int, default=4, help="probe+gather kernel variant (tools/kbench.py)")
     ap.add_argument("--direct", type=int, default=-1,
                     help="parameter-server tier of the miss path.  0: host threads gather the missed rows and "
                          "hipMemcpyAsync ships them (the reference's arrangement); 1: ps_direct_access (the GPU resolves "
@@ -291,7 +291,7 @@ def main():
     split = (a.split_probe != 0) and not a.direct     # host-gather tier only: the device-driven tier is faster fused
     for s in sessions:
         s.set_option("timing", 1)
-        s.set_option("probe_unroll", a.unroll)
+        s.set_option("probe_variant", a.unroll)
         s.set_option("split_probe", 1 if split else 0)
 
     # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
@@ -772,7 +772,7 @@ def direct_tier_leg(a, torch, hps, T, R, D, B, N, dev, outs, cfg):
     split = False   # the device-driven tier keeps the fused kernel (measured: 1.70 split vs 1.85 G lookups/s fused)
     for s in sessions:
         s.set_option("timing", 1)
-        s.set_option("probe_unroll", a.unroll)
+        s.set_option("probe_variant", a.unroll)
         s.set_option("split_probe", 1 if split else 0)
     C = int(np.ceil(a.cache_frac * R))
     resident = []

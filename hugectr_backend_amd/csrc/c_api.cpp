@@ -360,6 +360,8 @@ int hps_session_last_stats(hps_session_t* s, hps_lookup_stats_t* out) {
     for (int i = 0; i < 4; ++i) out->phase_ms[i] = s->s->last_phase_ms()[i];
     out->gpu_call_ms = s->s->last_gpu_call_ms();
     out->hit_gather_ms = s->s->last_gather_ms();
+    out->unique_keys = s->s->last_unique_key_count();
+    out->key_stage_ms = s->s->last_key_stage_ms();
     return Status::Ok();
   });
 }
@@ -369,14 +371,16 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
     if (!s || !name) return Error(Code::kInvalidArg, "null argument");
     const std::string n(name);
     if (n == "timing") s->s->set_timing(value != 0);
-    else if (n == "probe_unroll") {
-      // U + 100*rolled_outer_loop + 1000*sampled_stamps  (kernel variant selector, see LaunchProbeGather)
+    else if (n == "probe_variant" || n == "probe_unroll") {
+      // U + 100*no_dedup: U bucket lines in flight per 16-lane group of the probe kernel, tile-local input dedup on/off
       const int u = value % 100;
-      if (value < 0 || (u != 1 && u != 2 && u != 4 && u != 8) || (value / 100) % 10 > 2 || value / 1000 > 2)
-        return Error(Code::kInvalidArg, "probe_unroll must be U + 100*mode + 1000*stamp_mode with U in {1,2,4,8}, mode 0..2, stamp_mode 0..2");
-      s->s->set_probe_unroll(value);
-    } else if (n == "probe_balanced") {
-      s->s->set_probe_balanced(value != 0);
+      if (value < 0 || (u != 2 && u != 4 && u != 8) || value / 100 > 1)
+        return Error(Code::kInvalidArg, "probe_variant must be U + 100*no_dedup with U in {2,4,8}");
+      s->s->set_probe_variant(value);
+    } else if (n == "xcd_walk") {
+      s->s->set_xcd_walk(value != 0);
+    } else if (n == "keys_pinned_check") {
+      s->s->set_keys_pinned_check(value != 0);
     } else if (n == "host_gather") {
       s->s->set_force_host_gather(value != 0);
     } else if (n == "split_probe") {

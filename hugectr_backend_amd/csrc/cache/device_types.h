@@ -14,18 +14,36 @@ namespace hps {
 
 constexpr int kBucketSlots = HPS_BUCKET_SLOTS;  // 16
 constexpr int kMaxTables = 256;                  // per model
-// Per-call counter block of a lookup session (uint32 words, device + pinned host mirror):
-//   [0] missed keys of the call   [1 + t] unique missed keys of table t
-//   [kMaxTables + 1 .. + 4] insert statistics (dropped, inserted, refreshed, spare)
-//   [kTableMissBase + t] missed keys of table t, duplicates included (per-table hit rate); after the host has read
-//                        them the same words carry the per-table insertion mode to the kernels (1 = async, 0 = sync)
-constexpr int kTableMissBase = kMaxTables + 8;
-constexpr int kCountWords = 2 * kMaxTables + 8;
 constexpr int kProbeBlockThreads = 256;
 
-// slot_out[] encoding produced by the probe kernel and refined by the miss kernels
-constexpr int32_t kSlotMiss = -1;  // not in cache (before dedup)
-// after dedup: slot = -2 - uidx   (uidx = index of the key in its table's unique-miss segment)
+// ---- probe tiles -------------------------------------------------------------------------------------------
+// The probe kernel works on tiles of kTileKeys consecutive keys of ONE table (one workgroup per tile).  Everything a
+// tile hands to the later kernels of the call lives in "tile regions": region of tile b = [b*kTileKeys, (b+1)*kTileKeys)
+// of the per-call arrays below, filled from the front, with the fill counts in tile_cnt[b*4 ..].  No global atomic is
+// needed to build them (device-scope atomics on distinct addresses run at ~15 G/s on gfx950, on one 128-B line at
+// ~0.09 G/s: tools/micro/atomic_rate.hip).
+constexpr int kTileKeys = 1024;
+constexpr int kTileSet = 2048;   // LDS set entries of the tile-local input dedup (load <= 0.5)
+enum : int { kTileCntRepMiss = 0, kTileCntSentMiss = 1, kTileCntRepHit = 2 };
+
+// Per-call accumulator block (uint32 words in HBM, zeroed by the call's descriptor upload, copied back whole):
+//   line s in [0, kStatLines)      : [0] dropped [1] inserted [2] refreshed — insert statistics, block b of the insert
+//                                     kernel adds to line b % kStatLines (one line would serialise ~2,000 atomics)
+//   line kStatLines + t            : [kAccUniqMiss] unique missed keys of table t   [kAccUniqHit] unique hit keys of
+//                                     table t (counted only when the insertion policy needs the hit rate)
+//                                     [kAccSentMiss] missed keys of table t as sent (duplicates included: statistics)
+// One line = kAccStride words = 128 B = one L2 line per table.
+constexpr int kAccStride = 32;
+constexpr int kStatLines = 32;
+enum : int { kAccUniqMiss = 0, kAccUniqHit = 1, kAccSentMiss = 2 };
+constexpr int kAccWordsMax = (kStatLines + kMaxTables) * kAccStride;
+inline constexpr uint32_t AccTableWord(uint32_t t, int what) { return (uint32_t)(kStatLines + t) * kAccStride + (uint32_t)what; }
+
+// slot[] encoding produced by the probe kernel
+//   >= 0   cache slot of the key's row
+//   <= -2  missed: -2 - m, m = position of the key's tile representative in the tile regions (miss_key[m]);
+//          its row in the miss staging is uidx_of[rep_of[m]] once the miss-unique kernel has run
+constexpr int32_t kSlotMiss = -1;  // transient, inside the probe kernel only
 
 struct TableCacheDev {
   int64_t* bucket_keys;
@@ -35,7 +53,35 @@ struct TableCacheDev {
   uint32_t dim;
   float default_value;
   uint32_t flags;  // bit0: static cache (no stamp writes, no inserts)
+  uint32_t* claim; // [num_buckets*16] scratch word per slot for the unique-hit count (nullptr until a session needs it)
 };
+
+// One probe tile: keys [begin, begin + count) of the call's flat key array, all of table `table`.
+struct TileDesc {
+  uint64_t begin;
+  uint32_t count;
+  uint32_t table;
+};
+
+// Per-call work arrays of a lookup session (device pointers; passed to the kernels by value).
+struct CallWork {
+  const TileDesc* tiles;     // [num_tiles]
+  uint32_t num_tiles;
+  uint32_t call_tag;         // tags this call's entries of `set` (never 0)
+  int32_t* slot;             // [N]
+  uint32_t* tile_cnt;        // [num_tiles*4]
+  int64_t* miss_key;         // tile regions: key of the tile's r-th missed representative
+  int32_t* sent_i;           // tile regions: global index of every missed key of the tile, as sent
+  int32_t* hit_i;            // tile regions: global index of the tile's hit representatives (unique-hit count only)
+  int32_t* rep_of;           // tile regions: m -> m of the call-wide representative of the same (table, key)
+  int32_t* uidx_of;          // tile regions: valid at representatives: index in the table's unique-miss segment
+  unsigned long long* set;   // open addressing, entries (call_tag << 32 | m); other tags = free
+  uint64_t set_mask;
+  uint32_t* acc;             // accumulator block, layout above
+  int64_t* uniq_keys;        // [N] unique missed keys of table t at [key_start[t], key_start[t] + count)
+  int64_t* uniq_keys_host;   // the same array in host-mapped pinned memory (the host parameter server reads it)
+};
+
 
 // One lookup call.  Filled on the host (pinned), copied to the session's device buffer, then read by
 // every kernel of the call.  The reference's ProcessRequest builds the same per-table pointer slices

@@ -21,9 +21,9 @@ struct PsIndexDev {
 
 hipError_t LaunchPsIndexBuild(const int64_t* table_keys_devptr, uint64_t R, int64_t* d_keys, uint32_t* d_rows, uint64_t cap,
                               uint32_t* d_sentinel /*[2]: flag, row*/, hipStream_t stream);
-hipError_t LaunchMissDescBuild(const TableCacheDev* d_tables, uint32_t T, const uint32_t* d_counts, MissDesc* d_md,
-                               uint32_t* d_insert_stats, const uint32_t* d_table_mode /*optional: 1 = skip table*/,
-                               hipStream_t stream);
+// d_acc: a call's accumulator block (device_types.h); clear_stats: also zero its insert-statistics lines
+hipError_t LaunchMissDescBuild(const TableCacheDev* d_tables, uint32_t T, uint32_t* d_acc, MissDesc* d_md, bool clear_stats,
+                               const uint32_t* d_table_mode /*optional: 1 = skip table*/, hipStream_t stream);
 hipError_t LaunchPsFetchDirect(const PsIndexDev* d_index, uint32_t T, const MissDesc* d_md, const uint64_t* d_key_start,
                                const int64_t* d_uniq_keys, float* d_staging, uint8_t* d_found, uint64_t max_unique,
                                int grid_blocks /*0: default*/, hipStream_t stream);

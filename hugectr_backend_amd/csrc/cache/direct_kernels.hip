@@ -55,17 +55,19 @@ __global__ void hps_psindex_build_kernel(const int64_t* __restrict__ table_keys,
   }
 }
 
-// single block: staging layout of the call's unique misses, from the per-table unique counts of K_B1
-__global__ void hps_missdesc_build_kernel(const TableCacheDev* __restrict__ tables, uint32_t T,
-                                          const uint32_t* __restrict__ counts, MissDesc* __restrict__ md,
-                                          uint32_t* __restrict__ insert_stats,
+// single block: staging layout of the call's unique misses, from the per-table unique counts K_M left in the call's
+// accumulator block (device_types.h)
+__global__ void hps_missdesc_build_kernel(const TableCacheDev* __restrict__ tables, uint32_t T, uint32_t* __restrict__ acc,
+                                          MissDesc* __restrict__ md, uint32_t clear_stats,
                                           const uint32_t* __restrict__ table_mode) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (insert_stats) insert_stats[0] = insert_stats[1] = insert_stats[2] = insert_stats[3] = 0;  // saves a memset launch
+  if (blockIdx.x != 0) return;
+  if (clear_stats)  // a job that re-uses its accumulator block (the background inserter): saves a memset launch
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kStatLines * kAccStride; i += blockDim.x) acc[i] = 0;
+  if (threadIdx.x != 0) return;
   uint64_t fl = 0, uq = 0;
   for (uint32_t t = 0; t < T; ++t) {
     // table_mode (optional): tables in async-insert mode (1) take no part in the synchronous miss path
-    uint32_t c = counts[0] ? counts[1 + t] : 0u;
+    uint32_t c = acc[AccTableWord(t, kAccUniqMiss)];
     if (table_mode && table_mode[t] != 0) c = 0;
     fl = (fl + 3) & ~(uint64_t)3;
     md->useg_start[t] = uq;
@@ -150,9 +152,9 @@ hipError_t LaunchPsIndexBuild(const int64_t* table_keys_devptr, uint64_t R, int6
   return hipGetLastError();
 }
 
-hipError_t LaunchMissDescBuild(const TableCacheDev* d_tables, uint32_t T, const uint32_t* d_counts, MissDesc* d_md,
-                               uint32_t* d_insert_stats, const uint32_t* d_table_mode, hipStream_t stream) {
-  hipLaunchKernelGGL(hps_missdesc_build_kernel, dim3(1), dim3(64), 0, stream, d_tables, T, d_counts, d_md, d_insert_stats,
+hipError_t LaunchMissDescBuild(const TableCacheDev* d_tables, uint32_t T, uint32_t* d_acc, MissDesc* d_md, bool clear_stats,
+                               const uint32_t* d_table_mode, hipStream_t stream) {
+  hipLaunchKernelGGL(hps_missdesc_build_kernel, dim3(1), dim3(64), 0, stream, d_tables, T, d_acc, d_md, clear_stats ? 1u : 0u,
                      d_table_mode);
   return hipGetLastError();
 }

@@ -82,6 +82,38 @@ CacheCounters EmbeddingCache::counters() const {
   return counters_;
 }
 
+// Insert statistics come back as kStatLines lines of the accumulator block (device_types.h): sum and add.
+void EmbeddingCache::AddStatLines(const uint32_t* lines) {
+  uint64_t v[3] = {0, 0, 0};
+  for (int l = 0; l < kStatLines; ++l)
+    for (int k = 0; k < 3; ++k) v[k] += lines[(size_t)l * kAccStride + k];
+  std::lock_guard<std::mutex> lk(stat_mu_);
+  counters_.dropped += v[0];
+  counters_.inserted += v[1];
+  counters_.refreshed += v[2];
+}
+
+// One scratch word per cache slot, next to the LRU stamps: the probe kernel of a call whose insertion policy needs the
+// hit rate marks the slots it hits, and the miss-unique kernel counts the marks that survived (= distinct slots = unique
+// hit keys).  Probes of one cache run one at a time (BeginRead chains them), so one array per cache is enough.
+Status EmbeddingCache::EnsureClaimWords() {
+  if (has_claim_.load(std::memory_order_acquire)) return Status::Ok();
+  std::lock_guard<std::mutex> lk(order_mu_);
+  if (has_claim_.load(std::memory_order_relaxed)) return Status::Ok();
+  HIP_TRY(hipSetDevice(cfg_.device_id_));
+  HIP_TRY(hipDeviceSynchronize());   // no kernel may be reading the table descriptors while they are replaced
+  for (TableCacheDev& tb : h_tables_) {
+    uint32_t* c = nullptr;
+    HPS_RETURN_IF_ERROR(DevAlloc(&c, (size_t)tb.num_buckets * kBucketSlots));
+    allocations_.push_back(c);
+    tb.claim = c;
+  }
+  HIP_TRY(hipMemcpy(d_tables_, h_tables_.data(), h_tables_.size() * sizeof(TableCacheDev), hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  has_claim_.store(true, std::memory_order_release);
+  return Status::Ok();
+}
+
 // LRU epochs: one per lookup call, 32 bits.  Long before the counter wraps (at 10 k lookups/s that is five
 // days) all stamps are folded back so that "smaller = older" keeps holding.  Rare and heavy-handed on purpose:
 // the device is drained, every table's stamps are rewritten, the counter restarts above the kept span.
@@ -205,6 +237,7 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
     tb.dim = D;
     tb.default_value = p.default_value_for_each_table[t];
     tb.flags = static_ ? 1u : 0u;
+    tb.claim = nullptr;
     cfg_.embedding_vec_size_.push_back(D);
     cfg_.num_set_in_cache_.push_back(buckets);
     cfg_.capacity_rows_.push_back(cap);
@@ -235,9 +268,9 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   MissDesc* d_md = nullptr; uint64_t* d_zero_ks = nullptr; uint32_t* d_stats = nullptr;
   HPS_RETURN_IF_ERROR(DevAlloc(&d_md, 1));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_zero_ks, (size_t)kMaxTables + 1));
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_stats, 4));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_stats, (size_t)kStatLines * kAccStride));
   HIP_TRY(hipMemset(d_zero_ks, 0, sizeof(uint64_t) * ((size_t)kMaxTables + 1)));
-  HIP_TRY(hipMemset(d_stats, 0, 4 * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(d_stats, 0, (size_t)kStatLines * kAccStride * sizeof(uint32_t)));
   int64_t* d_keys = nullptr; float* d_rows = nullptr;
   size_t maxD = 1;
   for (size_t t = 0; t < T; ++t) maxD = std::max<size_t>(maxD, tables[t]->dim());
@@ -287,14 +320,9 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
       }
     }
   }
-  uint32_t stats[4] = {0, 0, 0, 0};
-  (void)hipMemcpy(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost);
-  {
-    std::lock_guard<std::mutex> lk(stat_mu_);
-    counters_.dropped += stats[0];
-    counters_.inserted += stats[1];
-    counters_.refreshed += stats[2];
-  }
+  std::vector<uint32_t> lines((size_t)kStatLines * kAccStride, 0u);
+  (void)hipMemcpy(lines.data(), d_stats, lines.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  AddStatLines(lines.data());
   (void)hipFree(d_keys); (void)hipFree(d_rows); (void)hipFree(d_md); (void)hipFree(d_zero_ks); (void)hipFree(d_stats);
   (void)hipFree(d_warm);
   epoch_.store(1);
@@ -366,7 +394,7 @@ struct EmbeddingCache::DirectInserter {
   hipEvent_t ev_copied = nullptr, ev_done = nullptr, ev_fetch = nullptr;
   int64_t* d_keys = nullptr;      // snapshot of the session's unique-key array (table-major, key_start offsets)
   uint64_t* d_key_start = nullptr;
-  uint32_t* d_counts = nullptr;   // [0] misses, [1..T] unique per table, [kMaxTables+1..+4] insert statistics
+  uint32_t* d_acc = nullptr;      // accumulator block of the job (device_types.h): stat lines, then the T table lines
   MissDesc* d_md = nullptr;
   float* d_staging = nullptr;
   uint8_t* d_found = nullptr;
@@ -380,7 +408,7 @@ void EmbeddingCache::FreeDirectInserter() {
   DirectInserter& I = *dins_;
   if (I.stream) { (void)hipStreamSynchronize(I.stream); (void)hipStreamDestroy(I.stream); }
   for (hipEvent_t e : {I.ev_copied, I.ev_done, I.ev_fetch}) if (e) (void)hipEventDestroy(e);
-  for (void* p : {(void*)I.d_keys, (void*)I.d_key_start, (void*)I.d_counts, (void*)I.d_md, (void*)I.d_staging, (void*)I.d_found})
+  for (void* p : {(void*)I.d_keys, (void*)I.d_key_start, (void*)I.d_acc, (void*)I.d_md, (void*)I.d_staging, (void*)I.d_found})
     if (p) (void)hipFree(p);
   delete dins_;
   dins_ = nullptr;
@@ -389,7 +417,7 @@ void EmbeddingCache::FreeDirectInserter() {
 // Part 1, on the calling lookup's thread: claim the (single) job slot and snapshot the session's unique missed keys
 // with copies enqueued on the session's stream (ordered after its dedup kernels, before its next call reuses them).
 Status EmbeddingCache::SubmitDirectInsert(hipStream_t session_stream, const uint64_t* d_key_start, const int64_t* d_uniq_keys,
-                                          const uint32_t* d_counts, const uint32_t* h_counts_override, uint64_t N,
+                                          const uint32_t* d_acc_tables, const uint32_t* h_acc_tables_override, uint64_t N,
                                           uint64_t unique_total, uint64_t staging_floats, bool* accepted) {
   *accepted = false;
   if (!direct_ || static_ || unique_total == 0) return Status::Ok();
@@ -404,7 +432,7 @@ Status EmbeddingCache::SubmitDirectInsert(hipStream_t session_stream, const uint
     HIP_TRY(hipEventCreateWithFlags(&dins_->ev_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&dins_->ev_fetch, hipEventDisableTiming));
     HPS_RETURN_IF_ERROR(DevAlloc(&dins_->d_key_start, (size_t)kMaxTables + 1));
-    HPS_RETURN_IF_ERROR(DevAlloc(&dins_->d_counts, (size_t)kMaxTables + 8));
+    HPS_RETURN_IF_ERROR(DevAlloc(&dins_->d_acc, (size_t)kAccWordsMax));
     HPS_RETURN_IF_ERROR(DevAlloc(&dins_->d_md, 1));
   }
   DirectInserter& I = *dins_;
@@ -424,10 +452,12 @@ Status EmbeddingCache::SubmitDirectInsert(hipStream_t session_stream, const uint
   HPS_RETURN_IF_ERROR(grow(&I.d_found, &I.cap_found, (size_t)unique_total));
   HIP_TRY(hipMemcpyAsync(I.d_keys, d_uniq_keys, N * sizeof(int64_t), hipMemcpyDeviceToDevice, session_stream));
   HIP_TRY(hipMemcpyAsync(I.d_key_start, d_key_start, (T + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, session_stream));
-  if (h_counts_override)  // mixed call: only the async tables' counts (pinned host words, stable until the call's final sync)
-    HIP_TRY(hipMemcpyAsync(I.d_counts, h_counts_override, (1 + T) * sizeof(uint32_t), hipMemcpyHostToDevice, session_stream));
+  uint32_t* dst_lines = I.d_acc + (size_t)kStatLines * kAccStride;
+  const size_t line_bytes = T * (size_t)kAccStride * sizeof(uint32_t);
+  if (h_acc_tables_override)  // mixed call: only the async tables' counts (pinned host words, stable until the call's final sync)
+    HIP_TRY(hipMemcpyAsync(dst_lines, h_acc_tables_override, line_bytes, hipMemcpyHostToDevice, session_stream));
   else
-    HIP_TRY(hipMemcpyAsync(I.d_counts, d_counts, (1 + T) * sizeof(uint32_t), hipMemcpyDeviceToDevice, session_stream));
+    HIP_TRY(hipMemcpyAsync(dst_lines, d_acc_tables, line_bytes, hipMemcpyDeviceToDevice, session_stream));
   HIP_TRY(hipEventRecord(I.ev_copied, session_stream));
   I.unique_total = unique_total;
   I.in_flight = true;
@@ -449,7 +479,7 @@ Status EmbeddingCache::FinishDirectInsert() {
   const size_t T = num_tables();
   HIP_TRY(hipStreamWaitEvent(I.stream, I.ev_copied, 0));
   const uint32_t epoch = NextEpoch();
-  hipError_t e = LaunchMissDescBuild(d_tables_, (uint32_t)T, I.d_counts, I.d_md, I.d_counts + kMaxTables + 1, nullptr, I.stream);
+  hipError_t e = LaunchMissDescBuild(d_tables_, (uint32_t)T, I.d_acc, I.d_md, /*clear_stats=*/true, nullptr, I.stream);
   // not part of the foreground fetch chain: a small grid that takes its time must not hold up a lookup's fetch
   if (e == hipSuccess)
     e = LaunchPsFetchDirect(d_index_, (uint32_t)T, I.d_md, I.d_key_start, I.d_keys, I.d_staging, I.d_found, I.unique_total,
@@ -458,16 +488,13 @@ Status EmbeddingCache::FinishDirectInsert() {
   HIP_TRY(hipStreamSynchronize(I.stream));
   BeginWrite(I.stream);
   e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, I.unique_total, I.d_key_start, I.d_keys, I.d_staging, I.d_found, epoch,
-                        I.d_counts + kMaxTables + 1, cu_count_, I.stream);
+                        I.d_acc, cu_count_, I.stream);
   EndWrite(I.stream);
   if (e != hipSuccess) return Error(Code::kInternal, "direct background insert launch failed: ", hipGetErrorString(e));
-  uint32_t st[4] = {0, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(st, I.d_counts + kMaxTables + 1, sizeof st, hipMemcpyDeviceToHost, I.stream));
+  std::vector<uint32_t> lines((size_t)kStatLines * kAccStride, 0u);
+  HIP_TRY(hipMemcpyAsync(lines.data(), I.d_acc, lines.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, I.stream));
   HIP_TRY(hipStreamSynchronize(I.stream));
-  std::lock_guard<std::mutex> lk2(stat_mu_);
-  counters_.dropped += st[0];
-  counters_.inserted += st[1];
-  counters_.refreshed += st[2];
+  AddStatLines(lines.data());
   return Status::Ok();
 }
 
@@ -507,27 +534,21 @@ void LookupSession::Release() {
   if (!cache_) return;
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
   cache_->ForgetReader(ev_read_);  // our reader event may still be registered with the cache
   cache_->ForgetReader(ev_probe_);
   cache_->ForgetFetch(ev_fetch_);
   auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
   auto dfree = [](void* p) { if (p) (void)hipFree(p); };
-  hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_call_); dfree(d_call_); hfree(h_call_probe_); dfree(d_call_probe_);
-  if (ev_g0_) (void)hipEventDestroy(ev_g0_);
-  if (ev_g1_) (void)hipEventDestroy(ev_g1_);
+  hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_block_); dfree(d_block_); hfree(h_acc_); dfree(d_mode_);
   hfree(h_md_); dfree(d_md_);
-  dfree(d_slot_); dfree(d_block_miss_); dfree(d_set_); dfree(d_counts_); hfree(h_counts_); hfree(h_mode_);
-  dfree(d_uniq_keys_); hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
-  if (ev_done_) (void)hipEventDestroy(ev_done_);
-  if (ev_read_) (void)hipEventDestroy(ev_read_);
-  if (ev_fetch_) (void)hipEventDestroy(ev_fetch_);
-  if (ev_t0_) (void)hipEventDestroy(ev_t0_);
-  if (ev_t1_) (void)hipEventDestroy(ev_t1_);
-  if (ev_f0_) (void)hipEventDestroy(ev_f0_);
-  if (ev_f1_) (void)hipEventDestroy(ev_f1_);
-  if (ev_c1_) (void)hipEventDestroy(ev_c1_);
-  if (ev_probe_) (void)hipEventDestroy(ev_probe_);
-  if (ev_copy_) (void)hipEventDestroy(ev_copy_);
+  dfree(work_.slot); dfree(work_.tile_cnt); dfree(work_.miss_key); dfree(work_.sent_i); dfree(work_.hit_i);
+  dfree(work_.rep_of); dfree(work_.uidx_of); dfree(work_.set); dfree(work_.uniq_keys);
+  hfree(h_mode_);
+  hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
+  for (hipEvent_t e : {ev_done_, ev_read_, ev_fetch_, ev_t0_, ev_t1_, ev_f0_, ev_f1_, ev_c1_, ev_probe_, ev_copy_, ev_keys_,
+                       ev_g0_, ev_g1_})
+    if (e) (void)hipEventDestroy(e);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
   stream_ = nullptr;
@@ -540,11 +561,15 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   tables_ = ps->tables_of(p.model_name);
   const size_t T = tables_.size();
   if (T == 0) return Error(Code::kNotFound, "model '", p.model_name, "' has no tables loaded in the parameter server");
+  if (T > (size_t)kMaxTables)
+    return Error(Code::kInvalidArg, "model '", p.model_name, "': ", T, " tables (supported: 1..", kMaxTables, ")");
   size_t per_sample = 0;
   for (size_t c : p.maxnum_catfeature_query_per_table_per_sample) per_sample += c;
   max_keys_ = p.max_batchsize * per_sample;  // model_instance_state.cpp:98-99
   if (max_keys_ == 0) return Error(Code::kInvalidArg, "model '", p.model_name, "': max_batch_size * sum(maxnum_catfeature...) is 0");
-  if (max_keys_ >= (1ull << 31) - 2) return Error(Code::kUnsupported, "more than 2^31 keys per request are not supported");
+  max_tiles_ = max_keys_ / kTileKeys + T;
+  if (max_tiles_ * (size_t)kTileKeys >= (1ull << 31) - 2)
+    return Error(Code::kUnsupported, "more than 2^31 keys per request are not supported");
   if (!p.use_gpu_embedding_cache) return Status::Ok();  // host-tier session: no device state at all
 
   if (!cache) return Error(Code::kInvalidArg, "model '", p.model_name, "' uses the GPU cache but no EmbeddingCache was given");
@@ -553,43 +578,55 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HIP_TRY(hipSetDevice(device_));
   HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&ev_copy_, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&ev_read_, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&ev_fetch_, hipEventDisableTiming));
-  HIP_TRY(hipEventCreate(&ev_t0_));
-  HIP_TRY(hipEventCreate(&ev_t1_));
-  HIP_TRY(hipEventCreate(&ev_f0_));
-  HIP_TRY(hipEventCreate(&ev_f1_));
-  HIP_TRY(hipEventCreate(&ev_c1_));
-  HIP_TRY(hipEventCreateWithFlags(&ev_probe_, hipEventDisableTiming));
+  for (hipEvent_t* e : {&ev_copy_, &ev_done_, &ev_read_, &ev_fetch_, &ev_probe_, &ev_keys_})
+    HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  for (hipEvent_t* e : {&ev_t0_, &ev_t1_, &ev_f0_, &ev_f1_, &ev_c1_, &ev_g0_, &ev_g1_}) HIP_TRY(hipEventCreate(e));
+  if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switches
+  if (const char* e = std::getenv("HPS_XCD_WALK")) xcd_walk_ = std::strtol(e, nullptr, 10) != 0;
+  if (const char* e = std::getenv("HPS_PROBE_VARIANT")) probe_variant_ = (int)std::strtol(e, nullptr, 10);
 
   HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_keys_, max_keys_));
-  HPS_RETURN_IF_ERROR(PinAlloc(&h_call_, 1));
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_call_, 1));
-  HPS_RETURN_IF_ERROR(PinAlloc(&h_call_probe_, 1));
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_call_probe_, 1));
-  HIP_TRY(hipEventCreate(&ev_g0_));
-  HIP_TRY(hipEventCreate(&ev_g1_));
-  if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switch
+  // call block: descriptor | accumulator block | tile descriptors
+  acc_words_ = (size_t)(kStatLines + T) * kAccStride;
+  block_acc_off_ = (sizeof(CallDesc) + 127) & ~(size_t)127;
+  block_tiles_off_ = block_acc_off_ + acc_words_ * sizeof(uint32_t);
+  const size_t block_bytes = block_tiles_off_ + max_tiles_ * sizeof(TileDesc);
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_block_, block_bytes));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_block_, block_bytes));
+  memset(h_block_, 0, block_bytes);
+  h_call_ = reinterpret_cast<CallDesc*>(h_block_);
+  d_call_ = reinterpret_cast<CallDesc*>(d_block_);
+  h_tiles_ = reinterpret_cast<TileDesc*>(h_block_ + block_tiles_off_);
+  d_acc_ = reinterpret_cast<uint32_t*>(d_block_ + block_acc_off_);
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_acc_, acc_words_));
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_mode_, (size_t)kMaxTables));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_mode_, (size_t)kMaxTables + (size_t)kMaxTables * kAccStride));
   HPS_RETURN_IF_ERROR(PinAlloc(&h_md_, 1));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_md_, 1));
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_slot_, max_keys_));
-  probe_blocks_cap_ = ProbeGridBlocks(max_keys_, cache_->cu_count());
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_block_miss_, probe_blocks_cap_));
-  set_cap_ = 1024;
-  while (set_cap_ < 2 * (uint64_t)max_keys_) set_cap_ <<= 1;
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_set_, set_cap_));
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_counts_, (size_t)kCountWords));
-  HPS_RETURN_IF_ERROR(PinAlloc(&h_counts_, (size_t)kCountWords));
-  HPS_RETURN_IF_ERROR(PinAlloc(&h_mode_, (size_t)2 * kMaxTables + 2));
-  HIP_TRY(hipMemset(d_counts_, 0, (size_t)kCountWords * sizeof(uint32_t)));
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_uniq_keys_, max_keys_));
+
+  const size_t regions = max_tiles_ * (size_t)kTileKeys;
+  CallWork& w = work_;
+  w.tiles = reinterpret_cast<const TileDesc*>(d_block_ + block_tiles_off_);
+  w.acc = d_acc_;
+  HPS_RETURN_IF_ERROR(DevAlloc(&w.slot, max_keys_));
+  HPS_RETURN_IF_ERROR(DevAlloc(&w.tile_cnt, max_tiles_ * 4));
+  HPS_RETURN_IF_ERROR(DevAlloc(&w.miss_key, regions));
+  HPS_RETURN_IF_ERROR(DevAlloc(&w.sent_i, regions));
+  HPS_RETURN_IF_ERROR(DevAlloc(&w.rep_of, regions));
+  HPS_RETURN_IF_ERROR(DevAlloc(&w.uidx_of, regions));
+  w.hit_i = nullptr;  // allocated with the first call whose policy needs the unique-key count
+  uint64_t set_cap = 1024;
+  while (set_cap < 2 * (uint64_t)max_keys_) set_cap <<= 1;
+  HPS_RETURN_IF_ERROR(DevAlloc(&w.set, set_cap));
+  HIP_TRY(hipMemset(w.set, 0, set_cap * sizeof(unsigned long long)));  // tag 0 is never used by a call
+  w.set_mask = set_cap - 1;
+  HPS_RETURN_IF_ERROR(DevAlloc(&w.uniq_keys, max_keys_));
   HPS_RETURN_IF_ERROR(PinAlloc(&h_uniq_keys_, max_keys_, hipHostMallocMapped));
   void* dv = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&dv, h_uniq_keys_, 0));
-  h_uniq_keys_devptr_ = (int64_t*)dv;
+  w.uniq_keys_host = (int64_t*)dv;
+  uniq_miss_.assign(T, 0);
   if (cache_->direct()) {
     // the device sizes the staging layout itself (hps_missdesc_build), so the buffer must hold the worst case:
     // every key of a full batch missing.  Device memory only — no pinned host staging in this mode.
@@ -638,6 +675,15 @@ Status LookupSession::EnsureStaging(size_t floats, size_t uniq) {
   return Status::Ok();
 }
 
+// The reference's contract: host key pointers in (docs/architecture.md:308-323).  The reference shell memcpy's the
+// request's keys into its (unpinned) key buffer on one thread and the engine copies that to the device
+// (hps.cc:586-597, hps_buffer.hpp:114-123).  Here:
+//   * keys that already sit in page-locked host memory as one flat table-major array (what ProcessRequest slices:
+//     model_instance_state.cpp:180-193; Triton hands GPU-instance backends pinned input buffers) are DMA'd from where
+//     they are — no host copy at all;
+//   * pageable keys are staged into the session's pinned buffer in pieces of 1 MB by the serving pool, and each
+//     piece's H2D copy is enqueued by the thread that staged it, so staging and DMA overlap (13.6 MB on one thread
+//     is 1.2 ms of memcpy — longer than the whole lookup).
 Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* vectors_per_table,
                              const size_t* num_keys_per_table, size_t num_tables) {
   if (num_tables != tables_.size())
@@ -651,21 +697,65 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
                  " (max_batch_size x sum(maxnum_catfeature_query_per_table_per_sample))");
   if (N == 0) return Status::Ok();
   HIP_TRY(hipSetDevice(device_));
-  // stage keys: pageable -> pinned (the reference memcpy's into its key buffer too, hps.cc:595-597,
-  // but its "PIN" buffer is plain malloc: hps_buffer.hpp:114-123) -> one async H2D copy.
-  size_t off = 0;
-  for (size_t t = 0; t < num_tables; ++t) {
-    if (num_keys_per_table[t]) {
-      if (!h_keys_per_table[t]) return Error(Code::kInvalidArg, "lookup: null key pointer for table ", t);
-      memcpy(h_keys_pinned_ + off, h_keys_per_table[t], num_keys_per_table[t] * sizeof(int64_t));
+  const auto tk0 = std::chrono::steady_clock::now();
+  bool flat = true;
+  const int64_t* base = nullptr;
+  {
+    const int64_t* expect = nullptr;
+    for (size_t t = 0; t < num_tables; ++t) {
+      const size_t n = num_keys_per_table[t];
+      if (n == 0) continue;
+      const int64_t* p = (const int64_t*)h_keys_per_table[t];
+      if (!p) return Error(Code::kInvalidArg, "lookup: null key pointer for table ", t);
+      if (!base) base = p;
+      else if (p != expect) flat = false;
+      expect = p + n;
     }
-    off += num_keys_per_table[t];
   }
-  HIP_TRY(hipMemcpyAsync(d_keys_, h_keys_pinned_, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+  bool direct_dma = false;
+  if (flat && keys_pinned_hint_ != 0) {
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof attr);
+    if (hipPointerGetAttributes(&attr, base) == hipSuccess && attr.type == hipMemoryTypeHost) direct_dma = true;
+    else (void)hipGetLastError();  // an unregistered pointer is not an error of ours
+  }
+  if (direct_dma) {
+    HIP_TRY(hipMemcpyAsync(d_keys_, base, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+  } else {
+    constexpr size_t kPieceKeys = (1u << 20) / sizeof(int64_t);
+    struct Piece { const int64_t* src; size_t off, n; };
+    std::vector<Piece> pieces;
+    size_t off = 0;
+    for (size_t t = 0; t < num_tables; ++t) {
+      const size_t n = num_keys_per_table[t];
+      const int64_t* p = (const int64_t*)h_keys_per_table[t];
+      for (size_t b = 0; b < n; b += kPieceKeys) pieces.push_back({p + b, off + b, std::min(kPieceKeys, n - b)});
+      off += n;
+    }
+    if (N <= 4 * kPieceKeys) {
+      for (const Piece& pc : pieces) memcpy(h_keys_pinned_ + pc.off, pc.src, pc.n * sizeof(int64_t));
+      HIP_TRY(hipMemcpyAsync(d_keys_, h_keys_pinned_, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+    } else {
+      // the pieces ride the second stream (any thread may enqueue there); the probe waits for the last of them
+      std::atomic<int> failed{0};
+      ThreadPool::Serving().ParallelFor(pieces.size(), [&](size_t i) {
+        const Piece& pc = pieces[i];
+        memcpy(h_keys_pinned_ + pc.off, pc.src, pc.n * sizeof(int64_t));
+        (void)hipSetDevice(device_);
+        if (hipMemcpyAsync(d_keys_ + pc.off, h_keys_pinned_ + pc.off, pc.n * sizeof(int64_t), hipMemcpyHostToDevice,
+                           copy_stream_) != hipSuccess)
+          failed.store(1);
+      });
+      if (failed.load()) return Error(Code::kInternal, "lookup: H2D copy of the keys failed: ", hipGetErrorString(hipGetLastError()));
+      HIP_TRY(hipEventRecord(ev_keys_, copy_stream_));
+      HIP_TRY(hipStreamWaitEvent(stream_, ev_keys_, 0));
+    }
+  }
+  key_stage_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
   return TimedLookupDevice(d_keys_, vectors_per_table, num_keys_per_table, num_tables);
 }
 
-// LookupDevice + (option "timing") the GPU-side span of the call: probe+gather start (after the waits on other
+// LookupDevice + (option "timing") the GPU-side span of the call: probe start (after the waits on other
 // sessions' kernels) to the last kernel of the call, by HIP events on the session's stream.
 Status LookupSession::TimedLookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
   const Status st = LookupDevice(d_keys_flat, d_out, n, T);
@@ -686,6 +776,7 @@ Status LookupSession::lookup_from_device(const int64_t* d_keys_flat, float* cons
   if (N > max_keys_) return Error(Code::kInvalidArg, "lookup: ", N, " keys exceed the session capacity of ", max_keys_);
   if (N == 0) return Status::Ok();
   HIP_TRY(hipSetDevice(device_));
+  key_stage_ms_ = 0.f;
   return TimedLookupDevice(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
 }
 
@@ -704,8 +795,64 @@ Status LookupSession::LookupHostTier(const void* const* h_keys_per_table, float*
   return ps_->FetchMulti(jobs);
 }
 
+// Call descriptor (the per-table slicing of ProcessRequest, model_instance_state.cpp:180-193), the probe tiles and the
+// zeroed accumulator block, uploaded with one copy.
+Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T, bool probe_only,
+                                  uint64_t* N_out) {
+  CallDesc& c = *h_call_;
+  c.num_tables = (uint32_t)T;
+  c.keys = d_keys_flat;
+  uint64_t N = 0;
+  uint32_t tiles = 0;
+  for (size_t t = 0; t < T; ++t) {
+    c.key_start[t] = N;
+    c.out[t] = probe_only ? nullptr : d_out[t];
+    if (!probe_only && n[t] && !d_out[t]) return Error(Code::kInvalidArg, "lookup: null output pointer for table ", t);
+    const uint32_t D = tables_[t]->dim();
+    c.vec_ok[t] = (!probe_only && (D & 3u) == 0 && ((uintptr_t)d_out[t] & 15u) == 0) ? 1 : 0;
+    for (uint64_t b = 0; b < n[t]; b += kTileKeys)
+      h_tiles_[tiles++] = TileDesc{N + b, (uint32_t)std::min<uint64_t>(kTileKeys, n[t] - b), (uint32_t)t};
+    N += n[t];
+  }
+  c.key_start[T] = N;
+  c.total_keys = N;
+  c.epoch = cache_->NextEpoch();
+  if (++call_tag_ == 0) {  // 2^32 calls later: entries of the first calls would look like this call's
+    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipMemsetAsync(work_.set, 0, (work_.set_mask + 1) * sizeof(unsigned long long), stream_));
+    call_tag_ = 1;
+  }
+  work_.num_tiles = tiles;
+  work_.call_tag = call_tag_;
+  HIP_TRY(hipMemcpyAsync(d_block_, h_block_, block_tiles_off_ + (size_t)tiles * sizeof(TileDesc), hipMemcpyHostToDevice, stream_));
+  *N_out = N;
+  return Status::Ok();
+}
+
+// After the accumulator block has come back: per-table unique miss counts, the call's statistics.
+Status LookupSession::ReadBackCounts(size_t T, uint64_t N, bool exact) {
+  uint64_t misses = 0, uniq = 0, uniq_keys = 0;
+  for (size_t t = 0; t < T; ++t) {
+    const uint32_t um = h_acc_[AccTableWord((uint32_t)t, kAccUniqMiss)];
+    uniq_miss_[t] = um;
+    uniq += um;
+    misses += h_acc_[AccTableWord((uint32_t)t, kAccSentMiss)];
+    if (exact) uniq_keys += (uint64_t)um + h_acc_[AccTableWord((uint32_t)t, kAccUniqHit)];
+  }
+  last_misses_ = misses;
+  last_unique_ = uniq;
+  last_unique_keys_ = uniq_keys;
+  std::lock_guard<std::mutex> lk(cache_->stat_mu_);
+  cache_->counters_.lookups += 1;
+  cache_->counters_.keys += N;
+  cache_->counters_.misses += misses;
+  cache_->counters_.unique_misses += uniq;
+  return Status::Ok();
+}
+
+void LookupSession::AddInsertStats() { cache_->AddStatLines(h_acc_); }
+
 Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
-  // ---- call descriptor: the per-table slicing of ProcessRequest (model_instance_state.cpp:180-193) ----
   // direct mode: no table reload may replace a pinned slab while our kernels read it
   std::shared_lock<std::shared_mutex> direct_lock;
   if (cache_->direct()) {
@@ -717,166 +864,149 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
   };
   phase_ms_[0] = phase_ms_[1] = phase_ms_[2] = phase_ms_[3] = 0.f;
-  CallDesc& c = *h_call_;
-  c.num_tables = (uint32_t)T;
-  c.keys = d_keys_flat;
-  uint64_t N = 0;
-  for (size_t t = 0; t < T; ++t) {
-    c.key_start[t] = N;
-    N += n[t];
-    c.out[t] = d_out[t];
-    if (n[t] && !d_out[t]) return Error(Code::kInvalidArg, "lookup: null output pointer for table ", t);
-    const uint32_t D = tables_[t]->dim();
-    c.vec_ok[t] = ((D & 3u) == 0 && ((uintptr_t)d_out[t] & 15u) == 0) ? 1 : 0;
+  last_gather_ms_ = 0.f;
+  // The insertion policy compares the table's hit rate over UNIQUE keys with the threshold
+  // (docs/hierarchical_parameter_server.md:69: "first determines the associated unique embedding keys";
+  // docs/architecture.md:66: "the real hit rate of the GPU embedding cache lookup"); a threshold outside (0,1) decides
+  // without the rate, and then the unique-hit count is not taken.
+  const bool exact = params_.hit_rate_threshold > 0.0f && params_.hit_rate_threshold < 1.0f;
+  if (exact) {
+    HPS_RETURN_IF_ERROR(cache_->EnsureClaimWords());
+    if (!work_.hit_i) HPS_RETURN_IF_ERROR(DevAlloc(&work_.hit_i, max_tiles_ * (size_t)kTileKeys));
   }
-  c.key_start[T] = N;
-  c.total_keys = N;
-  const uint32_t epoch = cache_->NextEpoch();
-  c.epoch = epoch;
-  const size_t desc_bytes = sizeof(CallDesc);
-  HIP_TRY(hipMemcpyAsync(d_call_, h_call_, desc_bytes, hipMemcpyHostToDevice, stream_));
+  uint64_t N = 0;
+  HPS_RETURN_IF_ERROR(PrepareCall(d_keys_flat, d_out, n, T, /*probe_only=*/false, &N));
+  const CallDesc& c = *h_call_;
+  const uint32_t epoch = c.epoch;
+  const CallWork& w = work_;
+  bool all128 = true;
+  for (size_t t = 0; t < T; ++t) all128 &= tables_[t]->dim() == 128 && c.vec_ok[t];
 
   // (option "host_gather": serve this session's misses the reference's way — host threads + H2D copy — although the
   //  cache is in ps_direct_access mode; the pinned tables serve both paths)
   const bool use_direct = cache_->direct() && !force_host_gather_;
   const bool fast_direct = use_direct && params_.hit_rate_threshold >= 1.0f && last_misses_ > 0;
-  // Split probe (host-gather tier, while calls keep missing): K_A only probes (75 us instead of 290), the miss counts
-  // reach the host right after the dedup, and the hit rows are gathered by K_G while the host threads gather the
-  // missed rows and the DMA engine uploads them — HBM-bound and PCIe-bound halves of one call side by side.
-  // (device-driven tier: measured and left fused.  With K_G on the session's stream and the staging layout + fetch kernel
-  //  on the second one, config 2 dropped from 1.85 to 1.70 G lookups/s: the fetch kernel then shares the memory system with
-  //  its own session's K_G as well as the other session's kernels, and falls from 0.78 to 0.70 of the PCIe peak.)
-  const bool split = split_probe_ && !use_direct && last_misses_ > 0 && N > 0;
-  bool all128 = true;
-  const CallDesc* d_probe_call = d_call_;
-  last_gather_ms_ = 0.f;
-  if (split) {
-    *h_call_probe_ = c;
-    for (size_t t = 0; t < T; ++t) {
-      h_call_probe_->out[t] = nullptr;
-      all128 &= tables_[t]->dim() == 128 && c.vec_ok[t];
-    }
-    HIP_TRY(hipMemcpyAsync(d_call_probe_, h_call_probe_, desc_bytes, hipMemcpyHostToDevice, stream_));
-    d_probe_call = d_call_probe_;
-  }
-
-  // ---- K_A: probe + gather hits ----
+  // Split arrangement (host-gather tier, while calls keep missing): the miss counts go to the host right behind the
+  // probe, and the hit rows are gathered by K_G while the host threads gather the missed rows and the DMA engine
+  // uploads them — HBM-bound and PCIe-bound halves of one call side by side.  Otherwise K_G runs before the counts
+  // are read (a call that missed nothing then needs no second synchronisation).
+  // (device-driven tier: measured and left un-split.  With K_G on the session's stream and the staging layout + fetch
+  //  kernel on the second one, config 2 dropped from 1.85 to 1.70 G lookups/s: the fetch kernel then shares the memory
+  //  system with its own session's K_G as well as the other session's kernels.)
+  const bool split = split_probe_ && !use_direct && last_misses_ > 0;
   const int cu = cache_->cu_count();
-  const uint32_t probe_blocks = ProbeGridBlocks(N, cu, probe_balanced_);
+  const uint32_t gather_blocks = GatherGridBlocks(N, cu);
+
+  // ---- K_P: tile dedup + probe;  K_M: call-wide unique misses (+ unique hits) ----
   cache_->BeginRead(stream_);
   if (timing_) (void)hipEventRecord(ev_t0_, stream_);
-  hipError_t e = LaunchProbeGather(d_probe_call, cache_->device_tables(), (uint32_t)T, N, d_slot_, d_block_miss_, probe_blocks,
-                                   probe_unroll_, stream_);
+  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), w, probe_variant_, exact, stream_);
+  if (e == hipSuccess) e = LaunchMissUnique(d_call_, cache_->device_tables(), w, exact, stream_);
   if (timing_) (void)hipEventRecord(ev_t1_, stream_);
-  if (split) (void)hipEventRecord(ev_probe_, stream_);   // other sessions' probes chain behind the probe alone
-  else cache_->EndRead(stream_, ev_read_);
-  // (split: the cache stays read-locked until K_G has read the slots; released below on every path)
-  auto end_split_read = [&]() { if (split) cache_->EndReadFused(stream_, ev_probe_, ev_read_); };
-  if (e != hipSuccess) { end_split_read(); return Error(Code::kInternal, "probe/gather launch failed: ", hipGetErrorString(e)); }
-
-  // ---- K_B: unique missed keys (all three kernels exit at once when nothing missed) ----
-  e = LaunchMissDedup(d_call_, c.key_start, (uint32_t)T, probe_blocks, d_slot_, d_block_miss_, d_set_, set_cap_,
-                      d_counts_, d_uniq_keys_, h_uniq_keys_devptr_, cu, stream_);
-  if (e != hipSuccess) { end_split_read(); return Error(Code::kInternal, "miss dedup launch failed: ", hipGetErrorString(e)); }
-  last_async_ = false;
-  auto account = [&]() {
-    const uint64_t misses = h_counts_[0];
-    uint64_t uniq = 0;
-    for (size_t t = 0; t < T; ++t) uniq += h_counts_[1 + t];
-    last_misses_ = misses;
-    last_unique_ = uniq;
-    std::lock_guard<std::mutex> lk(cache_->stat_mu_);
-    cache_->counters_.lookups += 1;
-    cache_->counters_.keys += N;
-    cache_->counters_.misses += misses;
-    cache_->counters_.unique_misses += uniq;
+  // other sessions' probes chain behind ours: behind K_P, and behind K_M too when it still reads the claim words
+  (void)hipEventRecord(ev_probe_, stream_);
+  auto gather = [&]() -> hipError_t {
+    if (timing_) (void)hipEventRecord(ev_g0_, stream_);
+    const hipError_t ge = LaunchGatherHits(d_call_, cache_->device_tables(), (uint32_t)T, N, w.slot, gather_blocks, all128, xcd_walk_, stream_);
+    if (timing_) (void)hipEventRecord(ev_g1_, stream_);
+    return ge;
   };
+  bool read_open = true;
+  // the cache stays read-locked until K_G has read the last slot: writers wait for ev_read_, probes for ev_probe_
+  auto end_read = [&]() { if (read_open) { cache_->EndReadFused(stream_, ev_probe_, ev_read_); read_open = false; } };
+  if (e != hipSuccess) { end_read(); return Error(Code::kInternal, "probe launch failed: ", hipGetErrorString(e)); }
+  if (!split) {
+    e = gather();
+    end_read();
+    if (e != hipSuccess) return Error(Code::kInternal, "hit gather launch failed: ", hipGetErrorString(e));
+  }
+  last_async_ = false;
+  table_async_.assign(T, 0);
   if (fast_direct) {
     // Device-driven miss path with the insertion policy fixed to "synchronous": nothing on the host depends
     // on the miss counts, so the whole call is enqueued without a round trip and the counts come back at the end.
     // (Only while the previous call of this session missed something: a fully resident working set is served
-    // faster by reading the counts first and stopping there — four empty kernels and a sync less.)
-    table_async_.assign(T, 0);
+    // faster by reading the counts first and stopping there.)
     const Status st = HandleMissesDirect(N, epoch, /*counts_known=*/false, nullptr);
-    if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
-    if (st.ok()) account();
+    if (timing_) { (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_); (void)hipEventElapsedTime(&last_gather_ms_, ev_g0_, ev_g1_); }
+    if (st.ok()) HPS_RETURN_IF_ERROR(ReadBackCounts(T, N, exact));
     phase_ms_[3] = ms_since(tc0);
     phase_ms_[2] = phase_ms_[3];  // no host phases on this path; [1] holds the fetch kernel's GPU time
     return st;
   }
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
-  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kTableMissBase + T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  {
+    const hipError_t ce = hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_);
+    if (ce != hipSuccess) { end_read(); return Error(Code::kInternal, "count read-back failed: ", hipGetErrorString(ce)); }
+  }
   (void)hipEventRecord(ev_done_, stream_);
   if (split) {
     // K_G behind the counts: it runs while the host reads them and works on the misses
-    if (timing_) (void)hipEventRecord(ev_g0_, stream_);
-    e = LaunchGatherHits(d_call_, cache_->device_tables(), (uint32_t)T, N, d_slot_, probe_blocks, all128, stream_);
-    if (timing_) (void)hipEventRecord(ev_g1_, stream_);
-    end_split_read();
+    e = gather();
+    end_read();
     if (e != hipSuccess) return Error(Code::kInternal, "hit gather launch failed: ", hipGetErrorString(e));
   }
   HIP_TRY(hipEventSynchronize(ev_done_));
   if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
-  account();
-  const uint64_t misses = h_counts_[0];
+  HPS_RETURN_IF_ERROR(ReadBackCounts(T, N, exact));
   phase_ms_[0] = phase_ms_[3] = ms_since(tc0);
-  table_async_.assign(T, 0);
   split_call_ = split;
-  if (misses == 0) {
-    if (split) {
-      HIP_TRY(hipStreamSynchronize(stream_));   // the hit rows are still being written
-      if (timing_) (void)hipEventElapsedTime(&last_gather_ms_, ev_g0_, ev_g1_);
-    }
+  if (last_unique_ == 0) {
+    if (split) HIP_TRY(hipStreamSynchronize(stream_));   // the hit rows are still being written
+    if (timing_) (void)hipEventElapsedTime(&last_gather_ms_, ev_g0_, ev_g1_);
     return Status::Ok();
   }
 
   // ---- insertion policy, decided per table as the reference's per-table lookup loop does
-  //      (docs/architecture.md:65-67): a table whose hit rate in this call reaches
-  //      hit_rate_threshold returns the default vector for its misses now and has them inserted in the
+  //      (docs/architecture.md:65-67): a table whose hit rate over the call's unique keys
+  //      reaches hit_rate_threshold returns the default vector for its misses now and has them inserted in the
   //      background; the other tables fetch, return and insert their missed rows before the call returns ----
   bool any_async = false, any_sync = false;
   for (size_t t = 0; t < T; ++t) {
-    const uint64_t n_t = c.key_start[t + 1] - c.key_start[t];
-    const uint64_t m_t = h_counts_[kTableMissBase + t];
-    if (m_t == 0 || n_t == 0) continue;
-    const bool as = 1.0 - (double)m_t / (double)n_t >= (double)params_.hit_rate_threshold;
+    const uint64_t um = uniq_miss_[t];
+    if (um == 0) continue;
+    bool as;
+    if (params_.hit_rate_threshold >= 1.0f) as = false;
+    else if (params_.hit_rate_threshold <= 0.0f) as = true;
+    else {
+      const uint64_t uk = um + h_acc_[AccTableWord((uint32_t)t, kAccUniqHit)];
+      as = 1.0 - (double)um / (double)uk >= (double)params_.hit_rate_threshold;
+    }
     table_async_[t] = as ? 1 : 0;
     any_async |= as;
     any_sync |= !as;
   }
   const uint32_t* d_mode = nullptr;
   if (any_async && any_sync) {
-    // mixed call: the per-table mode goes to the kernels through the words the per-table miss counts came back in
+    // mixed call: the kernels learn the per-table mode from a small device array
     for (size_t t = 0; t < T; ++t) h_mode_[t] = table_async_[t];
-    HIP_TRY(hipMemcpyAsync(d_counts_ + kTableMissBase, h_mode_, T * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-    d_mode = d_counts_ + kTableMissBase;
+    HIP_TRY(hipMemcpyAsync(d_mode_, h_mode_, T * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+    d_mode = d_mode_;
   }
   if (any_async) {
     last_async_ = true;
-    e = LaunchMissFillDefault(d_call_, cache_->device_tables(), N, d_slot_, d_mode, cu, stream_);
+    e = LaunchMissFillDefault(d_call_, cache_->device_tables(), w, d_mode, stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "default fill launch failed: ", hipGetErrorString(e));
     // hand the async tables' unique missed keys to the background inserter (best effort)
     if (use_direct) {
       // device-driven tier: the keys never leave the GPU; fetch + insert run on the cache's own stream
       uint64_t uniq = 0, floats = 0;
-      uint32_t* job_counts = h_mode_ + kMaxTables;   // [0] any misses, [1 + t] unique misses of the async tables
-      job_counts[0] = 1;
+      uint32_t* job_lines = h_mode_ + kMaxTables;   // T accumulator lines: unique misses of the async tables only
       for (size_t t = 0; t < T; ++t) {
-        const uint32_t cnt = table_async_[t] ? h_counts_[1 + t] : 0u;
-        job_counts[1 + t] = cnt;
+        const uint32_t cnt = table_async_[t] ? uniq_miss_[t] : 0u;
+        job_lines[t * kAccStride + kAccUniqMiss] = cnt;
         uniq += cnt;
         floats = ((floats + 3) & ~(uint64_t)3) + (uint64_t)cnt * tables_[t]->dim();
       }
       bool accepted = false;
-      HPS_RETURN_IF_ERROR(cache_->SubmitDirectInsert(stream_, d_call_->key_start, d_uniq_keys_, d_counts_, any_sync ? job_counts : nullptr,
-                                                     N, uniq, floats, &accepted));
+      HPS_RETURN_IF_ERROR(cache_->SubmitDirectInsert(stream_, d_call_->key_start, w.uniq_keys, d_acc_ + (size_t)kStatLines * kAccStride,
+                                                     any_sync ? job_lines : nullptr, N, uniq, floats, &accepted));
       if (accepted) ps_->RunDirectInsert(cache_);
     } else {
       std::vector<std::vector<int64_t>> job(T);
       for (size_t t = 0; t < T; ++t) {
         if (!table_async_[t]) continue;
-        const uint32_t cnt = h_counts_[1 + t];
-        job[t].assign(h_uniq_keys_ + c.key_start[t], h_uniq_keys_ + c.key_start[t] + cnt);
+        job[t].assign(h_uniq_keys_ + c.key_start[t], h_uniq_keys_ + c.key_start[t] + uniq_miss_[t]);
       }
       ps_->SubmitAsyncInsert(cache_, std::move(job));
     }
@@ -887,11 +1017,12 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     if (!any_sync) {
       if (timing_) (void)hipEventRecord(ev_c1_, stream_);
       HIP_TRY(hipStreamSynchronize(stream_));
+      if (timing_) (void)hipEventElapsedTime(&last_gather_ms_, ev_g0_, ev_g1_);
       return Status::Ok();
     }
   }
   const Status st = use_direct ? HandleMissesDirect(N, epoch, /*counts_known=*/true, d_mode) : HandleMisses(N, epoch);
-  if (split && timing_ && st.ok()) (void)hipEventElapsedTime(&last_gather_ms_, ev_g0_, ev_g1_);
+  if (timing_ && st.ok()) (void)hipEventElapsedTime(&last_gather_ms_, ev_g0_, ev_g1_);
   phase_ms_[3] = ms_since(tc0);
   phase_ms_[2] = phase_ms_[3] - phase_ms_[0] - phase_ms_[1];
   return st;
@@ -926,47 +1057,34 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
   while (cache_->direct_writers().load(std::memory_order_acquire) > 0) std::this_thread::yield();
   direct_lock = std::shared_lock<std::shared_mutex>(cache_->direct_mutex());
 
-  CallDesc& c = *h_call_;
-  c.num_tables = (uint32_t)T;
-  c.keys = d_keys_flat;
-  for (size_t t = 0; t < T; ++t) {
-    c.key_start[t] = (uint64_t)t * batch;
-    c.out[t] = nullptr;   // probe only
-    c.vec_ok[t] = 0;
-  }
-  c.key_start[T] = N;
-  c.total_keys = N;
-  const uint32_t epoch = cache_->NextEpoch();
-  c.epoch = epoch;
-  HIP_TRY(hipMemcpyAsync(d_call_, h_call_, sizeof(CallDesc), hipMemcpyHostToDevice, stream_));
+  std::vector<size_t> n(T, (size_t)batch);
+  uint64_t N2 = 0;
+  HPS_RETURN_IF_ERROR(PrepareCall(d_keys_flat, nullptr, n.data(), T, /*probe_only=*/true, &N2));
+  const uint32_t epoch = h_call_->epoch;
+  const CallWork& w = work_;
   const int cu = cache_->cu_count();
-  const uint32_t probe_blocks = ProbeGridBlocks(N, cu, probe_balanced_);
   // bottom MLP first: it needs nothing from the lookup and leaves the stream before the cache is read-locked
   const void* d_bottom = nullptr;
   HPS_RETURN_IF_ERROR(dense->BottomMlp(d_dense_features, batch, stream_, &d_bottom));
 
   cache_->BeginRead(stream_);   // ---- read lock: held (order mutex + reader event) until the interaction is enqueued ----
   if (timing_) (void)hipEventRecord(ev_t0_, stream_);
-  hipError_t e = LaunchProbeGather(d_call_, cache_->device_tables(), (uint32_t)T, N, d_slot_, d_block_miss_, probe_blocks,
-                                   probe_unroll_, stream_);
+  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), w, probe_variant_, false, stream_);
+  if (e == hipSuccess) e = LaunchMissUnique(d_call_, cache_->device_tables(), w, false, stream_);
   if (timing_) (void)hipEventRecord(ev_t1_, stream_);
   (void)hipEventRecord(ev_probe_, stream_);
-  if (e == hipSuccess)
-    e = LaunchMissDedup(d_call_, c.key_start, (uint32_t)T, probe_blocks, d_slot_, d_block_miss_, d_set_, set_cap_, d_counts_,
-                        d_uniq_keys_, h_uniq_keys_devptr_, cu, stream_);
-  if (e == hipSuccess)
-    e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, d_counts_ + kMaxTables + 1, nullptr, stream_);
+  if (e == hipSuccess) e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_acc_, d_md_, /*clear_stats=*/false, nullptr, stream_);
   if (e == hipSuccess) {
     cache_->BeginFetch(stream_);
     if (timing_) (void)hipEventRecord(ev_f0_, stream_);
-    e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, d_uniq_keys_, d_staging_, d_found_, N, 0,
+    e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, w.uniq_keys, d_staging_, d_found_, N, 0,
                             stream_);
     if (timing_) (void)hipEventRecord(ev_f1_, stream_);
     cache_->EndFetch(stream_, ev_fetch_);
   }
   if (e == hipSuccess)
-    e = LaunchLookupInteract(cache_->device_tables(), d_md_, d_slot_, d_staging_, d_bottom, batch, (uint32_t)T, dense->emb_dim(),
-                             dense->out_stride(), d_out_f16, cu, stream_);
+    e = LaunchLookupInteract(cache_->device_tables(), d_md_, w.slot, w.rep_of, w.uidx_of, d_staging_, d_bottom, batch, (uint32_t)T,
+                             dense->emb_dim(), dense->out_stride(), d_out_f16, cu, stream_);
   cache_->EndReadFused(stream_, ev_probe_, ev_read_);   // ---- read lock released (enqueue side) ----
   if (e != hipSuccess) return Error(Code::kInternal, "lookup_interact launch failed: ", hipGetErrorString(e));
   last_async_ = false;
@@ -977,31 +1095,20 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
     if (est_bytes > (2u << 20)) HIP_TRY(hipStreamSynchronize(stream_));
   }
   cache_->BeginWrite(stream_);
-
-  e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, N, d_call_->key_start, d_uniq_keys_, d_staging_, d_found_, epoch,
-                        d_counts_ + kMaxTables + 1, cu, stream_);
+  e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, N, d_call_->key_start, w.uniq_keys, d_staging_, d_found_, epoch,
+                        d_acc_, cu, stream_);
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
-  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kMaxTables + 5) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipStreamSynchronize(stream_));
   if (timing_) {
     (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
     (void)hipEventElapsedTime(&phase_ms_[1], ev_f0_, ev_f1_);
     (void)hipEventElapsedTime(&last_gpu_call_ms_, ev_t0_, ev_c1_);
   }
-  uint64_t uniq = 0;
-  for (size_t t = 0; t < T; ++t) uniq += h_counts_[1 + t];
-  last_misses_ = h_counts_[0];
-  last_unique_ = uniq;
-  std::lock_guard<std::mutex> lk(cache_->stat_mu_);
-  cache_->counters_.lookups += 1;
-  cache_->counters_.keys += N;
-  cache_->counters_.misses += last_misses_;
-  cache_->counters_.unique_misses += uniq;
-  cache_->counters_.dropped += h_counts_[kMaxTables + 1];
-  cache_->counters_.inserted += h_counts_[kMaxTables + 2];
-  cache_->counters_.refreshed += h_counts_[kMaxTables + 3];
+  HPS_RETURN_IF_ERROR(ReadBackCounts(T, N, false));
+  AddInsertStats();
   return Status::Ok();
 }
 
@@ -1012,17 +1119,16 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   const int cu = cache_->cu_count();
   const uint64_t max_unique = counts_known ? (uint64_t)last_unique_ : N;
   hipStream_t fs = stream_;
-  hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_counts_, d_md_, d_counts_ + kMaxTables + 1,
-                                     d_table_mode, fs);
+  hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_acc_, d_md_, /*clear_stats=*/false, d_table_mode, fs);
   if (e == hipSuccess) {
     cache_->BeginFetch(fs);
     if (timing_) (void)hipEventRecord(ev_f0_, fs);
-    e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, d_uniq_keys_, d_staging_,
+    e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, work_.uniq_keys, d_staging_,
                             d_found_, max_unique, 0, fs);
     if (timing_) (void)hipEventRecord(ev_f1_, fs);
     cache_->EndFetch(fs, ev_fetch_);
   }
-  if (e == hipSuccess) e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, N, d_slot_, d_staging_, cu, stream_);
+  if (e == hipSuccess) e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, d_staging_, stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "direct miss path launch failed: ", hipGetErrorString(e));
   // Keep the window in which other sessions' probes wait for our writer event down to the insert kernel: drain the
   // stream first, so the event is recorded behind the insert alone and not behind a millisecond of PCIe fetch.
@@ -1035,24 +1141,22 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
     if (est_bytes > (2u << 20)) HIP_TRY(hipStreamSynchronize(stream_));
   }
   cache_->BeginWrite(stream_);
-  e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, max_unique, d_call_->key_start, d_uniq_keys_,
-                        d_staging_, d_found_, epoch, d_counts_ + kMaxTables + 1, cu, stream_);
+  e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, max_unique, d_call_->key_start, work_.uniq_keys,
+                        d_staging_, d_found_, epoch, d_acc_, cu, stream_);
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
-  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)kMaxTables + 5) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipStreamSynchronize(stream_));
   if (timing_) (void)hipEventElapsedTime(&phase_ms_[1], ev_f0_, ev_f1_);  // direct path: [1] = the fetch kernel (GPU time)
-  std::lock_guard<std::mutex> lk(cache_->stat_mu_);
-  cache_->counters_.dropped += h_counts_[kMaxTables + 1];
-  cache_->counters_.inserted += h_counts_[kMaxTables + 2];
-  cache_->counters_.refreshed += h_counts_[kMaxTables + 3];
+  AddInsertStats();
   return Status::Ok();
 }
 
 // Synchronous miss path: parameter-server gather of the unique missed keys into pinned staging,
 // one H2D copy per chunk, missed rows scattered to the output, then inserted into the cache.
 Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
+  (void)N;
   const size_t T = tables_.size();
   const CallDesc& c = *h_call_;
   const int cu = cache_->cu_count();
@@ -1060,13 +1164,12 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
   size_t total_floats = 0, total_uniq = 0;
   for (size_t t = 0; t < T; ++t) {
     // tables in async-insert mode take no part here: their misses got the default vector (K_D)
-    ucnt[t] = (t < table_async_.size() && table_async_[t]) ? 0u : h_counts_[1 + t];
+    ucnt[t] = (t < table_async_.size() && table_async_[t]) ? 0u : uniq_miss_[t];
     total_floats += (size_t)ucnt[t] * tables_[t]->dim();
     total_uniq += ucnt[t];
   }
   const size_t cap_floats = kStagingCapBytes / sizeof(float);
   HPS_RETURN_IF_ERROR(EnsureStaging(std::min(total_floats, cap_floats), total_uniq));
-  HIP_TRY(hipMemsetAsync(d_counts_ + kMaxTables + 1, 0, 4 * sizeof(uint32_t), stream_));
 
   for (;;) {
     // ---- assemble the next chunk: whole tables while they fit, else a slice of one table ----
@@ -1098,18 +1201,15 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     constexpr size_t kPieceFloats = (4u << 20) / sizeof(float);
     std::vector<HierParameterServer::FetchJob> jobs;
     size_t piece_begin = SIZE_MAX, piece_end = 0;
-    unsigned piece_no = 0;
     bool used_copy_stream = false;
     auto flush = [&]() -> Status {
       if (jobs.empty()) return Status::Ok();
       const auto tf0 = std::chrono::steady_clock::now();
       HPS_RETURN_IF_ERROR(ps_->FetchMulti(jobs));
       phase_ms_[1] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tf0).count();
-      // (A/B on the MI355X box: alternating the pieces between two copy streams was slower — 1.24 vs 1.06
-      //  ms/step at two sessions — so every piece goes down the session's own stream.)
-      constexpr bool kTwoCopyStreams = false;
       // split call: the session's stream is busy with K_G, the pieces go down the copy stream
-      hipStream_t cs = (split_call_ || (kTwoCopyStreams && (piece_no++ & 1))) ? copy_stream_ : stream_;
+      // (A/B on the MI355X box: alternating the pieces between two copy streams was slower — 1.24 vs 1.06 ms/step)
+      hipStream_t cs = split_call_ ? copy_stream_ : stream_;
       HIP_TRY(hipMemcpyAsync(d_staging_ + piece_begin, h_staging_ + piece_begin, (piece_end - piece_begin) * sizeof(float),
                              hipMemcpyHostToDevice, cs));
       used_copy_stream |= (cs == copy_stream_);
@@ -1140,15 +1240,15 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       HIP_TRY(hipStreamWaitEvent(stream_, ev_copy_, 0));
     }
 
-    hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, N, d_slot_, d_staging_, cu, stream_);
+    hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, d_staging_, stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
     // Other sessions' probes wait for our writer event.  Let the PCIe copy and the scatter drain first,
     // so that the window in which the cache is "being written" is the insert kernel alone (tens of
     // microseconds) and not insert + the millisecond of H2D queued ahead of it on this stream.
     HIP_TRY(hipStreamSynchronize(stream_));
     cache_->BeginWrite(stream_);
-    e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, uq, d_call_->key_start, d_uniq_keys_,
-                          d_staging_, d_found_, epoch, d_counts_ + kMaxTables + 1, cu, stream_);
+    e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, uq, d_call_->key_start, work_.uniq_keys,
+                          d_staging_, d_found_, epoch, d_acc_, cu, stream_);
     cache_->EndWrite(stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
     // staging is reused by the next chunk
@@ -1156,13 +1256,9 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     HIP_TRY(hipStreamSynchronize(stream_));
     for (size_t t = 0; t < T; ++t) done[t] = md.chunk_hi[t];
   }
-  HIP_TRY(hipMemcpyAsync(h_counts_ + kMaxTables + 1, d_counts_ + kMaxTables + 1, 4 * sizeof(uint32_t),
-                         hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, (size_t)kStatLines * kAccStride * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipStreamSynchronize(stream_));
-  std::lock_guard<std::mutex> lk(cache_->stat_mu_);
-  cache_->counters_.dropped += h_counts_[kMaxTables + 1];
-  cache_->counters_.inserted += h_counts_[kMaxTables + 2];
-  cache_->counters_.refreshed += h_counts_[kMaxTables + 3];
+  AddInsertStats();
   return Status::Ok();
 }
 

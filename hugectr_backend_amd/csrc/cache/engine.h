@@ -69,7 +69,11 @@ class EmbeddingCache {
   const std::vector<TableCacheDev>& host_tables() const { return h_tables_; }
   int cu_count() const { return cu_count_; }
   CacheCounters counters() const;
+  void AddStatLines(const uint32_t* lines);   // insert statistics of one launch series: kStatLines accumulator lines
 
+  // Allocates the per-slot claim words the probe kernel needs to count a call's unique hit keys (only sessions whose
+  // insertion policy depends on the hit rate ask for them: 0 < hit_rate_threshold < 1).  Idempotent.
+  Status EnsureClaimWords();
   // slot index (>=0) or -1 per key, straight from the device tables; no LRU side effect (tests, refresh)
   Status Query(uint32_t table, const int64_t* h_keys, size_t n, int32_t* h_slots);
   // every resident key of one table (order unspecified)
@@ -125,6 +129,7 @@ class EmbeddingCache {
   hipEvent_t last_fetch_ = nullptr;         // most recent direct PCIe fetch of any session (fetches are chained)
   hipStream_t last_fetch_stream_ = nullptr;
   std::atomic<uint32_t> epoch_{1};
+  std::atomic<bool> has_claim_{false};
 
   mutable std::mutex stat_mu_;
   CacheCounters counters_;
@@ -144,9 +149,11 @@ class EmbeddingCache {
   // Async-insert mode of a direct cache: snapshot the calling session's unique missed keys (enqueued on the session's
   // stream) and fetch + insert them on the cache's own stream, no host thread involved.  Best effort like the host
   // inserter: *accepted = false when the previous job is still running (the batch's misses stay uncached).
+  // d_acc_tables / h_acc_tables_override: the T per-table lines of a call's accumulator block (device_types.h); the
+  // override (pinned host memory) carries the async tables' counts only when the call is mixed.
   Status SubmitDirectInsert(hipStream_t session_stream, const uint64_t* d_key_start, const int64_t* d_uniq_keys,
-                            const uint32_t* d_counts, const uint32_t* h_counts_override /*pinned, optional*/, uint64_t N,
-                            uint64_t unique_total, uint64_t staging_floats, bool* accepted);
+                            const uint32_t* d_acc_tables, const uint32_t* h_acc_tables_override /*pinned, optional*/,
+                            uint64_t N, uint64_t unique_total, uint64_t staging_floats, bool* accepted);
 
  private:
   struct DirectInserter;
@@ -197,15 +204,18 @@ class LookupSession {
   uint64_t last_miss_count() const { return last_misses_; }
   uint64_t last_unique_miss_count() const { return last_unique_; }
   bool last_call_async() const { return last_async_; }
-  float last_gpu_ms() const { return last_gpu_ms_; }      // probe+gather kernel time of the last call (HIP events)
-  float last_gather_ms() const { return last_gather_ms_; }  // hit-gather kernel of a split call (0 otherwise)
+  uint64_t last_unique_key_count() const { return last_unique_keys_; }  // 0 unless the policy needed it
+  float last_gpu_ms() const { return last_gpu_ms_; }      // probe + miss-unique kernels of the last call (HIP events)
+  float last_gather_ms() const { return last_gather_ms_; }  // hit-gather kernel of the last call
   void set_split_probe(bool b) { split_probe_ = b; }
+  void set_xcd_walk(bool b) { xcd_walk_ = b; }
+  float last_key_stage_ms() const { return key_stage_ms_; }
+  void set_keys_pinned_check(bool b) { keys_pinned_hint_ = b ? 1 : 0; }
   float last_gpu_call_ms() const { return last_gpu_call_ms_; }  // first kernel to last of the last call (HIP events)
   // host wall-clock phases of the last call (ms): [0] enqueue -> miss counts known, [1] parameter-server
   // gather, [2] H2D + scatter + insert until the stream drained, [3] whole call
   const float* last_phase_ms() const { return phase_ms_; }
-  void set_probe_unroll(int u) { probe_unroll_ = u; }
-  void set_probe_balanced(bool b) { probe_balanced_ = b; }
+  void set_probe_variant(int v) { probe_variant_ = v; }
   void set_force_host_gather(bool b) { force_host_gather_ = b; }
   void set_timing(bool on) { timing_ = on; }
   // per-session override of the model's hit_rate_threshold (sync vs async insertion, docs/architecture.md:65-67)
@@ -221,7 +231,8 @@ class LookupSession {
   Status HandleMisses(uint64_t N, uint32_t epoch);
   Status HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts_known, const uint32_t* d_table_mode);
   std::vector<uint8_t> table_async_;   // this call: 1 = the table's misses are served in async-insert mode
-  uint32_t* h_mode_ = nullptr;         // pinned: [0, kMaxTables) per-table mode words, then 1 + kMaxTables job counts
+  uint32_t* h_mode_ = nullptr;         // pinned: [0, kMaxTables) per-table mode words, then kMaxTables accumulator lines
+                                       // (the async tables' unique counts of a mixed call, for the background inserter)
   Status EnsureStaging(size_t floats, size_t uniq);
   void Release();
 
@@ -234,47 +245,54 @@ class LookupSession {
   hipStream_t copy_stream_ = nullptr;  // second H2D queue for the missed-row pieces
   hipEvent_t ev_copy_ = nullptr;
   hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr,
-             ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr, ev_probe_ = nullptr;
+             ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr, ev_probe_ = nullptr, ev_keys_ = nullptr;
   float last_gpu_call_ms_ = 0.f;
+  float key_stage_ms_ = 0.f;      // host side of lookup(): staging the keys and enqueueing their H2D copies
+  int keys_pinned_hint_ = 1;      // 1: flat key arrays in page-locked memory are DMA'd in place (option "keys_pinned_check")
   Status TimedLookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T);
 
   size_t max_keys_ = 0;           // max_batch * sum(maxnum_catfeature)
+  size_t max_tiles_ = 0;          // max_keys_ / kTileKeys + T (tiles never straddle tables)
   int64_t* h_keys_pinned_ = nullptr;
   int64_t* d_keys_ = nullptr;
-  CallDesc* h_call_ = nullptr;    // pinned
-  CallDesc* d_call_ = nullptr;
-  CallDesc* h_call_probe_ = nullptr;   // split probe: the same call with null output pointers (K_A probes only)
-  CallDesc* d_call_probe_ = nullptr;
-  hipEvent_t ev_g0_ = nullptr, ev_g1_ = nullptr;   // around the hit-gather kernel of a split call
+  // The call block: CallDesc | accumulator block (zeros) | TileDesc[max_tiles_], one pinned image and one device
+  // copy, uploaded with ONE H2D copy per call (every extra small copy or memset is a blit kernel on the stream).
+  char* h_block_ = nullptr;       // pinned
+  char* d_block_ = nullptr;
+  size_t block_acc_off_ = 0, block_tiles_off_ = 0, acc_words_ = 0;
+  CallDesc* h_call_ = nullptr;    // = h_block_
+  CallDesc* d_call_ = nullptr;    // = d_block_
+  TileDesc* h_tiles_ = nullptr;
+  uint32_t* d_acc_ = nullptr;
+  uint32_t* h_acc_ = nullptr;     // pinned mirror the accumulator block is copied back to
+  CallWork work_{};               // device pointers of the per-call work arrays
+  uint32_t* d_mode_ = nullptr;    // per-table insertion mode of a mixed call (1 = async)
+  uint32_t call_tag_ = 0;
+  hipEvent_t ev_g0_ = nullptr, ev_g1_ = nullptr;   // around the hit-gather kernel
   float last_gather_ms_ = 0.f;
-  bool split_call_ = false;      // the call in progress is split (HandleMisses routes its copies accordingly)
-  bool split_probe_ = true;      // host-gather tier: probe only, start the miss path, gather the hits meanwhile (§3.4c);
-                                 // HPS_SPLIT_PROBE=0 / session option split_probe=0 keep the fused kernel
+  bool split_call_ = false;      // the call in progress gathers its hits on stream_ while the miss path runs (copies go down copy_stream_)
+  bool split_probe_ = true;      // host-gather tier: start the miss path behind the probe, gather the hits meanwhile (§3.4c);
+                                 // HPS_SPLIT_PROBE=0 / session option split_probe=0: gather first, then the counts
+  bool xcd_walk_ = true;         // K_G: each XCD sweeps its own eighth of the key range (HPS_XCD_WALK=0: plain grid stride)
   MissDesc* h_md_ = nullptr;      // pinned
   MissDesc* d_md_ = nullptr;
-  int32_t* d_slot_ = nullptr;
-  uint32_t* d_block_miss_ = nullptr;
-  uint32_t probe_blocks_cap_ = 0;
-  int32_t* d_set_ = nullptr;
-  uint64_t set_cap_ = 0;
-  uint32_t* d_counts_ = nullptr;  // [0]=misses, [1..T]=unique misses per table, [T+1..T+3] insert stats
-  uint32_t* h_counts_ = nullptr;  // pinned mirror
-  int64_t* d_uniq_keys_ = nullptr;
-  int64_t* h_uniq_keys_ = nullptr;        // pinned, device-mapped
-  int64_t* h_uniq_keys_devptr_ = nullptr; // device view of the same memory
+  int64_t* h_uniq_keys_ = nullptr;        // pinned, device-mapped (work_.uniq_keys_host is its device view)
+  std::vector<uint32_t> uniq_miss_;       // this call: unique missed keys per table
   float* h_staging_ = nullptr;    // pinned
   float* d_staging_ = nullptr;
   uint8_t* h_found_ = nullptr;    // pinned
   uint8_t* d_found_ = nullptr;
   size_t staging_floats_ = 0, staging_uniq_ = 0;
+  Status PrepareCall(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T, bool probe_only, uint64_t* N_out);
+  Status ReadBackCounts(size_t T, uint64_t N, bool exact);
+  void AddInsertStats();
 
-  uint64_t last_misses_ = 0, last_unique_ = 0;
+  uint64_t last_misses_ = 0, last_unique_ = 0, last_unique_keys_ = 0;
   bool last_async_ = false;
   float last_gpu_ms_ = 0.f;
   float phase_ms_[4] = {0, 0, 0, 0};
-  int probe_unroll_ = 1102;  // U=2, rolled key-group loop (8 waves/SIMD), LRU stamp on 1/4 of the hits (tools/kbench.py)
+  int probe_variant_ = 4;    // K_P: U + 100 * no_dedup (U bucket lines in flight per 16-lane group; tools/kbench.py)
   bool force_host_gather_ = false;  // option "host_gather": host-thread gather + H2D even on a ps_direct_access cache
-  bool probe_balanced_ = false;  // equal chunks per wave costs more in occupancy than the tail it removes (kbench A/B)
   bool timing_ = false;
 };
 

@@ -7,26 +7,27 @@
 
 namespace hps {
 
-uint32_t ProbeGridBlocks(uint64_t N, int cu_count, bool balanced = false);
+uint32_t GatherGridBlocks(uint64_t N, int cu_count);
 
-hipError_t LaunchProbeGather(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                             int32_t* d_slot, uint32_t* d_block_miss, uint32_t grid, int unroll, hipStream_t stream);
+// K_P: one workgroup per tile of w.tiles.  variant = U + 100 * no_dedup (U in {2,4,8}).  claim: hit representatives
+// mark their slot's claim word (tables[t].claim must be allocated) so that K_M can count the call's unique hit keys.
+hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
+                            hipStream_t stream);
+// K_M: call-wide unique missed keys per table (+ exact: unique hit keys) into w.acc / w.uniq_keys / w.rep_of / w.uidx_of
+hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, bool exact,
+                            hipStream_t stream);
 
-hipError_t LaunchMissDedup(const CallDesc* d_call, const uint64_t* h_key_start, uint32_t T, uint32_t probe_blocks,
-                           int32_t* d_slot, const uint32_t* d_block_miss, int32_t* d_set, uint64_t set_cap,
-                           uint32_t* d_counts, int64_t* d_uniq_keys, int64_t* uniq_keys_host_mapped, int cu_count,
-                           hipStream_t stream);
-
-// K_G: hit rows cache -> output from the slot indices a probe-only K_A left (d_call carries the output pointers).
+// K_G: hit rows cache -> output from the slot indices K_P left (d_call carries the output pointers).
 hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, hipStream_t stream);
+                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream);
 
-hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tables, const MissDesc* d_md, uint64_t N,
-                             const int32_t* d_slot, const float* d_staging, int cu_count, hipStream_t stream);
+hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tables, const MissDesc* d_md, const CallWork& w,
+                             const float* d_staging, hipStream_t stream);
 
-hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, uint64_t N,
-                                 const int32_t* d_slot, const uint32_t* d_table_mode, int cu_count, hipStream_t stream);
+hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w,
+                                 const uint32_t* d_table_mode, hipStream_t stream);
 
+// d_stats: kStatLines lines of kAccStride words (insert statistics, see device_types.h)
 hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const MissDesc* d_md, uint64_t total_unique,
                              const uint64_t* d_key_start, const int64_t* d_uniq_keys, const float* d_staging,
                              const uint8_t* d_found, uint32_t epoch, uint32_t* d_stats, int cu_count,

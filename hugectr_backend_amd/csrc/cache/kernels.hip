@@ -1,18 +1,19 @@
 // HIP kernels of the GPU embedding cache, written for gfx950 (MI355X, wave64, 256 CUs / 8 XCDs).
 //
 // There is nothing to port: /root/reference contains no device code; the kernels are
-// defined by function, from docs/hierarchical_parameter_server.md:65-78 (dedup -> cache query -> miss ->
+// defined by function, from docs/hierarchical_parameter_server.md:65-78 (unique keys -> cache query -> miss ->
 // parameter server -> insert) and the north star in BASELINE.json.
 //
-//   K_A  hps_probe_gather      fused cache probe + hit-row gather           HBM-bound, the roofline kernel
-//   K_B0 hps_miss_begin        sum per-block miss counts, clear dedup set
-//   K_B1 hps_miss_dedup        unique missed keys per table (hash set + block prefix sum)
-//   K_B2 hps_miss_resolve      duplicates pick up their representative's index
-//   K_C1 hps_miss_scatter      missed rows: staging -> output
+//   K_P  hps_probe_tile        per tile of 1,024 keys of one table: input dedup in LDS, one bucket probe per
+//                              tile-unique key, slot index for every key, the tile's miss lists      (HBM, latency)
+//   K_M  hps_miss_unique       call-wide unique missed keys per table from the tiles' short miss lists;
+//                              optional exact count of the call's unique hit keys (insertion policy)
+//   K_G  hps_gather_hits       hit rows cache -> output from the slot indices   HBM-bound, the roofline kernel
+//   K_C1 hps_miss_scatter      missed rows: staging -> output (walks the tiles' miss lists, not the slot array)
 //   K_C2 hps_cache_insert      unique missed (key,row) -> bucket, LRU victim claimed by CAS
 //   K_D  hps_miss_fill_default async-insert mode: missed rows = default vector
 //
-// Work decomposition everywhere: one 16-lane group per key (4 keys per wave at a time).  A 16-lane group
+// Work decomposition of every row mover: one 16-lane group per key (4 keys per wave at a time).  A 16-lane group
 // reads one 128-B key bucket with a single 8-B load per lane and moves a D=128 row as 2 x 16 B per lane
 // (two fully coalesced 256-B segments), so every HBM request is a whole number of 64/128-B lines.
 #include <hip/hip_runtime.h>
@@ -39,43 +40,29 @@ __device__ __forceinline__ int find_table(const uint64_t* ks, int T, uint64_t i)
   return lo;
 }
 
-__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
-  const int lo = __shfl((int)(uint32_t)(uint64_t)v, src, 64);
-  const int hi = __shfl((int)(uint32_t)((uint64_t)v >> 32), src, 64);
-  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
   return ((uint64_t)uniform_u32((uint32_t)(v >> 32)) << 32) | uniform_u32((uint32_t)v);
 }
 
-// Per-table values every probe step needs; kept in LDS once per block.
+// Per-table values the gather kernel needs; kept in LDS once per block.
 struct __attribute__((aligned(16))) TableLds {
-  const int64_t* bucket_keys;
-  uint32_t* stamps;
   const float* rows;
   float* out;          // output slice of this table for this call
   uint64_t key_start;  // first global key index of this table
-  uint32_t num_buckets;
   uint32_t dim;
-  uint32_t flags;      // bit0 static cache, bit1 vec_ok
-  uint32_t pad;
+  uint32_t flags;      // bit1 vec_ok
 };
 
 __device__ __forceinline__ void load_tables_to_lds(TableLds* sh, uint64_t* sh_ks, const CallDesc* call,
                                                    const TableCacheDev* tables, int T) {
   for (int t = threadIdx.x; t < T; t += blockDim.x) {
     TableLds e;
-    e.bucket_keys = tables[t].bucket_keys;
-    e.stamps = tables[t].stamps;
     e.rows = tables[t].rows;
     e.out = call->out[t];
     e.key_start = call->key_start[t];
-    e.num_buckets = tables[t].num_buckets;
     e.dim = tables[t].dim;
-    e.flags = (tables[t].flags & 1u) | (call->vec_ok[t] ? 2u : 0u);
-    e.pad = 0;
+    e.flags = call->vec_ok[t] ? 2u : 0u;
     sh[t] = e;
   }
   for (int t = threadIdx.x; t <= T; t += blockDim.x) sh_ks[t] = call->key_start[t];
@@ -102,360 +89,300 @@ __device__ __forceinline__ void copy_row(const float* __restrict__ src, float* _
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K_A  fused probe + gather.
-// Each wave owns 64 consecutive keys per iteration (one coalesced 512-B key load); the 16 keys of
-// each quarter are then walked by that quarter's 16-lane group, kUnroll keys at a time so that
-// kUnroll bucket loads and then 2*kUnroll row loads per lane are in flight together.
-// Algorithmic bytes per key: 8 (key) + 4D (row read) + 4D (row write).
-// Overhead traffic: 128-B bucket line per key, 4-B slot index write, 4-B stamp write per hit.
-// ------------------------------------------------------------------------------------------------
-template <int U>
-struct ProbeGroup {  // one key group in flight: keys, their tables, bucket ids and the loaded bucket lane
-  int64_t k[U];
-  int tt[U];
-  uint32_t b[U];
-  int64_t bk[U];
-};
-
-// kOuter: unroll factor of the loop over the 16/kUnroll key groups of a chunk (1 = rolled: fewer VGPRs,
-// more waves per SIMD; 16/kUnroll = fully unrolled: the compiler overlaps consecutive groups;
-// 0 = rolled and software-pipelined by hand: next group's bucket loads issued before this group's rows).
-// kStampShift: the LRU stamp of a hit slot is rewritten for 1 in 2^kStampShift hits (hashed on key and
-// epoch): a blind 4-B store per hit is a read-modify-write of a whole DRAM sector.
-template <int kUnroll, int kOuter, int kStampShift>
-__global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_gather_kernel(
-    const CallDesc* __restrict__ call, const TableCacheDev* __restrict__ tables,
-    int32_t* __restrict__ slot_out, uint32_t* __restrict__ block_miss) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int T = (int)call->num_tables;
-  TableLds* sh_tab = reinterpret_cast<TableLds*>(smem);
-  uint64_t* sh_ks = reinterpret_cast<uint64_t*>(smem + sizeof(TableLds) * (size_t)T);
-  uint32_t* sh_cnt = reinterpret_cast<uint32_t*>(sh_ks + (T + 1));
-  load_tables_to_lds(sh_tab, sh_ks, call, tables, T);
-  __syncthreads();
-
-  const uint64_t N = call->total_keys;
-  const uint32_t epoch = call->epoch;
-  const int64_t* __restrict__ keys = call->keys;
+// Wave-aggregated append to a list whose fill count lives in LDS: every lane with `take` gets a distinct position.
+// Must be called by all lanes of the wave (take = false for lanes with nothing to append).
+__device__ __forceinline__ uint32_t lds_append(uint32_t* sh_count, bool take) {
+  const uint64_t bal = __ballot(take);
+  if (bal == 0) return 0;
   const int lane = lane_id();
-  const int g = lane >> 4;    // which 16-lane group of the wave
-  const int lig = lane & 15;  // lane in group
-  const uint64_t waves_total = (uint64_t)gridDim.x * (kProbeBlockThreads / 64);
-  const uint64_t wave_global = (uint64_t)blockIdx.x * (kProbeBlockThreads / 64) + (threadIdx.x >> 6);
-  const uint64_t chunks = (N + 63) / 64;
-  uint32_t my_misses = 0;
+  const int leader = __builtin_ctzll(bal);
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(sh_count, (uint32_t)__popcll(bal));
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  return base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+}
 
-  for (uint64_t chunk = wave_global; chunk < chunks; chunk += waves_total) {
-    const uint64_t i = chunk * 64 + (uint64_t)lane;
-    const bool valid = i < N;
-    const int64_t key = valid ? keys[i] : HPS_EMPTY_KEY;
-    // table of this lane's key: search once per wave, walk forward for lanes past a table boundary
-    const int t0 = (int)uniform_u32((uint32_t)find_table(sh_ks, T, chunk * 64));
-    int t = t0;
-    if (valid) { while (i >= sh_ks[t + 1]) ++t; }
-    int32_t my_slot = kSlotMiss;
-    // every lane hashes its OWN key once (64 hashes per chunk in one pass); the groups then pick the bucket
-    // index up with one cross-lane read instead of re-hashing the shuffled key in all 16 lanes of every step
-    const uint32_t my_bucket = hps_bucket_of(key, sh_tab[t].num_buckets);
+// ------------------------------------------------------------------------------------------------
+// K_P: probe, one workgroup per tile (<= kTileKeys consecutive keys of one table).
+//   1. keys -> LDS (coalesced), one hash per key: high half = cache bucket, low bits = LDS set position
+//   2. kDedup: tile-local input dedup — 32-bit LDS CAS claims a set entry with the key's tile-local index;
+//      a key that finds an equal key there takes that key as its representative.  Under the Zipf-like
+//      distributions of recommender traffic a third to a half of a tile's keys are duplicates.
+//   3. representatives only: 16-lane group per key, kU independent 128-B bucket lines in flight per group
+//      (the probe is latency-bound: bytes in flight decide its speed, not bandwidth)
+//   4. every key takes its representative's result: slot[i] >= 0, or -2 - m with m the representative's position in
+//      the tile's miss list; the lists the later kernels walk (missed representatives' keys, missed keys as sent,
+//      kClaim: hit representatives) are compacted in the tile's own region — no global atomic in this kernel.
+// kClaim (insertion policy needs the call's unique-key count): a hit representative writes its global key index
+// into the slot's claim word; after the kernel exactly one representative per distinct slot still finds its own
+// index there (K_M counts those).  Plain stores, no atomics.
+// Algorithmic bytes per key: 8 (key) + 4 (slot); overhead: one 128-B bucket line per tile-unique key.
+// ------------------------------------------------------------------------------------------------
+template <bool kDedup, bool kClaim, int kU>
+__global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(const CallDesc* __restrict__ call,
+                                                                            const TableCacheDev* __restrict__ tables,
+                                                                            const CallWork w) {
+  __shared__ int64_t sh_key[kTileKeys];
+  __shared__ uint32_t sh_bkt[kTileKeys];
+  __shared__ uint32_t sh_set[kDedup ? kTileSet : 1];
+  __shared__ uint16_t sh_rep[kTileKeys];
+  __shared__ int32_t sh_slot[kTileKeys];
+  __shared__ uint16_t sh_list[kTileKeys];
+  __shared__ uint32_t sh_cnt[4];  // representatives, missed representatives, missed keys as sent, hit representatives
 
-    // The body is instantiated twice: `uniform` = all 64 keys of the chunk belong to one table (every chunk
-    // except the ones that straddle a table boundary): the table descriptor sits in scalar registers, no
-    // per-key LDS reads and no table-id shuffle.
-    auto run = [&](auto uniform_tag, const TableLds& du) {
-      constexpr bool kUniform = decltype(uniform_tag)::value;
-      // phase 1 of a key group: kUnroll independent bucket-line loads
-      auto issue = [&](int jb, ProbeGroup<kUnroll>& G) {
+  const uint32_t tile = blockIdx.x;
+  const TileDesc td = w.tiles[tile];
+  const TableCacheDev tb = tables[td.table];
+  const uint32_t n = td.count;
+  const uint32_t tid = threadIdx.x;
+  const int64_t* __restrict__ keys = call->keys + td.begin;
+  const uint32_t epoch = call->epoch;
+  constexpr int kPerThread = kTileKeys / kProbeBlockThreads;
+
+  if (tid < 4) sh_cnt[tid] = 0;
+  if (kDedup) {
+    for (uint32_t e = tid; e < (uint32_t)kTileSet; e += kProbeBlockThreads) sh_set[e] = 0xFFFFFFFFu;
+  }
+  int64_t k[kPerThread];
+  uint32_t hlo[kPerThread];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int src = g * 16 + jb + u;
-          G.k[u] = shfl_i64(key, src);
-          G.b[u] = (uint32_t)__shfl((int)my_bucket, src, 64);
-          if (kUniform) {
-            G.tt[u] = 0;
-            G.bk[u] = du.bucket_keys[(uint64_t)G.b[u] * kBucketSlots + lig];
-          } else {
-            G.tt[u] = __shfl(t, src, 64);
-            G.bk[u] = sh_tab[G.tt[u]].bucket_keys[(uint64_t)G.b[u] * kBucketSlots + lig];
-          }
-        }
-      };
-      // phases 2-4: compare + group ballot -> slot; row loads; streaming stores (hit rows only)
-      auto finish = [&](int jb, const ProbeGroup<kUnroll>& G) {
-        int32_t s[kUnroll];
+  for (int q = 0; q < kPerThread; ++q) {
+    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    k[q] = j < n ? keys[j] : HPS_EMPTY_KEY;
+  }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const bool match = (G.bk[u] == G.k[u]) && (G.k[u] != HPS_EMPTY_KEY);
-          const uint64_t m = __ballot(match);
-          const uint32_t m16 = (uint32_t)(m >> (g * 16)) & 0xFFFFu;
-          s[u] = m16 ? (int32_t)(G.b[u] * kBucketSlots + (uint32_t)__builtin_ctz(m16)) : kSlotMiss;
-        }
+  for (int q = 0; q < kPerThread; ++q) {
+    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    const uint64_t h = hps_mix64((uint64_t)k[q]);
+    hlo[q] = (uint32_t)h;
+    if (j < n) {
+      sh_key[j] = k[q];
+      sh_bkt[j] = (uint32_t)(((h >> 32) * (uint64_t)tb.num_buckets) >> 32);  // == hps_bucket_of(key, num_buckets)
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. representatives ----
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int src = g * 16 + jb + u;
-          if (s[u] >= 0) {
-            const TableLds& d = kUniform ? du : sh_tab[G.tt[u]];
-            const uint32_t D = d.dim;
-            const uint64_t gi = chunk * 64 + (uint64_t)src;
-            const float* row = d.rows + (uint64_t)(uint32_t)s[u] * D;
-            float* dst = d.out + (gi - d.key_start) * D;
-            // out == nullptr: probe-only call (the fused lookup+interaction path reads the rows from the slots itself)
-            if (d.out != nullptr) copy_row<true>(row, dst, D, lig, (d.flags & 2u) != 0);
-            if (lig == 0 && !(d.flags & 1u)) {
-              bool touch = true;
-              if (kStampShift > 0)
-                touch = ((((uint32_t)s[u] * 0x9E3779B1u + epoch * 0x85EBCA6Bu) >> 13) & ((1u << kStampShift) - 1u)) == 0u;
-              if (touch) d.stamps[(uint32_t)s[u]] = epoch;
-            }
-          }
-          if (lane == src) my_slot = s[u];
-        }
-      };
-      if (kOuter == 0) {
-        // rolled + software-pipelined: the bucket loads of group j+1 are in flight while group j's rows move
-        ProbeGroup<kUnroll> cur, nxt;
-        issue(0, cur);
-#pragma unroll 1
-        for (int jb = 0; jb < 16; jb += kUnroll) {
-          if (jb + kUnroll < 16) issue(jb + kUnroll, nxt);
-          finish(jb, cur);
-          cur = nxt;
-        }
-      } else {
-#pragma unroll(kOuter > 0 ? kOuter : 1)
-        for (int jb = 0; jb < 16; jb += kUnroll) {
-          ProbeGroup<kUnroll> G;
-          issue(jb, G);
-          finish(jb, G);
-        }
+  for (int q = 0; q < kPerThread; ++q) {
+    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    uint32_t rep = j;
+    if (kDedup && j < n) {
+      uint32_t e = hlo[q] & (uint32_t)(kTileSet - 1);
+      for (;;) {
+        const uint32_t prev = atomicCAS(&sh_set[e], 0xFFFFFFFFu, j);
+        if (prev == 0xFFFFFFFFu) break;
+        if (sh_key[prev] == k[q]) { rep = prev; break; }
+        e = (e + 1) & (uint32_t)(kTileSet - 1);
       }
-    };
-    const uint64_t chunk_last = (chunk * 64 + 63 < N ? chunk * 64 + 63 : N - 1);
-    if (chunk_last < sh_ks[t0 + 1]) {
-      TableLds du;  // wave-uniform copy in scalar registers
-      du.bucket_keys = reinterpret_cast<const int64_t*>(uniform_u64((uint64_t)sh_tab[t0].bucket_keys));
-      du.stamps = reinterpret_cast<uint32_t*>(uniform_u64((uint64_t)sh_tab[t0].stamps));
-      du.rows = reinterpret_cast<const float*>(uniform_u64((uint64_t)sh_tab[t0].rows));
-      du.out = reinterpret_cast<float*>(uniform_u64((uint64_t)sh_tab[t0].out));
-      du.key_start = uniform_u64(sh_tab[t0].key_start);
-      du.num_buckets = uniform_u32(sh_tab[t0].num_buckets);
-      du.dim = uniform_u32(sh_tab[t0].dim);
-      du.flags = uniform_u32(sh_tab[t0].flags);
-      du.pad = 0;
-      run(std::true_type{}, du);
-    } else {
-      run(std::false_type{}, sh_tab[t0]);
     }
-    if (valid) {
-      slot_out[i] = my_slot;
-      my_misses += (my_slot < 0) ? 1u : 0u;
+    const bool is_rep = j < n && rep == j;
+    if (j < n) sh_rep[j] = (uint16_t)rep;
+    const uint32_t pos = lds_append(&sh_cnt[0], is_rep);
+    if (is_rep) sh_list[pos] = (uint16_t)j;
+  }
+  __syncthreads();
+
+  // ---- 3. one bucket probe per representative ----
+  const uint32_t nrep = sh_cnt[0];
+  const int lane = lane_id();
+  const int g16 = (int)(tid >> 4), gw = lane >> 4, lig = lane & 15;
+  for (uint32_t r0 = (uint32_t)g16 * kU; r0 < nrep; r0 += (kProbeBlockThreads / 16) * kU) {
+    uint32_t jj[kU], bb[kU];
+    int64_t bk[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const uint32_t r = r0 + u < nrep ? r0 + u : r0;
+      jj[u] = sh_list[r];
+      bb[u] = sh_bkt[jj[u]];
+      bk[u] = tb.bucket_keys[(uint64_t)bb[u] * kBucketSlots + lig];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t key = sh_key[jj[u]];
+      const bool match = bk[u] == key && key != HPS_EMPTY_KEY;
+      const uint32_t m16 = (uint32_t)(__ballot(match) >> (gw * 16)) & 0xFFFFu;
+      if (lig == 0 && r0 + u < nrep) {
+        int32_t s = kSlotMiss;
+        if (m16) {
+          s = (int32_t)(bb[u] * kBucketSlots + (uint32_t)__builtin_ctz(m16));
+          if (!(tb.flags & 1u)) {
+            // the LRU stamp is rewritten for 1 hit in 4 (hashed on slot and epoch): a blind 4-B store per hit is a
+            // read-modify-write of a whole DRAM sector
+            if (((((uint32_t)s * 0x9E3779B1u + epoch * 0x85EBCA6Bu) >> 13) & 3u) == 0u) tb.stamps[(uint32_t)s] = epoch;
+          }
+          if (kClaim) tb.claim[(uint32_t)s] = (uint32_t)(td.begin + jj[u]);
+        }
+        sh_slot[jj[u]] = s;
+      }
     }
   }
-
-  // per-block miss count (plain store; K_B0 sums them — no contended atomics on the hot path)
-  uint32_t w = my_misses;
-  for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
-  if (lane == 0) sh_cnt[threadIdx.x >> 6] = w;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-    for (int q = 0; q < kProbeBlockThreads / 64; ++q) tot += sh_cnt[q];
-    block_miss[blockIdx.x] = tot;
+
+  // ---- 4a. missed representatives take their place in the tile's miss list; hit representatives are listed ----
+  const uint32_t region = tile * (uint32_t)kTileKeys;
+#pragma unroll
+  for (int q = 0; q < kPerThread; ++q) {
+    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    const bool is_rep = j < n && sh_rep[j] == (uint16_t)j;
+    const int32_t s = is_rep ? sh_slot[j] : 0;
+    const bool miss = is_rep && s < 0;
+    const uint32_t pos = lds_append(&sh_cnt[1], miss);
+    if (miss) {
+      w.miss_key[region + pos] = k[q];
+      sh_slot[j] = -2 - (int32_t)(region + pos);
+    }
+    if (kClaim) {
+      const bool hit = is_rep && s >= 0;
+      const uint32_t hp = lds_append(&sh_cnt[3], hit);
+      if (hit) w.hit_i[region + hp] = (int32_t)(td.begin + j);
+    }
+  }
+  __syncthreads();
+  // ---- 4b. every key takes its representative's result ----
+#pragma unroll
+  for (int q = 0; q < kPerThread; ++q) {
+    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    const int32_t s = j < n ? sh_slot[sh_rep[j]] : 0;
+    if (j < n) w.slot[td.begin + j] = s;
+    const uint32_t pos = lds_append(&sh_cnt[2], s < 0);
+    if (s < 0) w.sent_i[region + pos] = (int32_t)(td.begin + j);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    w.tile_cnt[tile * 4 + kTileCntRepMiss] = sh_cnt[1];
+    w.tile_cnt[tile * 4 + kTileCntSentMiss] = sh_cnt[2];
+    w.tile_cnt[tile * 4 + kTileCntRepHit] = kClaim ? sh_cnt[3] : 0u;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K_B0: every block sums the per-block miss counts of K_A (a few KB, L2-resident), block 0 publishes
-// the total; when there are misses the dedup hash set is cleared (grid-stride) and the per-table
-// unique counters are zeroed.
-// counts layout: [0] = total misses of the call, [1 .. T] = unique misses per table.
+// K_M: call-wide unique missed keys per table.  One workgroup per tile walks the tile's missed representatives
+// (a few dozen at 95 % hit): each claims an entry of the session's open-addressing set with a 64-bit CAS on
+// (call tag, m); an entry carrying another call's tag is free, so the set is never cleared.  The winner is the
+// representative of its (table, key) for the whole call: winners are ranked inside the block and the block takes
+// its range of the table's unique segment with ONE atomic on the table's own accumulator line.  A loser learns
+// the winner's m from the CAS and records it (rep_of).  Unique keys go to HBM and, zero-copy, to the pinned host
+// array the parameter-server threads read.
+// kExact: also counts the tile's hit representatives that still own their slot's claim word (one per distinct
+// slot over the whole call): the call's unique hit keys per table.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* sh) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  uint32_t tot = 0;
-  for (unsigned q = 0; q < (blockDim.x + 63) / 64; ++q) tot += sh[q];
-  __syncthreads();
-  return tot;
-}
-
-__global__ __launch_bounds__(256) void hps_miss_begin_kernel(const uint32_t* __restrict__ block_miss,
-                                                              uint32_t probe_blocks, int32_t* __restrict__ set,
-                                                              uint64_t set_cap, uint32_t* __restrict__ counts,
-                                                              uint32_t T) {
-  __shared__ uint32_t sh[4];
-  uint32_t v = 0;
-  for (uint32_t b = threadIdx.x; b < probe_blocks; b += blockDim.x) v += block_miss[b];
-  const uint32_t total = block_sum_u32(v, sh);
-  if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) counts[0] = total;
-    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) { counts[1 + t] = 0; counts[kTableMissBase + t] = 0; }
-  }
-  if (total == 0) return;
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < set_cap;
-       e += (uint64_t)gridDim.x * blockDim.x)
-    set[e] = -1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K_B1: unique missed keys per table.  Blocks are aligned to tables (a block never straddles two
-// tables), one key per thread.  A missed key claims a slot of the open-addressing set with CAS on
-// the key's global index; the winner is the representative.  Winners are ranked inside the block
-// (ballot + LDS prefix) and the block takes its range of the table's unique segment with ONE atomic.
-// Representative i gets slot_out[i] = -2 - uidx and publishes its key at uniq_keys[key_start[t]+uidx]
-// (device copy) and in the host-mapped pinned mirror the parameter-server threads read.
-// ------------------------------------------------------------------------------------------------
-constexpr int kDedupBlock = 1024;
-
 __device__ __forceinline__ uint64_t set_hash(int64_t key, uint32_t t) {
   return hps_mix64((uint64_t)key ^ ((uint64_t)(t + 1) * 0xD6E8FEB86659FD93ull));
 }
 
-// block -> (table, first key) for table-aligned 1-D grids of `per_block` keys
-__device__ __forceinline__ bool block_to_table(const CallDesc* call, uint32_t per_block, uint32_t* t_out,
-                                               uint64_t* begin_out, uint64_t* end_out) {
-  uint64_t b = blockIdx.x;
-  const uint32_t T = call->num_tables;
-  for (uint32_t t = 0; t < T; ++t) {
-    const uint64_t n = call->key_start[t + 1] - call->key_start[t];
-    const uint64_t nb = (n + per_block - 1) / per_block;
-    if (b < nb) {
-      *t_out = t;
-      *begin_out = call->key_start[t] + b * per_block;
-      const uint64_t e = *begin_out + per_block;
-      *end_out = e < call->key_start[t + 1] ? e : call->key_start[t + 1];
-      return true;
-    }
-    b -= nb;
-  }
-  return false;
-}
-
-__global__ __launch_bounds__(kDedupBlock) void hps_miss_dedup_kernel(
-    const CallDesc* __restrict__ call, int32_t* __restrict__ slot_io, int32_t* __restrict__ set, uint64_t set_cap,
-    uint32_t* __restrict__ counts, int64_t* __restrict__ uniq_keys_dev, int64_t* __restrict__ uniq_keys_host) {
-  if (counts[0] == 0) return;
-  uint32_t t;
-  uint64_t begin, end;
-  if (!block_to_table(call, kDedupBlock, &t, &begin, &end)) return;
-  const uint64_t i = begin + threadIdx.x;
-  const int64_t* __restrict__ keys = call->keys;
-  const uint64_t mask = set_cap - 1;
-
-  bool winner = false;
-  int64_t key = 0;
-  const bool missed = i < end && slot_io[i] == kSlotMiss;
-  if (missed) {
-    key = keys[i];
-    uint64_t h = set_hash(key, t) & mask;
-    for (;;) {
-      const int32_t prev = atomicCAS(&set[h], -1, (int32_t)i);
-      if (prev == -1) { winner = true; break; }
-      // same table is implied: entries of other tables hash with another salt but may still collide,
-      // so compare the owning range too
-      const uint64_t pi = (uint64_t)(uint32_t)prev;
-      if (pi >= call->key_start[t] && pi < call->key_start[t + 1] && keys[pi] == key) break;  // duplicate
-      h = (h + 1) & mask;
-    }
-  }
-  // rank winners inside the block
-  __shared__ uint32_t sh_wave[kDedupBlock / 64];
-  __shared__ uint32_t sh_miss[kDedupBlock / 64];
+template <bool kExact>
+__global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __restrict__ call,
+                                                               const TableCacheDev* __restrict__ tables, const CallWork w) {
+  const uint32_t tile = blockIdx.x;
+  const uint32_t M = w.tile_cnt[tile * 4 + kTileCntRepMiss];
+  const uint32_t S = w.tile_cnt[tile * 4 + kTileCntSentMiss];
+  const uint32_t H = kExact ? w.tile_cnt[tile * 4 + kTileCntRepHit] : 0u;
+  if ((M | S | H) == 0) return;
+  __shared__ uint32_t sh_wave[4];
   __shared__ uint32_t sh_base;
-  const uint64_t bal = __ballot(winner);
-  const uint64_t bal_miss = __ballot(missed);
+  const uint32_t t = w.tiles[tile].table;
+  const uint32_t region = tile * (uint32_t)kTileKeys;
+  const uint32_t tid = threadIdx.x;
   const int lane = lane_id();
-  const uint32_t rank_in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-  if (lane == 0) { sh_wave[threadIdx.x >> 6] = (uint32_t)__popcll(bal); sh_miss[threadIdx.x >> 6] = (uint32_t)__popcll(bal_miss); }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0, miss = 0;
-    for (int w = 0; w < kDedupBlock / 64; ++w) { const uint32_t c = sh_wave[w]; sh_wave[w] = run; run += c; miss += sh_miss[w]; }
-    sh_base = run ? atomicAdd(&counts[1 + t], run) : 0u;
-    // missed keys of the table, duplicates included: the per-table hit rate behind the insertion policy
-    if (miss) atomicAdd(&counts[kTableMissBase + t], miss);
+  const unsigned long long tag = (unsigned long long)w.call_tag << 32;
+  const uint64_t ks = call->key_start[t];
+
+  for (uint32_t r0 = 0; r0 < M; r0 += 256) {
+    const uint32_t r = r0 + tid;
+    const bool active = r < M;
+    const uint32_t m = region + r;
+    bool winner = false;
+    uint32_t rep = m;
+    int64_t key = 0;
+    if (active) {
+      key = w.miss_key[m];
+      uint64_t h = set_hash(key, t) & w.set_mask;
+      unsigned long long cur = __hip_atomic_load(&w.set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        if ((cur & 0xFFFFFFFF00000000ull) != tag) {  // free: left by an earlier call
+          const unsigned long long prev = atomicCAS(&w.set[h], cur, tag | m);
+          if (prev == cur) { winner = true; break; }
+          cur = prev;  // somebody took it meanwhile: look at what is there now
+          continue;
+        }
+        const uint32_t pm = (uint32_t)cur;
+        if (w.miss_key[pm] == key && w.tiles[pm / (uint32_t)kTileKeys].table == t) { rep = pm; break; }
+        h = (h + 1) & w.set_mask;
+        cur = __hip_atomic_load(&w.set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    const uint64_t bal = __ballot(winner);
+    const uint32_t rank_in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) sh_wave[tid >> 6] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t run = 0;
+      for (int q = 0; q < 4; ++q) { const uint32_t c = sh_wave[q]; sh_wave[q] = run; run += c; }
+      sh_base = run ? atomicAdd(&w.acc[AccTableWord(t, kAccUniqMiss)], run) : 0u;
+    }
+    __syncthreads();
+    if (active) {
+      w.rep_of[m] = (int32_t)rep;
+      if (winner) {
+        const uint32_t u = sh_base + sh_wave[tid >> 6] + rank_in_wave;
+        w.uidx_of[m] = (int32_t)u;
+        w.uniq_keys[ks + u] = key;
+        w.uniq_keys_host[ks + u] = key;  // zero-copy store into pinned host memory
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (winner) {
-    const uint32_t uidx = sh_base + sh_wave[threadIdx.x >> 6] + rank_in_wave;
-    slot_io[i] = -2 - (int32_t)uidx;
-    const uint64_t pos = call->key_start[t] + uidx;
-    uniq_keys_dev[pos] = key;
-    uniq_keys_host[pos] = key;  // zero-copy store into pinned host memory
+  if (kExact && H) {
+    const uint32_t* __restrict__ claim = tables[t].claim;
+    uint32_t mine = 0;
+    for (uint32_t r = tid; r < H; r += 256) {
+      const int32_t i = w.hit_i[region + r];
+      mine += claim[(uint32_t)w.slot[i]] == (uint32_t)i ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if (lane == 0) sh_wave[tid >> 6] = mine;
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t tot = sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
+      if (tot) atomicAdd(&w.acc[AccTableWord(t, kAccUniqHit)], tot);
+    }
   }
+  if (tid == 0 && S) atomicAdd(&w.acc[AccTableWord(t, kAccSentMiss)], S);
 }
 
-// K_B2: a duplicate finds its representative through the set and copies its encoded index.
-__global__ __launch_bounds__(kDedupBlock) void hps_miss_resolve_kernel(const CallDesc* __restrict__ call,
-                                                                        int32_t* __restrict__ slot_io,
-                                                                        const int32_t* __restrict__ set,
-                                                                        uint64_t set_cap,
-                                                                        const uint32_t* __restrict__ counts) {
-  if (counts[0] == 0) return;
-  uint32_t t;
-  uint64_t begin, end;
-  if (!block_to_table(call, kDedupBlock, &t, &begin, &end)) return;
-  const uint64_t i = begin + threadIdx.x;
-  if (i >= end) return;
-  const int32_t s = slot_io[i];
-  if (s != kSlotMiss) return;  // hit, or a representative (<= -2)
-  const int64_t* __restrict__ keys = call->keys;
-  const int64_t key = keys[i];
-  const uint64_t mask = set_cap - 1;
-  uint64_t h = set_hash(key, t) & mask;
-  for (;;) {
-    const int32_t e = set[h];
-    if (e < 0) return;  // cannot happen: every missed key has a representative
-    const uint64_t pi = (uint64_t)(uint32_t)e;
-    if (pi >= call->key_start[t] && pi < call->key_start[t + 1] && keys[pi] == key) {
-      // representative's slot was finalised by the previous kernel
-      slot_io[i] = slot_io[pi];
-      return;
-    }
-    h = (h + 1) & mask;
-  }
+// index of a missed key's row in its table's unique-miss segment (slot <= -2)
+__device__ __forceinline__ uint32_t miss_uidx(const CallWork& w, int32_t slot) {
+  const uint32_t m = (uint32_t)(-2 - slot);
+  return (uint32_t)w.uidx_of[(uint32_t)w.rep_of[m]];
 }
 
 // ------------------------------------------------------------------------------------------------
-// K_C1: missed rows staging -> output.  Scans the slot array 64 keys per wave; missed keys of the wave
-// are handed to the four 16-lane groups round-robin.
+// K_C1: missed rows staging -> output.  One workgroup per tile walks the tile's list of missed keys (as sent),
+// a 16-lane group per key; tiles without misses leave at once.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hps_miss_scatter_kernel(const CallDesc* __restrict__ call,
                                                                 const TableCacheDev* __restrict__ tables,
-                                                                const MissDesc* __restrict__ md,
-                                                                const int32_t* __restrict__ slot_in,
+                                                                const MissDesc* __restrict__ md, const CallWork w,
                                                                 const float* __restrict__ staging) {
-  const uint64_t N = call->total_keys;
-  const int T = (int)call->num_tables;
-  const int lane = lane_id();
-  const int g = lane >> 4, lig = lane & 15;
-  const uint64_t waves_total = (uint64_t)gridDim.x * 4;
-  const uint64_t chunks = (N + 63) / 64;
-  for (uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < chunks; chunk += waves_total) {
-    const uint64_t i = chunk * 64 + (uint64_t)lane;
-    const int32_t s = i < N ? slot_in[i] : 0;
-    uint64_t todo = __ballot(s <= -2);
-    while (todo) {
-      // group g takes the g-th set bit (if any)
-      uint64_t m = todo;
-      int src = -1;
-      for (int q = 0; q <= g && m; ++q) { src = __builtin_ctzll(m); m &= m - 1; }
-      const bool have = __popcll(todo) > g;
-      // drop up to 4 bits
-      for (int q = 0; q < 4 && todo; ++q) todo &= todo - 1;
-      const int32_t ss = __shfl(s, have ? src : 0, 64);
-      if (!have) continue;
-      const uint64_t gi = chunk * 64 + (uint64_t)src;
-      const int t = find_table(call->key_start, T, gi);
-      const uint32_t uidx = (uint32_t)(-2 - ss);
-      if (uidx < md->chunk_lo[t] || uidx >= md->chunk_hi[t]) continue;  // other chunk of this call
-      const uint32_t D = tables[t].dim;
-      const float* row = staging + md->stage_off[t] + (uint64_t)(uidx - md->chunk_lo[t]) * D;
-      float* dst = call->out[t] + (gi - call->key_start[t]) * D;
-      // staging rows are packed (offset multiple of D): vector path needs D%4==0 and aligned out
-      copy_row<true>(row, dst, D, lig, call->vec_ok[t] != 0 && (md->stage_off[t] & 3) == 0);
-    }
+  const uint32_t tile = blockIdx.x;
+  const uint32_t S = w.tile_cnt[tile * 4 + kTileCntSentMiss];
+  if (S == 0) return;
+  const uint32_t t = w.tiles[tile].table;
+  const uint32_t lo = md->chunk_lo[t], hi = md->chunk_hi[t];
+  if (hi == lo) return;  // table served in async mode, or nothing of it in this chunk
+  const uint32_t D = tables[t].dim;
+  const uint64_t stage_off = md->stage_off[t];
+  const bool vec = call->vec_ok[t] != 0 && (stage_off & 3) == 0;  // staging rows are packed (offset multiple of D)
+  float* __restrict__ out = call->out[t];
+  const uint64_t ks = call->key_start[t];
+  const uint32_t region = tile * (uint32_t)kTileKeys;
+  const int lig = (int)(threadIdx.x & 15);
+  for (uint32_t r = threadIdx.x >> 4; r < S; r += 16) {
+    const int32_t i = w.sent_i[region + r];
+    const uint32_t u = miss_uidx(w, w.slot[i]);
+    if (u < lo || u >= hi) continue;  // other chunk of this call
+    copy_row<true>(staging + stage_off + (uint64_t)(u - lo) * D, out + ((uint64_t)i - ks) * D, D, lig, vec);
   }
 }
 
@@ -463,41 +390,31 @@ __global__ __launch_bounds__(256) void hps_miss_scatter_kernel(const CallDesc* _
 // (docs/architecture.md:32, docs/hierarchical_parameter_server.md:244-246).
 __global__ __launch_bounds__(256) void hps_miss_fill_default_kernel(const CallDesc* __restrict__ call,
                                                                      const TableCacheDev* __restrict__ tables,
-                                                                     const int32_t* __restrict__ slot_in,
+                                                                     const CallWork w,
                                                                      const uint32_t* __restrict__ table_mode) {
   // table_mode (optional): per table 1 = async insert (fill its misses), 0 = synchronous (leave them to K_C1)
-  const uint64_t N = call->total_keys;
-  const int T = (int)call->num_tables;
-  const int lane = lane_id();
-  const int g = lane >> 4, lig = lane & 15;
-  const uint64_t waves_total = (uint64_t)gridDim.x * 4;
-  const uint64_t chunks = (N + 63) / 64;
-  for (uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < chunks; chunk += waves_total) {
-    const uint64_t i = chunk * 64 + (uint64_t)lane;
-    const int32_t s = i < N ? slot_in[i] : 0;
-    uint64_t todo = __ballot(s < 0);
-    while (todo) {
-      uint64_t m = todo;
-      int src = -1;
-      for (int q = 0; q <= g && m; ++q) { src = __builtin_ctzll(m); m &= m - 1; }
-      const bool have = __popcll(todo) > g;
-      for (int q = 0; q < 4 && todo; ++q) todo &= todo - 1;
-      if (!have) continue;
-      const uint64_t gi = chunk * 64 + (uint64_t)src;
-      const int t = find_table(call->key_start, T, gi);
-      if (table_mode && table_mode[t] == 0) continue;
-      const uint32_t D = tables[t].dim;
-      const float dv = tables[t].default_value;
-      float* dst = call->out[t] + (gi - call->key_start[t]) * D;
-      for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = dv;
-    }
+  const uint32_t tile = blockIdx.x;
+  const uint32_t S = w.tile_cnt[tile * 4 + kTileCntSentMiss];
+  if (S == 0) return;
+  const uint32_t t = w.tiles[tile].table;
+  if (table_mode && table_mode[t] == 0) return;
+  const uint32_t D = tables[t].dim;
+  const float dv = tables[t].default_value;
+  float* __restrict__ out = call->out[t];
+  const uint64_t ks = call->key_start[t];
+  const uint32_t region = tile * (uint32_t)kTileKeys;
+  const int lig = (int)(threadIdx.x & 15);
+  for (uint32_t r = threadIdx.x >> 4; r < S; r += 16) {
+    const int32_t i = w.sent_i[region + r];
+    float* dst = out + ((uint64_t)i - ks) * D;
+    for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = dv;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K_G: hit rows cache -> output from the slot indices of a probe-only K_A ("split probe": the miss path of the call —
-// PCIe-bound — starts right after the 75-us probe and runs while this HBM-bound kernel moves the hits).
-// Same decomposition as K_A: a wave takes 64 keys, each 16-lane group walks its 16 keys kU at a time; with the slots
+// K_G: hit rows cache -> output from the slot indices K_P left (the miss path of the call — PCIe-bound — starts
+// right after the probe and runs while this HBM-bound kernel moves the hits).
+// A wave takes 64 keys, each 16-lane group walks its 16 keys kU at a time; with the slots
 // known up front every row load is independent (no bucket -> row dependency).
 // Algorithmic bytes per key: 4 (slot) + 4D (row read) + 4D (row write) for hits, 4 for misses.
 // ------------------------------------------------------------------------------------------------
@@ -506,7 +423,7 @@ __global__ __launch_bounds__(256) void hps_miss_fill_default_kernel(const CallDe
 template <int kU, bool kFast>
 __global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(const CallDesc* __restrict__ call,
                                                                              const TableCacheDev* __restrict__ tables,
-                                                                             const int32_t* __restrict__ slot_in) {
+                                                                             const int32_t* __restrict__ slot_in, uint32_t xcd_walk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = (int)call->num_tables;
   TableLds* sh_tab = reinterpret_cast<TableLds*>(smem);
@@ -516,10 +433,18 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(con
   const uint64_t N = call->total_keys;
   const int lane = lane_id();
   const int g = lane >> 4, lig = lane & 15;
-  const uint64_t waves_total = (uint64_t)gridDim.x * (kProbeBlockThreads / 64);
-  const uint64_t wave_global = (uint64_t)blockIdx.x * (kProbeBlockThreads / 64) + (threadIdx.x >> 6);
   const uint64_t chunks = (N + 63) / 64;
-  for (uint64_t chunk = wave_global; chunk < chunks; chunk += waves_total) {
+  // XCD-aware walk (speed only; nothing depends on it): workgroup b is dispatched to XCD b % 8, so each XCD gets one
+  // contiguous eighth of the key range and its workgroups sweep it front to back together.  KEYS is table-major:
+  // at any moment an XCD's CUs then work inside one or two tables, and the rows the batch repeats (the hot head of
+  // a Zipf-like key distribution) are re-read from that XCD's own 4-MB L2 instead of thrashing all eight L2s with
+  // the hot sets of every table at once.
+  const uint32_t nx = (xcd_walk && gridDim.x >= 8) ? 8u : 1u;
+  const uint32_t xcd = blockIdx.x % nx, xb = blockIdx.x / nx;
+  const uint32_t blocks_x = (gridDim.x - xcd + nx - 1) / nx;
+  const uint64_t c_lo = chunks * xcd / nx, c_hi = chunks * (xcd + 1) / nx;
+  const uint64_t waves_x = (uint64_t)blocks_x * (kProbeBlockThreads / 64);
+  for (uint64_t chunk = c_lo + (uint64_t)xb * (kProbeBlockThreads / 64) + (threadIdx.x >> 6); chunk < c_hi; chunk += waves_x) {
     const uint64_t i = chunk * 64 + (uint64_t)lane;
     const int32_t s = i < N ? slot_in[i] : -1;
     int t = (int)uniform_u32((uint32_t)find_table(sh_ks, T, chunk * 64));
@@ -583,7 +508,7 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
                                                                 const int64_t* __restrict__ uniq_keys,
                                                                 const float* __restrict__ staging,
                                                                 const uint8_t* __restrict__ found, uint32_t epoch,
-                                                                uint32_t* __restrict__ stats) {
+                                                                uint32_t* __restrict__ stats /* kStatLines lines of kAccStride words */) {
   const uint64_t total = md->useg_start[T];
   const int lane = lane_id();
   const int g = lane >> 4, lig = lane & 15;
@@ -656,7 +581,8 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
     copy_row<false>(row, dst, D, lig, (D & 3u) == 0 && (md->stage_off[t] & 3) == 0);
     if (lig == 0) { if (present) ++n_refreshed; else ++n_inserted; }
   }
-  // one atomic per block and counter (a per-key atomic on one word serialises the whole launch)
+  // one atomic per block and counter, spread over kStatLines lines of the accumulator block: atomics on one
+  // 128-B line serialise at ~90 per microsecond, and 2,048 blocks x 3 counters on one line cost 70 us
   __shared__ uint32_t sh_stat[3][4];
   uint32_t c0 = n_dropped, c1 = n_inserted, c2 = n_refreshed;
   for (int off = 32; off > 0; off >>= 1) {
@@ -668,7 +594,7 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
   __syncthreads();
   if (threadIdx.x < 3) {
     const uint32_t v = sh_stat[threadIdx.x][0] + sh_stat[threadIdx.x][1] + sh_stat[threadIdx.x][2] + sh_stat[threadIdx.x][3];
-    if (v) atomicAdd(&stats[threadIdx.x], v);
+    if (v) atomicAdd(&stats[(blockIdx.x % (uint32_t)kStatLines) * (uint32_t)kAccStride + threadIdx.x], v);
   }
 }
 
@@ -707,101 +633,68 @@ __global__ void hps_cache_query_kernel(TableCacheDev tb, const int64_t* __restri
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static inline uint32_t probe_grid(uint64_t N, int cu_count) {
+// Grid of the gather kernel: every wave walks 64-key chunks, all blocks resident at once (8 blocks of 4 waves per CU).
+uint32_t GatherGridBlocks(uint64_t N, int cu_count) {
   const uint64_t chunks = (N + 63) / 64;
   const uint64_t want = (chunks + 3) / 4;
-  const uint64_t cap = (uint64_t)cu_count * 8;  // 8 blocks of 256 threads per CU
+  const uint64_t cap = (uint64_t)cu_count * 8;
   return (uint32_t)(want < cap ? (want ? want : 1) : cap);
 }
 
-// Grid of the probe/gather kernel.  Every wave walks 64-key chunks with stride = number of waves, and all
-// blocks are resident at once (<= 8 blocks of 4 waves per CU), so the launch ends when the waves with the
-// most chunks end.  balanced: pick the wave count so that every wave gets the same number of chunks
-// (config 2: 26,624 chunks -> 6,656 waves x 4 chunks) instead of filling the machine (8,192 waves, a quarter
-// of which run a 4th chunk while the rest of the chip idles).
-uint32_t ProbeGridBlocks(uint64_t N, int cu_count, bool balanced) {
-  if (!balanced) return probe_grid(N, cu_count);
-  const uint64_t chunks = (N + 63) / 64;
-  const uint64_t cap_waves = (uint64_t)cu_count * 8 * (kProbeBlockThreads / 64);
-  if (chunks <= cap_waves) return probe_grid(N, cu_count);
-  const uint64_t k = (chunks + cap_waves - 1) / cap_waves;  // chunks per wave
-  const uint64_t waves = (chunks + k - 1) / k;
-  return (uint32_t)((waves + 3) / 4);
-}
-
-hipError_t LaunchProbeGather(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                             int32_t* d_slot, uint32_t* d_block_miss, uint32_t grid, int unroll, hipStream_t stream) {
-  const size_t smem = sizeof(TableLds) * (size_t)num_tables + sizeof(uint64_t) * ((size_t)num_tables + 1) +
-                      sizeof(uint32_t) * (kProbeBlockThreads / 64);
-  // `unroll` encodes the variant: U + 100*mode + 1000*stamp_mode  (U in {1,2,4,8};
-  //  mode 0 full unroll, 1 rolled, 2 rolled + pipelined; stamp_mode 0 every hit, 1 = 1/4 of hits, 2 = 1/16)
-  const int U = unroll % 100, mode = (unroll / 100) % 10, smode = unroll / 1000;
-#define HPS_PG(UU, OO, SS)                                                                                          \
-  hipLaunchKernelGGL((hps_probe_gather_kernel<UU, OO, SS>), dim3(grid), dim3(kProbeBlockThreads), smem, stream, d_call, \
-                     d_tables, d_slot, d_block_miss)
-#define HPS_PG_S(UU, OO) \
-  do { if (smode == 0) HPS_PG(UU, OO, 0); else if (smode == 1) HPS_PG(UU, OO, 2); else HPS_PG(UU, OO, 4); } while (0)
-#define HPS_PG_U(UU)                                 \
-  do {                                               \
-    if (mode == 1) HPS_PG_S(UU, 1);                  \
-    else if (mode == 2) HPS_PG_S(UU, 0);             \
-    else HPS_PG_S(UU, 16 / UU);                      \
+hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
+                            hipStream_t stream) {
+  if (w.num_tiles == 0) return hipSuccess;
+  // variant = U + 100 * no_dedup   (U in {2,4,8}: bucket lines in flight per 16-lane group)
+  const int U = variant % 100;
+  const bool dedup = (variant / 100) % 10 == 0;
+#define HPS_PT(DD, CC, UU)                                                                                               \
+  hipLaunchKernelGGL((hps_probe_tile_kernel<DD, CC, UU>), dim3(w.num_tiles), dim3(kProbeBlockThreads), 0, stream, d_call, \
+                     d_tables, w)
+#define HPS_PT_U(DD, CC)                          \
+  do {                                            \
+    if (U == 2) HPS_PT(DD, CC, 2);                \
+    else if (U == 8) HPS_PT(DD, CC, 8);           \
+    else HPS_PT(DD, CC, 4);                       \
   } while (0)
-  switch (U) {
-    case 1: HPS_PG_U(1); break;
-    case 2: HPS_PG_U(2); break;
-    case 8: HPS_PG_U(8); break;
-    default: HPS_PG_U(4); break;
-  }
-#undef HPS_PG_U
-#undef HPS_PG_S
-#undef HPS_PG
+  if (dedup) { if (claim) HPS_PT_U(true, true); else HPS_PT_U(true, false); }
+  else { if (claim) HPS_PT_U(false, true); else HPS_PT_U(false, false); }
+#undef HPS_PT_U
+#undef HPS_PT
   return hipGetLastError();
 }
 
-static inline uint32_t table_aligned_blocks(const uint64_t* key_start, uint32_t T, uint32_t per_block) {
-  uint64_t nb = 0;
-  for (uint32_t t = 0; t < T; ++t) nb += (key_start[t + 1] - key_start[t] + per_block - 1) / per_block;
-  return (uint32_t)(nb ? nb : 1);
-}
-
-hipError_t LaunchMissDedup(const CallDesc* d_call, const uint64_t* h_key_start, uint32_t T, uint32_t probe_blocks,
-                           int32_t* d_slot, const uint32_t* d_block_miss, int32_t* d_set, uint64_t set_cap,
-                           uint32_t* d_counts, int64_t* d_uniq_keys, int64_t* uniq_keys_host_mapped, int cu_count,
-                           hipStream_t stream) {
-  hipLaunchKernelGGL(hps_miss_begin_kernel, dim3((uint32_t)cu_count * 4), dim3(256), 0, stream, d_block_miss,
-                     probe_blocks, d_set, set_cap, d_counts, T);
-  const uint32_t nb = table_aligned_blocks(h_key_start, T, kDedupBlock);
-  hipLaunchKernelGGL(hps_miss_dedup_kernel, dim3(nb), dim3(kDedupBlock), 0, stream, d_call, d_slot, d_set, set_cap,
-                     d_counts, d_uniq_keys, uniq_keys_host_mapped);
-  hipLaunchKernelGGL(hps_miss_resolve_kernel, dim3(nb), dim3(kDedupBlock), 0, stream, d_call, d_slot,
-                     (const int32_t*)d_set, set_cap, (const uint32_t*)d_counts);
+hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, bool exact,
+                            hipStream_t stream) {
+  if (w.num_tiles == 0) return hipSuccess;
+  if (exact) hipLaunchKernelGGL(hps_miss_unique_kernel<true>, dim3(w.num_tiles), dim3(256), 0, stream, d_call, d_tables, w);
+  else hipLaunchKernelGGL(hps_miss_unique_kernel<false>, dim3(w.num_tiles), dim3(256), 0, stream, d_call, d_tables, w);
   return hipGetLastError();
 }
 
 hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, hipStream_t stream) {
+                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream) {
   if (N == 0) return hipSuccess;
   const size_t lds = sizeof(TableLds) * num_tables + sizeof(uint64_t) * (num_tables + 1);
   if (all_128_aligned)
-    hipLaunchKernelGGL((hps_gather_hits_kernel<4, true>), dim3(grid), dim3(kProbeBlockThreads), lds, stream, d_call, d_tables, d_slot);
+    hipLaunchKernelGGL((hps_gather_hits_kernel<4, true>), dim3(grid), dim3(kProbeBlockThreads), lds, stream, d_call, d_tables, d_slot,
+                       xcd_walk ? 1u : 0u);
   else
-    hipLaunchKernelGGL((hps_gather_hits_kernel<4, false>), dim3(grid), dim3(kProbeBlockThreads), lds, stream, d_call, d_tables, d_slot);
+    hipLaunchKernelGGL((hps_gather_hits_kernel<4, false>), dim3(grid), dim3(kProbeBlockThreads), lds, stream, d_call, d_tables, d_slot,
+                       xcd_walk ? 1u : 0u);
   return hipGetLastError();
 }
 
-hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tables, const MissDesc* d_md, uint64_t N,
-                             const int32_t* d_slot, const float* d_staging, int cu_count, hipStream_t stream) {
-  const uint32_t grid = probe_grid(N, cu_count);
-  hipLaunchKernelGGL(hps_miss_scatter_kernel, dim3(grid), dim3(256), 0, stream, d_call, d_tables, d_md, d_slot,
-                     d_staging);
+hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tables, const MissDesc* d_md, const CallWork& w,
+                             const float* d_staging, hipStream_t stream) {
+  if (w.num_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(hps_miss_scatter_kernel, dim3(w.num_tiles), dim3(256), 0, stream, d_call, d_tables, d_md, w, d_staging);
   return hipGetLastError();
 }
 
-hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, uint64_t N,
-                                 const int32_t* d_slot, const uint32_t* d_table_mode, int cu_count, hipStream_t stream) {
-  const uint32_t grid = probe_grid(N, cu_count);
-  hipLaunchKernelGGL(hps_miss_fill_default_kernel, dim3(grid), dim3(256), 0, stream, d_call, d_tables, d_slot, d_table_mode);
+hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w,
+                                 const uint32_t* d_table_mode, hipStream_t stream) {
+  if (w.num_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(hps_miss_fill_default_kernel, dim3(w.num_tiles), dim3(256), 0, stream, d_call, d_tables, w, d_table_mode);
   return hipGetLastError();
 }
 

@@ -84,12 +84,12 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
     HIP_TRY(hipMalloc((void**)&I.d_md, sizeof(MissDesc)));
     HIP_TRY(hipHostMalloc((void**)&I.h_ks, sizeof(uint64_t) * ((size_t)kMaxTables + 1), hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&I.d_ks, sizeof(uint64_t) * ((size_t)kMaxTables + 1)));
-    HIP_TRY(hipMalloc((void**)&I.d_stats, 4 * sizeof(uint32_t)));
-    HIP_TRY(hipHostMalloc((void**)&I.h_stats, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&I.d_stats, (size_t)kStatLines * kAccStride * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void**)&I.h_stats, (size_t)kStatLines * kAccStride * sizeof(uint32_t), hipHostMallocDefault));
   }
   Inserter& I = *ins_;
   std::vector<size_t> done(T, 0);
-  HIP_TRY(hipMemsetAsync(I.d_stats, 0, 4 * sizeof(uint32_t), I.stream));
+  HIP_TRY(hipMemsetAsync(I.d_stats, 0, (size_t)kStatLines * kAccStride * sizeof(uint32_t), I.stream));
   for (;;) {
     MissDesc& md = *I.h_md;
     size_t uq = 0, fl = 0;
@@ -129,12 +129,9 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(I.stream));
   }
-  HIP_TRY(hipMemcpyAsync(I.h_stats, I.d_stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, I.stream));
+  HIP_TRY(hipMemcpyAsync(I.h_stats, I.d_stats, (size_t)kStatLines * kAccStride * sizeof(uint32_t), hipMemcpyDeviceToHost, I.stream));
   HIP_TRY(hipStreamSynchronize(I.stream));
-  std::lock_guard<std::mutex> sl(stat_mu_);
-  counters_.dropped += I.h_stats[0];
-  counters_.inserted += I.h_stats[1];
-  counters_.refreshed += I.h_stats[2];
+  AddStatLines(I.h_stats);
   return Status::Ok();
 }
 

@@ -31,7 +31,8 @@ hipError_t LaunchDenseInteract(const float* d_emb, const void* d_bottom_f16, uin
                                uint32_t out_stride, void* d_out_f16, int cu_count, hipStream_t stream);
 
 // fused_kernels.hip: the interaction reading its rows from cache slots / miss staging (no OUTPUT0); T*D/4 <= 1024 chunks
-hipError_t LaunchLookupInteract(const TableCacheDev* d_tables, const MissDesc* d_md, const int32_t* d_slot, const float* d_staging,
+hipError_t LaunchLookupInteract(const TableCacheDev* d_tables, const MissDesc* d_md, const int32_t* d_slot, const int32_t* d_rep_of,
+                                const int32_t* d_uidx_of, const float* d_staging,
                                 const void* d_bottom_f16, uint64_t batch, uint32_t T, uint32_t D, uint32_t out_stride, void* d_out_f16,
                                 int cu_count, hipStream_t stream);
 

@@ -3,7 +3,8 @@
 // written and read again per lookup, 872 MB + 872 MB per 64 K batch at T = 26, D = 128) never exists.
 // Same arithmetic and output layout as hps_dense_interact_kernel (dense_kernels.hip); only the row source differs:
 //   slot >= 0   row = tables[t].rows + slot * D            (hit: the slot the probe recorded)
-//   slot <= -2  row = staging + stage_off[t] + (-2 - slot) * D   (miss: the row the fetch staged, or the default vector)
+//   slot <= -2  row = staging + stage_off[t] + uidx_of[rep_of[-2 - slot]] * D   (miss: the row the fetch staged, or the
+//               default vector; -2 - slot is the key's entry in the probe tiles' miss lists, cache/device_types.h)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,7 +25,8 @@ constexpr int kFZPad = 8;
 // NR float4 chunks per lane (NR*64 >= T*D/4), one wave per sample, 4 samples per block.
 template <int NR>
 __global__ __launch_bounds__(256) void hps_lookup_interact_kernel(const TableCacheDev* __restrict__ tables, const MissDesc* __restrict__ md,
-                                                                  const int32_t* __restrict__ slot_in, const float* __restrict__ staging,
+                                                                  const int32_t* __restrict__ slot_in, const int32_t* __restrict__ rep_of,
+                                                                  const int32_t* __restrict__ uidx_of, const float* __restrict__ staging,
                                                                   const _Float16* __restrict__ bottom, uint64_t batch, uint32_t T, uint32_t D,
                                                                   uint32_t out_stride, _Float16* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) _Float16 zlds[];
@@ -59,12 +61,16 @@ __global__ __launch_bounds__(256) void hps_lookup_interact_kernel(const TableCac
     int32_t s[NR];
 #pragma unroll
     for (int u = 0; u < NR; ++u) s[u] = slot_in[(uint64_t)(tq[u] >> 16) * batch + i];
+    // missed keys (few): entry of the tile miss lists -> call-wide representative -> row of the unique-miss segment
+    uint32_t mu[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) mu[u] = s[u] <= -2 ? (uint32_t)uidx_of[(uint32_t)rep_of[(uint32_t)(-2 - s[u])]] : 0u;
     f4v v[NR];
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
       const uint32_t t = tq[u] >> 16, col = tq[u] & 0xFFFFu;
       const float* hit = sh_rows[t] + (uint64_t)(uint32_t)(s[u] >= 0 ? s[u] : 0) * D;
-      const float* mis = staging + sh_stage[t] + (uint64_t)(uint32_t)(s[u] <= -2 ? -2 - s[u] : 0) * D;
+      const float* mis = staging + sh_stage[t] + (uint64_t)mu[u] * D;
       const float* src = s[u] >= 0 ? hit : mis;
       v[u] = *reinterpret_cast<const f4v*>(src + col);
     }
@@ -105,7 +111,8 @@ __global__ __launch_bounds__(256) void hps_lookup_interact_kernel(const TableCac
   }
 }
 
-hipError_t LaunchLookupInteract(const TableCacheDev* d_tables, const MissDesc* d_md, const int32_t* d_slot, const float* d_staging,
+hipError_t LaunchLookupInteract(const TableCacheDev* d_tables, const MissDesc* d_md, const int32_t* d_slot, const int32_t* d_rep_of,
+                                const int32_t* d_uidx_of, const float* d_staging,
                                 const void* d_bottom_f16, uint64_t batch, uint32_t T, uint32_t D, uint32_t out_stride, void* d_out_f16,
                                 int cu_count, hipStream_t stream) {
   if (batch == 0) return hipSuccess;
@@ -121,7 +128,7 @@ hipError_t LaunchLookupInteract(const TableCacheDev* d_tables, const MissDesc* d
   auto go = [&](auto kernel) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3((uint32_t)want), dim3(256), lds_bytes, stream, d_tables, d_md, d_slot, d_staging,
+    hipLaunchKernelGGL(kernel, dim3((uint32_t)want), dim3(256), lds_bytes, stream, d_tables, d_md, d_slot, d_rep_of, d_uidx_of, d_staging,
                        reinterpret_cast<const _Float16*>(d_bottom_f16), batch, T, D, out_stride, reinterpret_cast<_Float16*>(d_out_f16));
     return hipGetLastError();
   };

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <tuple>
 
 #include "../common/hps_hash.h"
@@ -16,24 +17,58 @@ VolatileTier::VolatileTier(uint32_t dim, const std::vector<size_t>& partition_ke
   if (!(target > 0.0) || !(target < 1.0)) target = 0.8;   // docs:487-489: strictly between 0 and 1
   for (size_t p = 0; p < partition_keys.size(); ++p) {
     Partition* P = new Partition();
-    P->cap = std::max<size_t>(1, std::min(params.overflow_margin, partition_keys[p]));
-    P->keep = std::max<size_t>(1, (size_t)std::floor((double)P->cap * target));
-    if (params.overflow_margin >= partition_keys[p]) P->keep = P->cap;   // can never overflow
-    uint64_t icap = 16;
-    while (icap < P->cap * 2) icap <<= 1;
-    P->index.assign(icap, Cell{0, kNoSlot});
-    P->mask = icap - 1;
-    P->keys = new int64_t[P->cap];
-    P->stamp = new std::atomic<uint64_t>[P->cap];
-    P->count = new std::atomic<uint32_t>[P->cap];
-    void* mem = nullptr;
-    const size_t bytes = std::max<size_t>(64, P->cap * (size_t)dim * sizeof(float));
-    if (posix_memalign(&mem, 64, (bytes + 63) / 64 * 64) != 0) mem = nullptr;
-    P->rows = (float*)mem;   // pages are touched only as slots fill
-    P->free_slots.reserve(P->cap);
-    for (size_t s = P->cap; s-- > 0;) P->free_slots.push_back((uint32_t)s);   // slot 0 is handed out first
+    P->limit = std::max<size_t>(1, params.overflow_margin);
+    // floor(limit * target) without leaving size_t for the "no margin" default (SIZE_MAX)
+    P->keep = P->limit >= (1ull << 52) ? P->limit : std::max<size_t>(1, (size_t)std::floor((double)P->limit * target));
+    // storage for what the table holds now; online updates and appended rows grow it (Grow) up to the limit
+    Grow(*P, std::max<size_t>(1, std::min(P->limit, partition_keys[p])));
     P->rng = hps_mix64(0x9E3779B97F4A7C15ull + p) | 1ull;
     parts_.push_back(P);
+  }
+}
+
+// (Re)allocates the slot slab for new_cap > cap slots, keeps every live slot where it is, rebuilds the index when
+// it would pass load 0.5.  Exclusive side only.
+void VolatileTier::Grow(Partition& P, size_t new_cap) {
+  if (new_cap <= P.cap) return;
+  int64_t* keys = new int64_t[new_cap];
+  std::atomic<uint64_t>* stamp = new std::atomic<uint64_t>[new_cap];
+  std::atomic<uint32_t>* count = new std::atomic<uint32_t>[new_cap];
+  void* mem = nullptr;
+  const size_t bytes = std::max<size_t>(64, new_cap * (size_t)dim_ * sizeof(float));
+  if (posix_memalign(&mem, 64, (bytes + 63) / 64 * 64) != 0) mem = nullptr;
+  if (!mem) { delete[] keys; delete[] stamp; delete[] count; throw std::bad_alloc(); }
+  float* rows = (float*)mem;   // pages are touched only as slots fill
+  for (const Cell& c : P.index) {
+    if (c.slot == kNoSlot) continue;
+    const uint32_t s = c.slot;
+    keys[s] = P.keys[s];
+    stamp[s].store(P.stamp[s].load(std::memory_order_relaxed), std::memory_order_relaxed);
+    count[s].store(P.count[s].load(std::memory_order_relaxed), std::memory_order_relaxed);
+    memcpy(rows + (size_t)s * dim_, P.rows + (size_t)s * dim_, (size_t)dim_ * sizeof(float));
+  }
+  delete[] P.keys; delete[] P.stamp; delete[] P.count; free(P.rows);
+  P.keys = keys; P.stamp = stamp; P.count = count; P.rows = rows;
+  // new slots are handed out lowest first, after the ones already free
+  std::vector<uint32_t> fresh;
+  fresh.reserve(new_cap - P.cap + P.free_slots.size());
+  for (size_t s = new_cap; s-- > P.cap;) fresh.push_back((uint32_t)s);
+  fresh.insert(fresh.end(), P.free_slots.begin(), P.free_slots.end());
+  P.free_slots.swap(fresh);
+  P.cap = new_cap;
+  uint64_t icap = 16;
+  while (icap < new_cap * 2) icap <<= 1;
+  if (icap > P.index.size()) {
+    std::vector<Cell> old;
+    old.swap(P.index);
+    P.index.assign(icap, Cell{0, kNoSlot});
+    P.mask = icap - 1;
+    for (const Cell& c : old) {
+      if (c.slot == kNoSlot) continue;
+      uint64_t i = Home(c.key, P.mask);
+      while (P.index[i].slot != kNoSlot) i = (i + 1) & P.mask;
+      P.index[i] = c;
+    }
   }
 }
 
@@ -97,9 +132,12 @@ void VolatileTier::Erase(Partition& P, int64_t key) {
   P.index[hole] = Cell{0, kNoSlot};
 }
 
-size_t VolatileTier::Prune(Partition& P) {
-  if (P.size <= P.keep) return 0;
-  const size_t drop = P.size - P.keep;
+// Drops the partition to `keep` entries, and at least `at_least` of them (a full partition whose keep equals its
+// limit still has to make room for the insert that called).
+size_t VolatileTier::Prune(Partition& P, size_t at_least) {
+  size_t drop = P.size > P.keep ? P.size - P.keep : 0;
+  drop = std::min(P.size, std::max(drop, at_least));
+  if (drop == 0) return 0;
   std::vector<uint32_t> live;
   live.reserve(P.size);
   for (const Cell& c : P.index) if (c.slot != kNoSlot) live.push_back(c.slot);
@@ -131,7 +169,8 @@ size_t VolatileTier::Insert(size_t partition, int64_t key, const float* row, uin
   uint32_t s = FindSlot(P, key);
   size_t evicted = 0;
   if (s == kNoSlot) {
-    if (P.size >= P.cap) evicted = Prune(P);
+    if (P.size >= P.limit) evicted = Prune(P, 1);
+    else if (P.free_slots.empty()) Grow(P, std::min(P.limit, std::max(P.cap * 2, P.cap + 16)));
     s = P.free_slots.back();
     P.free_slots.pop_back();
     uint64_t i = Home(key, P.mask);
@@ -170,7 +209,7 @@ VolatileTierStats VolatileTier::stats() const {
   for (const Partition* P : parts_) {
     std::shared_lock<std::shared_mutex> lk(P->mu);
     s.entries += P->size;
-    s.capacity += P->cap;
+    s.capacity += P->limit >= (1ull << 52) ? P->cap : P->limit;
     s.max_partition_entries = std::max<uint64_t>(s.max_partition_entries, P->size);
     s.lookups += P->lookups.load(std::memory_order_relaxed);
     s.hits += P->hits.load(std::memory_order_relaxed);

@@ -5,8 +5,11 @@
 // `overflow_policy` (evict_random / evict_least_used / evict_oldest); `cache_missed_embeddings` decides whether rows
 // found behind this tier are inserted into it (docs:497-500).  Decisions the documentation leaves open are fixed in
 // SURVEY.md Appendix C style and restated in oracle/hps_oracle.py (VolatileDbModel):
-//   * a partition never holds more than overflow_margin entries: the insert that would exceed it prunes first;
-//   * keep = max(1, floor(overflow_margin * overflow_resolution_target));
+//   * a partition never holds more than overflow_margin entries: the insert that would exceed it prunes first
+//     (the margin is the limit whatever the table held at load time: keys added later by online updates or appended
+//     rows count against the same margin; storage grows on demand up to it);
+//   * keep = max(1, floor(overflow_margin * overflow_resolution_target)); an insert into a full partition whose
+//     prune frees nothing (margin 1) evicts one entry by the policy;
 //   * evict_oldest orders by (last access stamp, key), evict_least_used by (access count, last access stamp, key),
 //     smallest first; a stamp is one tick per fetch call; an insert counts as one access;
 //   * evict_random draws from a per-partition xorshift64* seeded with the partition number.
@@ -27,7 +30,7 @@ struct VolatileTierStats {
 
 class VolatileTier {
  public:
-  // partition_keys[p]: upper bound on the distinct keys partition p can ever be asked to hold
+  // partition_keys[p]: distinct keys of partition p at load time — a sizing hint only, the limit is overflow_margin
   VolatileTier(uint32_t dim, const std::vector<size_t>& partition_keys, const VolatileDatabaseParams& params);
   ~VolatileTier();
   VolatileTier(const VolatileTier&) = delete;
@@ -60,7 +63,8 @@ class VolatileTier {
     mutable std::shared_mutex mu;
     std::vector<Cell> index;        // open addressing, linear probing, backward-shift deletion; slot == kNoSlot: empty
     uint64_t mask = 0;
-    size_t cap = 0;                 // slots
+    size_t limit = 0;               // overflow_margin: most entries the partition may hold
+    size_t cap = 0;                 // slots allocated so far (<= limit, grown on demand)
     size_t keep = 0;                // entries left after a prune
     size_t size = 0;
     int64_t* keys = nullptr;        // [cap]
@@ -75,7 +79,8 @@ class VolatileTier {
   static uint64_t Home(int64_t key, uint64_t mask);
   uint32_t FindSlot(const Partition& P, int64_t key) const;
   void Erase(Partition& P, int64_t key);
-  size_t Prune(Partition& P);
+  size_t Prune(Partition& P, size_t at_least);
+  void Grow(Partition& P, size_t new_cap);
 
   uint32_t dim_;
   DatabaseOverflowPolicy policy_;

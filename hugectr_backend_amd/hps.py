@@ -74,7 +74,7 @@ class CacheCounters(C.Structure):
 class LookupStats(C.Structure):
     _fields_ = [("misses", C.c_uint64), ("unique_misses", C.c_uint64), ("async_insert", C.c_int32),
                 ("probe_gather_ms", C.c_float), ("phase_ms", C.c_float * 4), ("gpu_call_ms", C.c_float),
-                ("hit_gather_ms", C.c_float)]
+                ("hit_gather_ms", C.c_float), ("unique_keys", C.c_uint64), ("key_stage_ms", C.c_float)]
 
 
 def _load() -> C.CDLL:
@@ -166,8 +166,9 @@ def device_count() -> int:
 class EmbeddingCache:
     """HugeCTR::EmbeddingCacheBase handle (shared by every session of one model on one device)."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, device: int = 0):
         self._h = handle
+        self.device = int(device)
 
     @property
     def num_tables(self) -> int:
@@ -257,7 +258,7 @@ class HierParameterServer:
     def get_embedding_cache(self, model: str, device: int):
         h = C.c_void_p()
         _check(LIB.hps_server_get_embedding_cache(self._h, model.encode(), device, C.byref(h)))
-        return EmbeddingCache(h) if h else None
+        return EmbeddingCache(h, device) if h else None
 
     def load_table_arrays(self, model: str, table: int, keys, rows):
         keys = np.ascontiguousarray(keys, dtype=np.int64)
@@ -329,13 +330,17 @@ class LookupSession:
         self.num_tables = int(mi.num_tables)
         self.dims = [int(server.table_info(model, t).embedding_vecsize) for t in range(self.num_tables)]
         self.use_gpu_cache = bool(mi.use_gpu_embedding_cache)
+        self.device = 0   # device of the session's embedding cache (create() sets it)
 
     @classmethod
     def create(cls, server: HierParameterServer, model: str, embedding_cache: EmbeddingCache | None) -> "LookupSession":
         h = C.c_void_p()
         _check(LIB.hps_session_create(server._h, model.encode(), embedding_cache._h if embedding_cache else None,
                                       C.byref(h)))
-        return cls(h, server, model)
+        s = cls(h, server, model)
+        if embedding_cache is not None:
+            s.device = embedding_cache.device
+        return s
 
     # -- the reference signature: lists of per-table pointers ---------------------------------------
     def lookup_ptrs(self, h_keys_ptrs: Sequence[int], vec_ptrs: Sequence[int], num_keys: Sequence[int]):
@@ -375,8 +380,10 @@ class LookupSession:
         if self.use_gpu_cache:
             import torch
             if out is None:
-                out = torch.empty(no, dtype=torch.float32, device="cuda")
-            assert out.is_cuda and out.dtype == torch.float32 and out.numel() >= no
+                out = torch.empty(no, dtype=torch.float32, device=torch.device("cuda", self.device))
+            assert out.is_cuda and out.dtype == torch.float32 and out.numel() >= no and out.is_contiguous()
+            # the engine writes on its own stream: whatever the caller's stream still does to `out` must be over
+            torch.cuda.current_stream(out.device).synchronize()
             base = out.data_ptr()
         else:
             if out is None:
@@ -391,9 +398,13 @@ class LookupSession:
         import torch
         num_keys = [int(n) for n in num_keys]
         _, ooff, nk, no = self._slices(num_keys)
-        assert d_keys.is_cuda and d_keys.dtype == torch.int64 and d_keys.numel() == nk
+        assert d_keys.is_cuda and d_keys.dtype == torch.int64 and d_keys.numel() == nk and d_keys.is_contiguous()
         if out is None:
             out = torch.empty(no, dtype=torch.float32, device=d_keys.device)
+        assert out.is_cuda and out.is_contiguous() and out.device == d_keys.device
+        # The engine reads d_keys and writes `out` on the session's own non-blocking stream: the torch stream that
+        # produced the keys (or still uses `out`) has to be done first.
+        torch.cuda.current_stream(d_keys.device).synchronize()
         base = out.data_ptr()
         self.lookup_device_ptrs(d_keys.data_ptr(), [base + 4 * o for o in ooff], num_keys)
         return out

@@ -72,16 +72,19 @@ typedef struct hps_cache_counters {
 } hps_cache_counters_t;
 
 typedef struct hps_lookup_stats {
-  uint64_t misses;         /* keys of the last call that were not resident */
-  uint64_t unique_misses;
+  uint64_t misses;         /* keys of the last call that were not resident (as sent: duplicates count) */
+  uint64_t unique_misses;  /* distinct (table, key) pairs among them */
   int32_t async_insert;    /* 1: answered in async-insert mode (missed keys returned the default vector) */
-  float probe_gather_ms;   /* HIP-event time of the probe+gather kernel (option "timing"=1), else 0 */
+  float probe_gather_ms;   /* HIP-event time of the probe kernels of the call: tile dedup + probe, miss-unique
+                              (option "timing"=1), else 0 */
   float phase_ms[4];       /* host wall clock of the last call: [0] until miss counts are known,
                               [1] host parameter-server gather (ps_direct_access: HIP-event time of the fetch kernel),
                               [2] H2D + scatter + insert, [3] whole call */
   float gpu_call_ms;       /* HIP-event span of the call on the session's stream, first kernel to last (option "timing"=1) */
-  float hit_gather_ms;     /* option "split_probe"=1: HIP-event time of the hit-gather kernel of a split call (probe_gather_ms
-                              is then the probe alone); 0 for a fused call */
+  float hit_gather_ms;     /* HIP-event time of the hit-gather kernel (option "timing"=1) */
+  uint64_t unique_keys;    /* distinct (table, key) pairs of the call — counted only when the insertion policy needs the
+                              hit rate (0 < hit_rate_threshold < 1), else 0 */
+  float key_stage_ms;      /* hps_session_lookup: host time spent staging the keys and enqueueing their H2D copies */
 } hps_lookup_stats_t;
 
 const char* hps_last_error(void);
@@ -185,10 +188,12 @@ int hps_session_lookup(hps_session_t* session, const void* const* h_keys_per_tab
 int hps_session_lookup_device(hps_session_t* session, const int64_t* d_keys_flat, float* const* d_vectors_per_table,
                               const size_t* num_keys_per_table, size_t num_tables);
 int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
-/* options: "timing" (0/1), "probe_unroll" (1,2,4,8), "hit_rate_threshold_permille" (per-session override of
- * the model's hit_rate_threshold: 1000 = always synchronous insertion, 0 = always asynchronous), "probe_balanced"
- * (0/1), "host_gather" (0/1: on a ps_direct_access cache, serve this session's misses the reference's way — host
- * threads gather, hipMemcpyAsync ships — e.g. to compare the two tiers on one deployment) */
+/* options: "timing" (0/1), "hit_rate_threshold_permille" (per-session override of the model's hit_rate_threshold:
+ * 1000 = always synchronous insertion, 0 = always asynchronous), "host_gather" (0/1: on a ps_direct_access cache, serve
+ * this session's misses the reference's way — host threads gather, hipMemcpyAsync ships — e.g. to compare the two tiers
+ * on one deployment), "split_probe" (0/1: read the miss counts back before / after the hit gather), and the kernel A/B
+ * switches "probe_variant" (U + 100*no_dedup, U in {2,4,8}), "xcd_walk" (0/1), "keys_pinned_check" (0/1: DMA flat
+ * page-locked key arrays in place instead of staging them) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 /* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------

@@ -123,15 +123,44 @@ def np_lookup(tables, keys, num_keys, defaults, resident=None) -> np.ndarray:
     return np.concatenate(out) if out else np.zeros(0, np.float32)
 
 
+def np_unique_counts(keys, num_keys, resident) -> list:
+    """Per table: (unique keys of the call, unique keys of the call that are not resident).  The engine "first
+    determines the associated unique embedding keys" of a batch and resolves those against the cache
+    (docs/hierarchical_parameter_server.md:69); both lengths drive the insertion policy below."""
+    keys = np.asarray(keys, dtype=np.int64).ravel()
+    out, off = [], 0
+    for t, n in enumerate(num_keys):
+        u = np.unique(keys[off:off + n])
+        off += n
+        out.append((int(u.size), int((~np.isin(u, np.asarray(resident[t], dtype=np.int64))).sum())))
+    return out
+
+
 def np_insert_modes(keys, num_keys, resident, hit_rate_threshold) -> list:
     """Insertion policy of one call, per table (docs/architecture.md:65-67): True = async
     (the table's hit rate in this call >= hit_rate_threshold: misses return the default vector and are inserted in
     the background), False = synchronous (missed rows are fetched, returned exactly and inserted before the call
     returns).  The reference loops over the tables of a request and decides for each; its hit rate is "the real hit
-    rate" of the table's lookup.  Restated here over the table's keys as sent (duplicates count); tables without
-    misses or without keys are synchronous by definition."""
-    keys = np.asarray(keys, dtype=np.int64).ravel()
+    rate of the GPU embedding cache lookup" (docs/architecture.md:66) — and what is looked up in the cache are the
+    batch's UNIQUE keys (docs/hierarchical_parameter_server.md:69).  So:
+
+        hit rate(t) = 1 - (unique keys of table t missing from the cache) / (unique keys of table t)
+
+    (SURVEY.md Appendix C4).  Round 1 restated this over the keys as sent, following the product of the time, which
+    deduplicated only the misses; that was a deviation without a reference citation and is corrected here.  Tables
+    without misses or without keys are synchronous by definition."""
     thr = float(np.float32(hit_rate_threshold))   # the configuration carries the threshold as a float (backend.cpp:372)
+    modes = []
+    for uniq, uniq_missing in np_unique_counts(keys, num_keys, resident):
+        modes.append(uniq_missing > 0 and 1.0 - uniq_missing / uniq >= thr)
+    return modes
+
+
+def np_insert_modes_keys_as_sent(keys, num_keys, resident, hit_rate_threshold) -> list:
+    """The round-1 definition (hit rate over the keys as sent, duplicates counted) — kept ONLY so that a test can show
+    the two definitions disagree on skewed batches and that the product follows np_insert_modes, not this."""
+    keys = np.asarray(keys, dtype=np.int64).ravel()
+    thr = float(np.float32(hit_rate_threshold))
     modes, off = [], 0
     for t, n in enumerate(num_keys):
         q = keys[off:off + n]
@@ -151,7 +180,8 @@ class VolatileDbModel:
     `overflow_margin * overflow_resolution_target` by `overflow_policy`; `initial_cache_rate` of the table (first rows
     in file order) is cached at start-up; `cache_missed_embeddings` inserts what had to be read from behind the tier.
     Pure-Python, single-threaded, small cases only.  Where the documentation is silent this model decides, and the
-    product follows it (csrc/ps/volatile_tier.h): keep = max(1, floor(margin * target)); evict_oldest orders by
+    product follows it (csrc/ps/volatile_tier.h): keep = max(1, floor(margin * target)), and a full partition whose
+    prune frees nothing evicts one entry; evict_oldest orders by
     (last access, key), evict_least_used by (access count, last access, key), smallest evicted first; one access
     stamp per fetch call; an insert counts as one access.  evict_random is not modelled beyond its sizes."""
 
@@ -165,13 +195,11 @@ class VolatileDbModel:
         self.live = {}                       # key -> row number of its last occurrence (duplicate keys: last wins)
         for r, k in enumerate(keys.tolist()):
             self.live[k] = r
-        per_part = [0] * self.P
-        for k in self.live:
-            per_part[self._p(k)] += 1
-        margin = overflow_margin if overflow_margin is not None else max(per_part + [1])
-        self.cap = [max(1, min(margin, c)) for c in per_part]
+        # the margin is the limit whatever the table held at load time (keys added later count against it too)
+        margin = int(overflow_margin) if overflow_margin is not None else None
         t = overflow_resolution_target if 0.0 < overflow_resolution_target < 1.0 else 0.8
-        self.keep = [c if margin >= n else max(1, int(np.floor(c * t))) for c, n in zip(self.cap, per_part)]
+        self.cap = [max(1, margin) if margin is not None else float("inf")] * self.P
+        self.keep = [max(1, int(np.floor(max(1, margin) * t))) if margin is not None else float("inf")] * self.P
         self.part = [dict() for _ in range(self.P)]      # key -> [stamp, count]
         self.clock = 0
         self.evictions = 0
@@ -193,7 +221,7 @@ class VolatileDbModel:
                     raise NotImplementedError("evict_random is only checked through sizes")
                 rank = (lambda kv: (kv[1][1], kv[1][0], kv[0])) if self.policy == "evict_least_used" else \
                        (lambda kv: (kv[1][0], kv[0]))
-                victims = sorted(part.items(), key=rank)[:len(part) - self.keep[p]]
+                victims = sorted(part.items(), key=rank)[:max(len(part) - self.keep[p], 1)]
                 for v, _ in victims:
                     del part[v]
                 self.evictions += len(victims)

@@ -360,9 +360,9 @@ def test_cold_batch_larger_than_one_staging_chunk(direct):
 @pytest.mark.parametrize("direct", [False], ids=["host_gather"])   # the device-driven tier keeps the fused kernel
 @pytest.mark.parametrize("dims", [[128, 128, 128], [16, 128, 1, 8]], ids=["all_128", "mixed_widths"])
 def test_split_probe_returns_the_same_rows(dims, direct):
-    """Option split_probe (host-gather tier): K_A probes only, the hit rows are moved by K_G while the misses are fetched.
-    Same rows and counts as the fused call, through ragged requests with duplicates, absent keys, empty tables, an
-    all-hit call (falls back to the fused kernel once nothing missed) and the async-insert policy."""
+    """Option split_probe (host-gather tier): the miss counts are read back right behind the probe and the hit rows are
+    moved by K_G while the misses are fetched.  Same rows and counts as the un-split order, through ragged requests with
+    duplicates, absent keys, empty tables, an all-hit call and the async-insert policy."""
     from oracle import hps_oracle as O
     rng = np.random.default_rng(len(dims))
     tables = make_tables([(30000 + 1000 * t, d) for t, d in enumerate(dims)])
@@ -401,3 +401,108 @@ def test_split_probe_returns_the_same_rows(dims, direct):
     out = s.lookup(q, nk).cpu().numpy()
     ref = O.np_lookup(tables, q, nk, defaults, resident=[res[t] if modes[t] else None for t in range(len(dims))])
     assert np.array_equal(_bits(out), _bits(ref))
+
+
+def test_policy_hit_rate_is_over_unique_keys():
+    """SURVEY.md App. C4 / docs/hierarchical_parameter_server.md:69: the hit rate behind the sync/async decision is
+    1 - unique misses / unique keys of the table in this call.  Two skewed tables on which the keys-as-sent reading
+    decides the opposite way; the product must follow the oracle (np_insert_modes) and report the unique-key count."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(404)
+    tables = make_tables([(6000, 32), (6000, 16)])
+    ps, cache, s = _mk("uniqpol", tables, maxcat=[1, 1], gpucacheper=0.5, hit_rate_threshold=0.8, defaults=[5.0, -2.0],
+                       max_batch=8192)
+    resident = [tk[cache.query(t, tk) >= 0] for t, (tk, _) in enumerate(tables)]
+    cold = [tk[cache.query(t, tk) < 0] for t, (tk, _) in enumerate(tables)]
+    # table 0: one resident key sent 7,000 times + 300 distinct cold keys: 96 % hit as sent, 1/301 over unique keys -> sync
+    q0 = np.concatenate([np.full(7000, resident[0][5]), cold[0][:300]])
+    # table 1: 2,000 distinct resident keys + one cold key sent 5,000 times: 29 % hit as sent, 2000/2001 unique -> async
+    q1 = np.concatenate([resident[1][:2000], np.full(5000, cold[1][7])])
+    rng.shuffle(q0)
+    rng.shuffle(q1)
+    nk = [q0.size, q1.size]
+    q = np.concatenate([q0, q1]).astype(np.int64)
+    modes = O.np_insert_modes(q, nk, resident, 0.8)
+    assert modes == [False, True]
+    assert O.np_insert_modes_keys_as_sent(q, nk, resident, 0.8) == [True, False]   # this test fails on that definition
+    out = s.lookup(q, nk).cpu().numpy()
+    ref = O.np_lookup(tables, q, nk, [5.0, -2.0], resident=[None, resident[1]])
+    assert np.array_equal(_bits(out), _bits(ref))
+    wrong = O.np_lookup(tables, q, nk, [5.0, -2.0], resident=[resident[0], None])
+    assert not np.array_equal(_bits(out), _bits(wrong))
+    st = s.last_stats()
+    uc = O.np_unique_counts(q, nk, resident)
+    assert st.async_insert == 1
+    assert st.unique_keys == sum(u for u, _ in uc) == 301 + 2001
+    assert st.unique_misses == sum(m for _, m in uc) == 301
+    assert st.misses == 300 + 5000
+
+
+@pytest.mark.parametrize("variant", [2, 4, 8, 102, 104, 108])
+@pytest.mark.parametrize("xcd_walk", [0, 1])
+def test_probe_variants_and_gather_walks_agree(variant, xcd_walk):
+    """Every variant of the probe kernel (bucket lines in flight per group; with and without the tile-local input
+    dedup) and both chunk walks of the gather kernel return the same rows and counts: ragged tables that end inside a
+    tile, tiles full of one key, keys absent everywhere, the sentinel key, an empty table."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(variant * 2 + xcd_walk)
+    tables = make_tables([(9000, 128), (5000, 128), (300, 4), (4000, 128)])
+    defaults = [0.5, 1.5, 2.5, 3.5]
+    ps, cache, s = _mk(f"var{variant}_{xcd_walk}", tables, maxcat=[2, 1, 1, 1], defaults=defaults, gpucacheper=0.3, max_batch=8192,
+                       hit_rate_threshold=0.9)
+    s.set_option("probe_variant", variant)
+    s.set_option("xcd_walk", xcd_walk)
+    for it in range(6):
+        nk = [int(rng.integers(1, 12000)), int(rng.integers(0, 8000)), int(rng.integers(0, 2100)), 0 if it == 2 else int(rng.integers(1, 3000))]
+        q = _queries(rng, tables, nk, miss_frac=0.03)
+        if it == 1:   # a whole tile (and more) of one key, resident or not
+            q[:2500] = tables[0][0][11]
+            q[nk[0]:nk[0] + min(nk[1], 1500)] = -77
+        if it == 3:
+            q[::97] = np.int64(-2**63)   # the engine's empty-slot marker is a legal query
+        res = [tk[cache.query(t, tk) >= 0] for t, (tk, _) in enumerate(tables)]
+        modes = O.np_insert_modes(q, nk, res, 0.9)
+        uc = O.np_unique_counts(q, nk, res)
+        out = s.lookup(q, nk).cpu().numpy()
+        ref = O.np_lookup(tables, q, nk, defaults, resident=[res[t] if modes[t] else None for t in range(4)])
+        assert np.array_equal(_bits(out), _bits(ref)), it
+        st = s.last_stats()
+        assert st.unique_misses == sum(m for _, m in uc), it
+        assert st.unique_keys == sum(u for u, _ in uc), it
+        cache.wait_async()
+
+
+def test_host_keys_staged_in_pieces_and_pinned_in_place():
+    """hps_session_lookup's three ways of getting host keys to the device — small request (one staging copy), large
+    pageable request (pieces staged and uploaded by the serving pool), flat page-locked array (DMA in place, checked
+    with and without the pointer check) — return the same rows."""
+    import torch
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(8)
+    tables = make_tables([(50000, 16), (50000, 8), (1000, 4)])
+    ps, cache, s = _mk("hostkeys", tables, maxcat=[1, 1, 1], gpucacheper=0.3, max_batch=700_000)
+    for nk in ([1000, 0, 50], [650_000, 640_123, 999]):
+        q = _queries(rng, tables, nk, miss_frac=0.02)
+        ref = O.np_lookup(tables, q, nk, [0.0] * 3)
+        out = s.lookup(q, nk).cpu().numpy()                       # pageable numpy memory
+        assert np.array_equal(_bits(out), _bits(ref))
+        assert s.last_stats().key_stage_ms > 0
+        pinned = torch.from_numpy(q).pin_memory()
+        for check in (1, 0):
+            s.set_option("keys_pinned_check", check)
+            out = s.lookup(pinned.numpy(), nk).cpu().numpy()
+            assert np.array_equal(_bits(out), _bits(ref))
+        s.set_option("keys_pinned_check", 1)
+        # per-table pointers that are NOT one flat array (each table from its own allocation)
+        parts, off = [], 0
+        for n in nk:
+            parts.append(np.array(q[off:off + n], copy=True))
+            off += n
+        outp = torch.empty(ref.size, dtype=torch.float32, device="cuda")
+        koff = 0
+        vptrs = []
+        for t, n in enumerate(nk):
+            vptrs.append(outp.data_ptr() + 4 * koff)
+            koff += n * tables[t][1].shape[1]
+        s.lookup_ptrs([p.ctypes.data if p.size else 0 for p in parts], vptrs, nk)
+        assert np.array_equal(_bits(outp.cpu().numpy()), _bits(ref))

@@ -237,3 +237,46 @@ def test_documented_overflow_example(tmp_path):
     st = ps.host_tier_stats("m", 0)
     assert (st["entries"], st["evictions"], st["overflows"]) == (9, 2, 1)
     assert np.array_equal(ps.host_tier_keys("m", 0), np.sort(k[2:11]))
+
+
+@pytest.mark.parametrize("persistent", [False, True])
+def test_margin_above_the_load_time_key_count_takes_new_keys(tmp_path, persistent):
+    """Round-1 advisor finding: with overflow_margin >= the keys a partition held at load time (the reference's own
+    example is overflow_margin = 10,000,000) a fully cached partition was "full", and the first NEW key — an online
+    update into a volatile-only tier, or a row appended to the store and then cached on its first fetch — popped an
+    empty free list (heap corruption).  The margin is the limit; storage grows on demand."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(5)
+    tables = make_tables([(1000, 8)])
+    k, r = tables[0]
+    vdb = {"overflow_margin": 10_000_000, "overflow_policy": "evict_oldest", "initial_cache_rate": 1.0,
+           "cache_missed_embeddings": True}
+    ps = _server(tmp_path, tables, vdb=vdb, pdb={} if persistent else None, partitions=4, defaults=[0.5])
+    assert ps.host_tier_stats("m", 0)["entries"] == 1000
+    new_k = np.arange(10**9, 10**9 + 300, dtype=np.int64)
+    new_r = rng.random((300, 8), dtype=np.float32)
+    for lo in range(0, 300, 64):                       # several rounds: the slabs have to grow more than once
+        ps.upsert("m", 0, new_k[lo:lo + 64], new_r[lo:lo + 64])
+    # volatile-only: the tier is the database and took the rows; persistent: they went to the store
+    assert ps.host_tier_stats("m", 0)["entries"] == (1000 if persistent else 1300)
+    q = np.concatenate([new_k, k[::7], [42 + 10**12]]).astype(np.int64)
+    for _ in range(2):                                 # the first fetch caches what came from the store
+        out, found = ps.fetch("m", 0, q, return_found=True)
+        ref = O.np_lookup([(np.concatenate([k, new_k]), np.concatenate([r, new_r]))], q, [q.size], [0.5]).reshape(q.size, -1)
+        assert np.array_equal(_bits(out), _bits(ref))
+        assert found[:-1].all() and not found[-1]
+    st = ps.host_tier_stats("m", 0)
+    assert st["entries"] == 1300 and st["evictions"] == 0
+    assert np.array_equal(ps.host_tier_keys("m", 0), np.sort(np.concatenate([k, new_k])))
+
+
+def test_margin_of_one_evicts_one_entry_per_insert(tmp_path):
+    """keep = max(1, floor(1 * 0.8)) = 1 = the margin: the prune frees nothing by itself, the insert still needs room."""
+    tables = make_tables([(50, 2)])
+    k, _ = tables[0]
+    vdb = {"overflow_margin": 1, "overflow_policy": "evict_oldest", "initial_cache_rate": 0.0, "cache_missed_embeddings": True}
+    ps = _server(tmp_path, tables, vdb=vdb, pdb={}, partitions=1)
+    for i in range(5):
+        ps.fetch("m", 0, k[i:i + 1])
+        assert np.array_equal(ps.host_tier_keys("m", 0), k[i:i + 1])
+    assert ps.host_tier_stats("m", 0)["evictions"] == 4

@@ -134,3 +134,21 @@ def test_insertion_policy_per_table_restatement():
     out = O.np_lookup(tables, q, nk, [9.0, 9.0, 9.0], resident=[resident[0], None, None]).reshape(-1, 4)
     assert (out[90:100] == 9.0).all() and np.array_equal(out[:90], rows[:90])     # async table: defaults for non-resident keys
     assert np.array_equal(out[100:200], rows)                                       # sync table: exact rows
+
+
+def test_insertion_policy_counts_unique_keys_not_keys_as_sent():
+    """SURVEY.md App. C4 / docs/hierarchical_parameter_server.md:69: the cache is queried with the batch's UNIQUE keys, so
+    the hit rate behind the sync/async decision is 1 - unique misses / unique keys.  A skewed batch separates the two
+    definitions: 900 copies of one resident key + 100 distinct cold keys is "90 % hit" over the keys as sent and
+    1/101 = 1 % hit over unique keys."""
+    from oracle import hps_oracle as O
+    tk = np.arange(1000, dtype=np.int64)
+    resident = [tk[:10]]
+    q = np.concatenate([np.full(900, 3, dtype=np.int64), np.arange(500, 600, dtype=np.int64)])
+    assert O.np_unique_counts(q, [1000], resident) == [(101, 100)]
+    assert O.np_insert_modes(q, [1000], resident, 0.8) == [False]               # 1 % < 80 %: synchronous
+    assert O.np_insert_modes_keys_as_sent(q, [1000], resident, 0.8) == [True]    # the round-1 reading says async
+    # and the other way round: distinct resident keys + one cold key repeated
+    q2 = np.concatenate([np.arange(10, dtype=np.int64), np.full(90, 700, dtype=np.int64)])
+    assert O.np_insert_modes(q2, [100], resident, 0.8) == [True]                 # 10/11 = 91 % unique hit rate
+    assert O.np_insert_modes_keys_as_sent(q2, [100], resident, 0.8) == [False]   # 10 % as sent

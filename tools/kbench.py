@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Kernel A/B bench: probe+gather kernel variants on the Criteo-shaped workload, one session, interleaved rounds.
+"""Kernel A/B bench: probe-kernel variants and gather walks on the Criteo-shaped workload, one session, interleaved rounds.
 
-    python tools/kbench.py --variants 4,104,1004,1104,2,102,108 --rounds 5 [--rows 10000000] [--hit 1.0]
+    python tools/kbench.py --variants 2,4,8,102,104,108 --xcd 0,1 --rounds 5 [--rows 10000000] [--hit 1.0]
 
-Variant code = U + 100*rolled_outer_loop + 1000*sampled_stamps (see LaunchProbeGather in csrc/cache/kernels.hip).
-Prints median / min kernel time per variant (HIP events on the session's stream) and the implied fraction of the
-8 TB/s HBM roofline at 1,032 algorithmic bytes per lookup.
+Variant code = U + 100*no_dedup (see LaunchProbeTiles in csrc/cache/kernels.hip); --xcd: chunk walk of the gather kernel
+(1 = each XCD sweeps its own eighth of the key range).  Prints median / min of the probe kernels (K_P + K_M) and of
+the gather kernel K_G (HIP events on the session's stream), and the pair's fraction of the 8 TB/s HBM roofline at
+SURVEY 8(d)'s 1,032 algorithmic bytes per lookup.
 """
 import argparse
 import sys
@@ -31,7 +32,8 @@ def main():
     ap.add_argument("--cache-frac", type=float, default=0.2)
     ap.add_argument("--hit", type=float, default=1.1)
     ap.add_argument("--zipf", type=float, default=1.05)
-    ap.add_argument("--balanced", default="1", help="comma list of 0/1: balanced grid (same chunk count per wave)")
+    ap.add_argument("--xcd", default="1", help="comma list of 0/1: XCD-aware chunk walk of the gather kernel")
+    ap.add_argument("--threshold-permille", type=int, default=1000, help="<1000: the policy needs the unique-key count (claim words)")
     a = ap.parse_args()
     import torch
     from hugectr_backend_amd import build as hb, hps
@@ -51,6 +53,7 @@ def main():
     cache = ps.get_embedding_cache("m", 0)
     s = hps.LookupSession.create(ps, "m", cache)
     s.set_option("timing", 1)
+    s.set_option("hit_rate_threshold_permille", a.threshold_permille)
     C = int(np.ceil(a.cache_frac * R))
     resident = []
     for t in range(T):
@@ -63,24 +66,26 @@ def main():
     out = torch.empty(N * D, dtype=torch.float32, device="cuda")
     nk = [Bn] * T
     print(f"setup {time.time() - t0:.1f}s", flush=True)
-    variants = [(int(v), int(b)) for v in a.variants.split(",") for b in a.balanced.split(",")]
+    variants = [(int(v), int(b)) for v in a.variants.split(",") for b in a.xcd.split(",")]
     res = {v: [] for v in variants}
-    for v, bal in variants:  # warm
-        s.set_option("probe_unroll", v)
-        s.set_option("probe_balanced", bal)
+    for v, x in variants:  # warm
+        s.set_option("probe_variant", v)
+        s.set_option("xcd_walk", x)
         s.lookup_device(batches[0], nk, out=out)
     for r in range(a.rounds):
-        for v, bal in variants:
-            s.set_option("probe_unroll", v)
-            s.set_option("probe_balanced", bal)
+        for v, x in variants:
+            s.set_option("probe_variant", v)
+            s.set_option("xcd_walk", x)
             for b in batches:
                 s.lookup_device(b, nk, out=out)
-                res[(v, bal)].append(s.last_stats().probe_gather_ms)
+                st = s.last_stats()
+                res[(v, x)].append((st.probe_gather_ms, st.hit_gather_ms))
     alg = N * (8 + 8 * D)
-    for v, bal in variants:
-        x = np.array(res[(v, bal)])
-        med, mn = float(np.median(x)), float(x.min())
-        print(f"variant {v:5d} balanced={bal}: median {med:.4f} ms  min {mn:.4f} ms  frac(median) {alg / (med * 1e-3) / 8e12:.3f}  n={x.size}")
+    for v, x in variants:
+        arr = np.array(res[(v, x)])
+        p, g = float(np.median(arr[:, 0])), float(np.median(arr[:, 1]))
+        print(f"variant {v:4d} xcd_walk={x}: probe median {p * 1e3:7.1f} us (min {arr[:, 0].min() * 1e3:7.1f})  gather median {g * 1e3:7.1f} us "
+              f"(min {arr[:, 1].min() * 1e3:7.1f})  frac(probe+gather) {alg / ((p + g) * 1e-3) / 8e12:.3f}  n={arr.shape[0]}")
 
 
 if __name__ == "__main__":
