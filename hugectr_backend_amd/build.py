@@ -131,6 +131,16 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
         if newer(out, deps):
             _link(out, deps, ["-ldl"])
         outs["mock_core"] = out
+    # native tools next to the libraries (binaries are git-ignored like the libraries; they travel with gpurun)
+    tool_src = ROOT / "tools" / "triton_abi_bench.cpp"
+    if tool_src.exists() and "mock" in groups:
+        out = LIB / "triton_abi_bench.bin"
+        if force or not out.exists() or out.stat().st_mtime < max(tool_src.stat().st_mtime,
+                                                                   (CSRC / "mock_triton" / "mock_core.h").stat().st_mtime,
+                                                                   (CSRC / "common" / "hps_hash.h").stat().st_mtime):
+            _run([HIPCC, f"--offload-arch={ARCH}", "-O2", "-std=c++17", "-Wall", "-Wno-unused-result", str(tool_src), "-o", str(out),
+                  "-ldl", "-pthread"])
+        outs["triton_abi_bench"] = out
     if verbose:
         for k, v in outs.items():
             print(f"{k}: {v}")

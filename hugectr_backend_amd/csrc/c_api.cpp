@@ -362,6 +362,9 @@ int hps_session_last_stats(hps_session_t* s, hps_lookup_stats_t* out) {
     out->hit_gather_ms = s->s->last_gather_ms();
     out->unique_keys = s->s->last_unique_key_count();
     out->key_stage_ms = s->s->last_key_stage_ms();
+    out->keys_narrowed = s->s->last_keys_narrow() ? 1 : 0;
+    out->scatter_ms = s->s->last_scatter_ms();
+    out->insert_ms = s->s->last_insert_ms();
     return Status::Ok();
   });
 }
@@ -381,6 +384,8 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       s->s->set_xcd_walk(value != 0);
     } else if (n == "keys_pinned_check") {
       s->s->set_keys_pinned_check(value != 0);
+    } else if (n == "narrow_keys") {
+      s->s->set_narrow_keys(value != 0);
     } else if (n == "host_gather") {
       s->s->set_force_host_gather(value != 0);
     } else if (n == "split_probe") {

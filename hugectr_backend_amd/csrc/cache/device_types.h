@@ -91,6 +91,8 @@ struct CallDesc {
   uint32_t epoch;           // LRU epoch of this call (monotonic per cache)
   uint64_t total_keys;      // N = sum n_t
   const int64_t* keys;      // flat, table-major, device
+  const uint32_t* keys32;   // not null: the same keys narrowed to 32 bits (every key of the call is in [0, 2^32); then
+                            // `keys` is not read) — halves the host->device bytes of a request's KEYS
   uint64_t key_start[kMaxTables + 1];  // prefix sums of n_t
   float* out[kMaxTables];              // device pointer of table t's output slice
   uint8_t vec_ok[kMaxTables];          // 1: D%4==0 and out[t] 16-B aligned -> float4 path

@@ -210,7 +210,11 @@ class LookupSession {
   void set_split_probe(bool b) { split_probe_ = b; }
   void set_xcd_walk(bool b) { xcd_walk_ = b; }
   float last_key_stage_ms() const { return key_stage_ms_; }
+  float last_scatter_ms() const { return last_scatter_ms_; }   // miss-scatter kernel of the last call (last chunk)
+  float last_insert_ms() const { return last_insert_ms_; }     // cache-insert kernel of the last call (last chunk)
   void set_keys_pinned_check(bool b) { keys_pinned_hint_ = b ? 1 : 0; }
+  void set_narrow_keys(bool b) { narrow_keys_ = b; narrow_backoff_ = 0; }
+  bool last_keys_narrow() const { return keys_narrow_; }
   float last_gpu_call_ms() const { return last_gpu_call_ms_; }  // first kernel to last of the last call (HIP events)
   // host wall-clock phases of the last call (ms): [0] enqueue -> miss counts known, [1] parameter-server
   // gather, [2] H2D + scatter + insert until the stream drained, [3] whole call
@@ -248,6 +252,9 @@ class LookupSession {
              ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr, ev_probe_ = nullptr, ev_keys_ = nullptr;
   float last_gpu_call_ms_ = 0.f;
   float key_stage_ms_ = 0.f;      // host side of lookup(): staging the keys and enqueueing their H2D copies
+  bool narrow_keys_ = true;       // option "narrow_keys": stage pageable keys as uint32 when they all fit
+  bool keys_narrow_ = false;      // this call's staged keys are uint32
+  int narrow_backoff_ = 0;        // calls left before narrowing is tried again after a wide key was seen
   int keys_pinned_hint_ = 1;      // 1: flat key arrays in page-locked memory are DMA'd in place (option "keys_pinned_check")
   Status TimedLookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T);
 
@@ -269,6 +276,8 @@ class LookupSession {
   uint32_t* d_mode_ = nullptr;    // per-table insertion mode of a mixed call (1 = async)
   uint32_t call_tag_ = 0;
   hipEvent_t ev_g0_ = nullptr, ev_g1_ = nullptr;   // around the hit-gather kernel
+  hipEvent_t ev_s0_ = nullptr, ev_s1_ = nullptr, ev_i0_ = nullptr, ev_i1_ = nullptr;   // around the miss scatter / the cache insert
+  float last_scatter_ms_ = 0.f, last_insert_ms_ = 0.f;
   float last_gather_ms_ = 0.f;
   bool split_call_ = false;      // the call in progress gathers its hits on stream_ while the miss path runs (copies go down copy_stream_)
   bool split_probe_ = true;      // host-gather tier: start the miss path behind the probe, gather the hits meanwhile (§3.4c);

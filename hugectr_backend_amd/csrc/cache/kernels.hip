@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
   const TableCacheDev tb = tables[td.table];
   const uint32_t n = td.count;
   const uint32_t tid = threadIdx.x;
+  const uint32_t* __restrict__ keys32 = call->keys32;   // wave-uniform: one of the two loops below
   const int64_t* __restrict__ keys = call->keys + td.begin;
   const uint32_t epoch = call->epoch;
   constexpr int kPerThread = kTileKeys / kProbeBlockThreads;
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
     const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
-    k[q] = j < n ? keys[j] : HPS_EMPTY_KEY;
+    if (keys32) k[q] = j < n ? (int64_t)(uint64_t)keys32[td.begin + j] : HPS_EMPTY_KEY;
+    else k[q] = j < n ? keys[j] : HPS_EMPTY_KEY;
   }
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {

@@ -202,6 +202,26 @@ static Status MaterializeStore(const std::string& src, const std::string& dst) {
   return Status::Ok();
 }
 
+// "synthetic://<rows>[?seed=<n>][&key0=<k>]"; false for anything else (then the string is a directory)
+static bool ParseSyntheticSource(const std::string& src, uint64_t* rows, uint64_t* seed, int64_t* key0) {
+  static const char kScheme[] = "synthetic://";
+  if (src.compare(0, sizeof(kScheme) - 1, kScheme) != 0) return false;
+  const char* c = src.c_str() + sizeof(kScheme) - 1;
+  char* end = nullptr;
+  const unsigned long long r = std::strtoull(c, &end, 10);
+  if (end == c) return false;   // e.g. "synthetic://name" of a model whose tables are injected later
+  *rows = r;
+  *seed = 20260929ull;
+  *key0 = 0;
+  while (*end == '?' || *end == '&') {
+    ++end;
+    if (std::strncmp(end, "seed=", 5) == 0) *seed = std::strtoull(end + 5, &end, 10);
+    else if (std::strncmp(end, "key0=", 5) == 0) *key0 = std::strtoll(end + 5, &end, 10);
+    else return false;
+  }
+  return *end == 0;
+}
+
 Status HierParameterServer::EnsureTables(const InferenceParams& p, bool load) {
   std::vector<std::shared_ptr<HostTable>> tabs;
   {
@@ -248,6 +268,17 @@ Status HierParameterServer::EnsureTables(const InferenceParams& p, bool load) {
           dir = store;
         }
         tabs[t]->SetTierOptions(tier);
+        // "synthetic://<rows>[?seed=<n>][&key0=<k>]" instead of a directory: the table of SURVEY.md 8(d)'s recipe (keys
+        // key0..key0+rows-1, hashed fp32 rows) generated straight into the host tier.  A deployment has files; this is how
+        // a benchmark loads the 133-GB Criteo-shaped model THROUGH the plugin boundary without writing 133 GB first.
+        uint64_t syn_rows = 0, syn_seed = 0;
+        int64_t syn_key0 = 0;
+        if (ParseSyntheticSource(p.sparse_model_files[t], &syn_rows, &syn_seed, &syn_key0)) {
+          if (tier.persistent || tier.tiered)
+            return Error(Code::kUnsupported, "model '", p.model_name, "': a synthetic:// table needs the plain in-memory host tier");
+          HPS_RETURN_IF_ERROR(tabs[t]->LoadSynthetic(syn_seed, (uint32_t)t, syn_key0, (size_t)syn_rows, pool_));
+          continue;
+        }
         HPS_RETURN_IF_ERROR(tabs[t]->LoadFromDir(dir, pool_));
       }
       return Status::Ok();

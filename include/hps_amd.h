@@ -85,6 +85,9 @@ typedef struct hps_lookup_stats {
   uint64_t unique_keys;    /* distinct (table, key) pairs of the call — counted only when the insertion policy needs the
                               hit rate (0 < hit_rate_threshold < 1), else 0 */
   float key_stage_ms;      /* hps_session_lookup: host time spent staging the keys and enqueueing their H2D copies */
+  float scatter_ms;        /* HIP-event time of the miss-scatter kernel (option "timing"=1; last staging chunk) */
+  float insert_ms;         /* HIP-event time of the cache-insert kernel (option "timing"=1; last staging chunk) */
+  int32_t keys_narrowed;   /* 1: the call's pageable keys all fitted 32 bits and crossed PCIe as uint32 */
 } hps_lookup_stats_t;
 
 const char* hps_last_error(void);
@@ -193,7 +196,8 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
  * this session's misses the reference's way — host threads gather, hipMemcpyAsync ships — e.g. to compare the two tiers
  * on one deployment), "split_probe" (0/1: read the miss counts back before / after the hit gather), and the kernel A/B
  * switches "probe_variant" (U + 100*no_dedup, U in {2,4,8}), "xcd_walk" (0/1), "keys_pinned_check" (0/1: DMA flat
- * page-locked key arrays in place instead of staging them) */
+ * page-locked key arrays in place instead of staging them), "narrow_keys" (0/1: pageable keys that all fit 32 bits
+ * cross PCIe as uint32) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 /* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------

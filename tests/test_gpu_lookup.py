@@ -506,3 +506,37 @@ def test_host_keys_staged_in_pieces_and_pinned_in_place():
             koff += n * tables[t][1].shape[1]
         s.lookup_ptrs([p.ctypes.data if p.size else 0 for p in parts], vptrs, nk)
         assert np.array_equal(_bits(outp.cpu().numpy()), _bits(ref))
+
+
+def test_pageable_keys_cross_pcie_as_uint32_when_they_fit():
+    """Staging narrows a request's keys to 32 bits when every key fits (checked while copying); one wide or negative key
+    anywhere in the request makes that call use the 8-byte copy; rows are exact either way."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(32)
+    tables = make_tables([(60000, 16), (60000, 8)])
+    big = tables[1][0].copy()
+    big[:100] += 1 << 40            # a table that also holds keys beyond 32 bits
+    tables[1] = (big, tables[1][1])
+    ps, cache, s = _mk("narrow", tables, maxcat=[1, 1], gpucacheper=0.3, max_batch=400_000)
+    nk = [300_000, 250_000]
+    q = np.concatenate([rng.choice(tables[0][0], nk[0]), rng.choice(big[100:], nk[1])]).astype(np.int64)
+    q[rng.integers(0, q.size, 5000)] = (1 << 32) - 1 - rng.integers(0, 1000, 5000)      # absent, but 32-bit
+    out = s.lookup(q, nk).cpu().numpy()
+    assert s.last_stats().keys_narrowed == 1
+    assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, nk, [0.0, 0.0])))
+    q2 = q.copy()
+    q2[nk[0] + 123_456] = big[7]      # one key of 41 bits in the last staging group
+    out = s.lookup(q2, nk).cpu().numpy()
+    assert s.last_stats().keys_narrowed == 0
+    assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q2, nk, [0.0, 0.0])))
+    out = s.lookup(q, nk).cpu().numpy()          # the session backs off for a while after a wide key
+    assert s.last_stats().keys_narrowed == 0
+    s.set_option("narrow_keys", 1)                # re-arms it
+    out = s.lookup(q, nk).cpu().numpy()
+    assert s.last_stats().keys_narrowed == 1
+    assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, nk, [0.0, 0.0])))
+    q3 = q.copy()
+    q3[5] = -9
+    out = s.lookup(q3, nk).cpu().numpy()
+    assert s.last_stats().keys_narrowed == 0
+    assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q3, nk, [0.0, 0.0])))

@@ -1,0 +1,294 @@
+// Native load generator for the Triton plugin boundary — what `perf_analyzer` is to the reference
+// (/root/reference/.gitlab-ci.yml:70 is the reference's only performance smoke: perf_analyzer against the hps backend).
+//
+// Plays tritonserver through the mock core (csrc/mock_triton, TEST INFRASTRUCTURE): dlopens libtriton_mock_core.so,
+// which dlopens libtriton_hps.so and calls TRITONBACKEND_Initialize / ModelInitialize / ModelInstanceInitialize; then
+// `instances` threads issue TRITONBACKEND_ModelInstanceExecute back to back, each request = one Criteo-shaped batch:
+//   KEYS     int64 [1, T*B]  host memory (pageable by default: the reference memcpy's them, hps.cc:586-597)
+//   NUMKEYS  int32 [1, T]
+//   OUTPUT0  fp32  [T*B*D]   device memory handed out by the core (TRITONBACKEND_OutputBuffer), as for a GPU instance
+// The model's tables come from the "synthetic://<rows>" source (csrc/cache/parameter_server.cpp), so the 26 x 10 M x 128
+// model loads through the plugin boundary without 133 GB of files.
+//
+// Timing follows bench.py: `blocks` timed blocks of `steps` requests (all instances together), the median block is the
+// result; p50/p99 over every timed request.  One response is checked against the table recipe at the end.
+// Prints ONE JSON line.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../hugectr_backend_amd/csrc/common/hps_hash.h"
+#include "../hugectr_backend_amd/csrc/mock_triton/mock_core.h"
+
+namespace {
+
+struct Args {
+  std::string lib_dir = "hugectr_backend_amd/lib";
+  int tables = 26, dim = 128, instances = 2, steps = 20, warmup = 5, blocks = 10, direct = 0, pinned_keys = 0;
+  long rows = 10000000, batch = 65536;
+  double cache_frac = 0.2, hit = 0.957, zipf = 1.05, threshold = 1.0;
+};
+
+#define API(name) decltype(&::name) name = nullptr
+struct Mock {
+  API(mock_last_error); API(mock_server_create); API(mock_server_destroy); API(mock_model_load); API(mock_model_unload);
+  API(mock_instance_create); API(mock_instance_destroy); API(mock_request_new); API(mock_request_delete);
+  API(mock_request_add_input_buffer); API(mock_request_add_requested_output); API(mock_request_set_output_buffer);
+  API(mock_instance_execute); API(mock_request_response_count); API(mock_request_release_count);
+  API(mock_request_error_code); API(mock_request_error_message); API(mock_request_response_int_param);
+  API(mock_instance_get_stats);
+};
+#undef API
+
+[[noreturn]] void die(const char* what, const char* detail = "") {
+  fprintf(stderr, "triton_abi_bench: %s %s\n", what, detail ? detail : "");
+  exit(2);
+}
+
+uint64_t mix(uint64_t x) { return hps_mix64(x); }
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Args a;
+  for (int i = 1; i + 1 < argc; i += 2) {
+    const std::string k = argv[i];
+    const char* v = argv[i + 1];
+    if (k == "--lib-dir") a.lib_dir = v;
+    else if (k == "--tables") a.tables = atoi(v);
+    else if (k == "--rows") a.rows = atol(v);
+    else if (k == "--dim") a.dim = atoi(v);
+    else if (k == "--batch") a.batch = atol(v);
+    else if (k == "--cache-frac") a.cache_frac = atof(v);
+    else if (k == "--hit") a.hit = atof(v);
+    else if (k == "--zipf") a.zipf = atof(v);
+    else if (k == "--instances") a.instances = atoi(v);
+    else if (k == "--steps") a.steps = atoi(v);
+    else if (k == "--warmup") a.warmup = atoi(v);
+    else if (k == "--blocks") a.blocks = atoi(v);
+    else if (k == "--direct") a.direct = atoi(v);
+    else if (k == "--pinned-keys") a.pinned_keys = atoi(v);
+    else if (k == "--threshold") a.threshold = atof(v);
+    else die("unknown option", argv[i]);
+  }
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);   // two instances' streams on separate hardware queues
+  const int T = a.tables, D = a.dim;
+  const long R = a.rows, B = a.batch;
+  const size_t N = (size_t)T * (size_t)B;
+
+  void* core = dlopen((a.lib_dir + "/libtriton_mock_core.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+  if (!core) die("cannot load the mock core:", dlerror());
+  Mock m;
+#define LOAD(name) if (!(m.name = (decltype(m.name))dlsym(core, #name))) die("missing symbol", #name)
+  LOAD(mock_last_error); LOAD(mock_server_create); LOAD(mock_server_destroy); LOAD(mock_model_load); LOAD(mock_model_unload);
+  LOAD(mock_instance_create); LOAD(mock_instance_destroy); LOAD(mock_request_new); LOAD(mock_request_delete);
+  LOAD(mock_request_add_input_buffer); LOAD(mock_request_add_requested_output); LOAD(mock_request_set_output_buffer);
+  LOAD(mock_instance_execute); LOAD(mock_request_response_count); LOAD(mock_request_release_count);
+  LOAD(mock_request_error_code); LOAD(mock_request_error_message); LOAD(mock_request_response_int_param);
+  LOAD(mock_instance_get_stats);
+#undef LOAD
+
+  // ---- ps.json + model configuration (what Triton derives from config.pbtxt) ----
+  char tmpl[] = "/tmp/hps_abi_bench_XXXXXX";
+  if (!mkdtemp(tmpl)) die("mkdtemp failed");
+  const std::string ps_path = std::string(tmpl) + "/ps.json";
+  {
+    std::string j = "{\"supportlonglong\": true, \"volatile_db\": {\"type\": \"hash_map\", \"num_partitions\": 8}, \"models\": [{";
+    j += "\"model\": \"criteo_dlrm\", \"sparse_files\": [";
+    for (int t = 0; t < T; ++t) j += (t ? ", \"synthetic://" : "\"synthetic://") + std::to_string(R) + "\"";
+    j += "], \"num_of_worker_buffer_in_pool\": " + std::to_string(std::max(3, a.instances));
+    auto list = [&](const char* key, const std::string& v) {
+      j += std::string(", \"") + key + "\": [";
+      for (int t = 0; t < T; ++t) j += (t ? ", " : "") + v;
+      j += "]";
+    };
+    list("embedding_vecsize_per_table", std::to_string(D));
+    list("maxnum_catfeature_query_per_table_per_sample", "1");
+    list("default_value_for_each_table", "0.0");
+    char buf[256];
+    snprintf(buf, sizeof buf, ", \"deployed_device_list\": [0], \"max_batch_size\": %ld, \"gpucache\": true, \"gpucacheper\": %.6f, "
+             "\"hit_rate_threshold\": %.6f, \"ps_direct_access\": %s}]}", B, a.cache_frac, a.threshold, a.direct ? "true" : "false");
+    j += buf;
+    FILE* f = fopen(ps_path.c_str(), "w");
+    if (!f) die("cannot write", ps_path.c_str());
+    fputs(j.c_str(), f);
+    fclose(f);
+  }
+  const std::string backend_cfg = "{\"cmdline\": {\"auto-complete-config\": \"true\", \"ps\": \"" + ps_path + "\"}}";
+  const std::string model_cfg =
+      "{\"name\": \"criteo_dlrm\", \"backend\": \"hps\", \"max_batch_size\": " + std::to_string(B) +
+      ", \"input\": [{\"name\": \"KEYS\", \"data_type\": \"TYPE_INT64\", \"dims\": [-1]}, {\"name\": \"NUMKEYS\", \"data_type\": "
+      "\"TYPE_INT32\", \"dims\": [-1]}], \"output\": [{\"name\": \"OUTPUT0\", \"data_type\": \"TYPE_FP32\", \"dims\": [-1]}], "
+      "\"instance_group\": [{\"count\": " + std::to_string(a.instances) + ", \"kind\": \"KIND_GPU\", \"gpus\": [0]}]}";
+
+  const double t_load0 = now_s();
+  mock_server_t* srv = nullptr;
+  if (m.mock_server_create((a.lib_dir + "/libtriton_hps.so").c_str(), "hps", backend_cfg.c_str(), 0, 0, &srv) != 0)
+    die("TRITONBACKEND_Initialize failed:", m.mock_last_error());
+  mock_model_t* model = nullptr;
+  if (m.mock_model_load(srv, "criteo_dlrm", 1, model_cfg.c_str(), &model) != 0) die("ModelInitialize failed:", m.mock_last_error());
+  std::vector<mock_instance_t*> inst(a.instances);
+  for (int i = 0; i < a.instances; ++i)
+    if (m.mock_instance_create(model, ("criteo_dlrm_0_" + std::to_string(i)).c_str(), 2, 0, &inst[i]) != 0)
+      die("ModelInstanceInitialize failed:", m.mock_last_error());
+  const double load_s = now_s() - t_load0;
+
+  // ---- key batches: per table B keys; with probability `hit` a Zipf-ranked key of the warmed range [0, C), else uniform
+  //      from the cold range [C, R) — bench.py's generator, on host threads ----
+  const long C = (long)std::ceil(a.cache_frac * (double)R);
+  std::vector<double> cdf((size_t)C);
+  {
+    double acc = 0;
+    for (long i = 0; i < C; ++i) { acc += 1.0 / std::pow((double)(i + 1), a.zipf); cdf[(size_t)i] = acc; }
+    for (long i = 0; i < C; ++i) cdf[(size_t)i] /= acc;
+  }
+  const int nbatch = a.warmup + a.steps * a.blocks;
+  int64_t* keys_all = nullptr;
+  const size_t key_bytes = (size_t)nbatch * N * sizeof(int64_t);
+  if (a.pinned_keys) {
+    if (hipHostMalloc((void**)&keys_all, key_bytes, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc of the key batches failed");
+  } else {
+    keys_all = (int64_t*)malloc(key_bytes);
+    if (!keys_all) die("out of memory for the key batches");
+  }
+  {
+    const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::atomic<long> next{0};
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < nth; ++w)
+      th.emplace_back([&] {
+        for (;;) {
+          const long job = next.fetch_add(1);   // one (batch, table) slice per job
+          if (job >= (long)nbatch * T) return;
+          const long b = job / T, t = job % T;
+          int64_t* dst = keys_all + (size_t)b * N + (size_t)t * (size_t)B;
+          uint64_t s = mix(0x5EEDull * 1315423911ull + (uint64_t)job);
+          for (long i = 0; i < B; ++i) {
+            s = mix(s + (uint64_t)i);
+            const double u = (double)(s >> 11) * (1.0 / 9007199254740992.0);
+            const uint64_t s2 = mix(s ^ 0xABCDEFull);
+            const double v = (double)(s2 >> 11) * (1.0 / 9007199254740992.0);
+            if (u < a.hit || R <= C) {
+              const long rank = (long)(std::lower_bound(cdf.begin(), cdf.end(), v) - cdf.begin());
+              dst[i] = std::min(rank, C - 1);
+            } else {
+              dst[i] = C + (long)(v * (double)(R - C));
+            }
+          }
+        }
+      });
+    for (auto& x : th) x.join();
+  }
+  std::vector<int32_t> numkeys((size_t)T, (int32_t)B);
+  std::vector<float*> d_out(a.instances, nullptr);
+  for (int i = 0; i < a.instances; ++i)
+    if (hipMalloc((void**)&d_out[i], N * (size_t)D * sizeof(float)) != hipSuccess) die("hipMalloc of OUTPUT0 failed");
+
+  // ---- request loop ----
+  std::atomic<long> next{0};
+  std::atomic<int> failed{0};
+  std::vector<std::vector<double>> lat(a.instances);
+  std::vector<long> last_batch(a.instances, -1);
+  auto run = [&](long first, long count, bool record) {
+    next.store(0);
+    std::vector<std::thread> th;
+    for (int w = 0; w < a.instances; ++w)
+      th.emplace_back([&, w] {
+        (void)hipSetDevice(0);
+        const int64_t kshape[2] = {1, (int64_t)N}, nshape[2] = {1, (int64_t)T};
+        for (;;) {
+          const long i = next.fetch_add(1);
+          if (i >= count) return;
+          const long b = first + i;
+          mock_request_t* rq = m.mock_request_new(std::to_string(b).c_str(), 0);
+          m.mock_request_add_input_buffer(rq, "KEYS", 9 /*INT64*/, kshape, 2, keys_all + (size_t)b * N, N * sizeof(int64_t),
+                                          a.pinned_keys ? 1 : 0, 0);
+          m.mock_request_add_input_buffer(rq, "NUMKEYS", 8 /*INT32*/, nshape, 2, numkeys.data(), (uint64_t)T * sizeof(int32_t), 0, 0);
+          m.mock_request_add_requested_output(rq, "OUTPUT0");
+          m.mock_request_set_output_buffer(rq, d_out[w], N * (size_t)D * sizeof(float), 2 /*GPU*/, 0);
+          const double t0 = now_s();
+          const int rc = m.mock_instance_execute(inst[w], &rq, 1);
+          const double dt = now_s() - t0;
+          if (rc != 0 || m.mock_request_error_code(rq) != -1 || m.mock_request_response_count(rq) != 1 ||
+              m.mock_request_release_count(rq) != 1) {
+            if (!failed.exchange(1))
+              fprintf(stderr, "request %ld failed: rc=%d code=%d %s\n", b, rc, m.mock_request_error_code(rq),
+                      m.mock_request_error_message(rq) ? m.mock_request_error_message(rq) : "");
+          }
+          if (record) lat[w].push_back(dt * 1e3);
+          last_batch[w] = b;
+          m.mock_request_delete(rq);
+        }
+      });
+    for (auto& x : th) x.join();
+  };
+  run(0, a.warmup, false);
+  (void)hipDeviceSynchronize();
+  std::vector<double> block_s;
+  for (int blk = 0; blk < a.blocks; ++blk) {
+    const double t0 = now_s();
+    run(a.warmup + (long)blk * a.steps, a.steps, true);
+    (void)hipDeviceSynchronize();
+    block_s.push_back(now_s() - t0);
+  }
+
+  // ---- one response against the table recipe: every key of [0, R) exists, row(t, k) is a pure function ----
+  long bad = 0, checked = 0;
+  {
+    const int w = 0;
+    const long b = last_batch[w];
+    std::vector<float> row((size_t)D);
+    for (int s = 0; s < 2048 && b >= 0; ++s) {
+      const size_t i = (size_t)(mix(77 + (uint64_t)s) % N);
+      const uint32_t t = (uint32_t)(i / (size_t)B);
+      const int64_t key = keys_all[(size_t)b * N + i];
+      if (hipMemcpy(row.data(), d_out[w] + i * (size_t)D, (size_t)D * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { ++bad; continue; }
+      const uint64_t rb = hps_synth_row_base(hps_synth_table_base(20260929ull, t), key);
+      for (int j = 0; j < D; ++j) {
+        uint32_t got;
+        memcpy(&got, &row[(size_t)j], 4);
+        if (got != hps_synth_elem_bits(rb, (uint32_t)j)) { ++bad; break; }
+      }
+      ++checked;
+    }
+  }
+  mock_instance_stats_t st{};
+  uint64_t ok_req = 0, reports = 0;
+  for (int i = 0; i < a.instances; ++i) { m.mock_instance_get_stats(inst[i], &st); ok_req += st.success_requests; reports += st.batch_reports; }
+
+  std::vector<double> all;
+  for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
+  std::sort(all.begin(), all.end());
+  std::vector<double> bs = block_s;
+  std::sort(bs.begin(), bs.end());
+  const double med = bs.empty() ? 0 : bs[bs.size() / 2];
+  auto pct = [&](double p) { return all.empty() ? 0.0 : all[std::min(all.size() - 1, (size_t)(p * (double)all.size()))]; };
+  printf("{\"through\": \"TRITONBACKEND_ModelInstanceExecute (libtriton_hps.so) driven by the mock Triton core, native caller\", "
+         "\"keys_memory\": \"%s\", \"output_memory\": \"device\", \"instances\": %d, \"steps_per_block\": %d, \"blocks\": %d, "
+         "\"lookups_per_s\": %.6g, \"ms_per_step\": %.6g, \"block_ms\": [", a.pinned_keys ? "host, page-locked" : "host, pageable",
+         a.instances, a.steps, a.blocks, med > 0 ? (double)a.steps * (double)N / med : 0.0, med / a.steps * 1e3);
+  for (size_t i = 0; i < block_s.size(); ++i) printf("%s%.4g", i ? ", " : "", block_s[i] * 1e3);
+  printf("], \"p50_request_ms\": %.5g, \"p99_request_ms\": %.5g, \"requests_ok_reported_by_backend\": %llu, \"batch_statistics_reports\": %llu, "
+         "\"failed\": %d, \"rows_checked_against_recipe\": %ld, \"rows_wrong\": %ld, \"model_load_seconds\": %.4g, \"ps_tier\": \"%s\"}\n",
+         pct(0.5), pct(0.99), (unsigned long long)ok_req, (unsigned long long)reports, failed.load(), checked, bad, load_s,
+         a.direct ? "device-driven (ps_direct_access)" : "host gather");
+  fflush(stdout);
+  for (auto* i : inst) m.mock_instance_destroy(i);
+  m.mock_model_unload(model);
+  m.mock_server_destroy(srv);
+  return failed.load() || bad ? 1 : 0;
+}
