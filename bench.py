@@ -3,18 +3,22 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" = one pass of the lookup hot path over one batch of synthetic keys that already sit in HBM
-(26 tables x 65,536 keys): cache probe (HIP), unique-miss extraction (HIP), hit-row gather (HIP) running
-while the parameter server fetches the missed rows (one GPU, >= 12 CPUs: host threads gather them and
-hipMemcpyAsync ships them, as in the reference; otherwise / --direct 1: the device-driven tier, a HIP kernel
-reading them out of pinned host memory, with the fused probe+gather kernel), scatter + cache insert (HIP).
-The other tier and the fused kernel are measured after the timed region and reported under extra_legs.
-Results are the exact fp32 rows (sync-insert mode, hit_rate_threshold=1.0), checked against the CPU
-oracle on a slice of every run.
+One "step" = one call of the reference's lookup contract — LookupSession::lookup(h_keys_per_table, d_vectors_per_table,
+num_keys_per_table), docs/architecture.md:308-323 — through the C ABI (hps_session_lookup) on one batch of synthetic keys
+(26 tables x 65,536 keys) that sit in ordinary HOST memory, as a Triton request's KEYS do (hps.cc:586-597): key staging +
+upload (narrowed to 32 bits when every key fits), tile-local input dedup + cache probe (HIP), call-wide unique misses
+(HIP), hit-row gather (HIP) running while the parameter server fetches the missed rows (one GPU, >= 12 CPUs: host threads
+gather them and hipMemcpyAsync ships them, as in the reference; otherwise / --direct 1: the device-driven tier, a HIP
+kernel reading them out of pinned host memory), scatter + cache insert (HIP).  Output rows land in HBM (Triton's device
+output buffer).  Results are the exact fp32 rows (sync-insert mode, hit_rate_threshold=1.0), checked against the CPU
+oracle on every run.
 
-N>1 (launched by torch.distributed.run, one rank per GPU): the reference's multi-GPU mode is
-"replicas only" (independent cache per GPU) — each rank serves its own batches, no
-data-path collective; RCCL is used for the barriers and the max-over-ranks time only.  scaling = weak.
+Timed region: W warm-up steps, then blocks of exactly K steps, each block bracketed by a barrier and a device
+synchronisation on both sides (max over ranks); `value` is K x N / the MEDIAN block, all block times are printed.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): the reference's multi-GPU mode is "replicas only"
+(independent cache per GPU) — each rank serves its own batches, no data-path collective; RCCL is used
+for the barriers and the max-over-ranks time only.  scaling = weak.
 
 Prints ONE JSON line on rank 0.
 """
@@ -43,6 +47,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--blocks", type=int, default=0,
+                    help="timed blocks of --steps steps each; 0 (default): ceil(240 / steps), at most 12 (12 blocks for --steps 20)")
     ap.add_argument("--tables", type=int, default=26)
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per table (BASELINE config 2: 1e7)")
     ap.add_argument("--dim", type=int, default=128)
@@ -55,9 +61,11 @@ def parse_args():
     ap.add_argument("--sessions", type=int, default=2, help="concurrent lookup sessions (Triton instance count)")
     ap.add_argument("--mode", choices=["sync", "async"], default="sync",
                     help="sync: exact rows (threshold 1.0); async: misses return default, inserted in background")
-    ap.add_argument("--distinct-batches", type=int, default=0,
-                    help="0: one fresh batch per step (warmup+steps distinct batches)")
-    ap.add_argument("--unroll", type=int, default=4, help="probe+gather kernel variant (tools/kbench.py)")
+    ap.add_argument("--distinct-batches", type=int, default=0, help="0: one fresh batch per step")
+    ap.add_argument("--probe-variant", type=int, default=4, help="probe kernel variant U + 100*no_dedup (tools/kbench.py)")
+    ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
+    ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
+    ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys as uint32 when every key of the request fits")
     ap.add_argument("--direct", type=int, default=-1,
                     help="parameter-server tier of the miss path.  0: host threads gather the missed rows and "
                          "hipMemcpyAsync ships them (the reference's arrangement); 1: ps_direct_access (the GPU resolves "
@@ -65,10 +73,13 @@ def parse_args():
                          "rank has at least 12 CPUs to itself, else device-driven — on one GPU the other tier is measured "
                          "right after the headline and reported under extra_legs")
     ap.add_argument("--split-probe", type=int, default=-1,
-                    help="1 / -1 (default): K_A probes only and the hit rows are moved by hps_gather_hits_kernel while the misses "
-                         "are fetched (DESIGN.md 3.4c); 0: fused probe+gather kernel")
+                    help="1 / -1 (default): the miss counts are read back right behind the probe and the hit rows are gathered "
+                         "while the misses are fetched (DESIGN.md 3.4c); 0: gather first")
     ap.add_argument("--no-direct-leg", action="store_true",
                     help="one GPU, host-gather headline: skip the device-driven-tier leg measured afterwards")
+    ap.add_argument("--no-triton-leg", action="store_true",
+                    help="one GPU: skip the leg through TRITONBACKEND_ModelInstanceExecute (tools/triton_abi_bench.cpp)")
+    ap.add_argument("--triton-timeout", type=float, default=240.0)
     ap.add_argument("--no-sharded-leg", action="store_true",
                     help="N>1: skip the BASELINE config 3 leg (one table sharded over the ranks, RCCL all-to-all)")
     ap.add_argument("--shard-rows", type=int, default=1 << 28,
@@ -79,8 +90,7 @@ def parse_args():
     ap.add_argument("--sharded-timeout", type=float, default=300.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true",
-                    help="skip the untimed all-hit and async-insert legs reported next to the headline")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs reported next to the headline")
     return ap.parse_args()
 
 
@@ -151,6 +161,78 @@ def make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, hit, nbatches):
     return out
 
 
+class Runner:
+    """Drives the lookup sessions of one deployment (server + cache): one host thread per session, each step one call of
+    the hot path on one batch, per-step statistics from the engine (HIP events on the session's stream)."""
+
+    MODES = ("host", "pinned", "device")
+
+    def __init__(self, torch, hps, sessions, T, B, D, dev):
+        self.torch, self.hps, self.sessions = torch, hps, sessions
+        self.T, self.B, self.D, self.N = T, B, D, T * B
+        self.outs = [torch.empty(self.N * D, dtype=torch.float32, device=torch.device("cuda", dev)) for _ in sessions]
+        self.nk = [B] * T
+        self.counts = hps.LookupSession.pack_counts(self.nk)
+        self.vptrs = [hps.LookupSession.pack_ptrs([o.data_ptr() + 4 * t * B * D for t in range(T)]) for o in self.outs]
+        self.lock = threading.Lock()
+        self.post_hooks = []   # per session: appended to every step (config 5: the dense step)
+        self.step_hooks = []   # per session: replaces the step
+
+    def pack_host(self, batch_np):
+        return self.hps.LookupSession.pack_ptrs([batch_np.ctypes.data + 8 * t * self.B for t in range(self.T)])
+
+    def run(self, batches, count, first=0, mode="host", sess=None, record=None):
+        """`count` steps over `batches` starting at index `first`, shared by the sessions in `sess`.
+        batches: mode host/pinned -> list of (array, packed pointers); mode device -> list of device tensors."""
+        sess = list(range(len(self.sessions))) if sess is None else sess
+        nxt = [0]
+
+        def worker(si):
+            s = self.sessions[si]
+            while True:
+                with self.lock:
+                    i = nxt[0]
+                    if i >= count:
+                        return
+                    nxt[0] += 1
+                b = batches[(first + i) % len(batches)]
+                t0 = time.perf_counter()
+                if self.step_hooks:
+                    self.step_hooks[si](si, b)
+                elif mode == "device":
+                    s.lookup_device(b, self.nk, out=self.outs[si])
+                else:
+                    s.lookup_packed(b[1], self.vptrs[si], self.counts)
+                if self.post_hooks:
+                    self.post_hooks[si](si)
+                dt = (time.perf_counter() - t0) * 1e3
+                if record is not None:
+                    st = s.last_stats()
+                    with self.lock:
+                        record.append((dt, st.probe_gather_ms, st.hit_gather_ms, st.scatter_ms, st.insert_ms, st.misses,
+                                       st.unique_misses, st.gpu_call_ms, [float(x) for x in st.phase_ms], st.key_stage_ms,
+                                       st.keys_narrowed))
+
+        th = [threading.Thread(target=worker, args=(si,)) for si in sess]
+        [x.start() for x in th]
+        [x.join() for x in th]
+
+
+def summarize(rec, N, D, dt, steps):
+    """One leg's figures from its per-step records."""
+    a = np.array([[r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[9]] for r in rec], dtype=np.float64)
+    probe, gather, scatter = float(a[:, 1].mean()), float(a[:, 2].mean()), float(a[:, 3].mean())
+    hbm_ms = probe + gather + scatter
+    return {
+        "lookups_per_s": steps * N / dt, "ms_per_step": dt / steps * 1e3,
+        "p50_call_ms": float(np.percentile(a[:, 0], 50)), "p99_call_ms": float(np.percentile(a[:, 0], 99)),
+        "probe_ms": probe, "gather_ms": gather, "scatter_ms": scatter, "insert_ms": float(a[:, 4].mean()),
+        "frac_of_hbm_peak_1032B_per_lookup": N * (8 + 8 * D) / (hbm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if hbm_ms > 0 else None,
+        "measured_hit_rate": 1.0 - float(a[:, 5].mean()) / N,
+        "key_stage_ms": float(a[:, 8].mean()),
+    }
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -159,15 +241,13 @@ def main():
     if world > 1:
         # share the host cores between the ranks' parameter-server pools
         os.environ.setdefault("HCTR_DEFAULT_CONCURRENCY", str(max(2, effective_cpus() // world)))
-    tier_auto = a.direct < 0
-    if tier_auto:
+    if a.direct < 0:
         # the host-gather tier needs host cores (its gather runs on ~14 threads per GPU); with fewer, or with several
         # replicas sharing one host, the device-driven tier, which needs none, is the one to run
         a.direct = 0 if (world == 1 and effective_cpus() >= 12) else 1
 
     # HIP spreads a process's streams over 4 hardware queues by default; two lookup sessions whose streams land on the
-    # same queue run strictly one after the other (measured: 1.30 instead of 1.85 G lookups/s for the device-driven tier
-    # after an earlier phase of the process had created other streams).  Must be in the environment before HIP starts.
+    # same queue run strictly one after the other.  Must be in the environment before HIP starts.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     from hugectr_backend_amd.gpu_wait import wait_for_gpu
     wait_for_gpu(30.0)   # a device that another process has just released can be invisible for a moment
@@ -198,13 +278,12 @@ def main():
     # host-memory guard: every rank keeps the full tables in its parameter server (replicas).  If the box
     # cannot hold them for all ranks, rows/table shrinks and the workload string says so.
     rows_requested = R
-    per_row = T * (4 * D + 64) + (2 * (4 * D + 48) if rank == 0 else 0)   # tables + index (+ oracle sample on rank 0)
-    budget = int(host_memory_budget() * 0.85 / world) - (8 << 30)
+    budget = int(host_memory_budget() * 0.85 / world) - (12 << 30)
     if world > 1:
         bt = torch.tensor([budget], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(bt, op=dist.ReduceOp.MIN)
         budget = int(bt.item())
-    per_row = T * (4 * D + 64) + 2 * (4 * D + 48)
+    per_row = T * (4 * D + 64) + T * 56 + 2 * (4 * D + 48)   # tables + index, the oracle's index of every table, its copy of two
     if R * per_row > budget:
         R = max(B, int(budget // per_row))
     setup_note = ""
@@ -232,12 +311,13 @@ def main():
             setup_note = f"; setup-time guard ({est:.0f} s estimated for the full tables on this box's shared host cores)"
     N = T * B
     model = "criteo_dlrm"
+    threshold = 1.0 if a.mode == "sync" else 0.5
     cfg = {
         "supportlonglong": True,
         "volatile_db": {"type": "hash_map", "num_partitions": 8},
         "models": [{
             "model": model,
-            "sparse_files": [f"synthetic://{t}" for t in range(T)],
+            "sparse_files": [f"synthetic://t{t}" for t in range(T)],
             "num_of_worker_buffer_in_pool": max(3, a.sessions),
             "embedding_vecsize_per_table": [D] * T,
             "maxnum_catfeature_query_per_table_per_sample": [1] * T,
@@ -246,10 +326,11 @@ def main():
             "max_batch_size": B,
             "gpucache": True,
             "gpucacheper": a.cache_frac,
-            "hit_rate_threshold": 1.0 if a.mode == "sync" else 0.5,
+            "hit_rate_threshold": threshold,
             "ps_direct_access": bool(a.direct),
         }],
     }
+
     def setup():
         t_setup = time.time()
         ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
@@ -288,11 +369,14 @@ def main():
         made = setup()
     ps, cache, t_tables, t_cache = made
     sessions = [hps.LookupSession.create(ps, model, cache) for _ in range(a.sessions)]
-    split = (a.split_probe != 0) and not a.direct     # host-gather tier only: the device-driven tier is faster fused
+    split = (a.split_probe != 0) and not a.direct     # host-gather tier only
     for s in sessions:
         s.set_option("timing", 1)
-        s.set_option("probe_variant", a.unroll)
+        s.set_option("probe_variant", a.probe_variant)
+        s.set_option("xcd_walk", a.xcd_walk)
         s.set_option("split_probe", 1 if split else 0)
+        s.set_option("narrow_keys", a.narrow_keys)
+        s.set_option("chain_gather", a.chain_gather)
 
     # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
     C = int(np.ceil(a.cache_frac * R))
@@ -302,125 +386,112 @@ def main():
         resident.append(k[cache.query(t, k) >= 0])
     resident_frac = float(np.mean([r.size / C for r in resident]))
 
+    # ---- timed region layout: W warm-up steps, then `blocks` blocks of exactly K steps, every step a fresh batch ----
+    K, W = a.steps, a.warmup
+    blocks = a.blocks if a.blocks > 0 else int(min(12, max(1, -(-240 // max(K, 1)))))
+    nb = W + K * blocks
+    if a.distinct_batches > 0:
+        nb = min(nb, a.distinct_batches)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(SEED + rank)
     cdf_d = torch.from_numpy(zipf_cdf(C, a.zipf)).cuda()
     resident_d = [torch.from_numpy(r).cuda() for r in resident]
-    nb = min(a.distinct_batches, a.steps + a.warmup) if a.distinct_batches > 0 else a.steps + a.warmup
-    batches_d = make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, a.hit, nb)
-    batches_h = [b.cpu().numpy() for b in batches_d[: min(8, nb)]]
-    del cdf_d, resident_d
-    outs = [torch.empty(N * D, dtype=torch.float32, device="cuda") for _ in sessions]
-    nk = [B] * T
+    run = Runner(torch, hps, sessions, T, B, D, dev)
+    # The reference's contract (docs/architecture.md:308-323; hps.cc:586-597): the keys of a request are in HOST memory.
+    # Generated on the device (fast), then moved to ordinary pageable numpy arrays, one per batch.
+    host_batches = []
+    for i in range(0, nb, 16):
+        for bt_ in make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, a.hit, min(16, nb - i)):
+            arr = bt_.cpu().numpy()
+            host_batches.append((arr, run.pack_host(arr)))
     torch.cuda.synchronize()
-
     ncpu = effective_cpus()
-    lat_ms, kern_ms, miss_ct, phases, uniq_ct, gpu_ms, gath_ms = [], [], [], [], [], [], []
-    lock = threading.Lock()
-    post_hooks = []   # per session: work appended to every step (the config-5 leg runs the dense step here)
-    step_hooks = []   # per session: replaces the step
 
-    def run_steps(count, record, first=0):
-        nxt = [0]
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-        def worker(si):
-            s = sessions[si]
-            while True:
-                with lock:
-                    i = nxt[0]
-                    if i >= count:
-                        return
-                    nxt[0] += 1
-                t0 = time.perf_counter()
-                if step_hooks:     # a leg that replaces the whole step (the fused lookup+interaction call)
-                    step_hooks[si](si, batches_d[(first + i) % len(batches_d)])
-                else:
-                    s.lookup_device(batches_d[(first + i) % len(batches_d)], nk, out=outs[si])
-                if post_hooks:
-                    post_hooks[si](si)
-                dt = (time.perf_counter() - t0) * 1e3
-                st = s.last_stats()
-                if record:
-                    with lock:
-                        lat_ms.append(dt)
-                        kern_ms.append(st.probe_gather_ms)
-                        gath_ms.append(st.hit_gather_ms)
-                        miss_ct.append(st.misses)
-                        uniq_ct.append(st.unique_misses)
-                        gpu_ms.append(st.gpu_call_ms)
-                        phases.append([float(x) for x in st.phase_ms])
-
-        th = [threading.Thread(target=worker, args=(si,)) for si in range(len(sessions))]
-        [x.start() for x in th]
-        [x.join() for x in th]
-
-    run_steps(a.warmup, False)
+    run.run(host_batches, W, 0, "host")
     if a.mode == "async":
         cache.wait_async()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    block_s, rec = [], []
     thr0 = cpu_throttle_stat()
-    t0 = time.perf_counter()
-    run_steps(a.steps, True, first=a.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    for blk in range(blocks):
+        barrier()
+        t0 = time.perf_counter()
+        run.run(host_batches, K, W + blk * K, "host", record=rec)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        block_s.append(el)
     thr1 = cpu_throttle_stat()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = float(np.median(block_s))
+    main_rec = list(rec)
 
     # ---- extra legs (outside the timed region; per-GPU numbers of this rank) --------------------------------
     extra = {}
-    main_lat, main_kern, main_miss, main_phases = list(lat_ms), list(kern_ms), list(miss_ct), list(phases)
-    main_uniq = list(uniq_ct)
-    main_gath = list(gath_ms)
-    for s in sessions:   # the extra legs measure the fused kernel (their kernel times are K_A's)
-        s.set_option("split_probe", 0)
-    main_gpu = list(gpu_ms)
-    if not a.no_extra_legs and world == 1:  # informational legs: single-GPU run only
-        def leg(batches, steps, sess_list):
-            lat_ms.clear(); kern_ms.clear(); miss_ct.clear(); phases.clear()
-            saved = sessions[:]
-            sessions[:] = sess_list
-            batches_d_saved = batches_d[:]
-            batches_d[:] = batches
-            run_steps(4, False)
-            torch.cuda.synchronize()
-            tl0 = time.perf_counter()
-            run_steps(steps, True, first=4)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - tl0
-            sessions[:] = saved
-            batches_d[:] = batches_d_saved
-            k = float(np.mean(kern_ms))
-            return {"lookups_per_s": steps * N / dt, "ms_per_step": dt / steps * 1e3, "avg_kernel_ms": k,
-                    "kernel_frac_of_hbm_peak": N * (8 + 8 * D) / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "measured_hit_rate": 1.0 - float(np.mean(miss_ct)) / N}
-
+    if not a.no_extra_legs and world == 1:
         gen2 = torch.Generator(device="cuda")
         gen2.manual_seed(SEED + 1000 + rank)
-        cdf_d = torch.from_numpy(zipf_cdf(C, a.zipf)).cuda()
-        resident_d = [torch.from_numpy(r).cuda() for r in resident]
+
+        def fresh(n, hit=None):
+            return make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit if hit is None else hit, n)
+
+        def leg(batches, steps, mode, sess=None):
+            r = []
+            run.run(batches, 4, 0, mode, sess)
+            torch.cuda.synchronize()
+            tl0 = time.perf_counter()
+            run.run(batches, steps, 4, mode, sess, record=r)
+            torch.cuda.synchronize()
+            return summarize(r, N, D, time.perf_counter() - tl0, steps)
+
         def run_legs():
-            # (1) every key resident: the GPU-side ceiling of the path, one session (kernel runs alone)
-            hot_batches = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, 1.1, 8)
-            extra["all_hit_one_session"] = leg(hot_batches, 24, sessions[:1])
-            # (2) the reference's default policy at this hit rate (hit_rate_threshold 0.9 < 0.95): missed keys
-            #     return the default vector now and are fetched + inserted in the background
-            fresh = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
+            # (1) KEYS already in HBM (hps_session_lookup_device, an addition to the reference's API): what the path does when
+            #     nothing but missed rows crosses PCIe — round 1's headline
+            dk = fresh(28)
+            extra["device_keys"] = leg(dk, 24, "device")
+            extra["device_keys"]["note"] = "hps_session_lookup_device: KEYS resident in HBM, same cache and sessions"
+            # (2) host keys in page-locked memory, one flat array per request (what Triton's pinned input pool hands over)
+            pinned = []
+            for bt_ in dk:
+                p = bt_.cpu().pin_memory()
+                pinned.append((p, run.pack_host(p.numpy())))
+            extra["pinned_host_keys"] = leg(pinned, 24, "pinned")
+            for s in sessions:
+                s.set_option("narrow_keys", 0)
+            extra["pinned_host_keys_8_byte_dma_in_place"] = leg(pinned, 24, "pinned")
+            hb_ = [(x.cpu().numpy(),) for x in dk]
+            hb_ = [(x[0], run.pack_host(x[0])) for x in hb_]
+            extra["pageable_host_keys_8_byte_staging"] = leg(hb_, 24, "host")
+            for s in sessions:
+                s.set_option("narrow_keys", a.narrow_keys)
+            del pinned, hb_
+            # (3) every key resident: the GPU-side ceiling of the path, one session (kernels run alone)
+            hot = fresh(8, 1.1)
+            extra["all_hit_one_session_device_keys"] = leg(hot, 24, "device", [0])
+            hoth = [(x.cpu().numpy(),) for x in hot]
+            hoth = [(x[0], run.pack_host(x[0])) for x in hoth]
+            extra["all_hit_two_sessions_host_keys"] = leg(hoth, 24, "host")
+            del hot, hoth
+            # (4) the reference's default policy (hit_rate_threshold 0.9): the hit rate over the call's UNIQUE keys decides;
+            #     async tables return the default vector for their misses and are filled in the background
+            fa = [(x.cpu().numpy(),) for x in fresh(28)]
+            fa = [(x[0], run.pack_host(x[0])) for x in fa]
             for s in sessions:
                 s.set_option("hit_rate_threshold_permille", 900)
-            extra["async_insert_threshold_0.9"] = leg(fresh, 24, sessions)
+            extra["policy_threshold_0.9"] = leg(fa, 24, "host")
+            extra["policy_threshold_0.9"]["calls_answered_async"] = int(sum(s.last_stats().async_insert for s in sessions))
             cache.wait_async()
             for s in sessions:
                 s.set_option("hit_rate_threshold_permille", 1000 if a.mode == "sync" else 500)
-            # (3) BASELINE config 5: the dense step (bottom MLP 13-512-256-D + dot interaction, fp16 MFMA) consuming
+            del fa
+            # (5) BASELINE config 5: the dense step (bottom MLP 13-512-256-D + dot interaction, fp16 MFMA) consuming
             #     OUTPUT0 where the lookup left it.  Kernel time alone, then lookup + dense per step with both sessions.
             if D % 32 == 0 and D <= 512 and T <= 31:
                 from hugectr_backend_amd.dense import DenseInteraction
@@ -435,58 +506,51 @@ def main():
                 xd = torch.randn(B, 13, device="cuda")
                 outd = [torch.empty((B, ops[0].out_stride), dtype=torch.float16, device="cuda") for _ in sessions]
                 for _ in range(3):
-                    ops[0].forward(xd, outs[0], B, out=outd[0])
+                    ops[0].forward(xd, run.outs[0], B, out=outd[0])
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
                 for _ in range(20):
-                    ops[0].forward(xd, outs[0], B, out=outd[0])
+                    ops[0].forward(xd, run.outs[0], B, out=outd[0])
                 e1.record()
                 torch.cuda.synchronize()
                 dense_ms = e0.elapsed_time(e1) / 20
                 dense_bytes = N * 4 * D + B * 13 * 4 + 2 * B * D * 2 + B * ops[0].out_stride * 2
                 dense_flops = 2 * B * (16 * 512 + 512 * 256 + 256 * D) + 2 * B * 32 * 32 * D
-                post_hooks[:] = [lambda si: (ops[si].forward(xd, outs[si], B, out=outd[si]),
-                                             torch.cuda.current_stream().synchronize()) for _ in sessions]
-                fresh5 = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
-                c5 = leg(fresh5, 24, sessions)
-                post_hooks[:] = []
+                run.post_hooks[:] = [lambda si: (ops[si].forward(xd, run.outs[si], B, out=outd[si]),
+                                                 torch.cuda.current_stream().synchronize()) for _ in sessions]
+                c5 = leg(fresh(28), 24, "device")
+                run.post_hooks[:] = []
                 c5.update({"dense_kernels_ms": dense_ms, "dense_algorithmic_bytes": dense_bytes,
                            "dense_frac_of_hbm_peak": dense_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "dense_mfma_tflops": dense_flops / (dense_ms * 1e-3) / 1e12,
                            "samples_per_s": c5["lookups_per_s"] / T,
-                           "note": "lookup (sync insert, exact rows) + bottom MLP 13-512-256-%d + dot interaction per step; "
-                                   "output [batch, %d] f16" % (D, ops[0].out_dim)})
+                           "note": "lookup (device keys, sync insert, exact rows) + bottom MLP 13-512-256-%d + dot interaction "
+                                   "per step; output [batch, %d] f16" % (D, ops[0].out_dim)})
                 extra["c5_lookup_plus_dense"] = c5
-                del fresh5
-                # (3b) the same step with the lookup fused into the interaction: probe only, rows read from the cache
-                #      slots / miss staging by the interaction kernel, OUTPUT0 never written (device-driven tier only)
                 if a.direct and a.mode == "sync":
-                    fresh5b = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
-                    step_hooks[:] = [lambda si, keys: ops[si].lookup_interact(sessions[si], keys, B, xd, out=outd[si]) for _ in sessions]
-                    c5f = leg(fresh5b, 24, sessions)
-                    step_hooks[:] = []
-                    c5f["probe_only_kernel_ms"] = c5f.pop("avg_kernel_ms")   # the probe moves no rows here:
-                    c5f.pop("kernel_frac_of_hbm_peak")                        # the gather roofline does not apply to it
+                    run.step_hooks[:] = [lambda si, keys: ops[si].lookup_interact(sessions[si], keys, B, xd, out=outd[si]) for _ in sessions]
+                    c5f = leg(fresh(28), 24, "device")
+                    run.step_hooks[:] = []
                     c5f.update({"samples_per_s": c5f["lookups_per_s"] / T,
                                 "note": "one call per step: probe, miss fetch, bottom MLP, interaction reading cache slots / staging, insert"})
                     extra["c5_fused_lookup_interact"] = c5f
-                    del fresh5b
-            # (4) the miss path arranged as in the reference (host threads gather the missed rows, hipMemcpyAsync ships
-            #     them) on the very same cache and tables: session option "host_gather"
-            if a.direct and a.mode == "sync":
-                fresh6 = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
-                for s in sessions:
-                    s.set_option("host_gather", 1)
-                extra["host_gather_tier_same_cache"] = leg(fresh6, 24, sessions)
-                for s in sessions:
-                    s.set_option("host_gather", 0)
-                del fresh6
-            # (5) the headline ran with the split probe: the same workload with the fused probe+gather kernel
-            if split and a.mode == "sync":
-                fresh7 = make_batches_gpu(torch, gen2, resident_d, cdf_d, R, C, B, a.hit, 28)
-                extra["fused_probe_gather_same_cache"] = leg(fresh7, 24, sessions)
-                del fresh7
+            # (6) the build's own CPU parameter server (the host tier, `gpucache=false` path of the reference:
+            #     docs/architecture.md:72) on the identical batches: hps_server_fetch per table, all host cores
+            outc = None
+            tcp0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - tcp0 < 4.0 and reps < 40:
+                q = host_batches[reps % len(host_batches)][0]
+                for t in range(T):
+                    outc = ps.fetch(model, t, q[t * B:(t + 1) * B])
+                reps += 1
+            tcp = time.perf_counter() - tcp0
+            extra["cpu_parameter_server_tier"] = {
+                "lookups_per_s": reps * N / tcp, "cores": ncpu,
+                "note": f"hps_server_fetch (host tier of this build) on the timed region's own batches, all {T} tables, "
+                        f"{reps} passes, rows into pageable host memory"}
+            del outc
 
         try:   # the legs are informational: a failure in one of them must not cost the headline line
             run_legs()
@@ -494,76 +558,95 @@ def main():
             extra["legs_error"] = repr(e)[:300]
             sys.stderr.write(f"[bench] extra legs stopped: {e!r}\n")
         finally:
-            post_hooks[:] = []
-            step_hooks[:] = []
+            run.post_hooks[:] = []
+            run.step_hooks[:] = []
             for s in sessions:
-                s.set_option("host_gather", 0)
+                s.set_option("narrow_keys", a.narrow_keys)
                 s.set_option("hit_rate_threshold_permille", 1000 if a.mode == "sync" else 500)
-        del cdf_d, resident_d
+    del cdf_d, resident_d
 
-    # ---- untimed parity check of the last step of session 0 against the CPU oracle (tables 0..1) ----
-    parity = None
+    # ---- untimed checks of one step against the CPU oracle, and the cpu_baseline leg ----
+    parity = parity_full = None
     cpu = None
     checker_note = None
     if rank == 0:
         def run_checker():
-            nonlocal parity, cpu
+            nonlocal parity, parity_full, cpu
             from oracle import hps_oracle as O
-            chk_tables = min(2, T)
-            # which batch did session 0 run last?  re-run one known batch to be sure
-            sessions[0].lookup_device(batches_d[0], nk, out=outs[0])
+            q = host_batches[0][0]
+            sessions[0].lookup_packed(host_batches[0][1], run.vptrs[0], run.counts)
             torch.cuda.synchronize()
-            got = outs[0][: chk_tables * B * D].cpu().numpy()
+            got_all = run.outs[0].cpu().numpy().reshape(N, D)
+            # (a) the oracle with ITS OWN copy of the first two tables (rows from the oracle's restatement of the recipe)
+            chk_tables = min(2, T)
             co = O.COracle()
-            sample_rows = []
+            keys_seq = np.arange(R, dtype=np.int64)
             for t in range(chk_tables):
                 rows = np.empty((R, D), dtype=np.float32)
-                # generate the oracle's copy of the table in parallel slabs (C code releases the GIL)
-                nth = ncpu
-                step = (R + nth - 1) // nth
+                step = (R + ncpu - 1) // ncpu
 
-                def gen(lo, t=t, rows=rows):
+                def gen_(lo, t=t, rows=rows):
                     hi = min(R, lo + step)
                     if hi > lo:
                         O.c_synth_rows(SEED, t, lo, hi - lo, D, out=rows[lo:hi])
 
-                th = [threading.Thread(target=gen, args=(lo,)) for lo in range(0, R, step)]
+                th = [threading.Thread(target=gen_, args=(lo,)) for lo in range(0, R, step)]
                 [x.start() for x in th]
                 [x.join() for x in th]
-                sample_rows.append(rows)
-            keys_seq = np.arange(R, dtype=np.int64)
-            for t in range(chk_tables):
-                co.add_table_arrays(keys_seq, sample_rows[t])
-            q = batches_h[0][: chk_tables * B]
-            ref = co.lookup(q, [B] * chk_tables, [0.0] * chk_tables, threads=ncpu)
+                co.add_table_arrays(keys_seq, rows)
+            ref = co.lookup(q[: chk_tables * B], [B] * chk_tables, [0.0] * chk_tables, threads=ncpu).reshape(-1, D)
+            got = got_all[: chk_tables * B]
             if a.mode == "sync":
                 parity = bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
-            else:
-                # async mode: resident keys exact, others default
-                same = got.view(np.uint32).reshape(-1, D) == ref.view(np.uint32).reshape(-1, D)
-                is_default = (got.reshape(-1, D) == 0.0).all(axis=1)
-                parity = bool((same.all(axis=1) | is_default).all())
+            else:   # async mode: resident keys exact, others default
+                same = (got.view(np.uint32) == ref.view(np.uint32)).all(axis=1)
+                parity = bool((same | (got == 0.0).all(axis=1)).all())
+            co.close()
+            del co
+            # (b) the WHOLE batch, all tables, with no hashing on the checking side: the tables' keys are 0..R-1 in file
+            #     order, so the expected row of key k is row k of the table as it sits in the host tier
+            if a.mode == "sync":
+                okf = True
+                for t in range(T):
+                    tk, tr = ps.table_data(model, t)
+                    qt = q[t * B:(t + 1) * B]
+                    okf &= bool(np.array_equal(tk[qt], qt))
+                    okf &= bool(np.array_equal(tr[qt].view(np.uint32), got_all[t * B:(t + 1) * B].view(np.uint32)))
+                parity_full = okf
+            if a.no_cpu_baseline or world > 1:
+                return
+            # ---- cpu_baseline: the oracle (a port of the reference's hash_map parameter-server lookup: a hash-map find per
+            # key, row copy or default) on the timed region's own batches, ALL tables, all host cores.  The oracle builds its
+            # own index over every table; the rows it copies are the host tier's (borrowed, read-only: no second 133 GB). ----
+            cb = O.COracle()
+            views = [ps.table_data(model, t) for t in range(T)]
+            errs = []
 
-            if not a.no_cpu_baseline and world == 1:  # timed on rank 0 at N=1 only (the other ranks' pools share the cores)
-                # ---- cpu_baseline: the oracle (a port of the reference's hash_map parameter-server lookup)
-                # on the same key batches, tables 0..chk_tables-1 only (bounded sample), all host cores ----
-                threads = ncpu  # the CPUs the container may use (cgroup quota), not the visible hardware threads
-                nkc = [B] * chk_tables
-                outc = np.empty(chk_tables * B * D, dtype=np.float32)
-                done, tc0 = 0, time.perf_counter()
-                reps = 0
-                while time.perf_counter() - tc0 < a.cpu_seconds and reps < 2000:
-                    qb = batches_h[reps % len(batches_h)][: chk_tables * B]
-                    co.lookup(qb, nkc, [0.0] * chk_tables, threads=threads, out=outc)
-                    done += qb.size
-                    reps += 1
-                tcpu = time.perf_counter() - tc0
-                cpu = {
-                    "value": done / tcpu, "unit": "lookups/s", "cores": threads, "kind": "port",
-                    "sample": f"{reps} passes over the first {chk_tables} of {T} tables' key slices "
-                              f"({chk_tables * B} keys/pass, {R} rows x {D} fp32 per table), oracle/hps_oracle.c "
-                              f"oracle_lookup_mt with {threads} threads",
-                }
+            def add(t):
+                try:
+                    cb.add_table_arrays_borrowed(t, *views[t])
+                except Exception as e:  # noqa: BLE001
+                    errs.append(e)
+
+            cb.reserve(T)
+            th = [threading.Thread(target=add, args=(t,)) for t in range(T)]
+            for i in range(0, T, ncpu):
+                [x.start() for x in th[i:i + ncpu]]
+                [x.join() for x in th[i:i + ncpu]]
+            if errs:
+                raise errs[0]
+            outc = np.empty(N * D, dtype=np.float32)
+            done, reps, tc0 = 0, 0, time.perf_counter()
+            while time.perf_counter() - tc0 < a.cpu_seconds and reps < 2000:
+                qb = host_batches[reps % len(host_batches)][0]
+                cb.lookup(qb, [B] * T, [0.0] * T, threads=ncpu, out=outc)
+                done += qb.size
+                reps += 1
+            tcpu = time.perf_counter() - tc0
+            cpu = {"value": done / tcpu, "unit": "lookups/s", "cores": ncpu, "kind": "port",
+                   "sample": f"{reps} whole batches of the timed region ({N} keys each, all {T} tables of {R} rows x {D} fp32), "
+                             f"oracle/hps_oracle.c oracle_lookup_mt with {ncpu} threads, rows written to pageable host memory"}
+            cb.close()
 
         try:   # the oracle is the checker; if it cannot run here the measurement still stands, marked unchecked
             run_checker()
@@ -571,50 +654,37 @@ def main():
             checker_note = repr(e)[:300]
             sys.stderr.write(f"[bench] oracle check / cpu baseline stopped: {e!r}\n")
 
+    res = None
     if rank == 0:
-        lat_ms, kern_ms, miss_ct, phases = main_lat, main_kern, main_miss, main_phases
-        # HBM traffic of the kernel comes from the committed rocprofv3 PMC passes (bench.py cannot run the
-        # profiler on itself): profiles/pmc_latest.json, written by tools/summarize_profile.py
-        traffic, traffic_src = None, None
+        m = summarize(main_rec, N, D, elapsed, K)
+        ph = np.array([r[8] for r in main_rec])
+        lat = np.array([r[0] for r in main_rec])
+        gpu_ms = np.array([r[7] for r in main_rec])
+        uniq = float(np.mean([r[6] for r in main_rec]))
+        hits = N * m["measured_hit_rate"]
+        probe, gather, scatter = m["probe_ms"], m["gather_ms"], m["scatter_ms"]
+        hbm_ms = probe + gather + scatter
+        alg = N * (8 + 8 * D)                       # 8 B key + 4D row read + 4D row write per lookup
+        achieved = alg / (hbm_ms * 1e-3) / 1e9
+        # HBM traffic of the kernels comes from the committed rocprofv3 PMC passes (bench.py cannot run the profiler on
+        # itself): profiles/pmc_latest.json, written by tools/summarize_profile.py
+        traffic = traffic_src = None
         try:
             pj = json.loads((ROOT / "profiles" / "pmc_latest.json").read_text())
-            if pj.get("workload_keys") == N and pj.get("dim") == D:
-                traffic = pj["pmc"]["hbm_bytes_per_launch_fetch_doubled"]
+            if pj.get("workload_keys") == N and pj.get("dim") == D and pj.get("round", 1) >= 2:
+                traffic = pj["pmc"]["hbm_bytes_per_call_fetch_doubled"]
                 traffic_src = pj.get("source")
         except Exception:
             pass
-        k_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
-        fetch_ms = float(np.mean(np.array(phases)[:, 1])) if phases else 0.0
-        alg_bytes = N * (8 + 8 * D)  # 8 B key + 4D row read + 4D row write per lookup
-        hits = N - (float(np.mean(miss_ct)) if miss_ct else 0.0)
-        g_ms = float(np.mean([g for g in main_gath if g > 0])) if any(g > 0 for g in main_gath) else 0.0
-        split_run = split and g_ms > 0
-        probe_ms = k_ms
-        roof_kernel = "hps_probe_gather_kernel"
-        if split_run:
-            # Split probe: the rows are moved by hps_gather_hits_kernel (the dominant, HBM-bound kernel of the call);
-            # K_A only probes.  Its algorithmic bytes: 4 B slot word per key + 4D read + 4D write per HIT.
-            # The pair against SURVEY 8(d)'s 1,032 B per lookup is reported next to it (frac_probe_plus_gather).
-            roof_kernel = "hps_gather_hits_kernel"
-            k_ms = g_ms
-            alg_bytes = int(N * 4 + hits * 8 * D)
-            traffic, traffic_src = None, None
-            try:   # the PMC passes of the same profile set, restricted to this kernel
-                if pj.get("workload_keys") == N and pj.get("dim") == D:
-                    traffic = pj["pmc_by_kernel"]["hps_gather_hits"]["hbm_bytes_per_launch_fetch_doubled"]
-                    traffic_src = pj.get("source")
-            except Exception:
-                pass
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        value = world * a.steps * N / elapsed
+        fetch_ms = float(ph[:, 1].mean()) if ph.size else 0.0
         res = {
             "metric": "embedding lookups/sec, Criteo 26-slot 64K batch",
-            "value": value,
+            "value": world * K * N / elapsed,
             "unit": "lookups/s",
             "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -625,116 +695,109 @@ def main():
                             + (f" (requested {rows_requested}; reduced to fit the host memory / setup time of {world} replicas{setup_note})" if R != rows_requested else "")
                             + f" x {D}-dim, {B} batch ({N} keys), "
                             f"gpucacheper {a.cache_frac}, 95% cache hit (resident-draw probability {a.hit}; see measured_hit_rate), "
-                            f"zipf {a.zipf} within the resident set, "
-                            f"{a.mode} insert, {a.sessions} lookup sessions, keys resident in HBM",
+                            f"zipf {a.zipf} within the resident set, {a.mode} insert, {a.sessions} lookup sessions, "
+                            f"keys on host (pageable int64 arrays handed to hps_session_lookup, the reference's LookupSession::lookup contract), "
+                            f"output rows in HBM",
                 "parallelism": "replicas" if world > 1 else "single",
                 "ps_tier": "device-driven (ps_direct_access)" if a.direct else
                            ("host gather" + (f" [{direct_note}]" if direct_note else "")),
+                "timed_region": f"{blocks} blocks of exactly {K} steps (barrier + synchronize on both sides, max over ranks), every step a "
+                                f"fresh batch; value = the MEDIAN block",
             },
-            "p50_batch_latency_ms": float(np.percentile(lat_ms, 50)) if lat_ms else None,
-            "p99_batch_latency_ms": float(np.percentile(lat_ms, 99)) if lat_ms else None,
-            # GPU side of a batch (HIP events on the session's stream: probe+gather start to the last kernel of the call)
-            "p50_batch_gpu_ms": float(np.percentile(main_gpu, 50)) if main_gpu else None,
-            "p99_batch_gpu_ms": float(np.percentile(main_gpu, 99)) if main_gpu else None,
-            "measured_hit_rate": 1.0 - float(np.mean(miss_ct)) / N if miss_ct else None,
+            "block_ms": [b * 1e3 for b in block_s],
+            "value_min_max_over_blocks": [world * K * N / max(block_s), world * K * N / min(block_s)],
+            "p50_batch_latency_ms": float(np.percentile(lat, 50)),
+            "p99_batch_latency_ms": float(np.percentile(lat, 99)),
+            # GPU side of a batch (HIP events on the session's stream: probe start to the last kernel of the call)
+            "p50_batch_gpu_ms": float(np.percentile(gpu_ms, 50)),
+            "p99_batch_gpu_ms": float(np.percentile(gpu_ms, 99)),
+            "measured_hit_rate": m["measured_hit_rate"],
+            "keys_narrowed_to_32_bits_fraction_of_calls": float(np.mean([r[10] for r in main_rec])),
+            "key_stage_ms_mean": m["key_stage_ms"],
             # the five slowest calls of the timed region: [end-to-end ms, ms until the miss counts are on the host,
             # ms inside the host gather calls, ms of upload tail + scatter + insert, ms of the whole call inside the engine]
-            # -- says which wait a multi-millisecond stall sat in
-            "slowest_calls_ms": [[round(l, 3)] + [round(x, 3) for x in ph]
-                                 for l, ph in sorted(zip(lat_ms, phases), key=lambda t: -t[0])[:5]] if lat_ms and phases else None,
-            # host side of the timed region: CPUs this process may use, and how often the cgroup's CPU quota stopped it
+            "slowest_calls_ms": [[round(l, 3)] + [round(x, 3) for x in p] for l, p in
+                                 sorted(zip(lat.tolist(), ph.tolist()), key=lambda t: -t[0])[:5]],
             "host": {"cpus": ncpu,
                      "cpu_quota_throttled_periods_in_timed_region": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
                      "cpu_quota_throttled_ms_in_timed_region": (thr1[1] - thr0[1]) / 1e3 if thr0 and thr1 else None},
             "resident_fraction_after_warmup": resident_frac,
             "roofline": {
                 "bound": "hbm",
-                "kernel": roof_kernel,
+                # every lookup priced at 1,032 algorithmic bytes over ALL HBM-side kernels of the lookup
+                "kernel": "hps_probe_tile_kernel + hps_miss_unique_kernel + hps_gather_hits_kernel + hps_miss_scatter_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_kernel_ms": k_ms,
-                # `frac` is measured inside the timed region, where the kernel shares the chip with the other
-                # session's PCIe fetch / dedup / insert kernels; the same kernel with nothing underneath
-                # (all-hit leg, one session) is reported next to it
-                "frac_kernel_alone": (extra.get("all_hit_one_session") or {}).get("kernel_frac_of_hbm_peak"),
-                # the same kernel, same cache, same workload and session count with the miss path arranged as in
-                # the reference (host gather + hipMemcpyAsync: the DMA engine does not disturb it; the job is slower)
-                "frac_with_host_gather_tier": (extra.get("host_gather_tier_same_cache") or {}).get("kernel_frac_of_hbm_peak"),
-                # the read side alone, and both against the measured copy ceiling of the part
-                "read_only_frac": ((N * 4 + hits * 4 * D) if split_run else N * (8 + 4 * D)) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+                "algorithmic_bytes_per_call": alg,
+                "kernel_ms_per_call": hbm_ms,
+                "probe_ms": probe, "gather_ms": gather, "scatter_ms": scatter,
+                "insert_ms_not_counted": m["insert_ms"],
+                "frac_probe_plus_gather": alg / ((probe + gather) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # the gather kernel alone on its own bytes (4 B slot per key + 8D per hit) — the dominant kernel
+                "frac_gather_own_bytes": (N * 4 + hits * 8 * D) / (gather * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_of_copy_ceiling_6290": achieved / 6290.0,
-                # SURVEY.md 8(d) prices every lookup at 8 + 4D + 4D bytes; the kernel itself moves rows only for the
-                # keys that hit (a missed key's row is written later by the scatter kernel).  Bytes the kernel really
-                # has to move = 8 per key + 8D per hit: the stricter figure, and the one to read at low hit rates
-                "frac_hit_rows_only": (((N * 4 if split_run else N * 8) + hits * 8 * D) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                                       if k_ms > 0 and miss_ct else None),
-                # split probe: the probe kernel's time, the pair priced at SURVEY 8(d)'s 1,032 B per lookup over both
-                # kernels' time, and the fused kernel on the same cache and workload (leg fused_probe_gather_same_cache)
-                "probe_kernel_ms": probe_ms if split_run else None,
-                "frac_probe_plus_gather": (N * (8 + 8 * D) / ((probe_ms + g_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS if split_run else None),
-                "frac_fused_kernel": (extra.get("fused_probe_gather_same_cache") or {}).get("kernel_frac_of_hbm_peak"),
+                # the whole job against the same roofline: at 95 % hit with synchronous insertion the path is bound by PCIe
+                # (every unique missed row + the keys cross the link once), not by HBM
+                "frac_end_to_end": alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
+                # the kernels with nothing underneath (all keys resident, one session)
+                "frac_kernels_alone": (extra.get("all_hit_one_session_device_keys") or {}).get("frac_of_hbm_peak_1032B_per_lookup"),
             },
-            # the other leg of the synchronous path: the missed rows cross PCIe once each.  Device-driven tier:
-            # HIP-event time of hps_ps_fetch_direct_kernel; bytes = unique missed rows x 4*D.
-            "roofline_pcie": ({
-                "bound": "pcie", "kernel": "hps_ps_fetch_direct_kernel",
-                "achieved": float(np.mean(main_uniq)) * 4 * D / (fetch_ms * 1e-3) / 1e9,
-                "peak": PCIE_PEAK_GBS, "unit": "GB/s",
-                "frac": float(np.mean(main_uniq)) * 4 * D / (fetch_ms * 1e-3) / 1e9 / PCIE_PEAK_GBS,
-                "avg_kernel_ms": fetch_ms, "unique_missed_rows_per_batch": float(np.mean(main_uniq)),
-            } if a.direct and fetch_ms > 0 else None),
+            "roofline_pcie": {
+                "bound": "pcie", "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                "bytes_per_step": uniq * 4 * D + N * (4 if np.mean([r[10] for r in main_rec]) > 0.5 else 8),
+                "achieved": (uniq * 4 * D + N * (4 if np.mean([r[10] for r in main_rec]) > 0.5 else 8)) / (elapsed / K) / 1e9,
+                "frac": (uniq * 4 * D + N * (4 if np.mean([r[10] for r in main_rec]) > 0.5 else 8)) / (elapsed / K) / 1e9 / PCIE_PEAK_GBS,
+                "unique_missed_rows_per_batch": uniq,
+                "fetch_kernel_ms": fetch_ms if a.direct else None,
+                "note": "host->device bytes of one step (unique missed rows + keys) over the step time: the floor of the synchronous path",
+            },
             # [1] = wall time of the host gather (host tier) or GPU time of the fetch kernel (device-driven tier)
-            "mean_phase_ms": dict(zip(["probe_gather_dedup_until_counts", "ps_fetch", "h2d_scatter_insert", "call"],
-                                      [float(x) for x in np.mean(np.array(phases), axis=0)])) if phases else None,
+            "mean_phase_ms": dict(zip(["probe_until_counts_on_host", "ps_fetch", "h2d_scatter_insert", "call"],
+                                      [float(x) for x in ph.mean(axis=0)])),
             "extra_legs": extra or None,
             "cpu_baseline": cpu,
             "parity_vs_oracle_bit_exact": parity,
+            "parity_full_batch_vs_direct_row_index": parity_full,
             "checker_note": checker_note,
             "setup_seconds": {"host_tables": t_tables, "gpu_cache_warmup": t_cache},
             "cache_counters": cache.counters(),
         }
-    else:
-        res = None
     for s in sessions:
         s.close()
 
-    # ---- one GPU, headline measured on the host-gather tier: the device-driven tier (ps_direct_access) on the same
-    #      workload right after, with the headline's resources released first (its tables are page-locked: a second
-    #      133 GB next to the first would not fit the box) ----
-    if world == 1 and not a.direct and not a.no_extra_legs and not a.no_direct_leg:
+    # ---- one GPU: legs that need the headline's memory back (its tables are 133 GB): the plugin boundary driven by the
+    #      native load generator, then the other parameter-server tier ----
+    if world == 1 and not a.no_extra_legs:
         import gc
-        del sessions, cache, ps, made
+        del sessions, cache, ps, made, run, host_batches
         gc.collect()
         torch.cuda.empty_cache()
-        try:
-            dleg = direct_tier_leg(a, torch, hps, T, R, D, B, N, dev, outs, cfg)
-        except Exception as e:  # noqa: BLE001
-            dleg = {"error": repr(e)[:300]}
-            sys.stderr.write(f"[bench] device-driven tier leg stopped: {e!r}\n")
-        fused = dleg.pop("c5_fused_lookup_interact", None) if isinstance(dleg, dict) else None
-        res["extra_legs"] = dict(res["extra_legs"] or {}, device_driven_tier=dleg)
-        if fused:
-            res["extra_legs"]["c5_fused_lookup_interact"] = fused
-        res["roofline"]["frac_under_device_driven_tier"] = dleg.get("kernel_frac_of_hbm_peak")
+        if not a.no_triton_leg:
+            res["extra_legs"] = dict(res["extra_legs"] or {}, triton_abi=triton_abi_leg(a, hb, T, R, D, B))
+        if not a.direct and not a.no_direct_leg:
+            try:
+                dleg = other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg)
+            except Exception as e:  # noqa: BLE001
+                dleg = {"error": repr(e)[:300]}
+                sys.stderr.write(f"[bench] device-driven tier leg stopped: {e!r}\n")
+            res["extra_legs"] = dict(res["extra_legs"] or {}, device_driven_tier=dleg)
 
     # ---- BASELINE config 3 leg (N > 1 only): ONE table sharded over the ranks, RCCL all-to-all of keys and rows ----
     # Runs after the headline measurement is complete and its resources are released; a watchdog prints the headline
     # line and ends every rank if the leg does not finish (a collective that hangs cannot be caught any other way).
     if world > 1 and not a.no_sharded_leg:
         import gc
-        del sessions, outs, batches_d, cache, ps, made
+        del sessions, cache, ps, made, run, host_batches
         gc.collect()
         torch.cuda.empty_cache()
 
         def give_up():
             if rank == 0:
-                res.setdefault("extra_legs", None)
-                res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3={"error": f"no result within {a.sharded_timeout} s"})
+                res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3={"error": f"no result within {a.sharded_timeout} s"})
                 print(json.dumps(res), flush=True)
             os._exit(0)
 
@@ -742,12 +805,12 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            leg = sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev)
+            leg3 = sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev)
         except Exception as e:  # noqa: BLE001
-            leg = {"error": repr(e)[:300]}
+            leg3 = {"error": repr(e)[:300]}
         dog.cancel()
         if rank == 0:
-            res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3=leg)
+            res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3=leg3)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
@@ -755,9 +818,32 @@ def main():
         dist.destroy_process_group()
 
 
-def direct_tier_leg(a, torch, hps, T, R, D, B, N, dev, outs, cfg):
+def triton_abi_leg(a, hb, T, R, D, B):
+    """The same workload through the plugin boundary: tools/triton_abi_bench.cpp (native, two threads) drives
+    TRITONBACKEND_ModelInstanceExecute of libtriton_hps.so through the mock Triton core — what perf_analyzer does to the
+    reference (.gitlab-ci.yml:70).  Own process: it loads the model through TRITONBACKEND_ModelInitialize itself."""
+    import subprocess
+    exe = hb.LIB / "triton_abi_bench.bin"
+    if not exe.exists():
+        return {"error": "tools/triton_abi_bench.cpp was not built"}
+    cmd = [str(exe), "--lib-dir", str(hb.LIB), "--tables", str(T), "--rows", str(R), "--dim", str(D), "--batch", str(B),
+           "--cache-frac", str(a.cache_frac), "--hit", str(a.hit), "--zipf", str(a.zipf), "--instances", str(a.sessions),
+           "--steps", "20", "--blocks", "6", "--warmup", "5", "--direct", str(int(bool(a.direct)))]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=a.triton_timeout)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            return {"error": f"rc={r.returncode}: {r.stderr[-300:]}"}
+        out = json.loads(line[-1])
+        out["rc"] = r.returncode
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
+def other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
     """The headline workload on a ps_direct_access deployment of the same model (own server: page-locked tables, device
-    index): two sessions, fresh batches, exact rows; then the fused lookup+interaction call of config 5."""
+    index): two sessions, fresh batches of host keys, exact rows."""
     model = cfg["models"][0]["model"]
     cfg = json.loads(json.dumps(cfg))
     cfg["models"][0]["ps_direct_access"] = True
@@ -769,106 +855,41 @@ def direct_tier_leg(a, torch, hps, T, R, D, B, N, dev, outs, cfg):
     cache = ps.get_embedding_cache(model, dev)
     t_setup = time.time() - t0
     sessions = [hps.LookupSession.create(ps, model, cache) for _ in range(a.sessions)]
-    split = False   # the device-driven tier keeps the fused kernel (measured: 1.70 split vs 1.85 G lookups/s fused)
     for s in sessions:
         s.set_option("timing", 1)
-        s.set_option("probe_variant", a.unroll)
-        s.set_option("split_probe", 1 if split else 0)
+        s.set_option("probe_variant", a.probe_variant)
+        s.set_option("xcd_walk", a.xcd_walk)
+        s.set_option("narrow_keys", a.narrow_keys)
     C = int(np.ceil(a.cache_frac * R))
     resident = []
     for t in range(T):
         k = np.arange(C, dtype=np.int64)
-        resident.append(k[cache.query(t, k) >= 0])
+        resident.append(torch.from_numpy(k[cache.query(t, k) >= 0]).cuda())
     gen = torch.Generator(device="cuda")
     gen.manual_seed(SEED + 555)
     cdf_d = torch.from_numpy(zipf_cdf(C, a.zipf)).cuda()
-    resident_d = [torch.from_numpy(r).cuda() for r in resident]
-    nk = [B] * T
-    lock = threading.Lock()
-
-    gath = []
-
-    def run(batches, count, first, record, step=None):
-        nxt = [0]
-        lat, kern, fetch, miss, uniq, gpu = [], [], [], [], [], []
-        gath.clear()
-
-        def worker(si):
-            s = sessions[si]
-            while True:
-                with lock:
-                    i = nxt[0]
-                    if i >= count:
-                        return
-                    nxt[0] += 1
-                keys = batches[(first + i) % len(batches)]
-                ts = time.perf_counter()
-                if step:
-                    step(si, keys)
-                else:
-                    s.lookup_device(keys, nk, out=outs[si])
-                dt = (time.perf_counter() - ts) * 1e3
-                st = s.last_stats()
-                if record:
-                    with lock:
-                        # split call: the HBM kernel of the call is the hit gather (the probe moved no rows)
-                        lat.append(dt); kern.append(st.hit_gather_ms if st.hit_gather_ms > 0 else st.probe_gather_ms)
-                        fetch.append(st.phase_ms[1]); gath.append(st.hit_gather_ms)
-                        miss.append(st.misses); uniq.append(st.unique_misses); gpu.append(st.gpu_call_ms)
-
-        th = [threading.Thread(target=worker, args=(si,)) for si in range(len(sessions))]
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        [x.start() for x in th]
-        [x.join() for x in th]
-        torch.cuda.synchronize()
-        return time.perf_counter() - t1, lat, kern, fetch, miss, uniq, gpu
-
+    run = Runner(torch, hps, sessions, T, B, D, dev)
     steps = 40
-    batches = make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, a.hit, steps + 8)
-    run(batches, 8, 0, False)
-    dt, lat, kern, fetch, miss, uniq, gpu = run(batches, steps, 8, True)
-    k_ms, f_ms = float(np.mean(kern)), float(np.mean(fetch))
-    split_run = split and any(g > 0 for g in gath)
-    hits = N - float(np.mean(miss))
-    kern_bytes = (N * 4 + hits * 8 * D) if split_run else N * (8 + 8 * D)
-    out = {
-        "lookups_per_s": steps * N / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "sessions": len(sessions),
-        "p50_batch_latency_ms": float(np.percentile(lat, 50)), "p99_batch_latency_ms": float(np.percentile(lat, 99)),
-        "p50_batch_gpu_ms": float(np.percentile(gpu, 50)),
-        "measured_hit_rate": 1.0 - float(np.mean(miss)) / N,
-        "hbm_kernel": "hps_gather_hits_kernel" if split_run else "hps_probe_gather_kernel",
-        "avg_kernel_ms": k_ms, "kernel_frac_of_hbm_peak": kern_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    hb_ = [(x.cpu().numpy(),) for x in make_batches_gpu(torch, gen, resident, cdf_d, R, C, B, a.hit, steps + 8)]
+    hb_ = [(x[0], run.pack_host(x[0])) for x in hb_]
+    rec = []
+    run.run(hb_, 8, 0, "host")
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run.run(hb_, steps, 8, "host", record=rec)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    out = summarize(rec, N, D, dt, steps)
+    f_ms = float(np.mean([r[8][1] for r in rec]))
+    uniq = float(np.mean([r[6] for r in rec]))
+    out.update({
+        "sessions": len(sessions), "steps": steps, "setup_seconds": t_setup,
         "roofline_pcie": {"bound": "pcie", "kernel": "hps_ps_fetch_direct_kernel", "avg_kernel_ms": f_ms,
-                          "achieved": float(np.mean(uniq)) * 4 * D / (f_ms * 1e-3) / 1e9 if f_ms > 0 else None,
-                          "peak": PCIE_PEAK_GBS, "unit": "GB/s",
-                          "frac": float(np.mean(uniq)) * 4 * D / (f_ms * 1e-3) / 1e9 / PCIE_PEAK_GBS if f_ms > 0 else None},
-        "setup_seconds": t_setup,
-        "note": "same workload, two sessions, exact rows; the GPU resolves the misses through a device index of the page-locked "
-                "host tables and reads the rows over PCIe itself (no host threads on the path)",
-    }
-    del batches
-    if D % 32 == 0 and D <= 512 and T <= 31 and a.mode == "sync":
-        from hugectr_backend_amd.dense import DenseInteraction
-        rngw = np.random.default_rng(SEED)
-        dims, k = [512, 256, D], 13
-        ws, bs = [], []
-        for n in dims:
-            ws.append(((rngw.random((k, n), dtype=np.float32) * 2 - 1) * (1.5 / np.sqrt(k))).astype(np.float32))
-            bs.append(((rngw.random(n, dtype=np.float32) - 0.3) * 0.2).astype(np.float32))
-            k = n
-        ops = [DenseInteraction(ws, bs, T, D, device=dev) for _ in sessions]
-        xd = torch.randn(B, 13, device="cuda")
-        outd = [torch.empty((B, ops[0].out_stride), dtype=torch.float16, device="cuda") for _ in sessions]
-        fb = make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, a.hit, 28)
-        step = lambda si, keys: ops[si].lookup_interact(sessions[si], keys, B, xd, out=outd[si])  # noqa: E731
-        run(fb, 4, 0, False, step)
-        dtf, latf, kernf, _, missf, _, _ = run(fb, 24, 4, True, step)
-        out["c5_fused_lookup_interact"] = {
-            "lookups_per_s": 24 * N / dtf, "ms_per_step": dtf / 24 * 1e3, "samples_per_s": 24 * B / dtf,
-            "measured_hit_rate": 1.0 - float(np.mean(missf)) / N, "probe_only_kernel_ms": float(np.mean(kernf)),
-            "note": "one call per step: probe, miss fetch, bottom MLP, interaction reading cache slots / staging, insert",
-        }
+                          "achieved": uniq * 4 * D / (f_ms * 1e-3) / 1e9 if f_ms > 0 else None, "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                          "frac": uniq * 4 * D / (f_ms * 1e-3) / 1e9 / PCIE_PEAK_GBS if f_ms > 0 else None},
+        "note": "same workload (host keys), two sessions, exact rows; the GPU resolves the misses through a device index of the "
+                "page-locked host tables and reads the rows over PCIe itself (no host threads on the miss path)",
+    })
     for s in sessions:
         s.close()
     return out

@@ -240,6 +240,19 @@ int hps_server_fetch(hps_server_t* sv, const char* model, uint32_t table, const 
   });
 }
 
+int hps_server_table_data(hps_server_t* sv, const char* model, uint32_t table, const int64_t** keys, const float** rows,
+                          uint64_t* num_rows) {
+  return Guard([&]() -> Status {
+    if (!sv || !model || !keys || !rows || !num_rows) return Error(Code::kInvalidArg, "null argument");
+    auto tabs = sv->ps->tables_of(model);
+    if (table >= tabs.size()) return Error(Code::kInvalidArg, "table index out of range");
+    *keys = tabs[table]->keys();
+    *rows = tabs[table]->size() ? tabs[table]->row_at(0) : nullptr;
+    *num_rows = tabs[table]->size();
+    return Status::Ok();
+  });
+}
+
 int hps_server_upsert(hps_server_t* sv, const char* model, uint32_t table, const int64_t* keys, const float* rows,
                       uint64_t n) {
   return Guard([&]() -> Status {
@@ -380,6 +393,8 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       if (value < 0 || (u != 2 && u != 4 && u != 8) || value / 100 > 1)
         return Error(Code::kInvalidArg, "probe_variant must be U + 100*no_dedup with U in {2,4,8}");
       s->s->set_probe_variant(value);
+    } else if (n == "chain_gather") {
+      s->s->set_chain_gather(value != 0);
     } else if (n == "xcd_walk") {
       s->s->set_xcd_walk(value != 0);
     } else if (n == "keys_pinned_check") {

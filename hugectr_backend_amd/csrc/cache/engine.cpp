@@ -651,7 +651,10 @@ Status LookupSession::EnsureStaging(size_t floats, size_t uniq) {
     if (floats > staging_floats_) {
       if (d_staging_) (void)hipFree(d_staging_);
       d_staging_ = nullptr;
-      want = std::max(floats, staging_floats_ * 2);
+      // half as much again as asked for: the miss count of a steady workload wobbles by a few per cent from call to
+      // call, and every growth is a page-locked allocation (tens of milliseconds in the middle of a lookup)
+      want = std::max(floats + floats / 2, staging_floats_ * 2);
+      want = std::min(want, std::max(floats, kStagingCapBytes / sizeof(float)));
       want = std::max<size_t>(want, 1u << 16);
       HPS_RETURN_IF_ERROR(DevAlloc(&d_staging_, want));
       staging_floats_ = want;
@@ -665,7 +668,7 @@ Status LookupSession::EnsureStaging(size_t floats, size_t uniq) {
     if (uniq > staging_uniq_) {
       if (d_found_) (void)hipFree(d_found_);
       d_found_ = nullptr;
-      size_t want = std::max(uniq, staging_uniq_ * 2);
+      size_t want = std::max(uniq + uniq / 2, staging_uniq_ * 2);
       want = std::max<size_t>(want, 1u << 12);
       HPS_RETURN_IF_ERROR(DevAlloc(&d_found_, want));
       staging_uniq_ = want;
@@ -731,9 +734,9 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
       for (size_t b = 0; b < n; b += kTaskKeys) tasks.push_back({p + b, off + b, std::min(kTaskKeys, n - b)});
       off += n;
     }
-    // (page-locked keys are narrowed too when the request is large: the link, not the host, bounds the path — measured
-    //  through the Triton ABI on config 2: 1.66 G lookups/s narrowed against 1.53 G with the 8-byte DMA in place)
-    const bool try_narrow = narrow_keys_ && narrow_backoff_ == 0 && N >= 4 * kTaskKeys;
+    // (page-locked keys are DMA'd in place, never narrowed: host threads read that memory an order of magnitude slower
+    //  than ordinary memory on the MI355X boxes — 0.41 against 2.66 G lookups/s in bench.py's pinned-keys legs)
+    const bool try_narrow = !direct_dma && narrow_keys_ && narrow_backoff_ == 0 && N >= 4 * kTaskKeys;
     if (narrow_backoff_ > 0) --narrow_backoff_;
     auto stage = [&](bool narrow) -> Status {
       std::atomic<int> wide{0};
@@ -938,7 +941,13 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   };
   bool read_open = true;
   // the cache stays read-locked until K_G has read the last slot: writers wait for ev_read_, probes for ev_probe_
-  auto end_read = [&]() { if (read_open) { cache_->EndReadFused(stream_, ev_probe_, ev_read_); read_open = false; } };
+  // (option chain_gather: other sessions' probes wait for our gather too — every HBM-bound kernel then runs alone)
+  auto end_read = [&]() {
+    if (!read_open) return;
+    if (chain_gather_) cache_->EndRead(stream_, ev_read_);
+    else cache_->EndReadFused(stream_, ev_probe_, ev_read_);
+    read_open = false;
+  };
   if (e != hipSuccess) { end_read(); return Error(Code::kInternal, "probe launch failed: ", hipGetErrorString(e)); }
   if (!split) {
     e = gather();

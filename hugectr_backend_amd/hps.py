@@ -107,6 +107,8 @@ def _load() -> C.CDLL:
         "hps_server_load_table_synthetic_shard": (C.c_int, [P, cp, u32, u64, i64, u64, u32, u32]),
         "hps_server_fetch": (C.c_int, [P, cp, u32, P, u64, P, P]),
         "hps_server_upsert": (C.c_int, [P, cp, u32, P, P, u64]),
+        "hps_server_table_data": (C.c_int, [P, cp, u32, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_float)),
+                                            C.POINTER(u64)]),
         "hps_server_host_tier_stats": (C.c_int, [P, cp, u32, C.POINTER(HostTierStats)]),
         "hps_server_host_tier_keys": (C.c_int, [P, cp, u32, P, u64, C.POINTER(u64)]),
         "hps_cache_num_tables": (C.c_int, [P]),
@@ -287,6 +289,16 @@ class HierParameterServer:
                                     found.ctypes.data if return_found else None))
         return (out, found) if return_found else out
 
+    def table_data(self, model: str, table: int):
+        """(keys[R], rows[R, D]) numpy views of the table as it sits in the host tier — no copy; valid until the table
+        is reloaded or updated (tests / benchmarks only)."""
+        kp, rp, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_float)(), C.c_uint64(0)
+        _check(LIB.hps_server_table_data(self._h, model.encode(), table, C.byref(kp), C.byref(rp), C.byref(n)))
+        R, D = int(n.value), int(self.table_info(model, table).embedding_vecsize)
+        if R == 0:
+            return np.zeros(0, np.int64), np.zeros((0, D), np.float32)
+        return (np.ctypeslib.as_array(kp, shape=(R,)), np.ctypeslib.as_array(rp, shape=(R, D)))
+
     def upsert(self, model: str, table: int, keys, rows):
         """Online update of the host tier: insert-or-overwrite rows."""
         keys = np.ascontiguousarray(keys, dtype=np.int64)
@@ -350,6 +362,19 @@ class LookupSession:
         vp = (C.c_void_p * T)(*[C.c_void_p(p) for p in vec_ptrs])
         nk = (C.c_size_t * T)(*[int(n) for n in num_keys])
         _check(LIB.hps_session_lookup(self._h, kp, vp, nk, T))
+
+    @staticmethod
+    def pack_ptrs(ptrs: Sequence[int]):
+        """ctypes array of pointers, built once for calls repeated with the same buffers (lookup_packed)."""
+        return (C.c_void_p * len(ptrs))(*[C.c_void_p(p) for p in ptrs])
+
+    @staticmethod
+    def pack_counts(num_keys: Sequence[int]):
+        return (C.c_size_t * len(num_keys))(*[int(n) for n in num_keys])
+
+    def lookup_packed(self, key_ptrs, vec_ptrs, counts):
+        """hps_session_lookup with arguments prepared by pack_ptrs / pack_counts (no per-call marshalling)."""
+        _check(LIB.hps_session_lookup(self._h, key_ptrs, vec_ptrs, counts, len(counts)))
 
     def lookup_device_ptrs(self, d_keys_ptr: int, vec_ptrs: Sequence[int], num_keys: Sequence[int]):
         T = len(num_keys)

@@ -139,6 +139,12 @@ int hps_server_load_table_synthetic_shard(hps_server_t* server, const char* mode
 int hps_server_fetch(hps_server_t* server, const char* model, uint32_t table, const int64_t* keys, uint64_t n,
                      float* out, uint8_t* found);
 
+/* Read-only view of one table of the host tier as it sits in memory: R keys and R x D rows in file order (a key repeated
+ * in the file appears more than once; the last one is the live row).  Valid until the table is reloaded or updated.
+ * For tests and benchmarks that check or time against the very same rows without a second copy of a 133-GB model. */
+int hps_server_table_data(hps_server_t* server, const char* model, uint32_t table, const int64_t** keys,
+                          const float** rows, uint64_t* num_rows);
+
 /* Online update of the host tier: insert-or-overwrite rows (duplicate keys: last wins).  The entry point a consumer of
  * the reference's update source would call per message batch (docs/architecture.md:104-180); GPU caches pick the
  * new rows up at their next refresh.  With a persistent database the rows are written through to the row store

@@ -307,6 +307,23 @@ class COracle:
         self._tables.append((h, D))
         self._keep.append((keys, rows))
 
+    def reserve(self, T: int):
+        """T empty table positions, to be filled (from several threads if wanted) by add_table_arrays_borrowed."""
+        self._tables = [None] * T
+        self._keep = [None] * T
+
+    def add_table_arrays_borrowed(self, t: int, keys, rows):
+        """Index table t over arrays the CALLER keeps alive (int64[R], float32[R, D], C-contiguous): no copy of the rows.
+        The index is the oracle's own (hps_oracle.c: table_index)."""
+        assert keys.dtype == np.int64 and rows.dtype == np.float32 and keys.flags.c_contiguous and rows.flags.c_contiguous
+        R, D = rows.shape
+        assert keys.shape == (R,)
+        h = self.L.oracle_table_from_arrays(keys.ctypes.data, rows.ctypes.data, R, D)
+        if not h:
+            raise MemoryError("oracle_table_from_arrays")
+        self._tables[t] = (h, D)
+        self._keep[t] = (keys, rows)
+
     def add_table_dir(self, dirpath, D):
         h = self.L.oracle_table_load(os.fsencode(str(dirpath)), D)
         if not h:

@@ -3,8 +3,8 @@
 
     python tools/summarize_profile.py <dir with kt/ pmc_FETCH_SIZE/ pmc_WRITE_SIZE/> <out.json>
 
-Kernel stats: top rows of *_kernel_stats.csv (names shortened).  PMC: mean FETCH_SIZE / WRITE_SIZE of the
-probe+gather kernel, converted as MI355X_MICROARCH.md §HBM prescribes: both counters are in KiB; on gfx950
+Kernel stats: top rows of *_kernel_stats.csv (names shortened).  PMC: mean FETCH_SIZE / WRITE_SIZE of every kernel
+of a lookup call, converted as MI355X_MICROARCH.md §HBM prescribes: both counters are in KiB; on gfx950
 FETCH_SIZE counts 128-B coalesced requests as 64 B, so wide streaming reads are doubled.  Reported both ways.
 """
 import csv
@@ -44,12 +44,18 @@ def main(d, out):
             got["hbm_bytes_per_launch_fetch_doubled"] = 2 * f + w
         return got
 
-    res["pmc"] = pmc_of("hps_probe_gather")
-    if res["pmc"]:
-        res["pmc"]["note"] = ("probe+gather kernel only (a probe-only launch when the run used the split probe), one session; "
-                              "FETCH_SIZE and WRITE_SIZE from separate --pmc passes; reads are 16 B/lane coalesced (rows) and "
-                              "8 B/lane (bucket lines), so the gfx950 x2 correction applies to the bulk of FETCH_SIZE")
-    res["pmc_by_kernel"] = {k: v for k, v in (("hps_probe_gather", res["pmc"]), ("hps_gather_hits", pmc_of("hps_gather_hits"))) if v}
+    kernels = ("hps_probe_tile", "hps_miss_unique", "hps_gather_hits", "hps_miss_scatter", "hps_cache_insert")
+    res["pmc_by_kernel"] = {k: v for k, v in ((k, pmc_of(k)) for k in kernels) if v}
+    # SURVEY 8(d)'s lookup = probe + unique + gather + scatter (the insert is cache maintenance, reported on its own)
+    call = [res["pmc_by_kernel"].get(k, {}) for k in kernels[:4]]
+    if all("hbm_bytes_per_launch_fetch_doubled" in c for c in call[:3]):
+        res["pmc"] = {
+            "hbm_bytes_per_call_fetch_doubled": sum(c.get("hbm_bytes_per_launch_fetch_doubled", 0.0) for c in call),
+            "hbm_bytes_per_call_raw": sum(c.get("hbm_bytes_per_launch_raw", 0.0) for c in call),
+            "note": "sum over hps_probe_tile + hps_miss_unique + hps_gather_hits + hps_miss_scatter, one launch of each per "
+                    "lookup call, one session; FETCH_SIZE and WRITE_SIZE from separate --pmc passes, both in KiB; on gfx950 "
+                    "FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM) — the bulk of "
+                    "the reads are 16 B/lane row segments and 128-B bucket lines"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res)[:1500])
 
