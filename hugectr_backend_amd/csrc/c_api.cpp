@@ -17,7 +17,10 @@
 using namespace hps;
 
 struct hps_server { std::shared_ptr<HierParameterServer> ps; std::vector<std::string> names; };
-struct hps_cache { std::shared_ptr<EmbeddingCache> cache; };
+// The handle the shell gets from get_embedding_cache(model, device): like the reference's EmbeddingCacheBase it knows its
+// parameter server and its model, so LookupSessionBase::create(params, cache) needs nothing else.  `cache` is null for a
+// model that runs without GPU cache (the reference hands out a cache object with use_gpu_embedding_cache = false there).
+struct hps_cache { std::shared_ptr<HierParameterServer> ps; std::string model; int device; std::shared_ptr<EmbeddingCache> cache; };
 struct hps_session { std::shared_ptr<HierParameterServer> ps; std::unique_ptr<LookupSession> s; };
 struct hps_dense { std::unique_ptr<DenseInteraction> d; };
 
@@ -196,8 +199,12 @@ int hps_server_refresh_embedding_cache(hps_server_t* sv, const char* model, int3
 int hps_server_get_embedding_cache(hps_server_t* sv, const char* model, int32_t device, hps_cache_t** out) {
   return Guard([&]() -> Status {
     if (!sv || !model || !out) return Error(Code::kInvalidArg, "null argument");
+    *out = nullptr;
+    InferenceParams p;
+    if (!sv->ps->model_params(model, &p)) return Status::Ok();   // unknown model: no cache (the reference returns nullptr)
     auto c = sv->ps->get_embedding_cache(model, device);
-    *out = c ? new hps_cache{std::move(c)} : nullptr;
+    if (!c && p.use_gpu_embedding_cache) return Status::Ok();     // GPU-cache model without a cache on this device
+    *out = new hps_cache{sv->ps, model, device, std::move(c)};
     return Status::Ok();
   });
 }
@@ -295,11 +302,20 @@ int hps_server_host_tier_keys(hps_server_t* sv, const char* model, uint32_t tabl
   });
 }
 
-int hps_cache_num_tables(hps_cache_t* c) { return c ? (int)c->cache->num_tables() : 0; }
+int hps_cache_num_tables(hps_cache_t* c) {
+  if (!c) return 0;
+  if (c->cache) return (int)c->cache->num_tables();
+  InferenceParams p;
+  return c->ps->model_params(c->model, &p) ? (int)p.num_tables() : 0;
+}
+
+int hps_cache_on_device(hps_cache_t* c) { return c && c->cache ? 1 : 0; }
 
 int hps_cache_table_info(hps_cache_t* c, uint32_t table, hps_cache_table_info_t* out) {
   return Guard([&]() -> Status {
-    if (!c || !out || table >= c->cache->num_tables()) return Error(Code::kInvalidArg, "bad cache/table");
+    if (!c || !out) return Error(Code::kInvalidArg, "null argument");
+    if (!c->cache) return Error(Code::kUnsupported, "model '", c->model, "' runs without GPU embedding cache");
+    if (table >= c->cache->num_tables()) return Error(Code::kInvalidArg, "table index out of range");
     const auto& cfg = c->cache->get_cache_config();
     out->embedding_vecsize = cfg.embedding_vec_size_[table];
     out->num_buckets = cfg.num_set_in_cache_[table];
@@ -311,6 +327,7 @@ int hps_cache_table_info(hps_cache_t* c, uint32_t table, hps_cache_table_info_t*
 int hps_cache_counters(hps_cache_t* c, hps_cache_counters_t* out) {
   return Guard([&]() -> Status {
     if (!c || !out) return Error(Code::kInvalidArg, "null argument");
+    if (!c->cache) return Error(Code::kUnsupported, "model '", c->model, "' runs without GPU embedding cache");
     const CacheCounters k = c->cache->counters();
     out->lookups = k.lookups; out->keys = k.keys; out->misses = k.misses; out->unique_misses = k.unique_misses;
     out->inserted = k.inserted; out->refreshed = k.refreshed; out->dropped = k.dropped; out->async_calls = k.async_calls;
@@ -321,6 +338,7 @@ int hps_cache_counters(hps_cache_t* c, hps_cache_counters_t* out) {
 int hps_cache_query(hps_cache_t* c, uint32_t table, const int64_t* h_keys, uint64_t n, int32_t* h_slots) {
   return Guard([&]() -> Status {
     if (!c || (n && (!h_keys || !h_slots))) return Error(Code::kInvalidArg, "null argument");
+    if (!c->cache) return Error(Code::kUnsupported, "model '", c->model, "' runs without GPU embedding cache");
     return c->cache->Query(table, h_keys, n, h_slots);
   });
 }
@@ -328,7 +346,7 @@ int hps_cache_query(hps_cache_t* c, uint32_t table, const int64_t* h_keys, uint6
 int hps_cache_wait_async(hps_cache_t* c) {
   return Guard([&]() -> Status {
     if (!c) return Error(Code::kInvalidArg, "null argument");
-    c->cache->WaitAsync();
+    if (c->cache) c->cache->WaitAsync();
     return Status::Ok();
   });
 }
@@ -341,6 +359,16 @@ int hps_session_create(hps_server_t* sv, const char* model, hps_cache_t* cache, 
     std::unique_ptr<LookupSession> s;
     HPS_RETURN_IF_ERROR(sv->ps->create_lookup_session(model, cache ? cache->cache : nullptr, &s));
     *out = new hps_session{sv->ps, std::move(s)};
+    return Status::Ok();
+  });
+}
+
+int hps_session_create_from_cache(hps_cache_t* cache, hps_session_t** out) {
+  return Guard([&]() -> Status {
+    if (!cache || !out) return Error(Code::kInvalidArg, "null argument");
+    std::unique_ptr<LookupSession> s;
+    HPS_RETURN_IF_ERROR(cache->ps->create_lookup_session(cache->model, cache->cache, &s));
+    *out = new hps_session{cache->ps, std::move(s)};
     return Status::Ok();
   });
 }

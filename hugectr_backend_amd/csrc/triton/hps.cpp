@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
+#include <exception>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -83,6 +84,28 @@ TRITONSERVER_Error* CollectInput(TRITONBACKEND_Input* input, uint32_t buffer_cou
   return nullptr;
 }
 
+// One tensor of a request as the lookup needs it: properties first, bytes later.
+struct RequestTensor {
+  TRITONBACKEND_Input* handle = nullptr;
+  TRITONSERVER_DataType datatype = TRITONSERVER_TYPE_INVALID;
+  uint64_t bytes = 0;
+  uint32_t buffers = 0;
+};
+
+TRITONSERVER_Error* OpenTensor(TRITONBACKEND_Request* request, const char* name, TRITONSERVER_DataType want, RequestTensor* out) {
+  RETURN_IF_ERROR(TRITONBACKEND_RequestInput(request, name, &out->handle));             // hps.cc:467-478
+  const int64_t* shape = nullptr;
+  uint32_t dims = 0;
+  RETURN_IF_ERROR(TRITONBACKEND_InputProperties(out->handle, nullptr, &out->datatype, &shape, &dims, &out->bytes,
+                                                &out->buffers));                         // hps.cc:517-542
+  HPS_TRITON_LOG(VERBOSE, "\t", name, ": ", TRITONSERVER_DataTypeString(out->datatype), ", ", out->bytes, " bytes in ", out->buffers,
+                 " buffer(s)");
+  if (out->datatype != want)
+    return HPS_TRITON_ERROR(INVALID_ARG, name, " must be ", TRITONSERVER_DataTypeString(want), ", the request carries ",
+                            TRITONSERVER_DataTypeString(out->datatype));
+  return nullptr;
+}
+
 // Everything that can fail for one request; any error becomes that request's error response.
 TRITONSERVER_Error* ExecuteOne(ModelInstanceState* instance_state, ModelState* model_state, TRITONBACKEND_Request* request,
                                TRITONBACKEND_Response* response, int64_t* num_of_samples, uint64_t* exec_start_ns) {
@@ -90,113 +113,96 @@ TRITONSERVER_Error* ExecuteOne(ModelInstanceState* instance_state, ModelState* m
   RETURN_IF_ERROR(TRITONBACKEND_RequestId(request, &request_id));                       // hps.cc:410-412
   uint64_t correlation_id = 0;
   RETURN_IF_ERROR(TRITONBACKEND_RequestCorrelationId(request, &correlation_id));        // hps.cc:414-417
-  uint32_t input_count = 0;
-  RETURN_IF_ERROR(TRITONBACKEND_RequestInputCount(request, &input_count));              // hps.cc:423-425
-  uint32_t requested_output_count = 0;
-  RETURN_IF_ERROR(TRITONBACKEND_RequestOutputCount(request, &requested_output_count));  // hps.cc:427-430
-  HPS_TRITON_LOG(VERBOSE, "request id = \"", request_id, "\", correlation_id = ", correlation_id,
-                 ", input_count = ", input_count, ", requested_output_count = ", requested_output_count);
+  uint32_t num_inputs = 0, num_outputs_wanted = 0;
+  RETURN_IF_ERROR(TRITONBACKEND_RequestInputCount(request, &num_inputs));               // hps.cc:423-425
+  RETURN_IF_ERROR(TRITONBACKEND_RequestOutputCount(request, &num_outputs_wanted));      // hps.cc:427-430
+  HPS_TRITON_LOG(VERBOSE, "request \"", request_id, "\" (correlation ", correlation_id, "): ", num_inputs, " inputs, ",
+                 num_outputs_wanted, " outputs wanted");
 
-  if (input_count != 2) return HPS_TRITON_ERROR(INVALID_ARG, "expected 2 inputs (KEYS and NUMKEYS), got ", input_count);
-  for (uint32_t i = 0; i < 2; ++i) {                                                    // hps.cc:446-465
-    const char* input_name;
-    RETURN_IF_ERROR(TRITONBACKEND_RequestInputName(request, i, &input_name));
-    if (strcmp(input_name, "KEYS") != 0 && strcmp(input_name, "NUMKEYS") != 0)
-      return HPS_TRITON_ERROR(INVALID_ARG, "expected input name as KEYS and NUMKEYS in request, but got ", input_name);
+  // the request's inputs by name: exactly KEYS and NUMKEYS (hps.cc:446-465)
+  if (num_inputs != 2) return HPS_TRITON_ERROR(INVALID_ARG, "a request carries the two inputs KEYS and NUMKEYS, this one has ", num_inputs);
+  for (uint32_t i = 0; i < num_inputs; ++i) {
+    const char* name = nullptr;
+    RETURN_IF_ERROR(TRITONBACKEND_RequestInputName(request, i, &name));
+    if (strcmp(name, "KEYS") != 0 && strcmp(name, "NUMKEYS") != 0)
+      return HPS_TRITON_ERROR(INVALID_ARG, "a request carries the inputs KEYS and NUMKEYS; '", name, "' is neither");
   }
-  TRITONBACKEND_Input* catcol_input = nullptr;
-  RETURN_IF_ERROR(TRITONBACKEND_RequestInput(request, "KEYS", &catcol_input));          // hps.cc:467-471
-  TRITONBACKEND_Input* numkeys_input = nullptr;
-  RETURN_IF_ERROR(TRITONBACKEND_RequestInput(request, "NUMKEYS", &numkeys_input));      // hps.cc:473-478
-  const char* requested_output_name = nullptr;
-  if (requested_output_count > 0)
-    RETURN_IF_ERROR(TRITONBACKEND_RequestOutputName(request, 0, &requested_output_name));  // hps.cc:483-489
-
-  TRITONSERVER_DataType cat_datatype, numkeys_datatype;                                 // hps.cc:517-542
-  const int64_t *cat_input_shape, *num_keys_shape;
-  uint32_t cat_dims_count, numkeys_dims_count, cat_input_buffer_count, numkeys_input_buffer_count;
-  uint64_t cat_byte_size, numkeys_byte_size;
-  RETURN_IF_ERROR(TRITONBACKEND_InputProperties(catcol_input, nullptr, &cat_datatype, &cat_input_shape, &cat_dims_count,
-                                                &cat_byte_size, &cat_input_buffer_count));
-  RETURN_IF_ERROR(TRITONBACKEND_InputProperties(numkeys_input, nullptr, &numkeys_datatype, &num_keys_shape,
-                                                &numkeys_dims_count, &numkeys_byte_size, &numkeys_input_buffer_count));
-  HPS_TRITON_LOG(VERBOSE, "\tinput KEYS: datatype = ", TRITONSERVER_DataTypeString(cat_datatype),
-                 ", byte_size = ", cat_byte_size, ", buffer_count = ", cat_input_buffer_count);
-  HPS_TRITON_LOG(VERBOSE, "\tinput NUMKEYS: datatype = ", TRITONSERVER_DataTypeString(numkeys_datatype),
-                 ", byte_size = ", numkeys_byte_size, ", buffer_count = ", numkeys_input_buffer_count);
-  if (cat_datatype != TRITONSERVER_TYPE_INT64)
-    return HPS_TRITON_ERROR(INVALID_ARG, "KEYS must be TYPE_INT64, got ", TRITONSERVER_DataTypeString(cat_datatype));
-  if (numkeys_datatype != TRITONSERVER_TYPE_INT32)
-    return HPS_TRITON_ERROR(INVALID_ARG, "NUMKEYS must be TYPE_INT32, got ", TRITONSERVER_DataTypeString(numkeys_datatype));
-
-  // only produce an output if one was requested (hps.cc:555)
-  if (requested_output_count == 0) return nullptr;
+  RequestTensor keys_in, counts_in;
+  RETURN_IF_ERROR(OpenTensor(request, "KEYS", TRITONSERVER_TYPE_INT64, &keys_in));
+  RETURN_IF_ERROR(OpenTensor(request, "NUMKEYS", TRITONSERVER_TYPE_INT32, &counts_in));
+  const char* output_name = nullptr;
+  if (num_outputs_wanted > 0) RETURN_IF_ERROR(TRITONBACKEND_RequestOutputName(request, 0, &output_name));  // hps.cc:483-489
+  if (num_outputs_wanted == 0) return nullptr;   // nothing to produce: an empty success response (hps.cc:555)
 
   const size_t T = instance_state->NumTables();
-  const int64_t numofcat = (int64_t)(cat_byte_size / sizeof(int64_t));                  // hps.cc:573
-  *num_of_samples = numofcat / model_state->CatNum();                                   // hps.cc:575
-  if (*num_of_samples > model_state->BatchSize())                                       // hps.cc:576-582
-    return HPS_TRITON_ERROR(UNSUPPORTED, "The number of Input samples greater than max batch size");
-  if (cat_byte_size % sizeof(int64_t) != 0)
-    return HPS_TRITON_ERROR(INVALID_ARG, "KEYS byte size ", cat_byte_size, " is not a multiple of 8");
-  if (numkeys_byte_size != T * sizeof(int32_t))
+  if (keys_in.bytes % sizeof(int64_t) != 0)
+    return HPS_TRITON_ERROR(INVALID_ARG, "KEYS holds ", keys_in.bytes, " bytes, not a whole number of int64 keys");
+  const int64_t num_keys = (int64_t)(keys_in.bytes / sizeof(int64_t));                  // hps.cc:573
+  *num_of_samples = num_keys / model_state->KeysPerSample();                            // hps.cc:575
+  if (*num_of_samples > model_state->MaxBatch())                                        // hps.cc:576-582
+    return HPS_TRITON_ERROR(UNSUPPORTED, "the request holds ", *num_of_samples, " samples, more than max batch size ",
+                            model_state->MaxBatch());
+  if (counts_in.bytes != T * sizeof(int32_t))
     return HPS_TRITON_ERROR(INVALID_ARG, "NUMKEYS must hold one int32 per embedding table (", T, "), got ",
-                            numkeys_byte_size / sizeof(int32_t));
+                            counts_in.bytes / sizeof(int32_t));
 
-  // ---- NUMKEYS -> num_keys_per_table (hps.cc:599-618) ----
-  int32_t numkeys_host[kMaxTables];
-  const void* nk_data = nullptr;
-  bool nk_on_device = false;
-  RETURN_IF_ERROR(CollectInput(numkeys_input, numkeys_input_buffer_count, numkeys_byte_size, false,
-                               instance_state->DeviceId(), numkeys_host, &nk_data, &nk_on_device));
-  const int32_t* nk = reinterpret_cast<const int32_t*>(nk_data);
-  std::vector<size_t> num_keys_per_table(T);
-  int64_t key_total = 0;
-  int64_t output_buffer_size = 0;                                                       // hps.cc:620-625
-  const InferenceParams& p = instance_state->GetModelConfigutation();
+  // ---- NUMKEYS -> keys per table, output size (hps.cc:599-625) ----
+  std::vector<int32_t>& counts_staging = instance_state->CountStaging(T);
+  const void* counts_data = nullptr;
+  bool counts_on_device = false;
+  RETURN_IF_ERROR(CollectInput(counts_in.handle, counts_in.buffers, counts_in.bytes, false, instance_state->DeviceId(),
+                               counts_staging.data(), &counts_data, &counts_on_device));
+  const int32_t* counts = reinterpret_cast<const int32_t*>(counts_data);
+  const InferenceParams& p = instance_state->Params();
+  std::vector<size_t> keys_per_table(T);
+  int64_t counted = 0, output_elems = 0;
   for (size_t t = 0; t < T; ++t) {
-    if (nk[t] < 0) return HPS_TRITON_ERROR(INVALID_ARG, "NUMKEYS[", t, "] is negative");
-    num_keys_per_table[t] = (size_t)nk[t];
-    key_total += nk[t];
-    output_buffer_size += (int64_t)p.embedding_vecsize_per_table[t] * nk[t];
+    if (counts[t] < 0) return HPS_TRITON_ERROR(INVALID_ARG, "NUMKEYS[", t, "] is negative");
+    keys_per_table[t] = (size_t)counts[t];
+    counted += counts[t];
+    output_elems += (int64_t)p.embedding_vecsize_per_table[t] * counts[t];
   }
-  if (key_total != numofcat)
-    return HPS_TRITON_ERROR(INVALID_ARG, "sum(NUMKEYS) = ", key_total, " but KEYS holds ", numofcat, " keys");
+  if (counted != num_keys) return HPS_TRITON_ERROR(INVALID_ARG, "NUMKEYS adds up to ", counted, " keys, KEYS holds ", num_keys);
 
-  // ---- KEYS (hps.cc:585-597) ----
-  const bool gpucache = model_state->GPUCache();
+  // ---- KEYS: read in place when they arrive in one buffer the session can consume (host memory, or this
+  //      instance's device); otherwise gathered into the instance's staging (hps.cc:585-597) ----
+  const bool gpucache = model_state->UsesGpuCache();
   const void* key_data = nullptr;
   bool keys_on_device = false;
-  // (the staging vector is sized once per instance; it is only written when KEYS arrive in several
-  //  buffers or in device memory the session cannot read in place)
-  RETURN_IF_ERROR(CollectInput(catcol_input, cat_input_buffer_count, cat_byte_size, gpucache, instance_state->DeviceId(),
-                               instance_state->KeyStaging((size_t)std::max<int64_t>(numofcat, 1)), &key_data,
-                               &keys_on_device));
+  RETURN_IF_ERROR(CollectInput(keys_in.handle, keys_in.buffers, keys_in.bytes, gpucache, instance_state->DeviceId(),
+                               instance_state->KeyStaging((size_t)std::max<int64_t>(num_keys, 1)), &key_data, &keys_on_device));
 
   // ---- output tensor (hps.cc:626-660) ----
-  TRITONBACKEND_Output* output;
-  RETURN_IF_ERROR(TRITONBACKEND_ResponseOutput(response, &output, requested_output_name, TRITONSERVER_TYPE_FP32,
-                                               &output_buffer_size, 1));
+  TRITONBACKEND_Output* output = nullptr;
+  RETURN_IF_ERROR(TRITONBACKEND_ResponseOutput(response, &output, output_name, TRITONSERVER_TYPE_FP32, &output_elems, 1));
   void* output_buffer = nullptr;
-  TRITONSERVER_MemoryType output_memory_type = gpucache ? TRITONSERVER_MEMORY_GPU : TRITONSERVER_MEMORY_CPU;
-  int64_t output_memory_type_id = gpucache ? instance_state->DeviceId() : 0;
-  RETURN_IF_ERROR(TRITONBACKEND_OutputBuffer(output, &output_buffer, (uint64_t)output_buffer_size * sizeof(float),
-                                             &output_memory_type, &output_memory_type_id));
-  bool out_on_device = output_memory_type == TRITONSERVER_MEMORY_GPU;
-  if (out_on_device && output_memory_type_id != instance_state->DeviceId())
-    return HPS_TRITON_ERROR(UNSUPPORTED, "output buffer is on device ", output_memory_type_id, ", the instance on device ",
+  TRITONSERVER_MemoryType output_memory = gpucache ? TRITONSERVER_MEMORY_GPU : TRITONSERVER_MEMORY_CPU;   // preference
+  int64_t output_memory_id = gpucache ? instance_state->DeviceId() : 0;
+  RETURN_IF_ERROR(TRITONBACKEND_OutputBuffer(output, &output_buffer, (uint64_t)output_elems * sizeof(float), &output_memory,
+                                             &output_memory_id));
+  const bool out_on_device = output_memory == TRITONSERVER_MEMORY_GPU;
+  if (out_on_device && output_memory_id != instance_state->DeviceId())
+    return HPS_TRITON_ERROR(UNSUPPORTED, "the output buffer is on device ", output_memory_id, ", the instance on device ",
                             instance_state->DeviceId());
 
   // ---- lookup (hps.cc:663-691) ----
-  HPS_TRITON_LOG(VERBOSE, "*****Processing request on device***** ", instance_state->DeviceId(), " for model ",
-                 instance_state->Name());
   *exec_start_ns = NowNs();
   HPS_ROCTX_RANGE(roctx_process, "ProcessRequest " + instance_state->Name());           // hps.cc:671
-  RETURN_IF_ERROR(instance_state->ProcessRequest(reinterpret_cast<const int64_t*>(key_data), keys_on_device,
-                                                 num_keys_per_table, reinterpret_cast<float*>(output_buffer), out_on_device,
-                                                 (size_t)output_buffer_size));
-  HPS_TRITON_LOG(VERBOSE, "******Processing request completed!******");
-  return nullptr;
+  return instance_state->ProcessRequest(reinterpret_cast<const int64_t*>(key_data), keys_on_device, keys_per_table,
+                                        reinterpret_cast<float*>(output_buffer), out_on_device, (size_t)output_elems);
+}
+
+// No C++ exception may cross the C ABI (std::bad_alloc from a vector, anything a dependency throws): every entry point
+// runs inside this.
+template <typename F>
+TRITONSERVER_Error* NoThrow(const char* entry, F&& body) {
+  try {
+    return body();
+  } catch (const std::exception& e) {
+    return HPS_TRITON_ERROR(INTERNAL, entry, ": ", e.what());
+  } catch (...) {
+    return HPS_TRITON_ERROR(INTERNAL, entry, ": unknown exception");
+  }
 }
 
 }  // namespace
@@ -204,6 +210,7 @@ TRITONSERVER_Error* ExecuteOne(ModelInstanceState* instance_state, ModelState* m
 extern "C" {
 
 TRITONSERVER_Error* TRITONBACKEND_Initialize(TRITONBACKEND_Backend* backend) {
+  return NoThrow("TRITONBACKEND_Initialize", [&]() -> TRITONSERVER_Error* {
   const char* name;
   RETURN_IF_ERROR(TRITONBACKEND_BackendName(backend, &name));
   HPS_TRITON_LOG(INFO, "TRITONBACKEND_Initialize: ", name);
@@ -243,17 +250,21 @@ TRITONSERVER_Error* TRITONBACKEND_Initialize(TRITONBACKEND_Backend* backend) {
   err = TRITONBACKEND_BackendSetState(backend, reinterpret_cast<void*>(hps_backend));
   if (err != nullptr) { delete hps_backend; return err; }
   return nullptr;
+  });
 }
 
-TRITONSERVER_Error* TRITONBACKEND_Finalize(TRITONBACKEND_Backend* backend) {             // hps.cc:142-155
+TRITONSERVER_Error* TRITONBACKEND_Finalize(TRITONBACKEND_Backend* backend) {
+  return NoThrow("TRITONBACKEND_Finalize", [&]() -> TRITONSERVER_Error* {             // hps.cc:142-155
   void* vstate;
   RETURN_IF_ERROR(TRITONBACKEND_BackendState(backend, &vstate));
   HPS_TRITON_LOG(INFO, "TRITONBACKEND_Backend Finalize: HPSBackend");
   delete reinterpret_cast<HPSBackend*>(vstate);
   return nullptr;
+  });
 }
 
-TRITONSERVER_Error* TRITONBACKEND_ModelInitialize(TRITONBACKEND_Model* model) {          // hps.cc:162-247
+TRITONSERVER_Error* TRITONBACKEND_ModelInitialize(TRITONBACKEND_Model* model) {
+  return NoThrow("TRITONBACKEND_ModelInitialize", [&]() -> TRITONSERVER_Error* {          // hps.cc:162-247
   const char* name;
   RETURN_IF_ERROR(TRITONBACKEND_ModelName(model, &name));
   uint64_t version;
@@ -283,25 +294,27 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInitialize(TRITONBACKEND_Model* model) { 
                             backend_state->ParameterServerJsonFile());
 
   ModelState* model_state;
-  RETURN_IF_ERROR(ModelState::Create(model, &model_state, ps, params, model_ps_version));
+  RETURN_IF_ERROR(ModelState::Open(model, ps, params, model_ps_version, &model_state));
   TRITONSERVER_Error* err = TRITONBACKEND_ModelSetState(model, reinterpret_cast<void*>(model_state));
   if (err == nullptr) {
     backend_state->UpdateModelVersion(name, version);                                   // hps.cc:226
-    err = model_state->ValidateModelConfig();                                           // hps.cc:232
+    err = model_state->CheckTensorContract();                                           // hps.cc:232
   }
-  if (err == nullptr) err = model_state->ParseModelConfig();                            // hps.cc:238
-  if (err == nullptr) err = model_state->Create_EmbeddingCache();                       // hps.cc:244
+  if (err == nullptr) err = model_state->ReadDeployment();                              // hps.cc:238
+  if (err == nullptr) err = model_state->AttachCaches();                                // hps.cc:244
   if (err != nullptr) {
     // Triton does not call ModelFinalize after a failed ModelInitialize: clean up here
     (void)TRITONBACKEND_ModelSetState(model, nullptr);
-    model_state->SetPSModelVersion(std::numeric_limits<uint64_t>::max());  // never tear down another version's caches
+    model_state->MarkServingVersion(std::numeric_limits<uint64_t>::max());  // never tear down another version's caches
     delete model_state;
     return err;
   }
   return nullptr;
+  });
 }
 
-TRITONSERVER_Error* TRITONBACKEND_ModelFinalize(TRITONBACKEND_Model* model) {            // hps.cc:252-274
+TRITONSERVER_Error* TRITONBACKEND_ModelFinalize(TRITONBACKEND_Model* model) {
+  return NoThrow("TRITONBACKEND_ModelFinalize", [&]() -> TRITONSERVER_Error* {            // hps.cc:252-274
   const char* name;
   RETURN_IF_ERROR(TRITONBACKEND_ModelName(model, &name));
   TRITONBACKEND_Backend* backend;
@@ -313,13 +326,15 @@ TRITONSERVER_Error* TRITONBACKEND_ModelFinalize(TRITONBACKEND_Model* model) {   
   RETURN_IF_ERROR(TRITONBACKEND_ModelState(model, &vstate));
   ModelState* model_state = reinterpret_cast<ModelState*>(vstate);
   if (model_state == nullptr) return nullptr;
-  if (backend_state != nullptr) model_state->SetPSModelVersion(backend_state->GetModelVersion(name));
+  if (backend_state != nullptr) model_state->MarkServingVersion(backend_state->GetModelVersion(name));
   HPS_TRITON_LOG(INFO, "TRITONBACKEND_ModelFinalize: delete model state");
   delete model_state;
   return nullptr;
+  });
 }
 
-TRITONSERVER_Error* TRITONBACKEND_ModelInstanceInitialize(TRITONBACKEND_ModelInstance* instance) {  // hps.cc:280-325
+TRITONSERVER_Error* TRITONBACKEND_ModelInstanceInitialize(TRITONBACKEND_ModelInstance* instance) {
+  return NoThrow("TRITONBACKEND_ModelInstanceInitialize", [&]() -> TRITONSERVER_Error* {  // hps.cc:280-325
   const char* name;
   RETURN_IF_ERROR(TRITONBACKEND_ModelInstanceName(instance, &name));
   TRITONBACKEND_Model* model;
@@ -334,23 +349,26 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInstanceInitialize(TRITONBACKEND_ModelIns
 
   ModelInstanceState* instance_state;
   RETURN_IF_ERROR(ModelInstanceState::Create(model_state, instance, &instance_state));
-  HPS_TRITON_LOG(INFO, "******Loading HPS ******");
-  TRITONSERVER_Error* err = instance_state->LoadHPSInstance();
+    TRITONSERVER_Error* err = instance_state->LoadHPSInstance();
   if (err == nullptr) err = TRITONBACKEND_ModelInstanceSetState(instance, reinterpret_cast<void*>(instance_state));
   if (err != nullptr) { delete instance_state; return err; }
   return nullptr;
+  });
 }
 
-TRITONSERVER_Error* TRITONBACKEND_ModelInstanceFinalize(TRITONBACKEND_ModelInstance* instance) {  // hps.cc:330-344
+TRITONSERVER_Error* TRITONBACKEND_ModelInstanceFinalize(TRITONBACKEND_ModelInstance* instance) {
+  return NoThrow("TRITONBACKEND_ModelInstanceFinalize", [&]() -> TRITONSERVER_Error* {  // hps.cc:330-344
   void* vstate;
   RETURN_IF_ERROR(TRITONBACKEND_ModelInstanceState(instance, &vstate));
   HPS_TRITON_LOG(INFO, "TRITONBACKEND_ModelInstanceFinalize: delete instance state");
   delete reinterpret_cast<ModelInstanceState*>(vstate);
   return nullptr;
+  });
 }
 
 TRITONSERVER_Error* TRITONBACKEND_ModelInstanceExecute(TRITONBACKEND_ModelInstance* instance,
                                                        TRITONBACKEND_Request** requests, const uint32_t request_count) {
+  return NoThrow("TRITONBACKEND_ModelInstanceExecute", [&]() -> TRITONSERVER_Error* {
   // Triton never calls this concurrently for one instance, but does for different instances/models:
   // only instance-local state is touched here (hps.cc:353-369).  BLOCKING execution policy.
   ModelInstanceState* instance_state;
@@ -419,6 +437,7 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInstanceExecute(TRITONBACKEND_ModelInstan
     LOG_IF_ERROR(TRITONBACKEND_RequestRelease(request, TRITONSERVER_REQUEST_RELEASE_ALL), "failed releasing request");
   }
   return nullptr;
+  });
 }
 
 }  // extern "C"

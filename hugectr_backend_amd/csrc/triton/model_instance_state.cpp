@@ -17,7 +17,7 @@ TRITONSERVER_Error* ModelInstanceState::Create(ModelState* model_state,
   // (model_instance_state.cpp:65-67 passes instance_params.device_id, left at gpu_shape.back() by
   // model_state.cpp:409); the documented intent is one session per listed GPU (docs/architecture.md:11),
   // so Triton's device id is used here.
-  if (!model_state->GPUCache()) device_id = 0;
+  if (!model_state->UsesGpuCache()) device_id = 0;
   *state = new ModelInstanceState(model_state, triton_model_instance, instance_name, instance_kind, device_id);
   return nullptr;
 }
@@ -32,15 +32,15 @@ ModelInstanceState::~ModelInstanceState() {
 }
 
 TRITONSERVER_Error* ModelInstanceState::LoadHPSInstance() {
-  if (model_state_->GPUCache()) {
-    embedding_cache_ = model_state_->GetEmbeddingCache(device_id_);
+  if (model_state_->UsesGpuCache()) {
+    embedding_cache_ = model_state_->CacheOn(device_id_);
     if (!embedding_cache_)
       return HPS_TRITON_ERROR(INVALID_ARG, "model ", model_state_->Name(), " has no embedding cache on device ", device_id_,
                               "; list the device in the instance_group 'gpus' and in 'deployed_device_list'");
   }
-  RETURN_IF_STATUS_ERROR(model_state_->ParameterServer()->create_lookup_session(model_state_->Name(), embedding_cache_,
+  RETURN_IF_STATUS_ERROR(model_state_->Server()->create_lookup_session(model_state_->Name(), embedding_cache_,
                                                                                  &lookupsession_));
-  HPS_TRITON_LOG(INFO, "******Loading HPS lookup session successfully");
+  HPS_TRITON_LOG(INFO, "instance ", name_, ": lookup session ready on device ", device_id_);
   return nullptr;
 }
 
@@ -52,9 +52,9 @@ int64_t* ModelInstanceState::KeyStaging(size_t count) {
 TRITONSERVER_Error* ModelInstanceState::ProcessRequest(const int64_t* keys, bool keys_on_device,
                                                        const std::vector<size_t>& num_keys_per_table, float* out,
                                                        bool out_on_device, size_t out_elems) {
-  const InferenceParams& p = model_state_->ModelInferencePara();
+  const InferenceParams& p = model_state_->Params();
   const size_t T = num_keys_per_table.size();
-  const bool gpu = model_state_->GPUCache();
+  const bool gpu = model_state_->UsesGpuCache();
 
   float* result = out;
   if (gpu && !out_on_device) {
@@ -64,7 +64,7 @@ TRITONSERVER_Error* ModelInstanceState::ProcessRequest(const int64_t* keys, bool
       if (hipSetDevice(device_id_) != hipSuccess) return HPS_TRITON_ERROR(INTERNAL, "hipSetDevice(", device_id_, ") failed");
       if (d_result_) (void)hipFree(d_result_);
       d_result_ = nullptr;
-      const size_t want = std::max(out_elems, (size_t)model_state_->BatchSize() *
+      const size_t want = std::max(out_elems, (size_t)model_state_->MaxBatch() *
                                                   [&] { size_t s = 0; for (size_t t = 0; t < p.num_tables(); ++t) s += p.embedding_vecsize_per_table[t] * p.maxnum_catfeature_query_per_table_per_sample[t]; return s; }());
       if (hipMalloc((void**)&d_result_, want * sizeof(float)) != hipSuccess)
         return HPS_TRITON_ERROR(INTERNAL, "failed to allocate the lookup result buffer (", want * sizeof(float), " bytes)");

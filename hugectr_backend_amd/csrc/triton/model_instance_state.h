@@ -31,8 +31,10 @@ class ModelInstanceState {
   TRITONSERVER_InstanceGroupKind Kind() const { return kind_; }
   ModelState* StateForModel() const { return model_state_; }
   TRITONBACKEND_ModelInstance* TritonModelInstance() { return triton_model_instance_; }
-  const InferenceParams& GetModelConfigutation() const { return model_state_->ModelInferencePara(); }
-  size_t NumTables() const { return model_state_->ModelInferencePara().num_tables(); }
+  const InferenceParams& Params() const { return model_state_->Params(); }
+  size_t NumTables() const { return model_state_->Params().num_tables(); }
+  // host staging for a NUMKEYS tensor that arrives in pieces or in device memory: one int32 per table
+  std::vector<int32_t>& CountStaging(size_t tables) { if (count_staging_.size() < tables) count_staging_.resize(tables); return count_staging_; }
   // host staging for KEYS that arrive in several buffers (or in device memory for a CPU-only model)
   int64_t* KeyStaging(size_t count);
 
@@ -49,6 +51,7 @@ class ModelInstanceState {
   std::shared_ptr<EmbeddingCache> embedding_cache_;
   std::unique_ptr<LookupSession> lookupsession_;
   std::vector<int64_t> key_staging_;
+  std::vector<int32_t> count_staging_;
   float* d_result_ = nullptr;  // device result buffer, only when Triton hands out a host output buffer
   size_t d_result_elems_ = 0;
 };

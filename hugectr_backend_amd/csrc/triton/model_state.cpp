@@ -6,245 +6,227 @@ namespace hps { namespace triton {
 
 namespace {
 
-TRITONSERVER_Error* ParseDims(const Json& obj, const char* key, std::vector<int64_t>* out) {
-  const Json* d = obj.Find(key);
-  if (!d || !d->is_array()) return HPS_TRITON_ERROR(INVALID_ARG, "model config: '", key, "' must be an array");
+// One tensor of the backend's fixed interface: what config.pbtxt has to declare for it.
+struct TensorRule {
+  const char* name;       // nullptr: any name (the output is addressed by position)
+  const char* data_type;
+};
+constexpr TensorRule kInputs[] = {{"KEYS", "TYPE_INT64"}, {"NUMKEYS", "TYPE_INT32"}};
+constexpr TensorRule kOutput = {nullptr, "TYPE_FP32"};
+
+std::string DimsText(const std::vector<int64_t>& dims) {
+  std::string s = "[";
+  for (size_t i = 0; i < dims.size(); ++i) s += (i ? ", " : "") + std::to_string(dims[i]);
+  return s + "]";
+}
+
+TRITONSERVER_Error* ReadIntList(const Json& obj, const char* key, const std::string& where, std::vector<int64_t>* out) {
   out->clear();
-  for (size_t i = 0; i < d->size(); ++i) {
-    int64_t v;
-    if (!d->at(i).AsInt(&v)) return HPS_TRITON_ERROR(INVALID_ARG, "model config: '", key, "' must hold integers");
+  const Json* list = obj.Find(key);
+  if (!list || !list->is_array()) return HPS_TRITON_ERROR(INVALID_ARG, where, ": '", key, "' has to be a list of integers");
+  for (size_t i = 0; i < list->size(); ++i) {
+    int64_t v = 0;
+    if (!list->at(i).AsInt(&v)) return HPS_TRITON_ERROR(INVALID_ARG, where, ": '", key, "' has to be a list of integers");
     out->push_back(v);
   }
   return nullptr;
 }
 
-std::string ShapeToString(const std::vector<int64_t>& s) {
-  std::string o = "[";
-  for (size_t i = 0; i < s.size(); ++i) { if (i) o += ","; o += std::to_string(s[i]); }
-  return o + "]";
+// data type as declared + variable first dimension (requests carry any number of keys)
+TRITONSERVER_Error* CheckTensor(const Json& tensor, const TensorRule& rule, const std::string& where) {
+  std::string data_type;
+  RETURN_IF_STATUS_ERROR(ParseField(data_type, tensor, "data_type", true));
+  if (data_type != rule.data_type)
+    return HPS_TRITON_ERROR(INVALID_ARG, where, " must be declared ", rule.data_type, ", the model configuration says ", data_type);
+  std::vector<int64_t> dims;
+  RETURN_IF_ERROR(ReadIntList(tensor, "dims", where, &dims));
+  if (dims.empty() || dims[0] != -1)
+    return HPS_TRITON_ERROR(INVALID_ARG, where, " must have a variable first dimension (dims: [-1]), the model configuration says ",
+                            DimsText(dims));
+  return nullptr;
 }
 
 }  // namespace
 
-ModelState::ModelState(TRITONBACKEND_Model* triton_model, const char* name, uint64_t version, uint64_t version_ps,
-                       Json&& model_config, std::shared_ptr<HierParameterServer> ps, const InferenceParams& params)
-    : triton_model_(triton_model), name_(name), version_(version), version_ps_(version_ps),
-      model_config_(std::move(model_config)), ps_(std::move(ps)), params_(params) {}
+ModelState::ModelState(TRITONBACKEND_Model* model, std::string name, uint64_t version, uint64_t serving_version, Json&& config,
+                       std::shared_ptr<HierParameterServer> server, const InferenceParams& params)
+    : triton_model_(model), name_(std::move(name)), version_(version), serving_version_(serving_version),
+      config_(std::move(config)), server_(std::move(server)), params_(params) {}
 
-TRITONSERVER_Error* ModelState::Create(TRITONBACKEND_Model* triton_model, ModelState** state,
-                                       std::shared_ptr<HierParameterServer> ps, const InferenceParams& params,
-                                       uint64_t model_ps_version) {
-  TRITONSERVER_Message* config_message;
-  RETURN_IF_ERROR(TRITONBACKEND_ModelConfig(triton_model, 1 /* config_version */, &config_message));
-  const char* buffer;
-  size_t byte_size;
-  RETURN_IF_ERROR(TRITONSERVER_MessageSerializeToJson(config_message, &buffer, &byte_size));
-  Json model_config;
-  std::string perr;
-  const bool ok = Json::Parse(std::string(buffer, byte_size), &model_config, &perr);
-  RETURN_IF_ERROR(TRITONSERVER_MessageDelete(config_message));  // model_state.cpp:89: the plugin owns this message
-  if (!ok) return HPS_TRITON_ERROR(INVALID_ARG, "failed to parse the model configuration: ", perr);
+TRITONSERVER_Error* ModelState::Open(TRITONBACKEND_Model* model, std::shared_ptr<HierParameterServer> server,
+                                     const InferenceParams& params, uint64_t serving_version, ModelState** out) {
+  // The configuration message belongs to the backend once Triton has handed it over: parse, then delete it whatever
+  // the parse said.
+  TRITONSERVER_Message* message = nullptr;
+  RETURN_IF_ERROR(TRITONBACKEND_ModelConfig(model, 1 /* config_version */, &message));
+  const char* text = nullptr;
+  size_t text_bytes = 0;
+  TRITONSERVER_Error* err = TRITONSERVER_MessageSerializeToJson(message, &text, &text_bytes);
+  Json config;
+  std::string parse_error;
+  const bool parsed = err == nullptr && Json::Parse(std::string(text, text_bytes), &config, &parse_error);
+  TRITONSERVER_Error* del_err = TRITONSERVER_MessageDelete(message);
+  if (err != nullptr) { if (del_err) TRITONSERVER_ErrorDelete(del_err); return err; }
+  RETURN_IF_ERROR(del_err);
+  if (!parsed) return HPS_TRITON_ERROR(INVALID_ARG, "the model configuration is not valid JSON: ", parse_error);
 
-  const char* model_name;
-  RETURN_IF_ERROR(TRITONBACKEND_ModelName(triton_model, &model_name));
-  uint64_t model_version;
-  RETURN_IF_ERROR(TRITONBACKEND_ModelVersion(triton_model, &model_version));
-  TRITONSERVER_Server* triton_server;
-  RETURN_IF_ERROR(TRITONBACKEND_ModelServer(triton_model, &triton_server));
-  (void)triton_server;
-
-  *state = new ModelState(triton_model, model_name, model_version, model_ps_version, std::move(model_config),
-                          std::move(ps), params);
+  const char* name = nullptr;
+  RETURN_IF_ERROR(TRITONBACKEND_ModelName(model, &name));
+  uint64_t version = 0;
+  RETURN_IF_ERROR(TRITONBACKEND_ModelVersion(model, &version));
+  TRITONSERVER_Server* triton_server = nullptr;   // asked for as the reference does; nothing here needs the handle
+  RETURN_IF_ERROR(TRITONBACKEND_ModelServer(model, &triton_server));
+  *out = new ModelState(model, name, version, serving_version, std::move(config), std::move(server), params);
   return nullptr;
 }
 
 ModelState::~ModelState() {
-  timer_.stop();  // joins the refresh threads before the caches go away
-  if (support_gpu_cache_ && version_ps_ == version_) {
-    // only the state of the latest loaded version tears the caches down (model_state.cpp:110-115)
-    (void)ps_->destory_embedding_cache_per_model(name_);
-    HPS_TRITON_LOG(INFO, "******Destorying Embedding Cache for model ", name_, " successfully");
+  timer_.stop();  // no refresh may be running while the caches go away
+  caches_.clear();
+  if (gpu_cache_ && serving_version_ == version_) {
+    const Status st = server_->destory_embedding_cache_per_model(name_);
+    if (st.ok()) HPS_TRITON_LOG(INFO, "model ", name_, " v", version_, ": embedding caches released");
+    else HPS_TRITON_LOG(ERROR, "model ", name_, ": releasing the embedding caches failed: ", st.message());
   }
-  embedding_cache_map_.clear();
 }
 
-std::shared_ptr<EmbeddingCache> ModelState::GetEmbeddingCache(int64_t device_id) {
-  auto it = embedding_cache_map_.find(device_id);
-  return it == embedding_cache_map_.end() ? nullptr : it->second;
+std::shared_ptr<EmbeddingCache> ModelState::CacheOn(int64_t device) const {
+  const auto it = caches_.find(device);
+  return it == caches_.end() ? nullptr : it->second;
 }
 
-void ModelState::EmbeddingCacheRefresh(const std::string& model_name, int device_id) {
-  HPS_TRITON_LOG(INFO, "The model ", model_name, " is refreshing the embedding cache asynchronously on device ",
-                 device_id, ".");
-  if (!freeze_embedding_) {
-    const Status st = ps_->update_database_per_model(params_);
-    if (!st.ok()) HPS_TRITON_LOG(ERROR, "update_database_per_model failed: ", st.message());
+void ModelState::ReloadThenRefresh(int device) {
+  HPS_TRITON_LOG(INFO, "model ", name_, ": version change, bringing the cache on device ", device, " up to date");
+  if (!keep_tables_) {
+    const Status st = server_->update_database_per_model(params_);
+    if (!st.ok()) HPS_TRITON_LOG(ERROR, "model ", name_, ": reloading the sparse files failed: ", st.message());
   }
-  if (support_gpu_cache_) {
-    const Status st = ps_->refresh_embedding_cache(model_name, device_id);
-    if (!st.ok()) HPS_TRITON_LOG(ERROR, "refresh_embedding_cache failed: ", st.message());
+  if (gpu_cache_) {
+    const Status st = server_->refresh_embedding_cache(name_, device);
+    if (!st.ok()) HPS_TRITON_LOG(ERROR, "model ", name_, ": cache refresh on device ", device, " failed: ", st.message());
   }
-  HPS_TRITON_LOG(INFO, "The model ", model_name,
-                 " has completed the asynchronous refresh of the embedding cache on device ", device_id, ".");
+  HPS_TRITON_LOG(INFO, "model ", name_, ": cache on device ", device, " is up to date");
 }
 
-void ModelState::Refresh_Embedding_Cache() {
-  const uint64_t t0 = NowNs();
-  for (int64_t dev : gpu_shape_) {
-    if (!support_gpu_cache_) continue;
-    HPS_TRITON_LOG(INFO, "The model ", name_, " is periodically refreshing the embedding cache asynchronously on device ", dev);
-    const Status st = ps_->refresh_embedding_cache(name_, (int)dev);
-    if (!st.ok()) HPS_TRITON_LOG(ERROR, "refresh_embedding_cache failed: ", st.message());
-    else HPS_TRITON_LOG(INFO, "The model ", name_, " has refreshed the embedding cache asynchronously on device ", dev);
+void ModelState::RefreshAllCaches() {
+  if (!gpu_cache_) return;
+  const uint64_t begin = NowNs();
+  for (int64_t device : devices_) {
+    const Status st = server_->refresh_embedding_cache(name_, (int)device);
+    if (!st.ok()) HPS_TRITON_LOG(ERROR, "model ", name_, ": periodic cache refresh on device ", device, " failed: ", st.message());
   }
-  HPS_TRITON_LOG(INFO, "Refresh embedding table execution time is ", (NowNs() - t0) / 1000000, " ms");
+  HPS_TRITON_LOG(INFO, "model ", name_, ": periodic cache refresh of ", devices_.size(), " device(s) took ",
+                 (NowNs() - begin) / 1000000, " ms");
 }
 
-TRITONSERVER_Error* ModelState::ValidateModelConfig() {
-  HPS_TRITON_LOG(INFO, "Verifying model configuration: ", model_config_.Dump());
-  // exactly two inputs: KEYS (TYPE_INT64) and NUMKEYS (TYPE_INT32), both with dims[0] == -1
-  {
-    const Json* inputs = model_config_.Find("input");
-    if (!inputs || !inputs->is_array()) return HPS_TRITON_ERROR(INVALID_ARG, "model config: 'input' must be an array");
-    if (inputs->size() != 2) return HPS_TRITON_ERROR(INVALID_ARG, "expect 2 input, got ", inputs->size());
-    for (size_t i = 0; i < 2; ++i) {
-      const Json& input = inputs->at(i);
-      std::string name, data_type;
-      RETURN_IF_STATUS_ERROR(ParseField(name, input, "name", true));
-      if (name != "KEYS" && name != "NUMKEYS")
-        return HPS_TRITON_ERROR(INVALID_ARG, "expected input name as KEYS and NUMKEYS, but got ", name);
-      RETURN_IF_STATUS_ERROR(ParseField(data_type, input, "data_type", true));
-      if (name == "KEYS" && data_type != "TYPE_INT64")
-        return HPS_TRITON_ERROR(INVALID_ARG, "expected KEYS input datatype as TYPE_INT64, got ", data_type);
-      if (name == "NUMKEYS" && data_type != "TYPE_INT32")
-        return HPS_TRITON_ERROR(INVALID_ARG, "expected NUMKEYS input datatype as TYPE_INT32, got ", data_type);
-      std::vector<int64_t> shape;
-      RETURN_IF_ERROR(ParseDims(input, "dims", &shape));
-      if (shape.empty() || shape[0] != -1)
-        return HPS_TRITON_ERROR(INVALID_ARG, "expected input shape equal -1, got ", ShapeToString(shape));
-    }
-    std::string n0, n1;
-    (void)ParseField(n0, inputs->at(0), "name", true);
-    (void)ParseField(n1, inputs->at(1), "name", true);
-    if (n0 == n1) return HPS_TRITON_ERROR(INVALID_ARG, "inputs must be one KEYS and one NUMKEYS, got two ", n0);
+TRITONSERVER_Error* ModelState::CheckTensorContract() {
+  HPS_TRITON_LOG(VERBOSE, "model ", name_, ": configuration ", config_.Dump());
+  const Json* inputs = config_.Find("input");
+  constexpr size_t kNumInputs = sizeof(kInputs) / sizeof(kInputs[0]);
+  if (!inputs || !inputs->is_array() || inputs->size() != kNumInputs)
+    return HPS_TRITON_ERROR(INVALID_ARG, "model ", name_, ": the backend takes exactly the inputs KEYS and NUMKEYS; the model "
+                            "configuration declares ", inputs && inputs->is_array() ? inputs->size() : 0, " input(s)");
+  bool seen[kNumInputs] = {};
+  for (size_t i = 0; i < inputs->size(); ++i) {
+    std::string name;
+    RETURN_IF_STATUS_ERROR(ParseField(name, inputs->at(i), "name", true));
+    size_t r = 0;
+    while (r < kNumInputs && name != kInputs[r].name) ++r;
+    if (r == kNumInputs || seen[r])
+      return HPS_TRITON_ERROR(INVALID_ARG, "model ", name_, ": the inputs must be one KEYS and one NUMKEYS, found '", name, "'",
+                              r < kNumInputs ? " twice" : "");
+    seen[r] = true;
+    RETURN_IF_ERROR(CheckTensor(inputs->at(i), kInputs[r], "input " + name));
   }
-  // exactly one output, TYPE_FP32, dims[0] == -1
-  {
-    const Json* outputs = model_config_.Find("output");
-    if (!outputs || !outputs->is_array()) return HPS_TRITON_ERROR(INVALID_ARG, "model config: 'output' must be an array");
-    if (outputs->size() != 1) return HPS_TRITON_ERROR(INVALID_ARG, "expect 1 output, got ", outputs->size());
-    const Json& output = outputs->at(0);
-    std::string data_type;
-    RETURN_IF_STATUS_ERROR(ParseField(data_type, output, "data_type", true));
-    if (data_type != "TYPE_FP32")
-      return HPS_TRITON_ERROR(INVALID_ARG, "expected  output datatype as TYPE_FP32, got ", data_type);
-    std::vector<int64_t> shape;
-    RETURN_IF_ERROR(ParseDims(output, "dims", &shape));
-    if (shape.empty() || shape[0] != -1)
-      return HPS_TRITON_ERROR(INVALID_ARG, "expected  output shape equal -1, got ", ShapeToString(shape));
-  }
-  return nullptr;
+  const Json* outputs = config_.Find("output");
+  if (!outputs || !outputs->is_array() || outputs->size() != 1)
+    return HPS_TRITON_ERROR(INVALID_ARG, "model ", name_, ": the backend produces exactly one output tensor; the model configuration "
+                            "declares ", outputs && outputs->is_array() ? outputs->size() : 0);
+  return CheckTensor(outputs->at(0), kOutput, "the output");
 }
 
-TRITONSERVER_Error* ModelState::ParseModelConfig() {
-  const Json* instance_group = model_config_.Find("instance_group");
-  if (!instance_group || !instance_group->is_array() || instance_group->size() == 0)
-    return HPS_TRITON_ERROR(INVALID_ARG, "expect at least one instance in instance group , got ",
-                            instance_group && instance_group->is_array() ? instance_group->size() : 0);
-  support_gpu_cache_ = params_.use_gpu_embedding_cache;
-  gpu_shape_.clear();
-  for (size_t i = 0; i < instance_group->size(); ++i) {
-    const Json& instance = instance_group->at(i);
+TRITONSERVER_Error* ModelState::ReadDeployment() {
+  gpu_cache_ = params_.use_gpu_embedding_cache;
+  devices_.clear();
+  const Json* groups = config_.Find("instance_group");
+  if (!groups || !groups->is_array() || groups->size() == 0)
+    return HPS_TRITON_ERROR(INVALID_ARG, "model ", name_, ": the model configuration needs at least one instance_group entry");
+  for (size_t g = 0; g < groups->size(); ++g) {
+    const Json& group = groups->at(g);
     std::string kind;
-    RETURN_IF_STATUS_ERROR(ParseField(kind, instance, "kind", true));
-    if (support_gpu_cache_) {
-      if (kind != "KIND_GPU")
-        return HPS_TRITON_ERROR(INVALID_ARG, "expect GPU kind instance in instance group , got ", kind);
-      std::vector<int64_t> gpu_list;
-      RETURN_IF_ERROR(ParseDims(instance, "gpus", &gpu_list));
-      for (int64_t id : gpu_list)
-        if (std::find(gpu_shape_.begin(), gpu_shape_.end(), id) == gpu_shape_.end()) gpu_shape_.push_back(id);
-    } else if (gpu_shape_.empty()) {
-      gpu_shape_.push_back(0);
-    }
+    RETURN_IF_STATUS_ERROR(ParseField(kind, group, "kind", true));
     int64_t count = 1;
-    RETURN_IF_STATUS_ERROR(ParseField(count, instance, "count", false));
+    RETURN_IF_STATUS_ERROR(ParseField(count, group, "count", false));
+    // every instance owns one lookup session = one worker buffer set of the parameter server
     if (count > params_.number_of_worker_buffers_in_pool)
-      return HPS_TRITON_ERROR(INVALID_ARG,
-                              "expect the number of instance(in instance_group) not larger than "
-                              "num_of_worker_buffer_in_pool that configured in Parameter Server json file , got ",
-                              count);
+      return HPS_TRITON_ERROR(INVALID_ARG, "model ", name_, ": instance_group asks for ", count, " instances, ps.json provides "
+                              "num_of_worker_buffer_in_pool = ", params_.number_of_worker_buffers_in_pool);
+    if (!gpu_cache_) continue;
+    if (kind != "KIND_GPU")
+      return HPS_TRITON_ERROR(INVALID_ARG, "model ", name_, " uses the GPU embedding cache: its instances must be KIND_GPU, not ", kind);
+    std::vector<int64_t> gpus;
+    RETURN_IF_ERROR(ReadIntList(group, "gpus", "instance_group", &gpus));
+    for (int64_t id : gpus)
+      if (std::find(devices_.begin(), devices_.end(), id) == devices_.end()) devices_.push_back(id);
+  }
+  if (!gpu_cache_) devices_.assign(1, 0);   // host-only model: one pseudo device
+
+  // refresh behaviour: ps.json defaults, overridden per model by config.pbtxt `parameters` (README.md:169-180)
+  refresh_every_s_ = params_.refresh_interval;
+  refresh_after_s_ = params_.refresh_delay;
+  if (const Json* parameters = config_.Find("parameters")) {
+    const struct { const char* key; float* f; bool* b; } knobs[] = {
+        {"refresh_interval", &refresh_every_s_, nullptr}, {"refresh_delay", &refresh_after_s_, nullptr}, {"freeze_sparse", nullptr, &keep_tables_}};
+    for (const auto& k : knobs) {
+      const Json* entry = parameters->Find(k.key);
+      if (!entry) continue;
+      if (k.f) RETURN_IF_STATUS_ERROR(ParseField(*k.f, *entry, "string_value", false));
+      else RETURN_IF_STATUS_ERROR(ParseField(*k.b, *entry, "string_value", false));
+    }
   }
 
-  // per-model parameters: refresh_interval / refresh_delay / freeze_sparse (README.md:169-180)
-  refresh_interval_ = params_.refresh_interval;
-  refresh_delay_ = params_.refresh_delay;
-  if (const Json* parameters = model_config_.Find("parameters")) {
-    if (const Json* v = parameters->Find("refresh_interval"))
-      RETURN_IF_STATUS_ERROR(ParseField(refresh_interval_, *v, "string_value", false));
-    if (const Json* v = parameters->Find("refresh_delay"))
-      RETURN_IF_STATUS_ERROR(ParseField(refresh_delay_, *v, "string_value", false));
-    if (const Json* v = parameters->Find("freeze_sparse"))
-      RETURN_IF_STATUS_ERROR(ParseField(freeze_embedding_, *v, "string_value", false));
-  }
-  HPS_TRITON_LOG(INFO, "refresh_interval = ", refresh_interval_, ", refresh_delay = ", refresh_delay_,
-                 ", freeze_sparse = ", freeze_embedding_);
-
-  cat_num_ = 0;
-  for (size_t c : params_.maxnum_catfeature_query_per_table_per_sample) cat_num_ += (int64_t)c;
-  if (cat_num_ <= 0) return HPS_TRITON_ERROR(INVALID_ARG, "expected at least one categorical feature, got ", cat_num_);
-  embedding_size_ = 0;
-  for (size_t d : params_.embedding_vecsize_per_table) embedding_size_ += (int64_t)d;
-
-  int64_t cfg_max_batch = 0;
-  RETURN_IF_STATUS_ERROR(ParseField(cfg_max_batch, model_config_, "max_batch_size", false));
-  if (cfg_max_batch < 0)
-    return HPS_TRITON_ERROR(INVALID_ARG, "expected max_batch_size should greater than or equal to 0 ",
-                            "(the configuration should be consistent in Parameter Server json file and config.pbtxt "
-                            "file), got ", cfg_max_batch);
-  max_batch_size_ = (int64_t)params_.max_batchsize;  // ps.json wins (model_state.cpp:366)
-  HPS_TRITON_LOG(INFO, "max_batch_size is ", max_batch_size_, " (ps.json); config.pbtxt says ", cfg_max_batch);
+  keys_per_sample_ = 0;
+  for (size_t c : params_.maxnum_catfeature_query_per_table_per_sample) keys_per_sample_ += (int64_t)c;
+  if (keys_per_sample_ <= 0)
+    return HPS_TRITON_ERROR(INVALID_ARG, "model ", name_, ": maxnum_catfeature_query_per_table_per_sample sums to ", keys_per_sample_);
+  int64_t pbtxt_batch = 0;
+  RETURN_IF_STATUS_ERROR(ParseField(pbtxt_batch, config_, "max_batch_size", false));
+  if (pbtxt_batch < 0) return HPS_TRITON_ERROR(INVALID_ARG, "model ", name_, ": max_batch_size must not be negative, got ", pbtxt_batch);
+  max_batch_ = (int64_t)params_.max_batchsize;   // the parameter server sized its buffers from ps.json: that value rules
+  if (pbtxt_batch != 0 && pbtxt_batch != max_batch_)
+    HPS_TRITON_LOG(WARN, "model ", name_, ": max_batch_size is ", pbtxt_batch, " in config.pbtxt and ", max_batch_,
+                   " in ps.json; requests are limited by the latter");
+  HPS_TRITON_LOG(INFO, "model ", name_, ": ", devices_.size(), " device(s), up to ", max_batch_, " samples x ", keys_per_sample_,
+                 " keys per request, refresh every ", refresh_every_s_, " s, refresh ", refresh_after_s_, " s after a version change",
+                 keep_tables_ ? " (sparse files frozen)" : "");
   return nullptr;
 }
 
-TRITONSERVER_Error* ModelState::Create_EmbeddingCache() {
-  if (!support_gpu_cache_ && ps_->tables_of(name_).empty()) {
-    // CPU-only model deployed online: its tables were not part of the start-up load.  (The reference only
-    // reloads the database on this path for GPU-cache models, model_state.cpp:377-393.)
-    HPS_TRITON_LOG(INFO, "Update Database of Parameter Server for model ", name_);
-    RETURN_IF_STATUS_ERROR(ps_->update_database_per_model(params_));
+TRITONSERVER_Error* ModelState::AttachCaches() {
+  // A model that was not in ps.json when the server started (online deployment) has neither tables nor caches yet.
+  const bool tables_missing = server_->tables_of(name_).empty();
+  const bool caches_missing = gpu_cache_ && !devices_.empty() && server_->get_embedding_cache(name_, (int)devices_[0]) == nullptr;
+  if (tables_missing || caches_missing) {
+    HPS_TRITON_LOG(INFO, "model ", name_, ": deployed online, loading its tables into the parameter server");
+    RETURN_IF_STATUS_ERROR(server_->update_database_per_model(params_));
+    if (caches_missing) RETURN_IF_STATUS_ERROR(server_->create_embedding_cache_per_model(params_));
   }
-  if (!gpu_shape_.empty() && support_gpu_cache_) {
-    if (ps_->get_embedding_cache(name_, (int)gpu_shape_[0]) == nullptr &&
-        embedding_cache_map_.find(gpu_shape_[0]) == embedding_cache_map_.end()) {
-      // model deployed online: its tables and caches do not exist yet (model_state.cpp:378-393)
-      HPS_TRITON_LOG(INFO, "Update Database of Parameter Server for model ", name_);
-      RETURN_IF_STATUS_ERROR(ps_->update_database_per_model(params_));
-      HPS_TRITON_LOG(INFO, "Create embedding cache for model ", name_);
-      RETURN_IF_STATUS_ERROR(ps_->create_embedding_cache_per_model(params_));
+  const bool version_changed = serving_version_ > 0 && serving_version_ != version_;
+  for (int64_t device : devices_) {
+    if (gpu_cache_) {
+      if (std::find(params_.deployed_devices.begin(), params_.deployed_devices.end(), (int)device) == params_.deployed_devices.end())
+        return HPS_TRITON_ERROR(INVALID_ARG, "model ", name_, ": instance_group lists GPU ", device,
+                                ", which is not in deployed_device_list of ps.json");
+      if (caches_.count(device)) continue;
+      auto cache = server_->get_embedding_cache(name_, (int)device);
+      if (!cache) return HPS_TRITON_ERROR(INTERNAL, "model ", name_, ": the parameter server has no embedding cache on device ", device);
+      caches_[device] = std::move(cache);
     }
+    // another version of this model was serving until now: its rows may differ — refresh once, off the request path
+    if (version_changed) timer_.startonce(refresh_after_s_, [this, device] { ReloadThenRefresh((int)device); });
   }
-  for (int64_t dev : gpu_shape_) {
-    if (support_gpu_cache_ &&
-        std::find(params_.deployed_devices.begin(), params_.deployed_devices.end(), (int)dev) ==
-            params_.deployed_devices.end())
-      return HPS_TRITON_ERROR(INVALID_ARG, "Please confirm that device ", dev,
-                              " is added to 'deployed_device_list' in the ps configuration file");
-    if (embedding_cache_map_.find(dev) == embedding_cache_map_.end()) {
-      if (support_gpu_cache_) {
-        HPS_TRITON_LOG(INFO, "******Creating Embedding Cache for model ", name_, " in device ", dev);
-        auto cache = ps_->get_embedding_cache(name_, (int)dev);
-        if (!cache) return HPS_TRITON_ERROR(INTERNAL, "no embedding cache for model ", name_, " on device ", dev);
-        embedding_cache_map_[dev] = std::move(cache);
-      }
-      if (version_ps_ > 0 && version_ps_ != version_) {
-        // a different version of this model was serving before: refresh once, asynchronously
-        timer_.startonce(refresh_delay_, [this, dev] { EmbeddingCacheRefresh(name_, (int)dev); });
-      }
-    }
-  }
-  if (refresh_interval_ > 1e-6f) timer_.start(refresh_interval_, [this] { Refresh_Embedding_Cache(); });
-  HPS_TRITON_LOG(INFO, "******Creating Embedding Cache for model ", name_, " successfully");
+  if (refresh_every_s_ > 1e-6f) timer_.start(refresh_every_s_, [this] { RefreshAllCaches(); });
+  HPS_TRITON_LOG(INFO, "model ", name_, " v", version_, ": ", caches_.size(), " embedding cache(s) attached");
   return nullptr;
 }
 

@@ -1,7 +1,9 @@
-// Per-model state shared by all instances of one Triton model: validated model config, the per-device
-// embedding caches, cache-refresh timers.
-// Counterpart of the reference's ModelState (/root/reference/hps_backend/include/model_state.hpp:45-176,
-// src/model_state.cpp).
+// What all instances of one Triton model share: the checked model configuration, the model's GPU embedding caches
+// (one per device it is deployed on) and the schedule that keeps them fresh.
+//
+// Same lifecycle and the same accept/reject decisions as the reference's ModelState
+// (/root/reference/hps_backend/src/model_state.cpp: configuration checks :180-371, cache creation and refresh scheduling
+// :373-432, refresh bodies :124-178, teardown :108-122); structure, names and wording are this project's.
 #pragma once
 #include <map>
 #include <memory>
@@ -17,52 +19,56 @@ namespace hps { namespace triton {
 
 class ModelState {
  public:
-  static TRITONSERVER_Error* Create(TRITONBACKEND_Model* triton_model, ModelState** state,
-                                    std::shared_ptr<HierParameterServer> ps, const InferenceParams& params,
-                                    uint64_t model_ps_version);                                   // model_state.cpp:65-106
-  ~ModelState();                                                                                  // model_state.cpp:108-122
+  // Reads the model configuration from Triton.  serving_version: the version of this model name the backend served
+  // last (0: none) — decides whether the caches need a refresh and who tears them down.
+  static TRITONSERVER_Error* Open(TRITONBACKEND_Model* model, std::shared_ptr<HierParameterServer> server,
+                                  const InferenceParams& params, uint64_t serving_version, ModelState** out);
+  ~ModelState();
 
-  TRITONSERVER_Error* ValidateModelConfig();   // model_state.cpp:180-261
-  TRITONSERVER_Error* ParseModelConfig();      // model_state.cpp:263-371
-  TRITONSERVER_Error* Create_EmbeddingCache(); // model_state.cpp:373-432
-  void SetPSModelVersion(uint64_t v) { version_ps_ = v; }                                         // model_state.cpp:58-63
+  // The three steps of ModelInitialize after Open, in this order:
+  TRITONSERVER_Error* CheckTensorContract();  // inputs KEYS int64 [-1] + NUMKEYS int32 [-1], one fp32 [-1] output
+  TRITONSERVER_Error* ReadDeployment();       // instance groups -> devices, refresh parameters, batch limits
+  TRITONSERVER_Error* AttachCaches();         // tables + caches for a model deployed online, refresh schedule
+
+  // ModelFinalize / a failed ModelInitialize tell the state which version is being served now: only the state of
+  // that version destroys the model's caches (an older version unloading later must leave them alone).
+  void MarkServingVersion(uint64_t v) { serving_version_ = v; }
 
   TRITONBACKEND_Model* TritonModel() { return triton_model_; }
   const std::string& Name() const { return name_; }
   uint64_t Version() const { return version_; }
-  int64_t BatchSize() const { return max_batch_size_; }
-  int64_t CatNum() const { return cat_num_; }
-  int64_t EmbeddingSize() const { return embedding_size_; }
-  bool GPUCache() const { return support_gpu_cache_; }
-  const InferenceParams& ModelInferencePara() const { return params_; }
-  std::shared_ptr<HierParameterServer> ParameterServer() { return ps_; }
-  std::shared_ptr<EmbeddingCache> GetEmbeddingCache(int64_t device_id);                            // model_state.hpp:170-173
-  const std::vector<int64_t>& DeviceList() const { return gpu_shape_; }
-  // refresh every cache of this model once (used by the timers; public for tests)
-  void Refresh_Embedding_Cache();                                                                  // model_state.cpp:144-178
-  void EmbeddingCacheRefresh(const std::string& model_name, int device_id);                        // model_state.cpp:124-142
+  int64_t MaxBatch() const { return max_batch_; }                // samples per request (ps.json's max_batch_size)
+  int64_t KeysPerSample() const { return keys_per_sample_; }     // sum of maxnum_catfeature_query_per_table_per_sample
+  bool UsesGpuCache() const { return gpu_cache_; }
+  const InferenceParams& Params() const { return params_; }
+  const std::shared_ptr<HierParameterServer>& Server() const { return server_; }
+  std::shared_ptr<EmbeddingCache> CacheOn(int64_t device) const;
+  const std::vector<int64_t>& Devices() const { return devices_; }
+
+  // Refresh bodies (run by the timers; public for tests)
+  void RefreshAllCaches();                     // periodic: every device
+  void ReloadThenRefresh(int device);          // once after a version change: re-read the sparse files, then refresh
 
  private:
-  ModelState(TRITONBACKEND_Model* triton_model, const char* name, uint64_t version, uint64_t version_ps,
-             Json&& model_config, std::shared_ptr<HierParameterServer> ps, const InferenceParams& params);
+  ModelState(TRITONBACKEND_Model* model, std::string name, uint64_t version, uint64_t serving_version, Json&& config,
+             std::shared_ptr<HierParameterServer> server, const InferenceParams& params);
 
   TRITONBACKEND_Model* triton_model_;
   std::string name_;
   uint64_t version_;
-  uint64_t version_ps_;
-  Json model_config_;
-  std::shared_ptr<HierParameterServer> ps_;
+  uint64_t serving_version_;
+  Json config_;
+  std::shared_ptr<HierParameterServer> server_;
   InferenceParams params_;
 
-  int64_t max_batch_size_ = 64;
-  int64_t cat_num_ = 0;
-  int64_t embedding_size_ = 0;
-  float refresh_interval_ = 0.f;
-  float refresh_delay_ = 0.f;
-  bool freeze_embedding_ = false;
-  bool support_gpu_cache_ = true;
-  std::vector<int64_t> gpu_shape_;
-  std::map<int64_t, std::shared_ptr<EmbeddingCache>> embedding_cache_map_;
+  int64_t max_batch_ = 0;
+  int64_t keys_per_sample_ = 0;
+  float refresh_every_s_ = 0.f;     // 0: no periodic refresh
+  float refresh_after_s_ = 0.f;     // delay of the one-shot refresh behind a version change
+  bool keep_tables_ = false;        // "freeze_sparse": a version change refreshes the caches without re-reading the files
+  bool gpu_cache_ = true;
+  std::vector<int64_t> devices_;
+  std::map<int64_t, std::shared_ptr<EmbeddingCache>> caches_;
   Timer timer_;
 };
 

@@ -112,6 +112,8 @@ def _load() -> C.CDLL:
         "hps_server_host_tier_stats": (C.c_int, [P, cp, u32, C.POINTER(HostTierStats)]),
         "hps_server_host_tier_keys": (C.c_int, [P, cp, u32, P, u64, C.POINTER(u64)]),
         "hps_cache_num_tables": (C.c_int, [P]),
+        "hps_cache_on_device": (C.c_int, [P]),
+        "hps_session_create_from_cache": (C.c_int, [P, C.POINTER(P)]),
         "hps_cache_table_info": (C.c_int, [P, u32, C.POINTER(CacheTableInfo)]),
         "hps_cache_counters": (C.c_int, [P, C.POINTER(CacheCounters)]),
         "hps_cache_query": (C.c_int, [P, u32, P, u64, P]),
@@ -148,6 +150,7 @@ EXPORTED_SYMBOLS = [
     "hps_server_create_embedding_cache_per_model", "hps_server_destroy_embedding_cache_per_model",
     "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
+    "hps_server_table_data", "hps_cache_on_device", "hps_session_create_from_cache",
     "hps_server_host_tier_stats", "hps_server_host_tier_keys", "hps_cache_num_tables", "hps_cache_table_info",
     "hps_cache_counters", "hps_cache_query", "hps_cache_wait_async", "hps_cache_release", "hps_session_create",
     "hps_session_destroy", "hps_session_lookup", "hps_session_lookup_device", "hps_session_last_stats",
@@ -172,6 +175,7 @@ class EmbeddingCache:
     def __init__(self, handle, device: int = 0):
         self._h = handle
         self.device = int(device)
+        self.on_device = True   # False: handle of a model that runs without GPU cache
 
     @property
     def num_tables(self) -> int:
@@ -261,7 +265,12 @@ class HierParameterServer:
     def get_embedding_cache(self, model: str, device: int):
         h = C.c_void_p()
         _check(LIB.hps_server_get_embedding_cache(self._h, model.encode(), device, C.byref(h)))
-        return EmbeddingCache(h, device) if h else None
+        if not h:
+            return None
+        c = EmbeddingCache(h, device)
+        if not LIB.hps_cache_on_device(h):   # gpucache=false model: the handle carries server + model only
+            c.on_device = False
+        return c
 
     def load_table_arrays(self, model: str, table: int, keys, rows):
         keys = np.ascontiguousarray(keys, dtype=np.int64)
@@ -353,6 +362,15 @@ class LookupSession:
         s = cls(h, server, model)
         if embedding_cache is not None:
             s.device = embedding_cache.device
+        return s
+
+    @classmethod
+    def create_from_cache(cls, server: HierParameterServer, model: str, embedding_cache: EmbeddingCache) -> "LookupSession":
+        """LookupSessionBase::create(inference_params, embedding_cache) — the cache handle knows server and model."""
+        h = C.c_void_p()
+        _check(LIB.hps_session_create_from_cache(embedding_cache._h, C.byref(h)))
+        s = cls(h, server, model)
+        s.device = embedding_cache.device
         return s
 
     # -- the reference signature: lists of per-table pointers ---------------------------------------

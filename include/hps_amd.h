@@ -121,8 +121,11 @@ int hps_server_create_embedding_cache_per_model(hps_server_t* server, const char
 int hps_server_destroy_embedding_cache_per_model(hps_server_t* server, const char* model);
 /* refresh_embedding_cache(model, device)                                     src/model_state.cpp:135,160 */
 int hps_server_refresh_embedding_cache(hps_server_t* server, const char* model, int32_t device);
-/* get_embedding_cache(model, device): *out = NULL (and HPS_OK) when there is none, like the
- * reference's nullptr.                                                       src/model_state.cpp:379,411 */
+/* get_embedding_cache(model, device): *out = NULL (and HPS_OK) when there is none (unknown model, or a GPU-cache model
+ * without a cache on that device), like the reference's nullptr.  A model that runs without GPU cache gets a handle too —
+ * the reference hands out a cache object with use_gpu_embedding_cache = false there — so that the shell's
+ * get_cache_config().num_emb_table_ and LookupSessionBase::create(params, cache) work for it.
+ *                                                                            src/model_state.cpp:379,411 */
 int hps_server_get_embedding_cache(hps_server_t* server, const char* model, int32_t device, hps_cache_t** out);
 
 /* Table injection without files (tests / bench).  rows: R x D fp32, keys: R int64. */
@@ -172,6 +175,8 @@ int hps_server_host_tier_keys(hps_server_t* server, const char* model, uint32_t 
 /* ---- EmbeddingCacheBase ----------------------------------------------------------------------- */
 /* get_cache_config().num_emb_table_                                src/model_instance_state.cpp:107-109,169 */
 int hps_cache_num_tables(hps_cache_t* cache);
+/* 1: the handle stands for device tables; 0: the model runs without GPU cache (lookups go to the host tier) */
+int hps_cache_on_device(hps_cache_t* cache);
 int hps_cache_table_info(hps_cache_t* cache, uint32_t table, hps_cache_table_info_t* out);
 int hps_cache_counters(hps_cache_t* cache, hps_cache_counters_t* out);
 /* residency probe without side effects: slots[i] = slot index or -1 */
@@ -185,6 +190,10 @@ void hps_cache_release(hps_cache_t* cache);
 /* LookupSessionBase::create(InferenceParams, embedding_cache)                src/model_instance_state.cpp:170-171
  * cache may be NULL for gpucache=false models. */
 int hps_session_create(hps_server_t* server, const char* model, hps_cache_t* cache, hps_session_t** out);
+/* The same with the reference's two arguments: the cache handle knows its parameter server and model (InferenceParams
+ * are the server's for that model).  LookupSessionBase::create(instance_params_, embedding_cache)
+ *                                                                            src/model_instance_state.cpp:170-171 */
+int hps_session_create_from_cache(hps_cache_t* cache, hps_session_t** out);
 void hps_session_destroy(hps_session_t* session);
 /* lookup(h_keys_per_table, d_vectors_per_table, num_keys_per_table): host key pointers in; device
  * (gpucache) or host (gpucache=false) vector pointers out; blocking.        src/model_instance_state.cpp:194-195

@@ -118,3 +118,25 @@ def test_host_tier_lookup_errors():
     with pytest.raises(hps.HpsError) as e:
         hps.LookupSession.create(ps, "ghost", None)
     assert e.value.code == hps.ERR_NOT_FOUND
+
+
+def test_cache_handle_of_a_cpu_only_model_creates_its_session():
+    """The shell asks get_embedding_cache(model, device) for every model and hands the result to
+    LookupSessionBase::create(params, cache) (model_instance_state.cpp:168-171): a model without GPU cache gets a handle
+    that knows its server and model, reports the table count and opens a host-tier session."""
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    tables = make_tables([(500, 4), (300, 8)])
+    ps = hps.HierParameterServer.create_from_dict(ps_config("cpuonly", tables, gpucache=False, maxcat=[1, 2], defaults=[0.5, 1.5]),
+                                                  load_tables=False)
+    for t, (k, r) in enumerate(tables):
+        ps.load_table_arrays("cpuonly", t, k, r)
+    cache = ps.get_embedding_cache("cpuonly", 0)
+    assert cache is not None and cache.on_device is False and cache.num_tables == 2
+    with pytest.raises(hps.HpsError):
+        cache.counters()
+    assert ps.get_embedding_cache("no_such_model", 0) is None
+    s = hps.LookupSession.create_from_cache(ps, "cpuonly", cache)
+    q = np.concatenate([tables[0][0][:10], [-5], tables[1][0][:20]]).astype(np.int64)
+    out = s.lookup(q, [11, 20])
+    assert np.array_equal(out.view(np.uint32), O.np_lookup(tables, q, [11, 20], [0.5, 1.5]).view(np.uint32))

@@ -156,7 +156,7 @@ def test_request_errors_become_error_responses_not_call_failures(wdl_server):
         assert (r.response_count, r.release_count, r.final) == (1, 1, True), r
     assert good.error_code == -1
     assert bad_name.error_code == tm.ERR["INVALID_ARG"] and "KEYS and NUMKEYS" in bad_name.error_message
-    assert too_big.error_code == tm.ERR["UNSUPPORTED"] and "greater than max batch size" in too_big.error_message
+    assert too_big.error_code == tm.ERR["UNSUPPORTED"] and "more than max batch size" in too_big.error_message
     for r in (mismatch, wrong_t, wrong_dt, neg):
         assert r.error_code == tm.ERR["INVALID_ARG"], r.error_message
     st = inst.stats()
@@ -173,19 +173,20 @@ def test_request_without_requested_output_gets_an_empty_success_response(wdl_ser
 
 
 @pytest.mark.parametrize("mutate,needle", [
-    (lambda c: c["input"].pop(), "expect 2 input"),
-    (lambda c: c["input"][0].update(name="IDS"), "KEYS and NUMKEYS"),
+    (lambda c: c["input"].pop(), "exactly the inputs KEYS and NUMKEYS"),
+    (lambda c: c["input"][0].update(name="IDS"), "one KEYS and one NUMKEYS"),
     (lambda c: c["input"][0].update(data_type="TYPE_INT32"), "TYPE_INT64"),
     (lambda c: c["input"][1].update(data_type="TYPE_FP32"), "TYPE_INT32"),
-    (lambda c: c["input"][0].update(dims=[26]), "shape equal -1"),
-    (lambda c: c["output"].append(dict(c["output"][0])), "expect 1 output"),
+    (lambda c: c["input"][0].update(dims=[26]), "variable first dimension"),
+    (lambda c: c["output"].append(dict(c["output"][0])), "exactly one output"),
     (lambda c: c["output"][0].update(data_type="TYPE_FP16"), "TYPE_FP32"),
-    (lambda c: c["output"][0].update(dims=[4]), "shape equal -1"),
-    (lambda c: c.update(instance_group=[]), "at least one instance"),
+    (lambda c: c["output"][0].update(dims=[4]), "variable first dimension"),
+    (lambda c: c.update(instance_group=[]), "at least one instance_group"),
     (lambda c: c["instance_group"][0].update(count=99), "num_of_worker_buffer_in_pool"),
 ])
 def test_model_config_validation_rejects_what_the_reference_rejects(wdl_server, mutate, needle):
-    """ModelState::ValidateModelConfig / ParseModelConfig (model_state.cpp:180-371)."""
+    """ModelState::CheckTensorContract / ReadDeployment: the accept/reject decisions of the reference's
+    ValidateModelConfig / ParseModelConfig (model_state.cpp:180-371)."""
     srv, _, _, _ = wdl_server
     cfg = tm.model_config("hps_wdl", kind="KIND_CPU", gpus=[])
     mutate(cfg)
