@@ -897,8 +897,10 @@ def other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
 
 def sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev):
     """One table of Rt rows x D sharded over the P ranks (owner = mix64(key) mod P), every rank resident at 100 % in
-    its own HBM; per step every rank looks up N/P uniform keys: counting sort by owner, all-to-all keys, local
-    lookup, all-to-all rows, un-permute (hugectr_backend_amd/sharded.py).  Global lookups/s = N x steps / time."""
+    its own HBM; per step every rank looks up N/P uniform keys through the engine's sharded session
+    (csrc/cache/shard_session.cpp: bucket by owner into fixed-capacity blocks, RCCL send/recv group of the keys, padded
+    local lookup, RCCL send/recv group of the rows, gather back — no count exchange, no host round trip inside a step).
+    Global lookups/s = N x steps / time."""
     from hugectr_backend_amd.sharded import ShardedLookup
     P, D = world, a.dim
     N = a.tables * a.batch
@@ -926,7 +928,7 @@ def sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev):
     ps.create_embedding_cache_per_model(model)
     cache = ps.get_embedding_cache(model, local_rank)
     sess = hps.LookupSession.create(ps, model, cache)
-    sl = ShardedLookup(sess)
+    sl = ShardedLookup(sess, max_local_keys=n_local)   # backend nccl: the engine's native RCCL session (no torch collectives per step)
     t_setup = time.time() - t0
     gen = torch.Generator(device="cuda")
     gen.manual_seed(SEED + 77 + rank)
@@ -971,6 +973,8 @@ def sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev):
         "xgmi_note": "row all-to-all is bounded by 7 links x ~153 GB/s per GPU (MI355X_MICROARCH.md); the figure above "
                      "divides by the WHOLE step time, not the collective's own",
         "parity_vs_oracle_bit_exact": bool(okt.item()), "backend": dist.get_backend(), "setup_seconds": t_setup,
+        "exchange": "native RCCL session (hps_shard_session_*)" if sl._native else "torch.distributed all_to_all (ranks share a GPU)",
+        "block_capacity_keys": getattr(sl, "last_capacity", None), "attempts_last_step": sl.last_attempts,
     }
     sess.close()
     return res

@@ -39,6 +39,7 @@ ENGINE_SRCS = [
     "ps/volatile_tier.cpp",
     "cache/kernels.hip",
     "cache/shard_kernels.hip",
+    "cache/shard_session.cpp",
     "cache/direct_kernels.hip",
     "cache/engine.cpp",
     "cache/parameter_server.cpp",

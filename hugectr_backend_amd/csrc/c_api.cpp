@@ -12,6 +12,7 @@
 
 #include "cache/engine.h"
 #include "cache/shard_kernels.h"
+#include "cache/shard_session.h"
 #include "dense/dense.h"
 
 using namespace hps;
@@ -23,6 +24,8 @@ struct hps_server { std::shared_ptr<HierParameterServer> ps; std::vector<std::st
 struct hps_cache { std::shared_ptr<HierParameterServer> ps; std::string model; int device; std::shared_ptr<EmbeddingCache> cache; };
 struct hps_session { std::shared_ptr<HierParameterServer> ps; std::unique_ptr<LookupSession> s; };
 struct hps_dense { std::unique_ptr<DenseInteraction> d; };
+struct hps_shard_group { std::shared_ptr<LocalShardGroup> g; };
+struct hps_shard_session { std::unique_ptr<ShardedSession> s; };
 
 namespace {
 // Runs when the library is loaded.  HIP maps a process's streams onto 4 hardware queues unless told otherwise; lookup
@@ -464,6 +467,70 @@ int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint6
     return Status::Ok();
   });
 }
+
+int hps_shard_unique_id(uint8_t* out128) {
+  return Guard([&]() -> Status {
+    if (!out128) return Error(Code::kInvalidArg, "null argument");
+    return ShardUniqueId(out128);
+  });
+}
+
+int hps_shard_session_create(hps_session_t* session, uint32_t rank, uint32_t world, const uint8_t* unique_id128, uint64_t max_local_keys,
+                             hps_shard_session_t** out) {
+  return Guard([&]() -> Status {
+    if (!session || !unique_id128 || !out) return Error(Code::kInvalidArg, "null argument");
+    if (!session->s->uses_gpu_cache()) return Error(Code::kUnsupported, "the native sharded lookup needs a GPU-cache session");
+    std::unique_ptr<ShardTransport> tr;
+    HPS_RETURN_IF_ERROR(MakeRcclTransport(rank, world, unique_id128, session->s->device(), &tr));
+    std::unique_ptr<ShardedSession> ss;
+    HPS_RETURN_IF_ERROR(ShardedSession::Create(session->s.get(), std::move(tr), (size_t)max_local_keys, &ss));
+    *out = new hps_shard_session{std::move(ss)};
+    return Status::Ok();
+  });
+}
+
+int hps_shard_group_create_local(uint32_t world, hps_shard_group_t** out) {
+  return Guard([&]() -> Status {
+    if (!out || world == 0 || world > 64) return Error(Code::kInvalidArg, "bad argument");
+    *out = new hps_shard_group{MakeLocalShardGroup(world)};
+    return Status::Ok();
+  });
+}
+
+void hps_shard_group_destroy(hps_shard_group_t* group) { delete group; }
+
+int hps_shard_session_create_local(hps_session_t* session, hps_shard_group_t* group, uint32_t rank, uint64_t max_local_keys,
+                                   hps_shard_session_t** out) {
+  return Guard([&]() -> Status {
+    if (!session || !group || !out) return Error(Code::kInvalidArg, "null argument");
+    std::unique_ptr<ShardTransport> tr;
+    HPS_RETURN_IF_ERROR(MakeLocalTransport(group->g, rank, &tr));
+    std::unique_ptr<ShardedSession> ss;
+    HPS_RETURN_IF_ERROR(ShardedSession::Create(session->s.get(), std::move(tr), (size_t)max_local_keys, &ss));
+    *out = new hps_shard_session{std::move(ss)};
+    return Status::Ok();
+  });
+}
+
+int hps_shard_session_lookup(hps_shard_session_t* shard, const int64_t* d_keys, uint64_t n, float* d_out) {
+  return Guard([&]() -> Status {
+    if (!shard) return Error(Code::kInvalidArg, "null argument");
+    return shard->s->Lookup(d_keys, (size_t)n, d_out);
+  });
+}
+
+int hps_shard_session_last_stats(hps_shard_session_t* shard, uint64_t* capacity, uint32_t* attempts, uint64_t* sent_per_rank, uint32_t world) {
+  return Guard([&]() -> Status {
+    if (!shard) return Error(Code::kInvalidArg, "null argument");
+    const ShardCallStats& st = shard->s->last_stats();
+    if (capacity) *capacity = st.capacity;
+    if (attempts) *attempts = st.attempts;
+    if (sent_per_rank) for (uint32_t p = 0; p < world && p < st.sent.size(); ++p) sent_per_rank[p] = st.sent[p];
+    return Status::Ok();
+  });
+}
+
+void hps_shard_session_destroy(hps_shard_session_t* shard) { delete shard; }
 
 int hps_dense_create(int device, uint32_t num_dense, uint32_t num_layers, const uint32_t* layer_dims, const float* const* weights,
                      const float* const* biases, uint32_t num_tables, uint32_t emb_dim, hps_dense_t** out) {

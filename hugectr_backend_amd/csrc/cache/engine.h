@@ -200,6 +200,13 @@ class LookupSession {
 
   const InferenceParams& params() const { return params_; }
   bool uses_gpu_cache() const { return cache_ != nullptr; }
+  // for the sharded session built on top of a lookup session (shard_session.h)
+  hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
+  size_t max_keys() const { return max_keys_; }
+  size_t num_tables() const { return tables_.size(); }
+  uint32_t table_dim(size_t t) const { return tables_[t]->dim(); }
+  int64_t any_key_of_table(size_t t) const { return tables_[t]->size() ? tables_[t]->keys()[0] : 0; }
   // last call's numbers
   uint64_t last_miss_count() const { return last_misses_; }
   uint64_t last_unique_miss_count() const { return last_unique_; }

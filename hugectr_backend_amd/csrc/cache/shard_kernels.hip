@@ -97,6 +97,92 @@ __global__ __launch_bounds__(256) void hps_shard_unpermute_kernel(const float* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fixed-capacity ("padded") exchange of the native sharded session (shard_session.cpp): every rank sends every peer a
+// block of `stride` = 2 + cap int64 words — [0] keys in the block, [1] 1 if this rank overflowed some block, then the
+// keys — so the all-to-all needs no count exchange, no host read-back and no stream synchronisation.
+// ------------------------------------------------------------------------------------------------
+// one block: totals + headers of the P send blocks + base offsets of the stable scatter (as hps_shard_scan)
+__global__ __launch_bounds__(64) void hps_shard_scan_padded_kernel(const uint32_t* __restrict__ hist, uint32_t blocks, uint32_t P,
+                                                                   uint64_t* __restrict__ offsets /*[blocks][P]: rank of the block's first key inside its shard*/,
+                                                                   int64_t* __restrict__ send, uint64_t stride, uint64_t cap,
+                                                                   uint64_t* __restrict__ totals) {
+  __shared__ uint32_t any_over;
+  if (threadIdx.x == 0) any_over = 0;
+  __syncthreads();
+  const uint32_t s = threadIdx.x;
+  uint64_t run = 0;
+  if (s < P) {
+    for (uint32_t b = 0; b < blocks; ++b) { offsets[(uint64_t)b * P + s] = run; run += hist[(uint64_t)b * P + s]; }
+    totals[s] = run;
+    if (run > cap) atomicOr(&any_over, 1u);
+  }
+  __syncthreads();
+  if (s < P) {
+    send[(uint64_t)s * stride] = (int64_t)(run < cap ? run : cap);
+    send[(uint64_t)s * stride + 1] = (int64_t)any_over;
+  }
+}
+
+// stable scatter into the padded send blocks; pos[i] = where key i's row will sit in the returned padded row layout
+__global__ __launch_bounds__(kShardBlock) void hps_shard_scatter_padded_kernel(const int64_t* __restrict__ keys, uint64_t n, uint32_t P,
+                                                                              const uint64_t* __restrict__ offsets,
+                                                                              int64_t* __restrict__ send, uint64_t stride, uint64_t cap,
+                                                                              uint32_t* __restrict__ pos) {
+  __shared__ uint32_t wave_cnt[kShardBlock / 64][kMaxShards];
+  const uint64_t i = (uint64_t)blockIdx.x * kShardBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool valid = i < n;
+  const int64_t key = valid ? keys[i] : 0;
+  const uint32_t own = valid ? owner_of(key, P) : 0xFFFFFFFFu;
+  for (uint32_t s = lane; s < P; s += 64) wave_cnt[wave][s] = 0;
+  __syncthreads();
+  uint32_t rank_in_wave = 0;
+  for (uint32_t s = 0; s < P; ++s) {
+    const uint64_t m = __ballot(own == s);
+    if (own == s) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave][s] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (valid) {
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w][own];
+    const uint64_t r = offsets[(uint64_t)blockIdx.x * P + own] + before + rank_in_wave;   // rank inside the shard's block
+    if (r < cap) send[(uint64_t)own * stride + 2 + r] = key;
+    pos[i] = (uint32_t)((uint64_t)own * cap + (r < cap ? r : cap - 1));   // overflowed keys: a valid slot; the call is retried
+  }
+}
+
+// received blocks -> one contiguous padded key array [P][cap] for the local lookup (unused slots: pad_key, a key the
+// local shard holds, so that they hit the cache); flags[0] |= any peer's overflow flag
+__global__ __launch_bounds__(256) void hps_shard_prepare_kernel(const int64_t* __restrict__ recv, uint32_t P, uint64_t stride, uint64_t cap,
+                                                                int64_t pad_key, int64_t* __restrict__ keys_pad, uint32_t* __restrict__ flags) {
+  const uint64_t total = (uint64_t)P * cap;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = e / cap, j = e - p * cap;
+    const uint64_t cnt = (uint64_t)recv[p * stride];
+    keys_pad[e] = j < cnt ? recv[p * stride + 2 + j] : pad_key;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < P && recv[(uint64_t)threadIdx.x * stride + 1] != 0) atomicOr(&flags[0], 1u);
+}
+
+// out[i] = rows[pos[i]]   (16-lane group per row, 16 B per lane; input order restored by construction)
+__global__ __launch_bounds__(256) void hps_shard_gather_back_kernel(const float* __restrict__ rows, const uint32_t* __restrict__ pos,
+                                                                    uint64_t n, uint32_t D, float* __restrict__ out, int vec) {
+  const int lig = threadIdx.x & 15;
+  const uint64_t groups_total = (uint64_t)gridDim.x * 16;
+  for (uint64_t i = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4); i < n; i += groups_total) {
+    const float* src = rows + (uint64_t)pos[i] * D;
+    float* dst = out + i * D;
+    if (vec) {
+      for (uint32_t c = (uint32_t)lig * 4; c < D; c += 64)
+        __builtin_nontemporal_store(*reinterpret_cast<const f4s*>(src + c), reinterpret_cast<f4s*>(dst + c));
+    } else {
+      for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = src[c];
+    }
+  }
+}
+
 uint32_t ShardOwnerHost(int64_t key, uint32_t P) { return (uint32_t)(hps_mix64((uint64_t)key) % P); }
 
 size_t ShardBucketWorkspaceBytes(uint64_t n, uint32_t P) {
@@ -115,6 +201,39 @@ hipError_t LaunchShardBucket(const int64_t* d_keys, uint64_t n, uint32_t P, int6
   hipLaunchKernelGGL(hps_shard_scan_kernel, dim3(1), dim3(64), 0, stream, hist, blocks, P, offsets, d_totals);
   hipLaunchKernelGGL(hps_shard_scatter_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, n, P, offsets, d_keys_sorted,
                      d_perm);
+  return hipGetLastError();
+}
+
+hipError_t LaunchShardBucketPadded(const int64_t* d_keys, uint64_t n, uint32_t P, uint64_t cap, int64_t* d_send, uint32_t* d_pos,
+                                   uint64_t* d_totals, void* d_workspace, hipStream_t stream) {
+  if (P == 0 || P > (uint32_t)kMaxShards || cap == 0) return hipErrorInvalidValue;
+  const uint64_t stride = cap + 2;
+  uint32_t blocks = (uint32_t)((n + kShardBlock - 1) / kShardBlock);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(d_workspace);
+  uint64_t* offsets = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_workspace) + (((size_t)(blocks ? blocks : 1) * P * sizeof(uint32_t) + 15) & ~(size_t)15));
+  if (blocks) hipLaunchKernelGGL(hps_shard_hist_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, n, P, hist);
+  hipLaunchKernelGGL(hps_shard_scan_padded_kernel, dim3(1), dim3(64), 0, stream, hist, blocks, P, offsets, d_send, stride, cap, d_totals);
+  if (blocks)
+    hipLaunchKernelGGL(hps_shard_scatter_padded_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, n, P, offsets, d_send,
+                       stride, cap, d_pos);
+  return hipGetLastError();
+}
+
+hipError_t LaunchShardPrepare(const int64_t* d_recv, uint32_t P, uint64_t cap, int64_t pad_key, int64_t* d_keys_pad, uint32_t* d_flags,
+                              hipStream_t stream) {
+  uint64_t want = ((uint64_t)P * cap + 255) / 256;
+  if (want > 2048) want = 2048;
+  if (want == 0) want = 1;
+  hipLaunchKernelGGL(hps_shard_prepare_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_recv, P, cap + 2, cap, pad_key, d_keys_pad, d_flags);
+  return hipGetLastError();
+}
+
+hipError_t LaunchShardGatherBack(const float* d_rows, const uint32_t* d_pos, uint64_t n, uint32_t D, float* d_out, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  uint64_t want = (n + 15) / 16;
+  if (want > 2048) want = 2048;
+  const int vec = ((D & 3u) == 0 && ((uintptr_t)d_rows & 15u) == 0 && ((uintptr_t)d_out & 15u) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(hps_shard_gather_back_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_rows, d_pos, n, D, d_out, vec);
   return hipGetLastError();
 }
 

@@ -129,6 +129,14 @@ def _load() -> C.CDLL:
         "hps_shard_bucket_workspace_bytes": (u64, [u64, u32]),
         "hps_shard_bucket_device": (C.c_int, [P, u64, u32, P, P, P, P, P]),
         "hps_shard_unpermute_device": (C.c_int, [P, P, u64, u32, P, P]),
+        "hps_shard_unique_id": (C.c_int, [P]),
+        "hps_shard_session_create": (C.c_int, [P, u32, u32, P, u64, C.POINTER(P)]),
+        "hps_shard_group_create_local": (C.c_int, [u32, C.POINTER(P)]),
+        "hps_shard_group_destroy": (None, [P]),
+        "hps_shard_session_create_local": (C.c_int, [P, P, u32, u64, C.POINTER(P)]),
+        "hps_shard_session_lookup": (C.c_int, [P, P, u64, P]),
+        "hps_shard_session_last_stats": (C.c_int, [P, C.POINTER(u64), C.POINTER(u32), P, u32]),
+        "hps_shard_session_destroy": (None, [P]),
         "hps_dense_create": (C.c_int, [C.c_int, u32, u32, P, P, P, u32, u32, C.POINTER(P)]),
         "hps_dense_destroy": (None, [P]),
         "hps_dense_out_dim": (u32, [P]),
@@ -151,6 +159,8 @@ EXPORTED_SYMBOLS = [
     "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
     "hps_server_table_data", "hps_cache_on_device", "hps_session_create_from_cache",
+    "hps_shard_unique_id", "hps_shard_session_create", "hps_shard_group_create_local", "hps_shard_group_destroy",
+    "hps_shard_session_create_local", "hps_shard_session_lookup", "hps_shard_session_last_stats", "hps_shard_session_destroy",
     "hps_server_host_tier_stats", "hps_server_host_tier_keys", "hps_cache_num_tables", "hps_cache_table_info",
     "hps_cache_counters", "hps_cache_query", "hps_cache_wait_async", "hps_cache_release", "hps_session_create",
     "hps_session_destroy", "hps_session_lookup", "hps_session_lookup_device", "hps_session_last_stats",

@@ -1,8 +1,16 @@
-"""Table-sharded (model-parallel) lookup over torch.distributed — BASELINE config 3.
+"""Table-sharded (model-parallel) lookup — BASELINE config 3.  Thin binding.
 
 Not in the reference (which only replicates: one independent cache per GPU); this is the
 north-star addition: one big table whose rows are partitioned over the P ranks of a node,
-``owner(key) = mix64(key) mod P``.  Per lookup and rank:
+``owner(key) = mix64(key) mod P``.
+
+GPU-cache sessions on a real multi-GPU node (process group backend "nccl"): the whole exchange runs inside the engine
+(`hps_shard_session_*`, csrc/cache/shard_session.cpp): RCCL send/recv groups on the lookup session's stream with
+fixed-capacity blocks — no count exchange, no host read-back, no stream synchronisation inside a call.  torch.distributed
+is used once, to hand rank 0's RCCL unique id to the other ranks.
+
+The torch.distributed variant below remains for host-tier shards (gpucache=false sessions, any CPU backend such as
+gloo: the world_size-2 CPU test) and for ranks that share one GPU on a development box.  Per lookup and rank it does:
 
     1. bucket the local keys by owner            HIP: hps_shard_bucket_device (stable counting sort)   [host tier: numpy]
     2. all-to-all of the per-destination counts  torch.distributed (RCCL over xGMI with backend "nccl")
@@ -47,7 +55,7 @@ class ShardedLookup:
     group   : torch.distributed process group (None = default group)
     """
 
-    def __init__(self, session: hps.LookupSession, group=None):
+    def __init__(self, session: hps.LookupSession, group=None, max_local_keys: int | None = None, native: bool | None = None):
         import torch.distributed as dist
         if session.num_tables != 1:
             raise hps.HpsError(hps.ERR_UNSUPPORTED, "ShardedLookup handles one table per session")
@@ -59,6 +67,60 @@ class ShardedLookup:
         self.rank = dist.get_rank(group)
         self.device_mode = session.use_gpu_cache
         self.last_sent = None  # per-destination key counts of the last call (for bandwidth accounting)
+        self.last_attempts = 1
+        self._native = None
+        if native is None:
+            native = self.device_mode and dist.get_backend(group) == "nccl"
+        if native:
+            self._init_native(max_local_keys)
+
+    def _init_native(self, max_local_keys):
+        """Rank 0 draws the RCCL unique id, torch.distributed carries it to the others, the engine does the rest."""
+        import torch
+        dist = self.dist
+        on_dev = dist.get_backend(self.group) == "nccl"
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            hps._check(hps.LIB.hps_shard_unique_id(buf))
+            uid = torch.tensor(list(buf), dtype=torch.uint8)
+        if on_dev:
+            uid = uid.cuda()
+        dist.broadcast(uid, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        raw = (C.c_uint8 * 128)(*uid.cpu().tolist())
+        if max_local_keys is None:
+            raise hps.HpsError(hps.ERR_INVALID_ARG, "the native sharded session needs max_local_keys")
+        h = C.c_void_p()
+        hps._check(hps.LIB.hps_shard_session_create(self.sess._h, self.rank, self.P, raw, int(max_local_keys), C.byref(h)))
+        self._native = h
+        self.max_local_keys = int(max_local_keys)
+
+    def _lookup_native(self, d_keys, out=None):
+        import torch
+        n = d_keys.numel()
+        assert d_keys.is_cuda and d_keys.dtype == torch.int64 and d_keys.is_contiguous()
+        if out is None:
+            out = torch.empty(max(n, 1) * self.dim, dtype=torch.float32, device=d_keys.device)
+        torch.cuda.current_stream(d_keys.device).synchronize()   # the engine works on the session's own stream
+        hps._check(hps.LIB.hps_shard_session_lookup(self._native, d_keys.data_ptr(), n, out.data_ptr()))
+        cap, att = C.c_uint64(0), C.c_uint32(0)
+        sent = (C.c_uint64 * self.P)()
+        hps._check(hps.LIB.hps_shard_session_last_stats(self._native, C.byref(cap), C.byref(att), sent, self.P))
+        self.last_sent = [int(x) for x in sent]
+        self.last_attempts = int(att.value)
+        self.last_capacity = int(cap.value)
+        return out[: n * self.dim]
+
+    def close(self):
+        if self._native:
+            hps.LIB.hps_shard_session_destroy(self._native)
+            self._native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
         """all_to_all_single; with a CPU-only backend (gloo: the 1-GPU development box, where the ranks share
@@ -135,6 +197,8 @@ class ShardedLookup:
     def lookup(self, keys):
         """keys: this rank's keys (torch CUDA int64 tensor in device mode, array-like in host mode).
         Returns the rows in input order (flat fp32: torch CUDA tensor / numpy array)."""
+        if self._native:
+            return self._lookup_native(keys)
         if self.device_mode:
             return self._lookup_device(keys)
         return self._lookup_host(np.asarray(keys))

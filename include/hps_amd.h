@@ -216,8 +216,36 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 /* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------
- * owner(key) = mix64(key) mod num_shards.  The exchange itself (RCCL all-to-all of keys, then of rows) is driven by
- * the host layer (hugectr_backend_amd/sharded.py, torch.distributed); these are its device-side pieces. */
+ * One table, rows partitioned by owner(key) = mix64(key) mod num_shards, one process per GPU.  The native sharded
+ * session drives the whole exchange itself — RCCL (ncclSend/ncclRecv groups over xGMI) on the lookup session's stream,
+ * fixed-capacity blocks, no count exchange and no host round trip inside a call (csrc/cache/shard_session.h):
+ *
+ *   hps_shard_unique_id(id)                     on rank 0; distribute the 128 bytes to the other ranks (any side channel)
+ *   hps_shard_session_create(session, rank, world, id, max_local_keys, &shard)     collective
+ *   hps_shard_session_lookup(shard, d_keys, n, d_out)                              collective, blocking
+ *
+ * `session` is the lookup session of a ONE-table GPU-cache model that holds this rank's shard
+ * (hps_server_load_table_synthetic_shard, or files holding only the rank's rows); its request capacity
+ * (max_batch_size x keys per sample) divided by world bounds the keys one rank may receive from one peer.
+ * hps_shard_group_* / hps_shard_session_create_local: the same session with `world` endpoints inside one process on one
+ * device (device-to-device copies instead of RCCL) — for tests and single-process deployments; every endpoint runs on
+ * its own thread. */
+typedef struct hps_shard_session hps_shard_session_t;
+typedef struct hps_shard_group hps_shard_group_t;
+int hps_shard_unique_id(uint8_t* out128);
+int hps_shard_session_create(hps_session_t* session, uint32_t rank, uint32_t world, const uint8_t* unique_id128,
+                             uint64_t max_local_keys, hps_shard_session_t** out);
+int hps_shard_group_create_local(uint32_t world, hps_shard_group_t** out);
+void hps_shard_group_destroy(hps_shard_group_t* group);
+int hps_shard_session_create_local(hps_session_t* session, hps_shard_group_t* group, uint32_t rank, uint64_t max_local_keys,
+                                   hps_shard_session_t** out);
+/* d_keys: n int64 on the session's device (this rank's keys); d_out: n x D fp32 rows in input order. */
+int hps_shard_session_lookup(hps_shard_session_t* shard, const int64_t* d_keys, uint64_t n, float* d_out);
+/* last call: keys per exchange block, attempts (2+ = a block overflowed and the capacity was doubled), keys sent to each rank */
+int hps_shard_session_last_stats(hps_shard_session_t* shard, uint64_t* capacity, uint32_t* attempts, uint64_t* sent_per_rank,
+                                 uint32_t world);
+void hps_shard_session_destroy(hps_shard_session_t* shard);
+/* The device-side pieces on their own (used by the host-tier variant in hugectr_backend_amd/sharded.py): */
 uint32_t hps_shard_owner(int64_t key, uint32_t num_shards);
 uint64_t hps_shard_bucket_workspace_bytes(uint64_t n, uint32_t num_shards);
 /* Stable bucket of n device keys by owner: d_keys_sorted grouped shard 0..P-1, d_perm[j] = input index of sorted key j,

@@ -136,3 +136,119 @@ def test_device_bucket_and_unpermute_kernels(P):
             exp = np.empty((n, D), np.float32)
             exp[ref_perm] = rows
             assert np.array_equal(_bits(out[: n * D].cpu().numpy()), _bits(exp.ravel()))
+
+
+def _native_shards(P, R=20000, D=128, cache_frac=0.5, max_local=30000, seed=3):
+    """P shard servers + sessions of one table in this process (each its own model on device 0)."""
+    from hugectr_backend_amd import hps, sharded
+    tables = make_tables([(R, D)], seed=seed)
+    keys, rows = tables[0]
+    made = []
+    for r in range(P):
+        my_k, my_r = sharded.shard_rows(keys, rows, r, P)
+        model = f"nshard{P}_{r}"
+        cfg = ps_config(model, [(my_k, my_r)], gpucache=True, gpucacheper=cache_frac, hit_rate_threshold=1.0, defaults=[2.0],
+                        maxcat=[1], max_batch=max_local * max(P, 2))
+        ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+        ps.load_table_arrays(model, 0, my_k, my_r)
+        ps.create_embedding_cache_per_model(model)
+        sess = hps.LookupSession.create(ps, model, ps.get_embedding_cache(model, 0))
+        made.append((ps, sess))
+    return tables, made
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [2, 4])
+def test_native_sharded_session_logical_shards_in_one_process(P):
+    """The engine's sharded session (fixed-capacity blocks, positions recorded by the bucket kernel, padded local lookup)
+    with P endpoints in one process: device-to-device copies stand in for RCCL, everything else is the production path.
+    Uniform keys, absent keys, ragged sizes, an empty request on one rank, and a skewed request that overflows the block
+    capacity (one hot key = one owner) and is repeated with twice the capacity."""
+    import ctypes as C
+    import threading
+    import torch
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    tables, made = _native_shards(P)
+    keys = tables[0][0]
+    max_local = 30000
+    grp = C.c_void_p()
+    hps._check(hps.LIB.hps_shard_group_create_local(P, C.byref(grp)))
+    shards = []
+    for r, (_, sess) in enumerate(made):
+        h = C.c_void_p()
+        hps._check(hps.LIB.hps_shard_session_create_local(sess._h, grp, r, max_local, C.byref(h)))
+        shards.append(h)
+    rng = np.random.default_rng(P)
+    rounds = []
+    for it in range(5):
+        per_rank = []
+        for r in range(P):
+            n = max_local if it == 3 else int(rng.integers(1, max_local))
+            if it == 1 and r == 0:
+                n = 0
+            q = np.where(rng.random(n) < 0.1, -1 - rng.integers(0, 1 << 40, n), rng.choice(keys, n)).astype(np.int64)
+            if it == 3:   # skew: most of every rank's keys are ONE key -> one owner's block overflows
+                q[: int(n * 0.8)] = keys[17]
+            per_rank.append(q)
+        rounds.append(per_rank)
+    errs, attempts = [], [[0] * len(rounds) for _ in range(P)]
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            for it, per_rank in enumerate(rounds):
+                q = per_rank[r]
+                dq = torch.from_numpy(q).cuda()
+                out = torch.empty(max(q.size, 1) * 128, dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                hps._check(hps.LIB.hps_shard_session_lookup(shards[r], dq.data_ptr(), q.size, out.data_ptr()))
+                att, cap = C.c_uint32(0), C.c_uint64(0)
+                sent = (C.c_uint64 * P)()
+                hps._check(hps.LIB.hps_shard_session_last_stats(shards[r], C.byref(cap), C.byref(att), sent, P))
+                attempts[r][it] = att.value
+                if sum(sent) != q.size:
+                    errs.append((r, it, "sent counts do not add up"))
+                ref = O.np_lookup(tables, q, [q.size], [2.0])
+                if not np.array_equal(_bits(out[: q.size * 128].cpu().numpy()), _bits(ref)):
+                    errs.append((r, it, "mismatch"))
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, "exception", repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errs, errs
+    assert all(a[0] == 1 for a in attempts)                 # uniform keys fit the first capacity
+    assert all(a[3] >= 2 for a in attempts)                 # the skewed round was repeated on every rank alike
+    for h in shards:
+        hps.LIB.hps_shard_session_destroy(h)
+    hps.LIB.hps_shard_group_destroy(grp)
+    for _, sess in made:
+        sess.close()
+
+
+@pytest.mark.gpu
+def test_native_sharded_session_over_rccl_single_rank():
+    """The RCCL transport itself (librccl loaded at first use, ncclCommInitRank, grouped ncclSend/ncclRecv on the session's
+    stream) with the one GPU of the box: a world of one rank exchanges with itself.  N > 1 needs one GPU per rank."""
+    import ctypes as C
+    import torch
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    tables, made = _native_shards(1, R=30000, seed=9)
+    _, sess = made[0]
+    uid = (C.c_uint8 * 128)()
+    hps._check(hps.LIB.hps_shard_unique_id(uid))
+    h = C.c_void_p()
+    hps._check(hps.LIB.hps_shard_session_create(sess._h, 0, 1, uid, 25000, C.byref(h)))
+    rng = np.random.default_rng(1)
+    for n in (1, 4096, 25000):
+        q = np.where(rng.random(n) < 0.05, -3 - rng.integers(0, 1 << 30, n), rng.choice(tables[0][0], n)).astype(np.int64)
+        dq = torch.from_numpy(q).cuda()
+        out = torch.empty(n * 128, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        hps._check(hps.LIB.hps_shard_session_lookup(h, dq.data_ptr(), n, out.data_ptr()))
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(O.np_lookup(tables, q, [n], [2.0])))
+    hps.LIB.hps_shard_session_destroy(h)
+    sess.close()
