@@ -64,6 +64,7 @@ def parse_args():
     ap.add_argument("--distinct-batches", type=int, default=0, help="0: one fresh batch per step")
     ap.add_argument("--probe-variant", type=int, default=4, help="probe kernel variant U + 100*no_dedup (tools/kbench.py)")
     ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
+    ap.add_argument("--stamp-every", type=int, default=4, help="LRU stamps rewritten for one hit in N (power of two)")
     ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
     ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys as uint32 when every key of the request fits")
     ap.add_argument("--direct", type=int, default=-1,
@@ -377,6 +378,7 @@ def main():
         s.set_option("split_probe", 1 if split else 0)
         s.set_option("narrow_keys", a.narrow_keys)
         s.set_option("chain_gather", a.chain_gather)
+        s.set_option("stamp_every", a.stamp_every)
 
     # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
     C = int(np.ceil(a.cache_frac * R))
@@ -537,13 +539,14 @@ def main():
                     extra["c5_fused_lookup_interact"] = c5f
             # (6) the build's own CPU parameter server (the host tier, `gpucache=false` path of the reference:
             #     docs/architecture.md:72) on the identical batches: hps_server_fetch per table, all host cores
-            outc = None
+            outc = np.empty((B, D), dtype=np.float32)   # one table's slice, reused (a fresh 33-MB array per fetch is page faults)
             tcp0 = time.perf_counter()
             reps = 0
             while time.perf_counter() - tcp0 < 4.0 and reps < 40:
                 q = host_batches[reps % len(host_batches)][0]
                 for t in range(T):
-                    outc = ps.fetch(model, t, q[t * B:(t + 1) * B])
+                    qt = q[t * B:(t + 1) * B]
+                    hps._check(hps.LIB.hps_server_fetch(ps._h, model.encode(), t, qt.ctypes.data, B, outc.ctypes.data, None))
                 reps += 1
             tcp = time.perf_counter() - tcp0
             extra["cpu_parameter_server_tier"] = {

@@ -89,6 +89,7 @@ struct CallWork {
 struct CallDesc {
   uint32_t num_tables;
   uint32_t epoch;           // LRU epoch of this call (monotonic per cache)
+  uint32_t stamp_mask;      // a hit slot's LRU stamp is rewritten when (hash(slot, epoch) & stamp_mask) == 0: 0 = every hit
   uint64_t total_keys;      // N = sum n_t
   const int64_t* keys;      // flat, table-major, device
   const uint32_t* keys32;   // not null: the same keys narrowed to 32 bits (every key of the call is in [0, 2^32); then

@@ -637,6 +637,14 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
     HPS_RETURN_IF_ERROR(DevAlloc(&d_found_, max_keys_));
     staging_floats_ = worst;
     staging_uniq_ = max_keys_;
+  } else {
+    // host-gather tier: page-locked staging for an eighth of a full request up front (a request that misses more grows
+    // it): the first calls of a fresh session then do not stop for a pinned allocation in the middle of a lookup
+    size_t floats = 0;
+    for (size_t t = 0; t < T; ++t)
+      floats += p.max_batchsize * p.maxnum_catfeature_query_per_table_per_sample[t] * (size_t)tables_[t]->dim();
+    floats = std::min(floats / 8 + 4 * T, kStagingCapBytes / sizeof(float));
+    HPS_RETURN_IF_ERROR(EnsureStaging(floats, max_keys_ / 8 + 1));
   }
   HIP_TRY(hipDeviceSynchronize());
   return Status::Ok();
@@ -845,6 +853,7 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   c.key_start[T] = N;
   c.total_keys = N;
   c.epoch = cache_->NextEpoch();
+  c.stamp_mask = stamp_mask_;
   if (++call_tag_ == 0) {  // 2^32 calls later: entries of the first calls would look like this call's
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemsetAsync(work_.set, 0, (work_.set_mask + 1) * sizeof(unsigned long long), stream_));
@@ -924,12 +933,15 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   const bool split = split_probe_ && !use_direct && last_misses_ > 0;
   const int cu = cache_->cu_count();
   const uint32_t gather_blocks = GatherGridBlocks(N, cu);
+  CallWork wk = work_;
+  // device-driven tier with synchronous insertion: nobody on the host reads the unique keys — spare the PCIe writes
+  if (use_direct && params_.hit_rate_threshold >= 1.0f) wk.uniq_keys_host = nullptr;
 
   // ---- K_P: tile dedup + probe;  K_M: call-wide unique misses (+ unique hits) ----
   cache_->BeginRead(stream_);
   if (timing_) (void)hipEventRecord(ev_t0_, stream_);
-  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), w, probe_variant_, exact, stream_);
-  if (e == hipSuccess) e = LaunchMissUnique(d_call_, cache_->device_tables(), w, exact, stream_);
+  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, exact, stream_);
+  if (e == hipSuccess) e = LaunchMissUnique(d_call_, cache_->device_tables(), wk, exact, stream_);
   if (timing_) (void)hipEventRecord(ev_t1_, stream_);
   // other sessions' probes chain behind ours: behind K_P, and behind K_M too when it still reads the claim words
   (void)hipEventRecord(ev_probe_, stream_);

@@ -217,6 +217,7 @@ class LookupSession {
   void set_split_probe(bool b) { split_probe_ = b; }
   void set_xcd_walk(bool b) { xcd_walk_ = b; }
   void set_chain_gather(bool b) { chain_gather_ = b; }
+  void set_stamp_every(uint32_t n) { uint32_t m = 1; while (m < n) m <<= 1; stamp_mask_ = m - 1; }
   float last_key_stage_ms() const { return key_stage_ms_; }
   float last_scatter_ms() const { return last_scatter_ms_; }   // miss-scatter kernel of the last call (last chunk)
   float last_insert_ms() const { return last_insert_ms_; }     // cache-insert kernel of the last call (last chunk)
@@ -290,6 +291,7 @@ class LookupSession {
   bool split_call_ = false;      // the call in progress gathers its hits on stream_ while the miss path runs (copies go down copy_stream_)
   bool split_probe_ = true;      // host-gather tier: start the miss path behind the probe, gather the hits meanwhile (§3.4c);
                                  // HPS_SPLIT_PROBE=0 / session option split_probe=0: gather first, then the counts
+  uint32_t stamp_mask_ = 3;      // LRU stamps rewritten for one hit in (stamp_mask_ + 1); option "stamp_every"
   bool chain_gather_ = false;    // other sessions' probes queue behind this session's gather as well as its probe
   bool xcd_walk_ = true;         // K_G: each XCD sweeps its own eighth of the key range (HPS_XCD_WALK=0: plain grid stride)
   MissDesc* h_md_ = nullptr;      // pinned

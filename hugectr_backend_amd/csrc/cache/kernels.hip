@@ -138,6 +138,7 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
   const uint32_t* __restrict__ keys32 = call->keys32;   // wave-uniform: one of the two loops below
   const int64_t* __restrict__ keys = call->keys + td.begin;
   const uint32_t epoch = call->epoch;
+  const uint32_t stamp_mask = call->stamp_mask;
   constexpr int kPerThread = kTileKeys / kProbeBlockThreads;
 
   if (tid < 4) sh_cnt[tid] = 0;
@@ -209,9 +210,9 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
         if (m16) {
           s = (int32_t)(bb[u] * kBucketSlots + (uint32_t)__builtin_ctz(m16));
           if (!(tb.flags & 1u)) {
-            // the LRU stamp is rewritten for 1 hit in 4 (hashed on slot and epoch): a blind 4-B store per hit is a
-            // read-modify-write of a whole DRAM sector
-            if (((((uint32_t)s * 0x9E3779B1u + epoch * 0x85EBCA6Bu) >> 13) & 3u) == 0u) tb.stamps[(uint32_t)s] = epoch;
+            // the LRU stamp is rewritten for a sample of the hits (hashed on slot and epoch; stamp_mask 3 = one in
+            // four): a blind 4-B store per hit is a read-modify-write of a whole DRAM sector
+            if (((((uint32_t)s * 0x9E3779B1u + epoch * 0x85EBCA6Bu) >> 13) & stamp_mask) == 0u) tb.stamps[(uint32_t)s] = epoch;
           }
           if (kClaim) tb.claim[(uint32_t)s] = (uint32_t)(td.begin + jj[u]);
         }
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __
         const uint32_t u = sh_base + sh_wave[tid >> 6] + rank_in_wave;
         w.uidx_of[m] = (int32_t)u;
         w.uniq_keys[ks + u] = key;
-        w.uniq_keys_host[ks + u] = key;  // zero-copy store into pinned host memory
+        if (w.uniq_keys_host) w.uniq_keys_host[ks + u] = key;  // zero-copy store into pinned host memory (host-gather tier)
       }
     }
     __syncthreads();
