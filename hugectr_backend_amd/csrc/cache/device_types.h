@@ -73,6 +73,7 @@ struct CallWork {
   int64_t* miss_key;         // tile regions: key of the tile's r-th missed representative
   int32_t* sent_i;           // tile regions: global index of every missed key of the tile, as sent
   int32_t* hit_i;            // tile regions: global index of the tile's hit representatives (unique-hit count only)
+  int32_t* hit_s;            // tile regions: their slots
   int32_t* rep_of;           // tile regions: m -> m of the call-wide representative of the same (table, key)
   int32_t* uidx_of;          // tile regions: valid at representatives: index in the table's unique-miss segment
   unsigned long long* set;   // open addressing, entries (call_tag << 32 | m); other tags = free

@@ -542,7 +542,7 @@ void LookupSession::Release() {
   auto dfree = [](void* p) { if (p) (void)hipFree(p); };
   hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_block_); dfree(d_block_); hfree(h_acc_); dfree(d_mode_);
   hfree(h_md_); dfree(d_md_);
-  dfree(work_.slot); dfree(work_.tile_cnt); dfree(work_.miss_key); dfree(work_.sent_i); dfree(work_.hit_i);
+  dfree(work_.slot); dfree(work_.tile_cnt); dfree(work_.miss_key); dfree(work_.sent_i); dfree(work_.hit_i); dfree(work_.hit_s);
   dfree(work_.rep_of); dfree(work_.uidx_of); dfree(work_.set); dfree(work_.uniq_keys);
   hfree(h_mode_);
   hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
@@ -615,7 +615,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HPS_RETURN_IF_ERROR(DevAlloc(&w.sent_i, regions));
   HPS_RETURN_IF_ERROR(DevAlloc(&w.rep_of, regions));
   HPS_RETURN_IF_ERROR(DevAlloc(&w.uidx_of, regions));
-  w.hit_i = nullptr;  // allocated with the first call whose policy needs the unique-key count
+  w.hit_i = w.hit_s = nullptr;  // allocated with the first call whose policy needs the unique-key count
   uint64_t set_cap = 1024;
   while (set_cap < 2 * (uint64_t)max_keys_) set_cap <<= 1;
   HPS_RETURN_IF_ERROR(DevAlloc(&w.set, set_cap));
@@ -910,6 +910,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   if (exact) {
     HPS_RETURN_IF_ERROR(cache_->EnsureClaimWords());
     if (!work_.hit_i) HPS_RETURN_IF_ERROR(DevAlloc(&work_.hit_i, max_tiles_ * (size_t)kTileKeys));
+    if (!work_.hit_s) HPS_RETURN_IF_ERROR(DevAlloc(&work_.hit_s, max_tiles_ * (size_t)kTileKeys));
   }
   uint64_t N = 0;
   HPS_RETURN_IF_ERROR(PrepareCall(d_keys_flat, d_out, n, T, /*probe_only=*/false, &N));

@@ -118,8 +118,8 @@ __device__ __forceinline__ uint32_t lds_append(uint32_t* sh_count, bool take) {
 // index there (K_M counts those).  Plain stores, no atomics.
 // Algorithmic bytes per key: 8 (key) + 4 (slot); overhead: one 128-B bucket line per tile-unique key.
 // ------------------------------------------------------------------------------------------------
-template <bool kDedup, bool kClaim, int kU>
-__global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(const CallDesc* __restrict__ call,
+template <bool kDedup, bool kClaim, int kU, int kThreads>
+__global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc* __restrict__ call,
                                                                             const TableCacheDev* __restrict__ tables,
                                                                             const CallWork w) {
   __shared__ int64_t sh_key[kTileKeys];
@@ -139,23 +139,23 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
   const int64_t* __restrict__ keys = call->keys + td.begin;
   const uint32_t epoch = call->epoch;
   const uint32_t stamp_mask = call->stamp_mask;
-  constexpr int kPerThread = kTileKeys / kProbeBlockThreads;
+  constexpr int kPerThread = kTileKeys / kThreads;
 
   if (tid < 4) sh_cnt[tid] = 0;
   if (kDedup) {
-    for (uint32_t e = tid; e < (uint32_t)kTileSet; e += kProbeBlockThreads) sh_set[e] = 0xFFFFFFFFu;
+    for (uint32_t e = tid; e < (uint32_t)kTileSet; e += kThreads) sh_set[e] = 0xFFFFFFFFu;
   }
   int64_t k[kPerThread];
   uint32_t hlo[kPerThread];
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
-    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    const uint32_t j = tid + (uint32_t)q * kThreads;
     if (keys32) k[q] = j < n ? (int64_t)(uint64_t)keys32[td.begin + j] : HPS_EMPTY_KEY;
     else k[q] = j < n ? keys[j] : HPS_EMPTY_KEY;
   }
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
-    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    const uint32_t j = tid + (uint32_t)q * kThreads;
     const uint64_t h = hps_mix64((uint64_t)k[q]);
     hlo[q] = (uint32_t)h;
     if (j < n) {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
   // ---- 2. representatives ----
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
-    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    const uint32_t j = tid + (uint32_t)q * kThreads;
     uint32_t rep = j;
     if (kDedup && j < n) {
       uint32_t e = hlo[q] & (uint32_t)(kTileSet - 1);
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
   const uint32_t nrep = sh_cnt[0];
   const int lane = lane_id();
   const int g16 = (int)(tid >> 4), gw = lane >> 4, lig = lane & 15;
-  for (uint32_t r0 = (uint32_t)g16 * kU; r0 < nrep; r0 += (kProbeBlockThreads / 16) * kU) {
+  for (uint32_t r0 = (uint32_t)g16 * kU; r0 < nrep; r0 += (kThreads / 16) * kU) {
     uint32_t jj[kU], bb[kU];
     int64_t bk[kU];
 #pragma unroll
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
   const uint32_t region = tile * (uint32_t)kTileKeys;
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
-    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    const uint32_t j = tid + (uint32_t)q * kThreads;
     const bool is_rep = j < n && sh_rep[j] == (uint16_t)j;
     const int32_t s = is_rep ? sh_slot[j] : 0;
     const bool miss = is_rep && s < 0;
@@ -238,14 +238,14 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
     if (kClaim) {
       const bool hit = is_rep && s >= 0;
       const uint32_t hp = lds_append(&sh_cnt[3], hit);
-      if (hit) w.hit_i[region + hp] = (int32_t)(td.begin + j);
+      if (hit) { w.hit_i[region + hp] = (int32_t)(td.begin + j); w.hit_s[region + hp] = s; }
     }
   }
   __syncthreads();
   // ---- 4b. every key takes its representative's result ----
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
-    const uint32_t j = tid + (uint32_t)q * kProbeBlockThreads;
+    const uint32_t j = tid + (uint32_t)q * kThreads;
     const int32_t s = j < n ? sh_slot[sh_rep[j]] : 0;
     if (j < n) w.slot[td.begin + j] = s;
     const uint32_t pos = lds_append(&sh_cnt[2], s < 0);
@@ -260,10 +260,10 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_probe_tile_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// K_M: call-wide unique missed keys per table.  One workgroup per tile walks the tile's missed representatives
+// K_M: call-wide unique missed keys per table.  One wave per tile walks the tile's missed representatives
 // (a few dozen at 95 % hit): each claims an entry of the session's open-addressing set with a 64-bit CAS on
 // (call tag, m); an entry carrying another call's tag is free, so the set is never cleared.  The winner is the
-// representative of its (table, key) for the whole call: winners are ranked inside the block and the block takes
+// representative of its (table, key) for the whole call: winners are ranked inside the wave (ballot) and the wave takes
 // its range of the table's unique segment with ONE atomic on the table's own accumulator line.  A loser learns
 // the winner's m from the CAS and records it (rep_of).  Unique keys go to HBM and, zero-copy, to the pinned host
 // array the parameter-server threads read.
@@ -277,29 +277,32 @@ __device__ __forceinline__ uint64_t set_hash(int64_t key, uint32_t t) {
 template <bool kExact>
 __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __restrict__ call,
                                                                const TableCacheDev* __restrict__ tables, const CallWork w) {
-  const uint32_t tile = blockIdx.x;
-  const uint32_t M = w.tile_cnt[tile * 4 + kTileCntRepMiss];
-  const uint32_t S = w.tile_cnt[tile * 4 + kTileCntSentMiss];
-  const uint32_t H = kExact ? w.tile_cnt[tile * 4 + kTileCntRepHit] : 0u;
-  if ((M | S | H) == 0) return;
-  __shared__ uint32_t sh_wave[4];
-  __shared__ uint32_t sh_base;
-  const uint32_t t = w.tiles[tile].table;
-  const uint32_t region = tile * (uint32_t)kTileKeys;
-  const uint32_t tid = threadIdx.x;
+  // ONE WAVE per tile (four tiles per workgroup): a tile's miss list is a few dozen entries, and with a wave as the unit
+  // the ranking needs no LDS and no barrier — every dependent global access removed from this kernel is a microsecond
+  // on the critical path between the probe and the miss counts reaching the host.
+  const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= w.num_tiles) return;
   const int lane = lane_id();
+  const uint32_t region = tile * (uint32_t)kTileKeys;
+  // the first list entries are loaded before the count is known (a slot past the end holds an old key: harmless)
+  const int64_t first_key = w.miss_key[region + (uint32_t)lane];
+  const uint32_t M = uniform_u32(w.tile_cnt[tile * 4 + kTileCntRepMiss]);
+  const uint32_t S = uniform_u32(w.tile_cnt[tile * 4 + kTileCntSentMiss]);
+  const uint32_t H = kExact ? uniform_u32(w.tile_cnt[tile * 4 + kTileCntRepHit]) : 0u;
+  if ((M | S | H) == 0) return;
+  const uint32_t t = uniform_u32(w.tiles[tile].table);
   const unsigned long long tag = (unsigned long long)w.call_tag << 32;
   const uint64_t ks = call->key_start[t];
 
-  for (uint32_t r0 = 0; r0 < M; r0 += 256) {
-    const uint32_t r = r0 + tid;
+  for (uint32_t r0 = 0; r0 < M; r0 += 64) {
+    const uint32_t r = r0 + (uint32_t)lane;
     const bool active = r < M;
     const uint32_t m = region + r;
     bool winner = false;
     uint32_t rep = m;
     int64_t key = 0;
     if (active) {
-      key = w.miss_key[m];
+      key = r0 == 0 ? first_key : w.miss_key[m];
       uint64_t h = set_hash(key, t) & w.set_mask;
       unsigned long long cur = __hip_atomic_load(&w.set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (;;) {
@@ -316,42 +319,47 @@ __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __
       }
     }
     const uint64_t bal = __ballot(winner);
-    const uint32_t rank_in_wave = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) sh_wave[tid >> 6] = (uint32_t)__popcll(bal);
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t run = 0;
-      for (int q = 0; q < 4; ++q) { const uint32_t c = sh_wave[q]; sh_wave[q] = run; run += c; }
-      sh_base = run ? atomicAdd(&w.acc[AccTableWord(t, kAccUniqMiss)], run) : 0u;
+    uint32_t base = 0;
+    if (bal) {
+      if (lane == 0) base = atomicAdd(&w.acc[AccTableWord(t, kAccUniqMiss)], (uint32_t)__popcll(bal));
+      base = uniform_u32(base);
     }
-    __syncthreads();
     if (active) {
       w.rep_of[m] = (int32_t)rep;
       if (winner) {
-        const uint32_t u = sh_base + sh_wave[tid >> 6] + rank_in_wave;
+        const uint32_t u = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         w.uidx_of[m] = (int32_t)u;
         w.uniq_keys[ks + u] = key;
         if (w.uniq_keys_host) w.uniq_keys_host[ks + u] = key;  // zero-copy store into pinned host memory (host-gather tier)
       }
     }
-    __syncthreads();
   }
   if (kExact && H) {
     const uint32_t* __restrict__ claim = tables[t].claim;
     uint32_t mine = 0;
-    for (uint32_t r = tid; r < H; r += 256) {
-      const int32_t i = w.hit_i[region + r];
-      mine += claim[(uint32_t)w.slot[i]] == (uint32_t)i ? 1u : 0u;
+    // four independent (list entry -> claim word) chains per lane and step: the claim reads are random 4-B accesses
+    for (uint32_t r0 = 0; r0 < H; r0 += 256) {
+      int32_t idx[4], sl[4];
+      uint32_t cw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t r = r0 + (uint32_t)u * 64 + (uint32_t)lane;
+        const uint32_t rr = r < H ? r : 0;
+        idx[u] = w.hit_i[region + rr];
+        sl[u] = w.hit_s[region + rr];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cw[u] = claim[(uint32_t)sl[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t r = r0 + (uint32_t)u * 64 + (uint32_t)lane;
+        mine += (r < H && cw[u] == (uint32_t)idx[u]) ? 1u : 0u;
+      }
     }
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-    if (lane == 0) sh_wave[tid >> 6] = mine;
-    __syncthreads();
-    if (tid == 0) {
-      const uint32_t tot = sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
-      if (tot) atomicAdd(&w.acc[AccTableWord(t, kAccUniqHit)], tot);
-    }
+    if (lane == 0 && mine) atomicAdd(&w.acc[AccTableWord(t, kAccUniqHit)], mine);
   }
-  if (tid == 0 && S) atomicAdd(&w.acc[AccTableWord(t, kAccSentMiss)], S);
+  if (lane == 0 && S) atomicAdd(&w.acc[AccTableWord(t, kAccSentMiss)], S);
 }
 
 // index of a missed key's row in its table's unique-miss segment (slot <= -2)
@@ -647,21 +655,28 @@ uint32_t GatherGridBlocks(uint64_t N, int cu_count) {
 hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
                             hipStream_t stream) {
   if (w.num_tiles == 0) return hipSuccess;
-  // variant = U + 100 * no_dedup   (U in {2,4,8}: bucket lines in flight per 16-lane group)
+  // variant = U + 100 * no_dedup + 1000 * wide   (U in {2,4,8}: bucket lines in flight per 16-lane group; wide: 512 threads
+  // per tile instead of 256 — twice the groups probing per workgroup, 32 waves per CU at 4 workgroups)
   const int U = variant % 100;
   const bool dedup = (variant / 100) % 10 == 0;
-#define HPS_PT(DD, CC, UU)                                                                                               \
-  hipLaunchKernelGGL((hps_probe_tile_kernel<DD, CC, UU>), dim3(w.num_tiles), dim3(kProbeBlockThreads), 0, stream, d_call, \
-                     d_tables, w)
+  const bool wide = (variant / 1000) % 10 != 0;
+#define HPS_PT(DD, CC, UU, TT)                                                                                  \
+  hipLaunchKernelGGL((hps_probe_tile_kernel<DD, CC, UU, TT>), dim3(w.num_tiles), dim3(TT), 0, stream, d_call, d_tables, w)
+#define HPS_PT_T(DD, CC, UU)                      \
+  do {                                            \
+    if (wide) HPS_PT(DD, CC, UU, 512);            \
+    else HPS_PT(DD, CC, UU, 256);                 \
+  } while (0)
 #define HPS_PT_U(DD, CC)                          \
   do {                                            \
-    if (U == 2) HPS_PT(DD, CC, 2);                \
-    else if (U == 8) HPS_PT(DD, CC, 8);           \
-    else HPS_PT(DD, CC, 4);                       \
+    if (U == 2) HPS_PT_T(DD, CC, 2);              \
+    else if (U == 8) HPS_PT_T(DD, CC, 8);         \
+    else HPS_PT_T(DD, CC, 4);                     \
   } while (0)
   if (dedup) { if (claim) HPS_PT_U(true, true); else HPS_PT_U(true, false); }
   else { if (claim) HPS_PT_U(false, true); else HPS_PT_U(false, false); }
 #undef HPS_PT_U
+#undef HPS_PT_T
 #undef HPS_PT
   return hipGetLastError();
 }
@@ -669,8 +684,9 @@ hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_table
 hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, bool exact,
                             hipStream_t stream) {
   if (w.num_tiles == 0) return hipSuccess;
-  if (exact) hipLaunchKernelGGL(hps_miss_unique_kernel<true>, dim3(w.num_tiles), dim3(256), 0, stream, d_call, d_tables, w);
-  else hipLaunchKernelGGL(hps_miss_unique_kernel<false>, dim3(w.num_tiles), dim3(256), 0, stream, d_call, d_tables, w);
+  const uint32_t blocks = (w.num_tiles + 3) / 4;   // one wave per tile
+  if (exact) hipLaunchKernelGGL(hps_miss_unique_kernel<true>, dim3(blocks), dim3(256), 0, stream, d_call, d_tables, w);
+  else hipLaunchKernelGGL(hps_miss_unique_kernel<false>, dim3(blocks), dim3(256), 0, stream, d_call, d_tables, w);
   return hipGetLastError();
 }
 

@@ -170,6 +170,6 @@ def test_instance_on_undeployed_device_is_rejected(tmp_path):
         assert e.value.code == tm.ERR["INVALID_ARG"] and "deployed_device_list" in e.value.msg
         with pytest.raises(tm.TritonError) as e:   # KIND_CPU instance for a GPU-cache model (model_state.cpp:287-290)
             srv.load_model("m", tm.model_config("m", kind="KIND_CPU", gpus=[]))
-        assert "GPU kind" in e.value.msg
+        assert "must be KIND_GPU" in e.value.msg
     finally:
         srv.shutdown()
