@@ -231,6 +231,9 @@ def summarize(rec, N, D, dt, steps):
         "frac_of_hbm_peak_1032B_per_lookup": N * (8 + 8 * D) / (hbm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if hbm_ms > 0 else None,
         "measured_hit_rate": 1.0 - float(a[:, 5].mean()) / N,
         "key_stage_ms": float(a[:, 8].mean()),
+        # the call as the engine sees it (steady_clock inside hps_session_lookup*, after the key staging): what is left
+        # after the kernels is descriptor upload, count read-back, launches and the final synchronisation
+        "engine_call_ms": float(np.mean([r[8][3] for r in rec])),
     }
 
 
@@ -748,6 +751,9 @@ def main():
                 "frac_end_to_end": alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
                 # the kernels with nothing underneath (all keys resident, one session)
                 "frac_kernels_alone": (extra.get("all_hit_one_session_device_keys") or {}).get("frac_of_hbm_peak_1032B_per_lookup"),
+                # an all-hit call of one session, inside the engine: call time over (probe + gather) kernel time
+                "all_hit_call_over_kernel_time": (lambda e: e["engine_call_ms"] / (e["probe_ms"] + e["gather_ms"]) if e else None)(
+                    extra.get("all_hit_one_session_device_keys")),
             },
             "roofline_pcie": {
                 "bound": "pcie", "peak": PCIE_PEAK_GBS, "unit": "GB/s",

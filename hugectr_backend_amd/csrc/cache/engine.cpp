@@ -23,6 +23,8 @@ namespace hps {
 namespace {
 
 constexpr size_t kStagingCapBytes = 256ull << 20;  // per-session staging chunk for missed rows
+constexpr uint64_t kSmallRequestKeys = 1u << 17;   // requests up to this many keys are probed in tiles of ...
+constexpr uint64_t kSmallTileKeys = 256;           // ... this many keys
 
 Status RequireDevice(int device) {
   int n = 0;
@@ -567,7 +569,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   for (size_t c : p.maxnum_catfeature_query_per_table_per_sample) per_sample += c;
   max_keys_ = p.max_batchsize * per_sample;  // model_instance_state.cpp:98-99
   if (max_keys_ == 0) return Error(Code::kInvalidArg, "model '", p.model_name, "': max_batch_size * sum(maxnum_catfeature...) is 0");
-  max_tiles_ = max_keys_ / kTileKeys + T;
+  max_tiles_ = std::max(max_keys_ / kTileKeys, std::min<size_t>(max_keys_, kSmallRequestKeys) / kSmallTileKeys) + T;
   if (max_tiles_ * (size_t)kTileKeys >= (1ull << 31) - 2)
     return Error(Code::kUnsupported, "more than 2^31 keys per request are not supported");
   if (!p.use_gpu_embedding_cache) return Status::Ok();  // host-tier session: no device state at all
@@ -840,14 +842,19 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   c.keys32 = (keys_narrow_ && d_keys_flat == d_keys_) ? reinterpret_cast<const uint32_t*>(d_keys_) : nullptr;
   uint64_t N = 0;
   uint32_t tiles = 0;
+  // Small requests get smaller tiles (a tile = one workgroup of the probe: a 28,672-key request in 1,024-key tiles would
+  // put 28 workgroups on 256 CUs).  The tile REGIONS stay kTileKeys apart, so nothing else changes.
+  uint64_t total = 0;
+  for (size_t t = 0; t < T; ++t) total += n[t];
+  const uint64_t tile_keys = total <= kSmallRequestKeys ? kSmallTileKeys : (uint64_t)kTileKeys;
   for (size_t t = 0; t < T; ++t) {
     c.key_start[t] = N;
     c.out[t] = probe_only ? nullptr : d_out[t];
     if (!probe_only && n[t] && !d_out[t]) return Error(Code::kInvalidArg, "lookup: null output pointer for table ", t);
     const uint32_t D = tables_[t]->dim();
     c.vec_ok[t] = (!probe_only && (D & 3u) == 0 && ((uintptr_t)d_out[t] & 15u) == 0) ? 1 : 0;
-    for (uint64_t b = 0; b < n[t]; b += kTileKeys)
-      h_tiles_[tiles++] = TileDesc{N + b, (uint32_t)std::min<uint64_t>(kTileKeys, n[t] - b), (uint32_t)t};
+    for (uint64_t b = 0; b < n[t]; b += tile_keys)
+      h_tiles_[tiles++] = TileDesc{N + b, (uint32_t)std::min<uint64_t>(tile_keys, n[t] - b), (uint32_t)t};
     N += n[t];
   }
   c.key_start[T] = N;

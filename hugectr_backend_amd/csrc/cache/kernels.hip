@@ -389,7 +389,9 @@ __global__ __launch_bounds__(256) void hps_miss_scatter_kernel(const CallDesc* _
   const uint64_t ks = call->key_start[t];
   const uint32_t region = tile * (uint32_t)kTileKeys;
   const int lig = (int)(threadIdx.x & 15);
-  for (uint32_t r = threadIdx.x >> 4; r < S; r += 16) {
+  // gridDim.y workgroups share a tile's list (few tiles = a small request: one workgroup per tile would copy its rows
+  // one after the other)
+  for (uint32_t r = blockIdx.y * 16 + (threadIdx.x >> 4); r < S; r += 16 * gridDim.y) {
     const int32_t i = w.sent_i[region + r];
     const uint32_t u = miss_uidx(w, w.slot[i]);
     if (u < lo || u >= hi) continue;  // other chunk of this call
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void hps_miss_fill_default_kernel(const CallDe
   const uint64_t ks = call->key_start[t];
   const uint32_t region = tile * (uint32_t)kTileKeys;
   const int lig = (int)(threadIdx.x & 15);
-  for (uint32_t r = threadIdx.x >> 4; r < S; r += 16) {
+  for (uint32_t r = blockIdx.y * 16 + (threadIdx.x >> 4); r < S; r += 16 * gridDim.y) {
     const int32_t i = w.sent_i[region + r];
     float* dst = out + ((uint64_t)i - ks) * D;
     for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = dv;
@@ -652,6 +654,13 @@ uint32_t GatherGridBlocks(uint64_t N, int cu_count) {
   return (uint32_t)(want < cap ? (want ? want : 1) : cap);
 }
 
+// workgroups per tile for the kernels that walk a tile's miss list: enough to put ~2,048 workgroups on the chip when the
+// request has few tiles, one or two per tile when it has many
+static inline uint32_t ListSubBlocks(uint32_t tiles) {
+  const uint32_t k = (2048 + tiles - 1) / tiles;
+  return k < 1 ? 1u : (k > 16 ? 16u : k);
+}
+
 hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
                             hipStream_t stream) {
   if (w.num_tiles == 0) return hipSuccess;
@@ -706,14 +715,16 @@ hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_table
 hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tables, const MissDesc* d_md, const CallWork& w,
                              const float* d_staging, hipStream_t stream) {
   if (w.num_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(hps_miss_scatter_kernel, dim3(w.num_tiles), dim3(256), 0, stream, d_call, d_tables, d_md, w, d_staging);
+  hipLaunchKernelGGL(hps_miss_scatter_kernel, dim3(w.num_tiles, ListSubBlocks(w.num_tiles)), dim3(256), 0, stream, d_call, d_tables, d_md,
+                     w, d_staging);
   return hipGetLastError();
 }
 
 hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w,
                                  const uint32_t* d_table_mode, hipStream_t stream) {
   if (w.num_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(hps_miss_fill_default_kernel, dim3(w.num_tiles), dim3(256), 0, stream, d_call, d_tables, w, d_table_mode);
+  hipLaunchKernelGGL(hps_miss_fill_default_kernel, dim3(w.num_tiles, ListSubBlocks(w.num_tiles)), dim3(256), 0, stream, d_call, d_tables,
+                     w, d_table_mode);
   return hipGetLastError();
 }
 
