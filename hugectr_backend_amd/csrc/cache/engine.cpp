@@ -944,6 +944,10 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   CallWork wk = work_;
   // device-driven tier with synchronous insertion: nobody on the host reads the unique keys — spare the PCIe writes
   if (use_direct && params_.hit_rate_threshold >= 1.0f) wk.uniq_keys_host = nullptr;
+  // (Tried: K_M without the zero-copy host stores — 12 us of its 23 inside a busy link — and a publish kernel for the keys
+  //  on the second stream next to K_G.  The persistent K_G owns every CU by the time the publish kernel is released, so
+  //  the counts reached the host after the gather: 0.38 instead of 0.22 ms.  LaunchMissPublish stays for a future use.)
+  const bool publish = false;
 
   // ---- K_P: tile dedup + probe;  K_M: call-wide unique misses (+ unique hits) ----
   cache_->BeginRead(stream_);
@@ -990,10 +994,18 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   }
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
   {
-    const hipError_t ce = hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_);
+    // split: unique keys and counts go to the host on the second stream while K_G takes the session's stream
+    hipStream_t cs = publish ? copy_stream_ : stream_;
+    hipError_t ce = hipSuccess;
+    if (publish) {
+      ce = hipEventRecord(ev_keys_, stream_);
+      if (ce == hipSuccess) ce = hipStreamWaitEvent(cs, ev_keys_, 0);
+      if (ce == hipSuccess) ce = LaunchMissPublish(d_call_, work_, (uint32_t)T, cs);
+    }
+    if (ce == hipSuccess) ce = hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, cs);
+    if (ce == hipSuccess) ce = hipEventRecord(ev_done_, cs);
     if (ce != hipSuccess) { end_read(); return Error(Code::kInternal, "count read-back failed: ", hipGetErrorString(ce)); }
   }
-  (void)hipEventRecord(ev_done_, stream_);
   if (split) {
     // K_G behind the counts: it runs while the host reads them and works on the misses
     e = gather();
@@ -1260,7 +1272,11 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     // on the copy engine while the host threads gather piece p+1, so the PCIe time (the floor of this
     // path: every missed row crosses the link once) hides most of the DRAM-latency-bound gather.
     HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, stream_));
-    constexpr size_t kPieceFloats = (4u << 20) / sizeof(float);
+    static const size_t kPieceFloats = [] {   // upload piece: HPS_PIECE_MB (A/B switch), default 4 MB
+      const char* e = std::getenv("HPS_PIECE_MB");
+      const long v = e ? std::strtol(e, nullptr, 10) : 0;
+      return (size_t)(v > 0 ? v : 4) * (1u << 20) / sizeof(float);
+    }();
     std::vector<HierParameterServer::FetchJob> jobs;
     size_t piece_begin = SIZE_MAX, piece_end = 0;
     bool used_copy_stream = false;

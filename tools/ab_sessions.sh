@@ -1,5 +1,5 @@
 # A/B runs of bench.py on the box: bash tools/ab_sessions.sh  (prints one line per configuration)
-for cfg in "--probe-variant 4" "--probe-variant 1004" "--probe-variant 1008" "--probe-variant 8"; do
+for cfg in "--chain-gather 0" "--chain-gather 1" "--chain-gather 0" "--chain-gather 1"; do
   python bench.py --steps 20 --warmup 5 --no-extra-legs --no-cpu-baseline $cfg 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
