@@ -944,10 +944,9 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   CallWork wk = work_;
   // device-driven tier with synchronous insertion: nobody on the host reads the unique keys — spare the PCIe writes
   if (use_direct && params_.hit_rate_threshold >= 1.0f) wk.uniq_keys_host = nullptr;
-  // (Tried: K_M without the zero-copy host stores — 12 us of its 23 inside a busy link — and a publish kernel for the keys
-  //  on the second stream next to K_G.  The persistent K_G owns every CU by the time the publish kernel is released, so
-  //  the counts reached the host after the gather: 0.38 instead of 0.22 ms.  LaunchMissPublish stays for a future use.)
-  const bool publish = false;
+  // (Tried and withdrawn: K_M without the zero-copy host stores — 12 us of its 23 inside a busy link — and a publish kernel
+  //  for the keys on the second stream next to K_G.  The persistent K_G owns every CU by the time the publish kernel is
+  //  released, so the counts reached the host after the gather: 0.38 instead of 0.22 ms.)
 
   // ---- K_P: tile dedup + probe;  K_M: call-wide unique misses (+ unique hits) ----
   cache_->BeginRead(stream_);
@@ -994,16 +993,8 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   }
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
   {
-    // split: unique keys and counts go to the host on the second stream while K_G takes the session's stream
-    hipStream_t cs = publish ? copy_stream_ : stream_;
-    hipError_t ce = hipSuccess;
-    if (publish) {
-      ce = hipEventRecord(ev_keys_, stream_);
-      if (ce == hipSuccess) ce = hipStreamWaitEvent(cs, ev_keys_, 0);
-      if (ce == hipSuccess) ce = LaunchMissPublish(d_call_, work_, (uint32_t)T, cs);
-    }
-    if (ce == hipSuccess) ce = hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, cs);
-    if (ce == hipSuccess) ce = hipEventRecord(ev_done_, cs);
+    hipError_t ce = hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_);
+    if (ce == hipSuccess) ce = hipEventRecord(ev_done_, stream_);
     if (ce != hipSuccess) { end_read(); return Error(Code::kInternal, "count read-back failed: ", hipGetErrorString(ce)); }
   }
   if (split) {

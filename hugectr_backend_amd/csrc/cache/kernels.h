@@ -17,9 +17,6 @@ hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_table
 hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, bool exact,
                             hipStream_t stream);
 
-// unique missed keys HBM -> the pinned host array (w.uniq_keys_host), for a K_M that ran with that pointer null
-hipError_t LaunchMissPublish(const CallDesc* d_call, const CallWork& w, uint32_t num_tables, hipStream_t stream);
-
 // K_G: hit rows cache -> output from the slot indices K_P left (d_call carries the output pointers).
 hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
                             const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream);

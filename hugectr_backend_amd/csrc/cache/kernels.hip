@@ -362,16 +362,6 @@ __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __
   if (lane == 0 && S) atomicAdd(&w.acc[AccTableWord(t, kAccSentMiss)], S);
 }
 
-// Hand-off of the unique missed keys to the host parameter server, off the probe's critical path: K_M with
-// uniq_keys_host == nullptr leaves them in HBM only, and this kernel — on the session's second stream, next to the hit
-// gather — writes them into the pinned host array (zero-copy stores over PCIe: 12 us of K_M inside a busy link).
-__global__ __launch_bounds__(256) void hps_miss_publish_kernel(const CallDesc* __restrict__ call, const CallWork w, uint32_t sub_blocks) {
-  const uint32_t t = blockIdx.x / sub_blocks, sub = blockIdx.x % sub_blocks;
-  const uint32_t u = w.acc[AccTableWord(t, kAccUniqMiss)];
-  const uint64_t ks = call->key_start[t];
-  for (uint32_t i = sub * 256 + threadIdx.x; i < u; i += sub_blocks * 256) w.uniq_keys_host[ks + i] = w.uniq_keys[ks + i];
-}
-
 // index of a missed key's row in its table's unique-miss segment (slot <= -2)
 __device__ __forceinline__ uint32_t miss_uidx(const CallWork& w, int32_t slot) {
   const uint32_t m = (uint32_t)(-2 - slot);
@@ -706,13 +696,6 @@ hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_table
   const uint32_t blocks = (w.num_tiles + 3) / 4;   // one wave per tile
   if (exact) hipLaunchKernelGGL(hps_miss_unique_kernel<true>, dim3(blocks), dim3(256), 0, stream, d_call, d_tables, w);
   else hipLaunchKernelGGL(hps_miss_unique_kernel<false>, dim3(blocks), dim3(256), 0, stream, d_call, d_tables, w);
-  return hipGetLastError();
-}
-
-hipError_t LaunchMissPublish(const CallDesc* d_call, const CallWork& w, uint32_t num_tables, hipStream_t stream) {
-  if (num_tables == 0 || !w.uniq_keys_host) return hipSuccess;
-  const uint32_t sub = num_tables >= 64 ? 1u : (64u + num_tables - 1) / num_tables;   // ~64+ workgroups in all
-  hipLaunchKernelGGL(hps_miss_publish_kernel, dim3(num_tables * sub), dim3(256), 0, stream, d_call, w, sub);
   return hipGetLastError();
 }
 

@@ -140,3 +140,34 @@ def test_cache_handle_of_a_cpu_only_model_creates_its_session():
     q = np.concatenate([tables[0][0][:10], [-5], tables[1][0][:20]]).astype(np.int64)
     out = s.lookup(q, [11, 20])
     assert np.array_equal(out.view(np.uint32), O.np_lookup(tables, q, [11, 20], [0.5, 1.5]).view(np.uint32))
+
+
+def test_synthetic_table_source_and_table_data_view(tmp_path):
+    """sparse_files entries of the form synthetic://<rows>[?seed=..&key0=..] load the SURVEY 8(d) recipe table instead of a
+    directory (how a benchmark puts a full-size model behind the plugin boundary); hps_server_table_data hands out the
+    table as it sits in the host tier without a copy.  Rows must equal the ORACLE's restatement of the recipe."""
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    R, D = 5000, 16
+    cfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8},
+           "models": [{"model": "syn", "sparse_files": [f"synthetic://{R}", f"synthetic://{R // 2}?seed=7&key0=1000"],
+                       "num_of_worker_buffer_in_pool": 1, "embedding_vecsize_per_table": [D, 4],
+                       "maxnum_catfeature_query_per_table_per_sample": [1, 1], "default_value_for_each_table": [0.0, 9.0],
+                       "deployed_device_list": [0], "max_batch_size": 4096, "gpucache": False}]}
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=True)
+    k0, r0 = ps.table_data("syn", 0)
+    k1, r1 = ps.table_data("syn", 1)
+    assert np.array_equal(k0, np.arange(R)) and np.array_equal(k1, 1000 + np.arange(R // 2))
+    assert np.array_equal(r0.view(np.uint32), O.np_synth_rows(O.SEED, 0, k0, D).view(np.uint32))
+    assert np.array_equal(r1.view(np.uint32), O.np_synth_rows(7, 1, k1, 4).view(np.uint32))
+    s = hps.LookupSession.create(ps, "syn", None)
+    q = np.array([0, R - 1, R, 1000, 999, 1000 + R // 2 - 1], dtype=np.int64)
+    out = s.lookup(q, [3, 3])
+    exp = np.concatenate([O.np_synth_rows(O.SEED, 0, q[:2], D).ravel(), np.zeros(D, np.float32),
+                          O.np_synth_rows(7, 1, q[3:4], 4).ravel(), np.full(4, 9.0, np.float32),
+                          O.np_synth_rows(7, 1, q[5:6], 4).ravel()])
+    assert np.array_equal(out.view(np.uint32), exp.view(np.uint32))
+    # a malformed source is a directory name, and that directory does not exist
+    cfg["models"][0]["sparse_files"][0] = "synthetic://12abc"
+    with pytest.raises(hps.HpsError):
+        hps.HierParameterServer.create_from_dict(cfg, load_tables=True)
