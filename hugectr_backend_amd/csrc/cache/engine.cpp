@@ -1326,15 +1326,18 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
     // staging is reused by the next chunk
     if (timing_) (void)hipEventRecord(ev_c1_, stream_);
+    bool last = true;
+    for (size_t t = 0; t < T; ++t) last &= md.chunk_hi[t] == ucnt[t];
+    if (last)   // the insert statistics ride the call's final synchronisation
+      HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, (size_t)kStatLines * kAccStride * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     if (timing_) {
       (void)hipEventElapsedTime(&last_scatter_ms_, ev_s0_, ev_s1_);
       (void)hipEventElapsedTime(&last_insert_ms_, ev_i0_, ev_i1_);
     }
     for (size_t t = 0; t < T; ++t) done[t] = md.chunk_hi[t];
+    if (last) break;
   }
-  HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, (size_t)kStatLines * kAccStride * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-  HIP_TRY(hipStreamSynchronize(stream_));
   AddInsertStats();
   return Status::Ok();
 }
