@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -733,6 +734,7 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     else (void)hipGetLastError();  // an unregistered pointer is not an error of ours
   }
   keys_narrow_ = false;
+  stage_pool_ms_ = stage_enqueue_ms_ = 0.f;
   {
     constexpr size_t kTaskKeys = 32768, kGroupKeys = (4u << 20) / sizeof(int64_t);
     struct Task { const int64_t* src; size_t off, n; };
@@ -764,12 +766,17 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
       while (g0 < tasks.size()) {
         size_t g1 = g0, keys_in_group = 0;
         while (g1 < tasks.size() && (keys_in_group == 0 || keys_in_group + tasks[g1].n <= kGroupKeys)) keys_in_group += tasks[g1++].n;
+        const auto tp0 = std::chrono::steady_clock::now();
         if (g1 - g0 <= 2) for (size_t i = g0; i < g1; ++i) body(i);
         else ThreadPool::Serving().ParallelFor(g1 - g0, [&](size_t i) { body(g0 + i); });
+        const auto tp1 = std::chrono::steady_clock::now();
         if (narrow && wide.load(std::memory_order_relaxed)) return Status::Ok();   // caller restages wide
         const size_t first = tasks[g0].off, count = tasks[g1 - 1].off + tasks[g1 - 1].n - first;
         if (narrow) HIP_TRY(hipMemcpyAsync(dev32 + first, dst32 + first, count * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
         else HIP_TRY(hipMemcpyAsync(d_keys_ + first, h_keys_pinned_ + first, count * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+        const auto tp2 = std::chrono::steady_clock::now();
+        stage_pool_ms_ += std::chrono::duration<float, std::milli>(tp1 - tp0).count();
+        stage_enqueue_ms_ += std::chrono::duration<float, std::milli>(tp2 - tp1).count();
         g0 = g1;
       }
       if (narrow) keys_narrow_ = true;
@@ -788,7 +795,15 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     }
   }
   key_stage_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
-  return TimedLookupDevice(d_keys_, vectors_per_table, num_keys_per_table, num_tables);
+  const Status st_ = TimedLookupDevice(d_keys_, vectors_per_table, num_keys_per_table, num_tables);
+  static const bool kTraceCalls = std::getenv("HPS_TRACE_TAIL") != nullptr;   // diagnostic: where did a slow call spend its time
+  if (kTraceCalls) {
+    const float all = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
+    if (all > 5.0f)
+      fprintf(stderr, "[hps call] %.2f ms: key staging %.2f (pool %.2f, H2D enqueue %.2f), counts on host %.2f, ps fetch %.2f, tail %.2f, engine call %.2f (direct_dma %d narrow %d)\n",
+              all, key_stage_ms_, stage_pool_ms_, stage_enqueue_ms_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3], (int)direct_dma, (int)keys_narrow_);
+  }
+  return st_;
 }
 
 // LookupDevice + (option "timing") the GPU-side span of the call: probe start (after the waits on other
@@ -1309,20 +1324,28 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       HIP_TRY(hipStreamWaitEvent(stream_, ev_copy_, 0));
     }
 
+    static const bool kTrace = std::getenv("HPS_TRACE_TAIL") != nullptr;
+    const auto tt0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tt0).count(); };
+    float tr[6] = {0, 0, 0, 0, 0, 0};
     if (timing_) (void)hipEventRecord(ev_s0_, stream_);
     hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, d_staging_, stream_);
+    tr[0] = since();
     if (timing_) (void)hipEventRecord(ev_s1_, stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
     // Other sessions' probes wait for our writer event.  Let the PCIe copy and the scatter drain first,
     // so that the window in which the cache is "being written" is the insert kernel alone (tens of
     // microseconds) and not insert + the millisecond of H2D queued ahead of it on this stream.
     HIP_TRY(hipStreamSynchronize(stream_));
+    tr[1] = since();
     cache_->BeginWrite(stream_);
+    tr[2] = since();
     if (timing_) (void)hipEventRecord(ev_i0_, stream_);
     e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, uq, d_call_->key_start, work_.uniq_keys,
                           d_staging_, d_found_, epoch, d_acc_, cu, stream_);
     if (timing_) (void)hipEventRecord(ev_i1_, stream_);
     cache_->EndWrite(stream_);
+    tr[3] = since();
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
     // staging is reused by the next chunk
     if (timing_) (void)hipEventRecord(ev_c1_, stream_);
@@ -1331,6 +1354,10 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     if (last)   // the insert statistics ride the call's final synchronisation
       HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, (size_t)kStatLines * kAccStride * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
+    tr[4] = since();
+    if (kTrace && tr[4] > 3.0f)
+      fprintf(stderr, "[hps tail] scatter-enqueued %.2f  drained %.2f  write-lock %.2f  insert-enqueued %.2f  done %.2f ms (fetch %.2f ms before)\n",
+              tr[0], tr[1], tr[2], tr[3], tr[4], phase_ms_[1]);
     if (timing_) {
       (void)hipEventElapsedTime(&last_scatter_ms_, ev_s0_, ev_s1_);
       (void)hipEventElapsedTime(&last_insert_ms_, ev_i0_, ev_i1_);

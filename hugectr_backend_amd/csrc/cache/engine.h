@@ -260,6 +260,7 @@ class LookupSession {
   hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr,
              ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr, ev_probe_ = nullptr, ev_keys_ = nullptr;
   float last_gpu_call_ms_ = 0.f;
+  float stage_pool_ms_ = 0.f, stage_enqueue_ms_ = 0.f;   // key staging: time in the pool loops / in the H2D enqueues
   float key_stage_ms_ = 0.f;      // host side of lookup(): staging the keys and enqueueing their H2D copies
   bool narrow_keys_ = true;       // option "narrow_keys": stage pageable keys as uint32 when they all fit
   bool keys_narrow_ = false;      // this call's staged keys are uint32

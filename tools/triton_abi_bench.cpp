@@ -25,6 +25,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -198,6 +199,24 @@ int main(int argc, char** argv) {
   for (int i = 0; i < a.instances; ++i)
     if (hipMalloc((void**)&d_out[i], N * (size_t)D * sizeof(float)) != hipSuccess) die("hipMalloc of OUTPUT0 failed");
 
+  // ---- stall watchdog: a thread that does nothing but sleep 200 us at a time and notes every wake-up that comes more than
+  //      2 ms late.  A late wake-up that coincides with a slow request means the whole process stood still (CPU quota of an
+  //      enclosing cgroup, a frozen container, the hypervisor) — nothing the request path did. ----
+  std::atomic<bool> dog_stop{false};
+  std::vector<std::pair<double, double>> dog_gaps;   // (time since start [s], gap [ms])
+  const double dog_t0 = now_s();
+  std::thread dog([&] {
+    double last = now_s();
+    while (!dog_stop.load(std::memory_order_relaxed)) {
+      usleep(200);
+      const double t = now_s();
+      if (t - last > 0.002) dog_gaps.emplace_back(last - dog_t0, (t - last) * 1e3);
+      last = t;
+    }
+  });
+  std::vector<std::pair<double, double>> slow_requests;   // (start since dog_t0 [s], duration [ms]) of requests over 5 ms
+  std::mutex slow_mu;
+
   // ---- request loop ----
   std::atomic<long> next{0};
   std::atomic<int> failed{0};
@@ -230,6 +249,7 @@ int main(int argc, char** argv) {
                       m.mock_request_error_message(rq) ? m.mock_request_error_message(rq) : "");
           }
           if (record) lat[w].push_back(dt * 1e3);
+          if (record && dt > 0.005) { std::lock_guard<std::mutex> lk(slow_mu); slow_requests.emplace_back(t0 - dog_t0, dt * 1e3); }
           last_batch[w] = b;
           m.mock_request_delete(rq);
         }
@@ -245,6 +265,9 @@ int main(int argc, char** argv) {
     (void)hipDeviceSynchronize();
     block_s.push_back(now_s() - t0);
   }
+
+  dog_stop.store(true);
+  dog.join();
 
   // ---- one response against the table recipe: every key of [0, R) exists, row(t, k) is a pure function ----
   long bad = 0, checked = 0;
@@ -283,9 +306,21 @@ int main(int argc, char** argv) {
          a.instances, a.steps, a.blocks, med > 0 ? (double)a.steps * (double)N / med : 0.0, med / a.steps * 1e3);
   for (size_t i = 0; i < block_s.size(); ++i) printf("%s%.4g", i ? ", " : "", block_s[i] * 1e3);
   printf("], \"p50_request_ms\": %.5g, \"p99_request_ms\": %.5g, \"requests_ok_reported_by_backend\": %llu, \"batch_statistics_reports\": %llu, "
-         "\"failed\": %d, \"rows_checked_against_recipe\": %ld, \"rows_wrong\": %ld, \"model_load_seconds\": %.4g, \"ps_tier\": \"%s\"}\n",
+         "\"failed\": %d, \"rows_checked_against_recipe\": %ld, \"rows_wrong\": %ld, \"model_load_seconds\": %.4g, \"ps_tier\": \"%s\", ",
          pct(0.5), pct(0.99), (unsigned long long)ok_req, (unsigned long long)reports, failed.load(), checked, bad, load_s,
          a.direct ? "device-driven (ps_direct_access)" : "host gather");
+  // requests over 5 ms, and for each the watchdog gaps that overlap it
+  printf("\"slow_requests_ms\": [");
+  int coincide = 0;
+  for (size_t i = 0; i < slow_requests.size(); ++i) {
+    double overlap = 0;
+    for (const auto& g : dog_gaps)
+      if (g.first < slow_requests[i].first + slow_requests[i].second * 1e-3 && g.first + g.second * 1e-3 > slow_requests[i].first) overlap = std::max(overlap, g.second);
+    coincide += overlap > 0;
+    printf("%s[%.2f, %.2f]", i ? ", " : "", slow_requests[i].second, overlap);
+  }
+  printf("], \"slow_requests_note\": \"[request ms, longest late wake-up (ms) of an idle watchdog thread during it]\", "
+         "\"slow_requests_with_process_wide_stall\": %d, \"watchdog_late_wakeups_over_2ms\": %zu}\n", coincide, dog_gaps.size());
   fflush(stdout);
   for (auto* i : inst) m.mock_instance_destroy(i);
   m.mock_model_unload(model);
