@@ -173,3 +173,64 @@ def test_instance_on_undeployed_device_is_rejected(tmp_path):
         assert "must be KIND_GPU" in e.value.msg
     finally:
         srv.shutdown()
+
+
+def test_large_request_keys_staged_narrowed_pinned_or_split_over_buffers(tmp_path):
+    """A request large enough for the key staging to go through the serving pool (>= 131,072 keys) through the plugin:
+    pageable KEYS that fit 32 bits (cross PCIe as uint32), the same with one 41-bit key (8-byte fallback), KEYS in
+    page-locked memory reported as CPU_PINNED (DMA in place), and KEYS delivered in two buffers (concatenated by the
+    shell) — identical rows every time."""
+    import torch
+    from oracle import hps_oracle as O
+    tables = make_tables([(80000, 8), (60000, 4)], seed=21)
+    wide = tables[1][0].copy()
+    wide[:50] += 1 << 40
+    tables[1] = (wide, tables[1][1])
+    srv, _ = _deploy(tmp_path, {"big": (tables, [1, 1], [0.5, -1.0])}, gpucacheper=0.4, hit_rate_threshold=1.0, max_batch=200000)
+    try:
+        inst = srv.load_model("big", tm.model_config("big", gpus=[0], max_batch_size=200000)).create_instance("big_0", tm.KIND_GPU, 0)
+        rng = np.random.default_rng(5)
+        nk = [150000, 120000]
+        q = np.concatenate([rng.choice(tables[0][0], nk[0]), rng.choice(wide[50:], nk[1])]).astype(np.int64)
+        q[::101] = (1 << 31) + np.arange(q[::101].size)      # absent, 32-bit
+        n_out = nk[0] * 8 + nk[1] * 4
+
+        def run(keys, mode):
+            out = torch.full((n_out,), float("nan"), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            req = tm.Request(mode)
+            keep = None
+            if mode == "pinned":
+                keep = torch.from_numpy(keys).pin_memory()
+                req.add_input_raw("KEYS", tm.TYPE_INT64, [1, keys.size], keep.data_ptr(), keys.nbytes, tm.MEM_CPU_PINNED, 0)
+            elif mode == "two_buffers":
+                a, b = np.ascontiguousarray(keys[:100001]), np.ascontiguousarray(keys[100001:])
+                req.add_input_raw("KEYS", tm.TYPE_INT64, [1, keys.size], a.ctypes.data, a.nbytes, tm.MEM_CPU, 0)
+                # the mock appends a second buffer to the same tensor
+                from ctypes import c_void_p
+                shp = np.asarray([1, keys.size], dtype=np.int64)
+                tm._check(tm.lib().mock_request_add_input_buffer(req._h, b"KEYS", tm.TYPE_INT64, shp.ctypes.data, 2, c_void_p(b.ctypes.data),
+                                                                 b.nbytes, tm.MEM_CPU, 0))
+                keep = (a, b, shp)
+            else:
+                req.add_input("KEYS", keys.reshape(1, -1))
+            req.add_input("NUMKEYS", np.asarray([nk], np.int32)).request_output("OUTPUT0")
+            req.set_output_buffer(out.data_ptr(), n_out * 4, tm.MEM_GPU, 0, keep=out)
+            inst.execute([req])
+            assert (req.response_count, req.release_count, req.error_code) == (1, 1, -1), (mode, req.error_message)
+            torch.cuda.synchronize()
+            res = out.cpu().numpy()
+            req.close()
+            del keep
+            return res
+
+        ref = O.np_lookup(tables, q, nk, [0.5, -1.0])
+        for mode in ("pageable", "pageable", "pinned", "two_buffers"):
+            assert np.array_equal(_bits(run(q, mode)), _bits(ref)), mode
+        q2 = q.copy()
+        q2[nk[0] + 7] = wide[3]          # a 41-bit key: this request cannot be narrowed
+        ref2 = O.np_lookup(tables, q2, nk, [0.5, -1.0])
+        assert np.array_equal(_bits(run(q2, "pageable")), _bits(ref2))
+        assert np.array_equal(_bits(run(q, "pageable")), _bits(ref))
+    finally:
+        srv.shutdown()
