@@ -117,6 +117,19 @@ def cpu_throttle_stat():
         return None
 
 
+def cpu_times():
+    """(steal seconds of the machine, CPU seconds this process has used): steal time is what a hypervisor took away from
+    the guest's CPUs; the process's CPU seconds per wall second say how close the run is to the CPU budget."""
+    steal = None
+    try:
+        f = open("/proc/stat").readline().split()
+        steal = int(f[8]) / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        pass
+    t = os.times()
+    return steal, t.user + t.system
+
+
 def host_memory_budget() -> int:
     """Bytes of host RAM this container may still take: MemAvailable clipped by the cgroup limit."""
     avail = 1 << 62
@@ -418,11 +431,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # no collector pass of the interpreter inside the timed region (a full pass over a torch process's objects takes tens of
+    # milliseconds and holds the GIL the session threads need between two calls)
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     run.run(host_batches, W, 0, "host")
     if a.mode == "async":
         cache.wait_async()
     block_s, rec = [], []
     thr0 = cpu_throttle_stat()
+    ct0, wall0 = cpu_times(), time.perf_counter()
     for blk in range(blocks):
         barrier()
         t0 = time.perf_counter()
@@ -435,6 +455,8 @@ def main():
             el = float(tt.item())
         block_s.append(el)
     thr1 = cpu_throttle_stat()
+    ct1, wall1 = cpu_times(), time.perf_counter()
+    gc.enable()
     elapsed = float(np.median(block_s))
     main_rec = list(rec)
 
@@ -726,7 +748,9 @@ def main():
                                  sorted(zip(lat.tolist(), ph.tolist()), key=lambda t: -t[0])[:5]],
             "host": {"cpus": ncpu,
                      "cpu_quota_throttled_periods_in_timed_region": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
-                     "cpu_quota_throttled_ms_in_timed_region": (thr1[1] - thr0[1]) / 1e3 if thr0 and thr1 else None},
+                     "cpu_quota_throttled_ms_in_timed_region": (thr1[1] - thr0[1]) / 1e3 if thr0 and thr1 else None,
+                     "hypervisor_steal_ms_in_timed_region": (ct1[0] - ct0[0]) * 1e3 if ct0[0] is not None and ct1[0] is not None else None,
+                     "process_cpus_busy_in_timed_region": (ct1[1] - ct0[1]) / max(wall1 - wall0, 1e-9)},
             "resident_fraction_after_warmup": resident_frac,
             "roofline": {
                 "bound": "hbm",

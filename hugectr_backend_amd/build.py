@@ -41,6 +41,7 @@ ENGINE_SRCS = [
     "cache/shard_kernels.hip",
     "cache/shard_session.cpp",
     "cache/direct_kernels.hip",
+    "cache/copy_engines.cpp",
     "cache/engine.cpp",
     "cache/parameter_server.cpp",
     "dense/dense_kernels.hip",

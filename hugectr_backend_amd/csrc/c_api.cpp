@@ -4,12 +4,15 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <memory>
 #include <string>
 
+#include "cache/copy_engines.h"
 #include "cache/engine.h"
 #include "cache/shard_kernels.h"
 #include "cache/shard_session.h"
@@ -313,6 +316,19 @@ int hps_cache_num_tables(hps_cache_t* c) {
 }
 
 int hps_cache_on_device(hps_cache_t* c) { return c && c->cache ? 1 : 0; }
+
+int hps_wake_copy_engines(int device, char* buf, uint64_t cap) {
+  const std::string report = WakeCopyEngines(device);
+  if (buf && cap) {
+    const size_t n = std::min<size_t>(report.size(), (size_t)cap - 1);
+    memcpy(buf, report.data(), n);
+    buf[n] = 0;
+  }
+  // "<up> engines host->device, <down> device->host, ..." or "skipped: ..."
+  int up = 0, down = 0;
+  if (sscanf(report.c_str(), "%d engines host->device, %d device->host", &up, &down) != 2) return 0;
+  return up + down;
+}
 
 int hps_cache_table_info(hps_cache_t* c, uint32_t table, hps_cache_table_info_t* out) {
   return Guard([&]() -> Status {

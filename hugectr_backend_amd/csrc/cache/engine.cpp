@@ -1,4 +1,5 @@
 #include "engine.h"
+#include "copy_engines.h"
 
 #include <hip/hip_runtime.h>
 
@@ -202,6 +203,14 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
                             const std::vector<std::shared_ptr<HostTable>>& tables, int device) {
   HPS_RETURN_IF_ERROR(RequireDevice(device));
   HIP_TRY(hipSetDevice(device));
+  {
+    // every SDMA engine takes one tiny copy now, while the model loads (copy_engines.h); HPS_WAKE_COPY_ENGINES=0: A/B
+    const char* e = std::getenv("HPS_WAKE_COPY_ENGINES");
+    if (!(e && e[0] == '0')) {
+      const std::string report = WakeCopyEngines(device);
+      if (std::getenv("HPS_TRACE_TAIL")) fprintf(stderr, "[hps] copy engines of device %d: %s\n", device, report.c_str());
+    }
+  }
   model_ = model;
   const size_t T = tables.size();
   if (T == 0 || T > (size_t)kMaxTables)

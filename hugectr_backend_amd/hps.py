@@ -113,6 +113,7 @@ def _load() -> C.CDLL:
         "hps_server_host_tier_keys": (C.c_int, [P, cp, u32, P, u64, C.POINTER(u64)]),
         "hps_cache_num_tables": (C.c_int, [P]),
         "hps_cache_on_device": (C.c_int, [P]),
+        "hps_wake_copy_engines": (C.c_int, [C.c_int, C.c_char_p, u64]),
         "hps_session_create_from_cache": (C.c_int, [P, C.POINTER(P)]),
         "hps_cache_table_info": (C.c_int, [P, u32, C.POINTER(CacheTableInfo)]),
         "hps_cache_counters": (C.c_int, [P, C.POINTER(CacheCounters)]),
@@ -158,7 +159,7 @@ EXPORTED_SYMBOLS = [
     "hps_server_create_embedding_cache_per_model", "hps_server_destroy_embedding_cache_per_model",
     "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
-    "hps_server_table_data", "hps_cache_on_device", "hps_session_create_from_cache",
+    "hps_server_table_data", "hps_cache_on_device", "hps_wake_copy_engines", "hps_session_create_from_cache",
     "hps_shard_unique_id", "hps_shard_session_create", "hps_shard_group_create_local", "hps_shard_group_destroy",
     "hps_shard_session_create_local", "hps_shard_session_lookup", "hps_shard_session_last_stats", "hps_shard_session_destroy",
     "hps_server_host_tier_stats", "hps_server_host_tier_keys", "hps_cache_num_tables", "hps_cache_table_info",
@@ -177,6 +178,14 @@ def _check(rc: int):
 
 def device_count() -> int:
     return int(LIB.hps_device_count())
+
+
+def wake_copy_engines(device: int = 0):
+    """(engines that took a copy, one-line report): one tiny copy through every SDMA engine of the device in both
+    directions, once per process (cache creation does it on its own; csrc/cache/copy_engines.h)."""
+    buf = C.create_string_buffer(256)
+    n = int(LIB.hps_wake_copy_engines(int(device), buf, 256))
+    return n, buf.value.decode()
 
 
 class EmbeddingCache:

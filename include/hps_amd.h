@@ -183,6 +183,11 @@ int hps_cache_counters(hps_cache_t* cache, hps_cache_counters_t* out);
 int hps_cache_query(hps_cache_t* cache, uint32_t table, const int64_t* h_keys, uint64_t n, int32_t* h_slots);
 /* wait for queued async insertions */
 int hps_cache_wait_async(hps_cache_t* cache);
+/* The SDMA copy engines of a device take one tiny copy each (both directions), once per process and device; cache creation
+ * does this on its own while the model loads (csrc/cache/copy_engines.h: otherwise the HIP runtime creates an engine's queue
+ * inside some request's hipMemcpyAsync, 7-12 ms during which every HIP call of the process waits).  Writes a one-line report
+ * ("16 engines host->device, 16 device->host, 140 ms") into buf; returns the number of engines that took a copy. */
+int hps_wake_copy_engines(int device, char* buf, uint64_t cap);
 /* drop this handle's reference (the shared_ptr copy the shell holds)         src/model_instance_state.cpp:158 */
 void hps_cache_release(hps_cache_t* cache);
 

@@ -540,3 +540,15 @@ def test_pageable_keys_cross_pcie_as_uint32_when_they_fit():
     out = s.lookup(q3, nk).cpu().numpy()
     assert s.last_stats().keys_narrowed == 0
     assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q3, nk, [0.0, 0.0])))
+
+
+def test_copy_engines_are_woken_once_per_device():
+    """Cache creation sends one tiny copy through every SDMA engine (copy_engines.h); the C ABI reports what it did and
+    a second call is a table look-up."""
+    import time
+    from hugectr_backend_amd import hps
+    n, report = hps.wake_copy_engines(0)
+    assert n >= 2 and "host->device" in report, report
+    t0 = time.perf_counter()
+    assert hps.wake_copy_engines(0) == (n, report)
+    assert time.perf_counter() - t0 < 0.01

@@ -171,3 +171,11 @@ def test_synthetic_table_source_and_table_data_view(tmp_path):
     cfg["models"][0]["sparse_files"][0] = "synthetic://12abc"
     with pytest.raises(hps.HpsError):
         hps.HierParameterServer.create_from_dict(cfg, load_tables=True)
+
+
+def test_copy_engine_wakeup_is_skipped_without_a_device():
+    from hugectr_backend_amd import hps
+    if hps.device_count() > 0:
+        pytest.skip("a GPU is present")
+    n, report = hps.wake_copy_engines(0)
+    assert n == 0 and report.startswith("skipped"), report
