@@ -107,6 +107,34 @@ def effective_cpus() -> int:
     return n
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> {0, 1, 2, 3, 8, 10, 11}"""
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_local_cpus(pci_bdf, allowed, sysfs="/sys"):
+    """CPUs of the NUMA node the GPU hangs off, clipped to `allowed` — or None when the machine has one node, the kernel
+    does not know the GPU's node, or too few CPUs would be left.  N replicas on a two-socket node each keep their host
+    tables (first touch) and their gather threads next to their own GPU's PCIe root instead of behind the socket link."""
+    try:
+        nodes = [d for d in os.listdir(os.path.join(sysfs, "devices/system/node")) if d.startswith("node") and d[4:].isdigit()]
+        if len(nodes) < 2:
+            return None
+        dev = os.path.join(sysfs, "bus/pci/devices", pci_bdf)
+        if int(open(os.path.join(dev, "numa_node")).read()) < 0:
+            return None
+        cpus = parse_cpulist(open(os.path.join(dev, "local_cpulist")).read()) & set(allowed)
+        return cpus if len(cpus) >= 4 else None
+    except Exception:
+        return None
+
+
 def cpu_throttle_stat():
     """(nr_throttled, throttled_usec) of this container's cgroup, or None: a run whose timed region was throttled by the
     CPU quota shows multi-millisecond stalls in its p99 that have nothing to do with the GPU path."""
@@ -280,6 +308,18 @@ def main():
     local_rank = dev
     torch.cuda.set_device(dev)
     coll_dev = "cpu" if shared_gpu else "cuda"
+    numa_note = None
+    if world > 1 and not shared_gpu and hasattr(os, "sched_setaffinity"):
+        # threads created from here on (the engine's pools, the table loaders) inherit the mask
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            cpus = gpu_local_cpus(bdf, os.sched_getaffinity(0))
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                numa_note = f"rank bound to the {len(cpus)} CPUs local to GPU {bdf}"
+        except Exception as e:  # noqa: BLE001
+            numa_note = f"no NUMA binding ({e!r})"
     if world > 1:
         if shared_gpu:
             dist.init_process_group("gloo")
@@ -746,7 +786,7 @@ def main():
             # ms inside the host gather calls, ms of upload tail + scatter + insert, ms of the whole call inside the engine]
             "slowest_calls_ms": [[round(l, 3)] + [round(x, 3) for x in p] for l, p in
                                  sorted(zip(lat.tolist(), ph.tolist()), key=lambda t: -t[0])[:5]],
-            "host": {"cpus": ncpu,
+            "host": {"cpus": ncpu, "numa": numa_note,
                      "cpu_quota_throttled_periods_in_timed_region": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
                      "cpu_quota_throttled_ms_in_timed_region": (thr1[1] - thr0[1]) / 1e3 if thr0 and thr1 else None,
                      "hypervisor_steal_ms_in_timed_region": (ct1[0] - ct0[0]) * 1e3 if ct0[0] is not None and ct1[0] is not None else None,
