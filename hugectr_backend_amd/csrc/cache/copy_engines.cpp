@@ -49,7 +49,7 @@ int WakeDirection(const HsaApi& api, void* dst, hsa_agent_t dst_agent, const voi
     if (api.signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) break;
     if (api.copy_on_engine(dst, dst_agent, src, src_agent, bytes, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)bit, false) ==
         HSA_STATUS_SUCCESS) {
-      // bounded wait (one second): a copy of a few KB that does not finish is left alone rather than waited for
+      // bounded wait (10^9 ticks of the HSA system clock, seconds): a copy of a few KB that does not finish is left alone
       if (api.signal_wait(sig, HSA_SIGNAL_CONDITION_LT, 1, 1000000000ull, HSA_WAIT_STATE_BLOCKED) < 1) ++woken;
     }
     (void)api.signal_destroy(sig);
