@@ -604,14 +604,25 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   block_acc_off_ = (sizeof(CallDesc) + 127) & ~(size_t)127;
   block_tiles_off_ = block_acc_off_ + acc_words_ * sizeof(uint32_t);
   const size_t block_bytes = block_tiles_off_ + max_tiles_ * sizeof(TileDesc);
-  HPS_RETURN_IF_ERROR(PinAlloc(&h_block_, block_bytes));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_block_, block_bytes, hipHostMallocMapped));
   HPS_RETURN_IF_ERROR(DevAlloc(&d_block_, block_bytes));
   memset(h_block_, 0, block_bytes);
   h_call_ = reinterpret_cast<CallDesc*>(h_block_);
   d_call_ = reinterpret_cast<CallDesc*>(d_block_);
   h_tiles_ = reinterpret_cast<TileDesc*>(h_block_ + block_tiles_off_);
   d_acc_ = reinterpret_cast<uint32_t*>(d_block_ + block_acc_off_);
-  HPS_RETURN_IF_ERROR(PinAlloc(&h_acc_, acc_words_));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_acc_, acc_words_ + kAccStride, hipHostMallocMapped));
+  memset(h_acc_, 0, (acc_words_ + kAccStride) * sizeof(uint32_t));
+  h_seq_ = h_acc_ + acc_words_;
+  {
+    void* dv = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dv, h_block_, 0));
+    h_block_dev_ = dv;
+    HIP_TRY(hipHostGetDevicePointer(&dv, h_acc_, 0));
+    h_acc_dev_ = (uint32_t*)dv;
+    h_seq_dev_ = h_acc_dev_ + acc_words_;
+    if (const char* e = std::getenv("HPS_ZC_CONTROL")) zc_control_ = e[0] != '0';
+  }
   HPS_RETURN_IF_ERROR(DevAlloc(&d_mode_, (size_t)kMaxTables));
   HPS_RETURN_IF_ERROR(PinAlloc(&h_mode_, (size_t)kMaxTables + (size_t)kMaxTables * kAccStride));
   HPS_RETURN_IF_ERROR(PinAlloc(&h_md_, 1));
@@ -892,9 +903,51 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   }
   work_.num_tiles = tiles;
   work_.call_tag = call_tag_;
-  HIP_TRY(hipMemcpyAsync(d_block_, h_block_, block_tiles_off_ + (size_t)tiles * sizeof(TileDesc), hipMemcpyHostToDevice, stream_));
+  const size_t block_bytes = block_tiles_off_ + (size_t)tiles * sizeof(TileDesc);
+  if (zc_control_) {
+    const hipError_t pe = LaunchPull16(h_block_dev_, d_block_, block_bytes, stream_);
+    if (pe != hipSuccess) return Error(Code::kInternal, "call block pull launch failed: ", hipGetErrorString(pe));
+  } else {
+    HIP_TRY(hipMemcpyAsync(d_block_, h_block_, block_bytes, hipMemcpyHostToDevice, stream_));
+  }
   *N_out = N;
   return Status::Ok();
+}
+
+Status LookupSession::PushWords(uint32_t words) {
+  if (zc_control_) {
+    if (++push_seq_ == 0) push_seq_ = 1;
+    const hipError_t e = LaunchPushWords(d_acc_, h_acc_dev_, words, h_seq_dev_, push_seq_, stream_);
+    if (e != hipSuccess) return Error(Code::kInternal, "accumulator push launch failed: ", hipGetErrorString(e));
+  } else {
+    HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, (size_t)words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  }
+  HIP_TRY(hipEventRecord(ev_done_, stream_));
+  return Status::Ok();
+}
+
+Status LookupSession::WaitPushed() {
+  if (!zc_control_) { HIP_TRY(hipEventSynchronize(ev_done_)); return Status::Ok(); }
+  const uint32_t want = push_seq_;
+  // poll the sequence word for a while (the usual wait is tens of microseconds), looking at the event now and then so that a
+  // failed stream ends the wait; a long wait (a millisecond of uploads ahead of the push) goes to the runtime's own wait
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t i = 1;; ++i) {
+    if (__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) == want) return Status::Ok();
+    __builtin_ia32_pause();
+    if ((i & 511u) == 0) {
+      const hipError_t q = hipEventQuery(ev_done_);
+      if (q != hipSuccess && q != hipErrorNotReady) return Error(Code::kInternal, "lookup stream failed: ", hipGetErrorString(q));
+      if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+    }
+  }
+  HIP_TRY(hipEventSynchronize(ev_done_));
+  // the push kernel has retired: its stores are on their way; give the last one the time to land
+  for (uint32_t i = 0; i < (1u << 24); ++i) {
+    if (__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) == want) return Status::Ok();
+    __builtin_ia32_pause();
+  }
+  return Error(Code::kInternal, "accumulator push did not arrive");
 }
 
 // After the accumulator block has come back: per-table unique miss counts, the call's statistics.
@@ -1017,9 +1070,8 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   }
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
   {
-    hipError_t ce = hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_);
-    if (ce == hipSuccess) ce = hipEventRecord(ev_done_, stream_);
-    if (ce != hipSuccess) { end_read(); return Error(Code::kInternal, "count read-back failed: ", hipGetErrorString(ce)); }
+    const Status ps = PushWords((uint32_t)acc_words_);
+    if (!ps.ok()) { end_read(); return ps; }
   }
   if (split) {
     // K_G behind the counts: it runs while the host reads them and works on the misses
@@ -1027,7 +1079,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     end_read();
     if (e != hipSuccess) return Error(Code::kInternal, "hit gather launch failed: ", hipGetErrorString(e));
   }
-  HIP_TRY(hipEventSynchronize(ev_done_));
+  HPS_RETURN_IF_ERROR(WaitPushed());
   if (timing_) (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
   HPS_RETURN_IF_ERROR(ReadBackCounts(T, N, exact));
   phase_ms_[0] = phase_ms_[3] = ms_since(tc0);
@@ -1181,8 +1233,8 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
-  HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-  HIP_TRY(hipStreamSynchronize(stream_));
+  HPS_RETURN_IF_ERROR(PushWords((uint32_t)acc_words_));
+  HPS_RETURN_IF_ERROR(WaitPushed());
   if (timing_) {
     (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
     (void)hipEventElapsedTime(&phase_ms_[1], ev_f0_, ev_f1_);
@@ -1231,8 +1283,8 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
-  HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, acc_words_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-  HIP_TRY(hipStreamSynchronize(stream_));
+  HPS_RETURN_IF_ERROR(PushWords((uint32_t)acc_words_));
+  HPS_RETURN_IF_ERROR(WaitPushed());
   if (timing_) {
     (void)hipEventElapsedTime(&phase_ms_[1], ev_f0_, ev_f1_);  // direct path: [1] = the fetch kernel (GPU time)
     (void)hipEventElapsedTime(&last_scatter_ms_, ev_s0_, ev_s1_);
@@ -1360,9 +1412,12 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     if (timing_) (void)hipEventRecord(ev_c1_, stream_);
     bool last = true;
     for (size_t t = 0; t < T; ++t) last &= md.chunk_hi[t] == ucnt[t];
-    if (last)   // the insert statistics ride the call's final synchronisation
-      HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, (size_t)kStatLines * kAccStride * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    if (last) {   // the insert statistics ride the call's final synchronisation
+      HPS_RETURN_IF_ERROR(PushWords((uint32_t)kStatLines * kAccStride));
+      HPS_RETURN_IF_ERROR(WaitPushed());
+    } else {
+      HIP_TRY(hipStreamSynchronize(stream_));
+    }
     tr[4] = since();
     if (kTrace && tr[4] > 3.0f)
       fprintf(stderr, "[hps tail] scatter-enqueued %.2f  drained %.2f  write-lock %.2f  insert-enqueued %.2f  done %.2f ms (fetch %.2f ms before)\n",

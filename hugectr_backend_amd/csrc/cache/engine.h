@@ -282,6 +282,16 @@ class LookupSession {
   TileDesc* h_tiles_ = nullptr;
   uint32_t* d_acc_ = nullptr;
   uint32_t* h_acc_ = nullptr;     // pinned mirror the accumulator block is copied back to
+  // Control words over the compute queue (kernels.hip: hps_pull16 / hps_push_words) instead of SDMA copies: device views of
+  // the two pinned images, the sequence word a push publishes last and the host polls.  HPS_ZC_CONTROL=0: hipMemcpyAsync.
+  bool zc_control_ = true;
+  const void* h_block_dev_ = nullptr;
+  uint32_t* h_acc_dev_ = nullptr;
+  uint32_t* h_seq_ = nullptr;      // = h_acc_ + acc_words_ (own 128-B line)
+  uint32_t* h_seq_dev_ = nullptr;
+  uint32_t push_seq_ = 0;
+  Status PushWords(uint32_t words);   // enqueue: d_acc_[0..words) -> h_acc_, then the sequence word; records ev_done_
+  Status WaitPushed();                // host: until the last PushWords has landed (or the stream reports an error)
   CallWork work_{};               // device pointers of the per-call work arrays
   uint32_t* d_mode_ = nullptr;    // per-table insertion mode of a mixed call (1 = async)
   uint32_t call_tag_ = 0;

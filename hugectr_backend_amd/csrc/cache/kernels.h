@@ -33,6 +33,11 @@ hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const Mi
                              const uint8_t* d_found, uint32_t epoch, uint32_t* d_stats, int cu_count,
                              hipStream_t stream);
 
+// control words over the compute queue (kernels.hip): call block host -> HBM (bytes rounded up to 16), accumulator words
+// HBM -> host followed by a sequence word
+hipError_t LaunchPull16(const void* src_host_devptr, void* dst, size_t bytes, hipStream_t stream);
+hipError_t LaunchPushWords(const uint32_t* src, uint32_t* dst_host_devptr, uint32_t words, uint32_t* seq_host_devptr, uint32_t seq,
+                           hipStream_t stream);
 hipError_t LaunchCacheClear(int64_t* d_keys, uint32_t* d_stamps, uint64_t slots, hipStream_t stream);
 
 // stamps > keep_from -> stamp - keep_from + 1 ; other used stamps -> 1 ; 0 stays 0

@@ -741,6 +741,39 @@ hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const Mi
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Control words of a call over the compute queue instead of the SDMA engines.  A copy of a few KB placed between two
+// kernels of one stream costs two hand-offs between the compute queue and an SDMA queue (signal + barrier packet each way,
+// 10-20 us together); a small kernel that reads or writes page-locked host memory directly stays on the queue.
+//   pull: call block (descriptor | zeroed accumulators | tile descriptors) host -> HBM, 16 B per lane
+//   push: accumulator words HBM -> host, then a sequence word the waiting host thread polls
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hps_pull16_kernel(const uint4* __restrict__ src_host, uint4* __restrict__ dst, uint32_t n16) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n16) dst[i] = src_host[i];
+}
+
+__global__ __launch_bounds__(256) void hps_push_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst_host,
+                                                             uint32_t words, uint32_t* __restrict__ seq_host, uint32_t seq) {
+  for (uint32_t i = threadIdx.x; i < words; i += 256u) dst_host[i] = src[i];
+  __threadfence_system();   // every lane's words are on their way before the barrier lets lane 0 publish
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t LaunchPull16(const void* src_host_devptr, void* dst, size_t bytes, hipStream_t stream) {
+  const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+  if (n16 == 0) return hipSuccess;
+  hipLaunchKernelGGL(hps_pull16_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, (const uint4*)src_host_devptr, (uint4*)dst, n16);
+  return hipGetLastError();
+}
+
+hipError_t LaunchPushWords(const uint32_t* src, uint32_t* dst_host_devptr, uint32_t words, uint32_t* seq_host_devptr, uint32_t seq,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(hps_push_words_kernel, dim3(1), dim3(256), 0, stream, src, dst_host_devptr, words, seq_host_devptr, seq);
+  return hipGetLastError();
+}
+
 hipError_t LaunchCacheClear(int64_t* d_keys, uint32_t* d_stamps, uint64_t slots, hipStream_t stream) {
   uint64_t want = (slots + 255) / 256;
   if (want > 4096) want = 4096;
