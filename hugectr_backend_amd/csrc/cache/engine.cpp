@@ -24,6 +24,7 @@ namespace hps {
 
 namespace {
 
+constexpr size_t kInPlaceStagingBytes = 256u << 10;   // missed rows of a chunk up to this size are read by the kernels where the host gathered them
 constexpr size_t kStagingCapBytes = 256ull << 20;  // per-session staging chunk for missed rows
 constexpr uint64_t kSmallRequestKeys = 1u << 17;   // requests up to this many keys are probed in tiles of ...
 constexpr uint64_t kSmallTileKeys = 256;           // ... this many keys
@@ -597,7 +598,12 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   if (const char* e = std::getenv("HPS_XCD_WALK")) xcd_walk_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_PROBE_VARIANT")) probe_variant_ = (int)std::strtol(e, nullptr, 10);
 
-  HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_, hipHostMallocMapped));
+  {
+    void* dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, h_keys_pinned_, 0) == hipSuccess) h_keys_dev_ = (const int64_t*)dv;
+    else (void)hipGetLastError();
+  }
   HPS_RETURN_IF_ERROR(DevAlloc(&d_keys_, max_keys_));
   // call block: descriptor | accumulator block | tile descriptors
   acc_words_ = (size_t)(kStatLines + T) * kAccStride;
@@ -625,8 +631,12 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   }
   HPS_RETURN_IF_ERROR(DevAlloc(&d_mode_, (size_t)kMaxTables));
   HPS_RETURN_IF_ERROR(PinAlloc(&h_mode_, (size_t)kMaxTables + (size_t)kMaxTables * kAccStride));
-  HPS_RETURN_IF_ERROR(PinAlloc(&h_md_, 1));
-  HPS_RETURN_IF_ERROR(DevAlloc(&d_md_, 1));
+  HPS_RETURN_IF_ERROR(PinAlloc(&h_md_, 2, hipHostMallocMapped));   // (2: the pull kernel moves whole 16-B units)
+  HPS_RETURN_IF_ERROR(DevAlloc(&d_md_, 2));
+  {
+    void* dv = nullptr;
+    h_md_dev_ = hipHostGetDevicePointer(&dv, h_md_, 0) == hipSuccess ? (const MissDesc*)dv : nullptr;
+  }
 
   const size_t regions = max_tiles_ * (size_t)kTileKeys;
   CallWork& w = work_;
@@ -690,7 +700,9 @@ Status LookupSession::EnsureStaging(size_t floats, size_t uniq) {
       HPS_RETURN_IF_ERROR(DevAlloc(&d_staging_, want));
       staging_floats_ = want;
     }
-    HPS_RETURN_IF_ERROR(PinAlloc(&h_staging_, staging_floats_));
+    HPS_RETURN_IF_ERROR(PinAlloc(&h_staging_, staging_floats_, hipHostMallocMapped));
+    void* dv = nullptr;
+    h_staging_dev_ = hipHostGetDevicePointer(&dv, h_staging_, 0) == hipSuccess ? (const float*)dv : nullptr;
   }
   if (uniq > staging_uniq_ || (!h_found_ && uniq > 0)) {
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -704,7 +716,9 @@ Status LookupSession::EnsureStaging(size_t floats, size_t uniq) {
       HPS_RETURN_IF_ERROR(DevAlloc(&d_found_, want));
       staging_uniq_ = want;
     }
-    HPS_RETURN_IF_ERROR(PinAlloc(&h_found_, staging_uniq_));
+    HPS_RETURN_IF_ERROR(PinAlloc(&h_found_, staging_uniq_, hipHostMallocMapped));
+    void* dv = nullptr;
+    h_found_dev_ = hipHostGetDevicePointer(&dv, h_found_, 0) == hipSuccess ? (const uint8_t*)dv : nullptr;
   }
   return Status::Ok();
 }
@@ -755,6 +769,28 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
   }
   keys_narrow_ = false;
   stage_pool_ms_ = stage_enqueue_ms_ = 0.f;
+  if (zc_control_ && N <= kSmallRequestKeys && h_keys_dev_) {
+    // Small request (at most 1 MB of keys): the probe kernel reads the keys out of page-locked host memory itself — the
+    // caller's buffer when that is page-locked, else the session's staging buffer after one memcpy — instead of waiting for
+    // an SDMA copy and the hand-off between the queues (tools/ab_zc_control.sh).
+    const int64_t* dev_view = nullptr;
+    if (direct_dma) {
+      void* dv = nullptr;
+      if (hipHostGetDevicePointer(&dv, const_cast<int64_t*>(base), 0) == hipSuccess) dev_view = (const int64_t*)dv;
+      else (void)hipGetLastError();
+    }
+    if (!dev_view) {
+      size_t off = 0;
+      for (size_t t = 0; t < num_tables; ++t) {
+        const size_t n = num_keys_per_table[t];
+        if (n) memcpy(h_keys_pinned_ + off, h_keys_per_table[t], n * sizeof(int64_t));
+        off += n;
+      }
+      dev_view = h_keys_dev_;
+    }
+    key_stage_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
+    return TimedLookupDevice(dev_view, vectors_per_table, num_keys_per_table, num_tables);
+  }
   {
     constexpr size_t kTaskKeys = 32768, kGroupKeys = (4u << 20) / sizeof(int64_t);
     struct Task { const int64_t* src; size_t off, n; };
@@ -1338,7 +1374,16 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     // Gather and upload in pieces of a few MB (runs of consecutive tables): the H2D copy of piece p runs
     // on the copy engine while the host threads gather piece p+1, so the PCIe time (the floor of this
     // path: every missed row crosses the link once) hides most of the DRAM-latency-bound gather.
-    HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, stream_));
+    // A small chunk (a small request, or a big one that missed little) is not uploaded at all: the scatter and insert kernels
+    // read the gathered rows out of the page-locked staging buffer themselves, and the descriptor is pulled by a kernel — three
+    // SDMA copies and their queue hand-offs less on the path of a request that takes 0.15 ms in all.
+    const bool in_place = zc_control_ && fl * sizeof(float) <= kInPlaceStagingBytes && h_staging_dev_ && h_found_dev_ && h_md_dev_;
+    if (in_place) {
+      const hipError_t pe = LaunchPull16(h_md_dev_, d_md_, sizeof(MissDesc), stream_);
+      if (pe != hipSuccess) return Error(Code::kInternal, "miss descriptor pull launch failed: ", hipGetErrorString(pe));
+    } else {
+      HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, stream_));
+    }
     static const size_t kPieceFloats = [] {   // upload piece: HPS_PIECE_MB (A/B switch), default 4 MB
       const char* e = std::getenv("HPS_PIECE_MB");
       const long v = e ? std::strtol(e, nullptr, 10) : 0;
@@ -1354,10 +1399,12 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       phase_ms_[1] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tf0).count();
       // split call: the session's stream is busy with K_G, the pieces go down the copy stream
       // (A/B on the MI355X box: alternating the pieces between two copy streams was slower — 1.24 vs 1.06 ms/step)
-      hipStream_t cs = split_call_ ? copy_stream_ : stream_;
-      HIP_TRY(hipMemcpyAsync(d_staging_ + piece_begin, h_staging_ + piece_begin, (piece_end - piece_begin) * sizeof(float),
-                             hipMemcpyHostToDevice, cs));
-      used_copy_stream |= (cs == copy_stream_);
+      if (!in_place) {
+        hipStream_t cs = split_call_ ? copy_stream_ : stream_;
+        HIP_TRY(hipMemcpyAsync(d_staging_ + piece_begin, h_staging_ + piece_begin, (piece_end - piece_begin) * sizeof(float),
+                               hipMemcpyHostToDevice, cs));
+        used_copy_stream |= (cs == copy_stream_);
+      }
       jobs.clear();
       piece_begin = SIZE_MAX; piece_end = 0;
       return Status::Ok();
@@ -1379,7 +1426,9 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       }
     }
     HPS_RETURN_IF_ERROR(flush());
-    HIP_TRY(hipMemcpyAsync(d_found_, h_found_, uq, hipMemcpyHostToDevice, stream_));
+    if (!in_place) HIP_TRY(hipMemcpyAsync(d_found_, h_found_, uq, hipMemcpyHostToDevice, stream_));
+    const float* rows_src = in_place ? h_staging_dev_ : d_staging_;
+    const uint8_t* found_src = in_place ? h_found_dev_ : d_found_;
     if (used_copy_stream) {
       HIP_TRY(hipEventRecord(ev_copy_, copy_stream_));
       HIP_TRY(hipStreamWaitEvent(stream_, ev_copy_, 0));
@@ -1390,20 +1439,21 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     auto since = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tt0).count(); };
     float tr[6] = {0, 0, 0, 0, 0, 0};
     if (timing_) (void)hipEventRecord(ev_s0_, stream_);
-    hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, d_staging_, stream_);
+    hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, rows_src, stream_);
     tr[0] = since();
     if (timing_) (void)hipEventRecord(ev_s1_, stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
     // Other sessions' probes wait for our writer event.  Let the PCIe copy and the scatter drain first,
     // so that the window in which the cache is "being written" is the insert kernel alone (tens of
     // microseconds) and not insert + the millisecond of H2D queued ahead of it on this stream.
-    HIP_TRY(hipStreamSynchronize(stream_));
+    // (a chunk read in place has nothing queued ahead but its own scatter: no drain, one host wait for the whole call)
+    if (!in_place) HIP_TRY(hipStreamSynchronize(stream_));
     tr[1] = since();
     cache_->BeginWrite(stream_);
     tr[2] = since();
     if (timing_) (void)hipEventRecord(ev_i0_, stream_);
     e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, uq, d_call_->key_start, work_.uniq_keys,
-                          d_staging_, d_found_, epoch, d_acc_, cu, stream_);
+                          rows_src, found_src, epoch, d_acc_, cu, stream_);
     if (timing_) (void)hipEventRecord(ev_i1_, stream_);
     cache_->EndWrite(stream_);
     tr[3] = since();

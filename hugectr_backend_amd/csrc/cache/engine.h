@@ -271,6 +271,7 @@ class LookupSession {
   size_t max_keys_ = 0;           // max_batch * sum(maxnum_catfeature)
   size_t max_tiles_ = 0;          // max_keys_ / kTileKeys + T (tiles never straddle tables)
   int64_t* h_keys_pinned_ = nullptr;
+  const int64_t* h_keys_dev_ = nullptr;   // device view of h_keys_pinned_ (small requests: the probe reads the keys from there)
   int64_t* d_keys_ = nullptr;
   // The call block: CallDesc | accumulator block (zeros) | TileDesc[max_tiles_], one pinned image and one device
   // copy, uploaded with ONE H2D copy per call (every extra small copy or memset is a blit kernel on the stream).
@@ -306,6 +307,9 @@ class LookupSession {
   bool chain_gather_ = false;    // other sessions' probes queue behind this session's gather as well as its probe
   bool xcd_walk_ = true;         // K_G: each XCD sweeps its own eighth of the key range (HPS_XCD_WALK=0: plain grid stride)
   MissDesc* h_md_ = nullptr;      // pinned
+  const MissDesc* h_md_dev_ = nullptr;     // device views of the pinned miss descriptor / staging rows / found flags (small chunks)
+  const float* h_staging_dev_ = nullptr;
+  const uint8_t* h_found_dev_ = nullptr;
   MissDesc* d_md_ = nullptr;
   int64_t* h_uniq_keys_ = nullptr;        // pinned, device-mapped (work_.uniq_keys_host is its device view)
   std::vector<uint32_t> uniq_miss_;       // this call: unique missed keys per table
