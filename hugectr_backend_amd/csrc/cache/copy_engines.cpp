@@ -33,6 +33,9 @@ struct HsaApi {
     signal_destroy = (decltype(signal_destroy))dlsym(h, "hsa_signal_destroy");
     signal_wait = (decltype(signal_wait))dlsym(h, "hsa_signal_wait_scacquire");
     ok = pointer_info && engine_status && copy_on_engine && signal_create && signal_destroy && signal_wait;
+    // drop our reference again: the HIP runtime keeps the library loaded for as long as these pointers are used, and an
+    // extra reference changes the order in which the process unloads it at exit
+    dlclose(h);
   }
 };
 
