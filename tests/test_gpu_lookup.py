@@ -552,3 +552,28 @@ def test_copy_engines_are_woken_once_per_device():
     t0 = time.perf_counter()
     assert hps.wake_copy_engines(0) == (n, report)
     assert time.perf_counter() - t0 < 0.01
+
+
+@pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
+def test_control_words_by_kernels_or_by_copies_same_rows(direct, monkeypatch):
+    """The call block, the miss counts, a small request's keys and a small miss chunk travel by kernels that touch page-locked
+    memory (default) or by hipMemcpyAsync (HPS_ZC_CONTROL=0, read when a session is created).  Both arrangements, request
+    sizes on either side of the small-request limit (131,072 keys) and miss volumes on either side of the in-place limit
+    (256 KB of rows), pageable and page-locked keys, three calls each: exact rows."""
+    import torch
+    from oracle import hps_oracle as O
+    tables = make_tables([(80000, 16), (80000, 32), (2000, 4)])
+    for zc in ("1", "0"):
+        monkeypatch.setenv("HPS_ZC_CONTROL", zc)
+        rng = np.random.default_rng(77)
+        ps, cache, s = _mk(f"zc{zc}_{int(direct)}", tables, maxcat=[1, 1, 1], gpucacheper=0.25, max_batch=200_000,
+                           extra={"ps_direct_access": direct})
+        for nk, miss in (([900, 1100, 40], 0.02), ([60_000, 60_000, 900], 0.002), ([60_000, 60_000, 900], 0.3),
+                         ([150_000, 140_000, 1500], 0.001), ([150_000, 140_000, 1500], 0.2)):
+            for rep in range(3):
+                q = _queries(rng, tables, nk, miss_frac=miss)
+                ref = O.np_lookup(tables, q, nk, [0.0] * 3)
+                keys = torch.from_numpy(q).pin_memory().numpy() if rep == 1 else q
+                out = s.lookup(keys, nk).cpu().numpy()
+                assert np.array_equal(_bits(out), _bits(ref)), (zc, nk, miss, rep)
+        s.close()
