@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--distinct-batches", type=int, default=0, help="0: one fresh batch per step")
     ap.add_argument("--probe-variant", type=int, default=1004, help="probe kernel variant U + 100*no_dedup + 1000*wide (tools/kbench.py)")
     ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
-    ap.add_argument("--stamp-every", type=int, default=4, help="LRU stamps rewritten for one hit in N (power of two)")
+    ap.add_argument("--stamp-every", type=int, default=1, help="LRU stamps rewritten for one hit in N (power of two; 1 = every hit, exact recency)")
     ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
     ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys as uint32 when every key of the request fits")
     ap.add_argument("--direct", type=int, default=-1,

@@ -303,7 +303,7 @@ class LookupSession {
   bool split_call_ = false;      // the call in progress gathers its hits on stream_ while the miss path runs (copies go down copy_stream_)
   bool split_probe_ = true;      // host-gather tier: start the miss path behind the probe, gather the hits meanwhile (§3.4c);
                                  // HPS_SPLIT_PROBE=0 / session option split_probe=0: gather first, then the counts
-  uint32_t stamp_mask_ = 3;      // LRU stamps rewritten for one hit in (stamp_mask_ + 1); option "stamp_every"
+  uint32_t stamp_mask_ = 0;      // LRU stamps rewritten for one hit in (stamp_mask_ + 1); option "stamp_every" (default 1: every hit, exact recency)
   bool chain_gather_ = false;    // other sessions' probes queue behind this session's gather as well as its probe
   bool xcd_walk_ = true;         // K_G: each XCD sweeps its own eighth of the key range (HPS_XCD_WALK=0: plain grid stride)
   MissDesc* h_md_ = nullptr;      // pinned
