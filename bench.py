@@ -901,7 +901,7 @@ def triton_abi_leg(a, hb, T, R, D, B):
         return {"error": "tools/triton_abi_bench.cpp was not built"}
     cmd = [str(exe), "--lib-dir", str(hb.LIB), "--tables", str(T), "--rows", str(R), "--dim", str(D), "--batch", str(B),
            "--cache-frac", str(a.cache_frac), "--hit", str(a.hit), "--zipf", str(a.zipf), "--instances", str(a.sessions),
-           "--steps", "20", "--blocks", "6", "--warmup", "5", "--direct", str(int(bool(a.direct)))]
+           "--steps", "20", "--blocks", "12", "--warmup", "5", "--direct", str(int(bool(a.direct)))]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=a.triton_timeout)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
