@@ -6,7 +6,7 @@
 One "step" = one call of the reference's lookup contract — LookupSession::lookup(h_keys_per_table, d_vectors_per_table,
 num_keys_per_table), docs/architecture.md:308-323 — through the C ABI (hps_session_lookup) on one batch of synthetic keys
 (26 tables x 65,536 keys) that sit in ordinary HOST memory, as a Triton request's KEYS do (hps.cc:586-597): key staging +
-upload (narrowed to 32 bits when every key fits), tile-local input dedup + cache probe (HIP), call-wide unique misses
+upload (narrowed to 3 or 4 bytes per key when every key fits), tile-local input dedup + cache probe (HIP), call-wide unique misses
 (HIP), hit-row gather (HIP) running while the parameter server fetches the missed rows (one GPU, >= 12 CPUs: host threads
 gather them and hipMemcpyAsync ships them, as in the reference; otherwise / --direct 1: the device-driven tier, a HIP
 kernel reading them out of pinned host memory), scatter + cache insert (HIP).  Output rows land in HBM (Triton's device
@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
     ap.add_argument("--stamp-every", type=int, default=1, help="LRU stamps rewritten for one hit in N (power of two; 1 = every hit, exact recency)")
     ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
-    ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys as uint32 when every key of the request fits")
+    ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys narrower when every key of the request fits: 1 = 3-byte packing or uint32, 2 = uint32 only, 0 = off")
     ap.add_argument("--direct", type=int, default=-1,
                     help="parameter-server tier of the miss path.  0: host threads gather the missed rows and "
                          "hipMemcpyAsync ships them (the reference's arrangement); 1: ps_direct_access (the GPU resolves "
@@ -253,7 +253,7 @@ class Runner:
                     with self.lock:
                         record.append((dt, st.probe_gather_ms, st.hit_gather_ms, st.scatter_ms, st.insert_ms, st.misses,
                                        st.unique_misses, st.gpu_call_ms, [float(x) for x in st.phase_ms], st.key_stage_ms,
-                                       st.keys_narrowed))
+                                       st.keys_narrowed, st.key_bytes))
 
         th = [threading.Thread(target=worker, args=(si,)) for si in sess]
         [x.start() for x in th]
@@ -781,6 +781,7 @@ def main():
             "p99_batch_gpu_ms": float(np.percentile(gpu_ms, 99)),
             "measured_hit_rate": m["measured_hit_rate"],
             "keys_narrowed_to_32_bits_fraction_of_calls": float(np.mean([r[10] for r in main_rec])),
+            "key_bytes_over_pcie_mean": float(np.mean([r[11] for r in main_rec])),
             "key_stage_ms_mean": m["key_stage_ms"],
             # the five slowest calls of the timed region: [end-to-end ms, ms until the miss counts are on the host,
             # ms inside the host gather calls, ms of upload tail + scatter + insert, ms of the whole call inside the engine]
@@ -821,9 +822,9 @@ def main():
             },
             "roofline_pcie": {
                 "bound": "pcie", "peak": PCIE_PEAK_GBS, "unit": "GB/s",
-                "bytes_per_step": uniq * 4 * D + N * (4 if np.mean([r[10] for r in main_rec]) > 0.5 else 8),
-                "achieved": (uniq * 4 * D + N * (4 if np.mean([r[10] for r in main_rec]) > 0.5 else 8)) / (elapsed / K) / 1e9,
-                "frac": (uniq * 4 * D + N * (4 if np.mean([r[10] for r in main_rec]) > 0.5 else 8)) / (elapsed / K) / 1e9 / PCIE_PEAK_GBS,
+                "bytes_per_step": uniq * 4 * D + N * float(np.mean([r[11] for r in main_rec])),
+                "achieved": (uniq * 4 * D + N * float(np.mean([r[11] for r in main_rec]))) / (elapsed / K) / 1e9,
+                "frac": (uniq * 4 * D + N * float(np.mean([r[11] for r in main_rec]))) / (elapsed / K) / 1e9 / PCIE_PEAK_GBS,
                 "unique_missed_rows_per_batch": uniq,
                 "fetch_kernel_ms": fetch_ms if a.direct else None,
                 "note": "host->device bytes of one step (unique missed rows + keys) over the step time: the floor of the synchronous path",

@@ -423,6 +423,7 @@ int hps_session_last_stats(hps_session_t* s, hps_lookup_stats_t* out) {
     out->unique_keys = s->s->last_unique_key_count();
     out->key_stage_ms = s->s->last_key_stage_ms();
     out->keys_narrowed = s->s->last_keys_narrow() ? 1 : 0;
+    out->key_bytes = s->s->last_key_bytes();
     out->scatter_ms = s->s->last_scatter_ms();
     out->insert_ms = s->s->last_insert_ms();
     return Status::Ok();
@@ -450,7 +451,7 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
     } else if (n == "keys_pinned_check") {
       s->s->set_keys_pinned_check(value != 0);
     } else if (n == "narrow_keys") {
-      s->s->set_narrow_keys(value != 0);
+      s->s->set_narrow_keys(value);
     } else if (n == "host_gather") {
       s->s->set_force_host_gather(value != 0);
     } else if (n == "split_probe") {

@@ -768,6 +768,7 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     else (void)hipGetLastError();  // an unregistered pointer is not an error of ours
   }
   keys_narrow_ = false;
+  key_bytes_ = 8;
   stage_pool_ms_ = stage_enqueue_ms_ = 0.f;
   if (zc_control_ && N <= kSmallRequestKeys && h_keys_dev_) {
     // Small request (at most 1 MB of keys): the probe kernel reads the keys out of page-locked host memory itself — the
@@ -806,17 +807,41 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     //  than ordinary memory on the MI355X boxes — 0.41 against 2.66 G lookups/s in bench.py's pinned-keys legs)
     const bool try_narrow = !direct_dma && narrow_keys_ && narrow_backoff_ == 0 && N >= 4 * kTaskKeys;
     if (narrow_backoff_ > 0) --narrow_backoff_;
-    auto stage = [&](bool narrow) -> Status {
-      std::atomic<int> wide{0};
-      uint32_t* dst32 = reinterpret_cast<uint32_t*>(h_keys_pinned_);
-      uint32_t* dev32 = reinterpret_cast<uint32_t*>(d_keys_);
+    const bool try_pack24 = try_narrow && pack24_keys_ && narrow24_backoff_ == 0;
+    if (narrow24_backoff_ > 0) --narrow24_backoff_;
+    // stage(width): the keys leave at `width` bytes each — 8 as they are, 4 as uint32, 3 packed little-endian.  A narrower
+    // width is optimistic: every task ORs its keys together while it copies, and the first group that saw a key too wide
+    // ends the attempt (the caller restages at the next width; `seen` tells it which one can work).
+    uint64_t seen = 0;
+    auto stage = [&](int width) -> Status {
+      std::atomic<uint64_t> high_or{0};
+      uint8_t* dst8 = reinterpret_cast<uint8_t*>(h_keys_pinned_);
+      uint8_t* dev8 = reinterpret_cast<uint8_t*>(d_keys_);
       auto body = [&](size_t i) {
         const Task& tk = tasks[i];
-        if (!narrow) { memcpy(h_keys_pinned_ + tk.off, tk.src, tk.n * sizeof(int64_t)); return; }
+        if (width == 8) { memcpy(h_keys_pinned_ + tk.off, tk.src, tk.n * sizeof(int64_t)); return; }
         uint64_t high = 0;
-        uint32_t* d = dst32 + tk.off;
-        for (size_t j = 0; j < tk.n; ++j) { const uint64_t k = (uint64_t)tk.src[j]; high |= k; d[j] = (uint32_t)k; }
-        if (high >> 32) wide.store(1, std::memory_order_relaxed);
+        if (width == 4) {
+          uint32_t* d = reinterpret_cast<uint32_t*>(dst8) + tk.off;
+          for (size_t j = 0; j < tk.n; ++j) { const uint64_t k = (uint64_t)tk.src[j]; high |= k; d[j] = (uint32_t)k; }
+        } else {
+          // 4-byte stores 3 bytes apart: each overwrites the spare byte of the one before; the task's last key is written
+          // byte by byte (the byte behind it belongs to another task)
+          uint8_t* d = dst8 + 3 * tk.off;
+          size_t j = 0;
+          for (; j + 1 < tk.n; ++j) {
+            const uint64_t k = (uint64_t)tk.src[j];
+            high |= k;
+            const uint32_t v = (uint32_t)k;
+            memcpy(d + 3 * j, &v, 4);
+          }
+          if (tk.n) {
+            const uint64_t k = (uint64_t)tk.src[j];
+            high |= k;
+            d[3 * j] = (uint8_t)k; d[3 * j + 1] = (uint8_t)(k >> 8); d[3 * j + 2] = (uint8_t)(k >> 16);
+          }
+        }
+        if (high >> (8 * width)) high_or.fetch_or(high, std::memory_order_relaxed);
       };
       size_t g0 = 0;
       while (g0 < tasks.size()) {
@@ -826,28 +851,38 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
         if (g1 - g0 <= 2) for (size_t i = g0; i < g1; ++i) body(i);
         else ThreadPool::Serving().ParallelFor(g1 - g0, [&](size_t i) { body(g0 + i); });
         const auto tp1 = std::chrono::steady_clock::now();
-        if (narrow && wide.load(std::memory_order_relaxed)) return Status::Ok();   // caller restages wide
+        if (width < 8 && (seen = high_or.load(std::memory_order_relaxed)) != 0) return Status::Ok();   // caller restages wider
         const size_t first = tasks[g0].off, count = tasks[g1 - 1].off + tasks[g1 - 1].n - first;
-        if (narrow) HIP_TRY(hipMemcpyAsync(dev32 + first, dst32 + first, count * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-        else HIP_TRY(hipMemcpyAsync(d_keys_ + first, h_keys_pinned_ + first, count * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(dev8 + first * (size_t)width, dst8 + first * (size_t)width, count * (size_t)width, hipMemcpyHostToDevice, stream_));
         const auto tp2 = std::chrono::steady_clock::now();
         stage_pool_ms_ += std::chrono::duration<float, std::milli>(tp1 - tp0).count();
         stage_enqueue_ms_ += std::chrono::duration<float, std::milli>(tp2 - tp1).count();
         g0 = g1;
       }
-      if (narrow) keys_narrow_ = true;
+      key_bytes_ = width;
+      keys_narrow_ = width < 8;
       return Status::Ok();
     };
-    if (try_narrow) {
-      HPS_RETURN_IF_ERROR(stage(true));
-      if (!keys_narrow_) {
-        narrow_backoff_ = 256;   // wide keys in this traffic: plain copies for the next calls
-        HIP_TRY(hipStreamSynchronize(stream_));   // narrowed groups already in flight read the staging buffer we are about to rewrite
+    key_bytes_ = 8;
+    bool staged = false;
+    if (try_pack24) {
+      HPS_RETURN_IF_ERROR(stage(3));
+      staged = keys_narrow_;
+      if (!staged) {
+        narrow24_backoff_ = 256;   // keys of more than 24 bits in this traffic
+        HIP_TRY(hipStreamSynchronize(stream_));   // groups already in flight read the staging buffer we are about to rewrite
       }
     }
-    if (!keys_narrow_) {
+    if (!staged && try_narrow && (seen >> 32) == 0) {
+      seen = 0;
+      HPS_RETURN_IF_ERROR(stage(4));
+      staged = keys_narrow_;
+      if (!staged) HIP_TRY(hipStreamSynchronize(stream_));
+    }
+    if (!staged) {
+      if (try_narrow) narrow_backoff_ = 256;   // wide (or negative) keys in this traffic: plain copies for the next calls
       if (direct_dma) HIP_TRY(hipMemcpyAsync(d_keys_, base, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
-      else HPS_RETURN_IF_ERROR(stage(false));
+      else HPS_RETURN_IF_ERROR(stage(8));
     }
   }
   key_stage_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
@@ -885,6 +920,7 @@ Status LookupSession::lookup_from_device(const int64_t* d_keys_flat, float* cons
   HIP_TRY(hipSetDevice(device_));
   key_stage_ms_ = 0.f;
   keys_narrow_ = false;
+  key_bytes_ = 8;
   return TimedLookupDevice(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
 }
 
@@ -910,7 +946,9 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   CallDesc& c = *h_call_;
   c.num_tables = (uint32_t)T;
   c.keys = d_keys_flat;
-  c.keys32 = (keys_narrow_ && d_keys_flat == d_keys_) ? reinterpret_cast<const uint32_t*>(d_keys_) : nullptr;
+  const bool staged_narrow = keys_narrow_ && d_keys_flat == d_keys_;
+  c.keys32 = (staged_narrow && key_bytes_ == 4) ? reinterpret_cast<const uint32_t*>(d_keys_) : nullptr;
+  c.keys24 = (staged_narrow && key_bytes_ == 3) ? reinterpret_cast<const uint8_t*>(d_keys_) : nullptr;
   uint64_t N = 0;
   uint32_t tiles = 0;
   // Small requests get smaller tiles (a tile = one workgroup of the probe: a 28,672-key request in 1,024-key tiles would

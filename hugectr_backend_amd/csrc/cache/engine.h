@@ -222,8 +222,9 @@ class LookupSession {
   float last_scatter_ms() const { return last_scatter_ms_; }   // miss-scatter kernel of the last call (last chunk)
   float last_insert_ms() const { return last_insert_ms_; }     // cache-insert kernel of the last call (last chunk)
   void set_keys_pinned_check(bool b) { keys_pinned_hint_ = b ? 1 : 0; }
-  void set_narrow_keys(bool b) { narrow_keys_ = b; narrow_backoff_ = 0; }
+  void set_narrow_keys(int mode) { narrow_keys_ = mode != 0; pack24_keys_ = mode == 1; narrow_backoff_ = 0; narrow24_backoff_ = 0; }   // 0 off, 1 uint32 + 3-byte packing, 2 uint32 only
   bool last_keys_narrow() const { return keys_narrow_; }
+  int last_key_bytes() const { return key_bytes_; }   // bytes per key the last host-keys call moved over PCIe: 8, 4 or 3
   float last_gpu_call_ms() const { return last_gpu_call_ms_; }  // first kernel to last of the last call (HIP events)
   // host wall-clock phases of the last call (ms): [0] enqueue -> miss counts known, [1] parameter-server
   // gather, [2] H2D + scatter + insert until the stream drained, [3] whole call
@@ -263,8 +264,11 @@ class LookupSession {
   float stage_pool_ms_ = 0.f, stage_enqueue_ms_ = 0.f;   // key staging: time in the pool loops / in the H2D enqueues
   float key_stage_ms_ = 0.f;      // host side of lookup(): staging the keys and enqueueing their H2D copies
   bool narrow_keys_ = true;       // option "narrow_keys": stage pageable keys as uint32 when they all fit
+  bool pack24_keys_ = true;       // ... and at 3 bytes each when they all fit 24 bits (option value 2 turns only this off)
   bool keys_narrow_ = false;      // this call's staged keys are uint32
   int narrow_backoff_ = 0;        // calls left before narrowing is tried again after a wide key was seen
+  int narrow24_backoff_ = 0;      // the same for the 3-byte packing after a key of 25..32 bits
+  int key_bytes_ = 8;
   int keys_pinned_hint_ = 1;      // 1: flat key arrays in page-locked memory are DMA'd in place (option "keys_pinned_check")
   Status TimedLookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T);
 

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   const TableCacheDev tb = tables[td.table];
   const uint32_t n = td.count;
   const uint32_t tid = threadIdx.x;
-  const uint32_t* __restrict__ keys32 = call->keys32;   // wave-uniform: one of the two loops below
+  const uint32_t* __restrict__ keys32 = call->keys32;   // wave-uniform: one of the three loads below
+  const uint8_t* __restrict__ keys24 = call->keys24;
   const int64_t* __restrict__ keys = call->keys + td.begin;
   const uint32_t epoch = call->epoch;
   const uint32_t stamp_mask = call->stamp_mask;
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
     const uint32_t j = tid + (uint32_t)q * kThreads;
-    if (keys32) k[q] = j < n ? (int64_t)(uint64_t)keys32[td.begin + j] : HPS_EMPTY_KEY;
+    if (keys24) {
+      const uint8_t* p = keys24 + 3ull * (td.begin + j);   // consecutive lanes read consecutive 3-byte keys
+      k[q] = j < n ? (int64_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) : HPS_EMPTY_KEY;
+    } else if (keys32) k[q] = j < n ? (int64_t)(uint64_t)keys32[td.begin + j] : HPS_EMPTY_KEY;
     else k[q] = j < n ? keys[j] : HPS_EMPTY_KEY;
   }
 #pragma unroll

@@ -75,7 +75,7 @@ class LookupStats(C.Structure):
     _fields_ = [("misses", C.c_uint64), ("unique_misses", C.c_uint64), ("async_insert", C.c_int32),
                 ("probe_gather_ms", C.c_float), ("phase_ms", C.c_float * 4), ("gpu_call_ms", C.c_float),
                 ("hit_gather_ms", C.c_float), ("unique_keys", C.c_uint64), ("key_stage_ms", C.c_float),
-                ("scatter_ms", C.c_float), ("insert_ms", C.c_float), ("keys_narrowed", C.c_int32)]
+                ("scatter_ms", C.c_float), ("insert_ms", C.c_float), ("keys_narrowed", C.c_int32), ("key_bytes", C.c_int32)]
 
 
 def _load() -> C.CDLL:

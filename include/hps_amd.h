@@ -87,7 +87,8 @@ typedef struct hps_lookup_stats {
   float key_stage_ms;      /* hps_session_lookup: host time spent staging the keys and enqueueing their H2D copies */
   float scatter_ms;        /* HIP-event time of the miss-scatter kernel (option "timing"=1; last staging chunk) */
   float insert_ms;         /* HIP-event time of the cache-insert kernel (option "timing"=1; last staging chunk) */
-  int32_t keys_narrowed;   /* 1: the call's pageable keys all fitted 32 bits and crossed PCIe as uint32 */
+  int32_t keys_narrowed;   /* 1: the call's pageable keys all fitted 32 bits and crossed PCIe narrower than 8 bytes */
+  int32_t key_bytes;       /* bytes per key that crossed PCIe in the last host-keys call: 8, 4 (uint32) or 3 (packed, keys < 2^24) */
 } hps_lookup_stats_t;
 
 const char* hps_last_error(void);

@@ -522,7 +522,7 @@ def test_pageable_keys_cross_pcie_as_uint32_when_they_fit():
     q = np.concatenate([rng.choice(tables[0][0], nk[0]), rng.choice(big[100:], nk[1])]).astype(np.int64)
     q[rng.integers(0, q.size, 5000)] = (1 << 32) - 1 - rng.integers(0, 1000, 5000)      # absent, but 32-bit
     out = s.lookup(q, nk).cpu().numpy()
-    assert s.last_stats().keys_narrowed == 1
+    assert s.last_stats().keys_narrowed == 1 and s.last_stats().key_bytes == 4   # 3-byte packing tried first, keys of 32 bits seen
     assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, nk, [0.0, 0.0])))
     q2 = q.copy()
     q2[nk[0] + 123_456] = big[7]      # one key of 41 bits in the last staging group
@@ -577,3 +577,41 @@ def test_control_words_by_kernels_or_by_copies_same_rows(direct, monkeypatch):
                 out = s.lookup(keys, nk).cpu().numpy()
                 assert np.array_equal(_bits(out), _bits(ref)), (zc, nk, miss, rep)
         s.close()
+
+
+def test_pageable_keys_below_2_to_24_cross_pcie_at_three_bytes():
+    """Keys that all fit 24 bits are packed at 3 bytes each while staging; one key of 25..32 bits anywhere makes that call use
+    uint32 (and the session stops trying the packing for a while); exact rows either way, also when a table's slice starts
+    at an odd byte offset of the packed array."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(24)
+    tables = make_tables([(70000, 16), (70000, 8), (500, 4)])
+    keys1 = tables[1][0].copy()
+    keys1[:50] += 1 << 27            # a few keys of table 1 need 28 bits
+    tables[1] = (keys1, tables[1][1])
+    ps, cache, s = _mk("pack24", tables, maxcat=[1, 1, 1], gpucacheper=0.3, max_batch=400_000)
+    nk = [200_001, 180_003, 333]
+    small = [tables[0][0], keys1[50:], tables[2][0]]
+    q = np.concatenate([rng.choice(k, n) for k, n in zip(small, nk)]).astype(np.int64)
+    q[rng.integers(0, q.size, 3000)] = (1 << 24) - 1 - rng.integers(0, 500, 3000)       # absent, 24 bits
+    for rep in range(2):
+        out = s.lookup(q, nk).cpu().numpy()
+        st = s.last_stats()
+        assert (st.keys_narrowed, st.key_bytes) == (1, 3)
+        assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, nk, [0.0] * 3)))
+    q2 = q.copy()
+    q2[nk[0] + 150_000] = keys1[3]       # 28 bits, in a late staging group of table 1
+    out = s.lookup(q2, nk).cpu().numpy()
+    assert s.last_stats().key_bytes == 4
+    assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q2, nk, [0.0] * 3)))
+    out = s.lookup(q, nk).cpu().numpy()                # packing is not tried again right away
+    assert s.last_stats().key_bytes == 4
+    assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, nk, [0.0] * 3)))
+    s.set_option("narrow_keys", 1)                     # re-arms it
+    out = s.lookup(q, nk).cpu().numpy()
+    assert s.last_stats().key_bytes == 3
+    q3 = q.copy()
+    q3[7] = 1 << 40
+    out = s.lookup(q3, nk).cpu().numpy()
+    assert s.last_stats().key_bytes == 8 and s.last_stats().keys_narrowed == 0
+    assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q3, nk, [0.0] * 3)))
