@@ -650,11 +650,15 @@ __global__ void hps_cache_query_kernel(TableCacheDev tb, const int64_t* __restri
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-// Grid of the gather kernel: every wave walks 64-key chunks, all blocks resident at once (8 blocks of 4 waves per CU).
+// Grid of the gather kernel: one 64-key chunk per wave up to 32 workgroups per CU (config 2: 6,656 workgroups, each wave one
+// chunk), a grid-stride walk beyond that.  Round 2 first ran it persistent (8 resident workgroups per CU walking all chunks):
+// the same speed (243-246 against 246-249 us), but with every wave slot held until the kernel's end another session's scatter
+// kernel that arrived meanwhile could take the whole rest of the gather (max 194-245 us against 55-70 us with this grid;
+// profiles/round2/kernel_time_distribution_within_runs.txt).
 uint32_t GatherGridBlocks(uint64_t N, int cu_count) {
   const uint64_t chunks = (N + 63) / 64;
   const uint64_t want = (chunks + 3) / 4;
-  const uint64_t cap = (uint64_t)cu_count * 8;
+  const uint64_t cap = (uint64_t)cu_count * 32;
   return (uint32_t)(want < cap ? (want ? want : 1) : cap);
 }
 
