@@ -1,5 +1,6 @@
 #include "engine.h"
 #include "copy_engines.h"
+#include "key_pack.h"
 
 #include <hip/hip_runtime.h>
 
@@ -820,27 +821,8 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
       auto body = [&](size_t i) {
         const Task& tk = tasks[i];
         if (width == 8) { memcpy(h_keys_pinned_ + tk.off, tk.src, tk.n * sizeof(int64_t)); return; }
-        uint64_t high = 0;
-        if (width == 4) {
-          uint32_t* d = reinterpret_cast<uint32_t*>(dst8) + tk.off;
-          for (size_t j = 0; j < tk.n; ++j) { const uint64_t k = (uint64_t)tk.src[j]; high |= k; d[j] = (uint32_t)k; }
-        } else {
-          // 4-byte stores 3 bytes apart: each overwrites the spare byte of the one before; the task's last key is written
-          // byte by byte (the byte behind it belongs to another task)
-          uint8_t* d = dst8 + 3 * tk.off;
-          size_t j = 0;
-          for (; j + 1 < tk.n; ++j) {
-            const uint64_t k = (uint64_t)tk.src[j];
-            high |= k;
-            const uint32_t v = (uint32_t)k;
-            memcpy(d + 3 * j, &v, 4);
-          }
-          if (tk.n) {
-            const uint64_t k = (uint64_t)tk.src[j];
-            high |= k;
-            d[3 * j] = (uint8_t)k; d[3 * j + 1] = (uint8_t)(k >> 8); d[3 * j + 2] = (uint8_t)(k >> 16);
-          }
-        }
+        const uint64_t high = width == 4 ? PackKeys32(tk.src, tk.n, reinterpret_cast<uint32_t*>(dst8) + tk.off)
+                                         : PackKeys24(tk.src, tk.n, dst8 + 3 * tk.off);
         if (high >> (8 * width)) high_or.fetch_or(high, std::memory_order_relaxed);
       };
       size_t g0 = 0;

@@ -1,0 +1,41 @@
+// Narrowing a request's int64 keys while they are copied into the page-locked staging buffer (engine.cpp, lookup()): the keys
+// cross PCIe at the width they need.  Each routine copies one task's keys and returns the OR of everything it saw, so that the
+// caller learns from one pass whether the width was enough (a negative key has its top bits set and fails every narrow width).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+namespace hps {
+
+// dst[j] = (uint32_t)src[j]
+inline uint64_t PackKeys32(const int64_t* src, size_t n, uint32_t* dst) {
+  uint64_t high = 0;
+  for (size_t j = 0; j < n; ++j) { const uint64_t k = (uint64_t)src[j]; high |= k; dst[j] = (uint32_t)k; }
+  return high;
+}
+
+// 3 bytes per key, little-endian, dst[3j .. 3j+2]; writes exactly 3*n bytes.  4-byte stores 3 bytes apart, each overwriting the
+// spare byte of the one before; the last key is written byte by byte (the byte behind it belongs to somebody else).
+inline uint64_t PackKeys24(const int64_t* src, size_t n, uint8_t* dst) {
+  uint64_t high = 0;
+  if (n == 0) return 0;
+  size_t j = 0;
+  for (; j + 1 < n; ++j) {
+    const uint64_t k = (uint64_t)src[j];
+    high |= k;
+    const uint32_t v = (uint32_t)k;
+    memcpy(dst + 3 * j, &v, 4);
+  }
+  const uint64_t k = (uint64_t)src[j];
+  high |= k;
+  dst[3 * j] = (uint8_t)k;
+  dst[3 * j + 1] = (uint8_t)(k >> 8);
+  dst[3 * j + 2] = (uint8_t)(k >> 16);
+  return high;
+}
+
+// what the probe kernel reads back (kernels.hip, K_P)
+inline uint32_t UnpackKey24(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+
+}  // namespace hps

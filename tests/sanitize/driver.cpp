@@ -14,6 +14,7 @@
 #include <thread>
 #include <vector>
 
+#include "cache/key_pack.h"
 #include "common/config.h"
 #include "common/hps_hash.h"
 #include "ps/host_table.h"
@@ -231,9 +232,39 @@ static int run_tiered() {
   return 0;
 }
 
+// Key narrowing of the lookup's staging step (csrc/cache/key_pack.h) on buffers of exactly the size it may touch: under ASan
+// a byte too many is a heap-buffer-overflow.  Task boundaries as engine.cpp cuts them: consecutive tasks pack into one array.
+static int run_keypack() {
+  std::mt19937_64 rng(24);
+  for (size_t n : {size_t(0), size_t(1), size_t(2), size_t(3), size_t(31), size_t(32768), size_t(100001)}) {
+    std::vector<int64_t> keys(n);
+    for (auto& k : keys) k = (int64_t)(rng() & 0xFFFFFFu);
+    std::unique_ptr<uint8_t[]> packed(new uint8_t[3 * n + (n ? 0 : 1)]);
+    // three tasks of uneven size, as if three pool threads packed their ranges side by side
+    const size_t cut1 = n / 3, cut2 = n / 3 + n / 2 > n ? n : n / 3 + n / 2;
+    uint64_t high = 0;
+    high |= hps::PackKeys24(keys.data(), cut1, packed.get());
+    high |= hps::PackKeys24(keys.data() + cut2, n - cut2, packed.get() + 3 * cut2);   // out of order on purpose
+    high |= hps::PackKeys24(keys.data() + cut1, cut2 - cut1, packed.get() + 3 * cut1);
+    CHECK((high >> 24) == 0);
+    for (size_t j = 0; j < n; ++j) CHECK(hps::UnpackKey24(packed.get() + 3 * j) == (uint32_t)keys[j]);
+    std::unique_ptr<uint32_t[]> p32(new uint32_t[n + (n ? 0 : 1)]);
+    CHECK((hps::PackKeys32(keys.data(), n, p32.get()) >> 32) == 0);
+    for (size_t j = 0; j < n; ++j) CHECK(p32[j] == (uint32_t)keys[j]);
+    if (n >= 3) {
+      keys[n / 2] = (int64_t)1 << 27;
+      CHECK((hps::PackKeys24(keys.data(), n, packed.get()) >> 24) != 0 && (hps::PackKeys32(keys.data(), n, p32.get()) >> 32) == 0);
+      keys[n / 2] = -5;
+      CHECK((hps::PackKeys24(keys.data(), n, packed.get()) >> 24) != 0 && (hps::PackKeys32(keys.data(), n, p32.get()) >> 32) != 0);
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "all";
   int rc = 0;
+  if (what == "keypack" || what == "all") rc |= run_keypack();
   if (what == "tiered" || what == "all") rc |= run_tiered();
   if (what == "parse" || what == "all") rc |= run_parse();
   if (what == "table" || what == "all") rc |= run_table();

@@ -48,7 +48,7 @@ def _run(binary, what, env_extra):
         report[-3000:]
 
 
-@pytest.mark.parametrize("what", ["parse", "table", "threads", "tiered"])
+@pytest.mark.parametrize("what", ["parse", "table", "threads", "tiered", "keypack"])
 def test_host_side_under_asan_ubsan(binaries, what):
     # leak checking is off: the HIP runtime library keeps process-lifetime allocations of its own
     _run(binaries["asan"], what, {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
