@@ -64,7 +64,6 @@ def parse_args():
     ap.add_argument("--distinct-batches", type=int, default=0, help="0: one fresh batch per step")
     ap.add_argument("--probe-variant", type=int, default=1004, help="probe kernel variant U + 100*no_dedup + 1000*wide (tools/kbench.py)")
     ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
-    ap.add_argument("--stamp-every", type=int, default=1, help="LRU stamps rewritten for one hit in N (power of two; 1 = every hit, exact recency)")
     ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
     ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys narrower when every key of the request fits: 1 = 3-byte packing or uint32, 2 = uint32 only, 0 = off")
     ap.add_argument("--direct", type=int, default=-1,
@@ -434,7 +433,6 @@ def main():
         s.set_option("split_probe", 1 if split else 0)
         s.set_option("narrow_keys", a.narrow_keys)
         s.set_option("chain_gather", a.chain_gather)
-        s.set_option("stamp_every", a.stamp_every)
 
     # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
     C = int(np.ceil(a.cache_frac * R))

@@ -441,9 +441,10 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       if (value < 0 || (u != 2 && u != 4 && u != 8) || (value / 100) % 10 > 1 || value / 1000 > 1)
         return Error(Code::kInvalidArg, "probe_variant must be U + 100*no_dedup + 1000*wide with U in {2,4,8}");
       s->s->set_probe_variant(value);
-    } else if (n == "stamp_every") {
-      if (value < 1 || value > 1024) return Error(Code::kInvalidArg, "stamp_every must be 1..1024");
-      s->s->set_stamp_every((uint32_t)value);
+    } else if (n == "exclusive_kernels") {
+      s->s->set_exclusive_kernels(value != 0);
+    } else if (n == "narrow_publish") {
+      s->s->set_narrow_publish(value != 0);
     } else if (n == "chain_gather") {
       s->s->set_chain_gather(value != 0);
     } else if (n == "xcd_walk") {

@@ -1,10 +1,22 @@
 // Plain-old-data shared between host code and the HIP kernels of the GPU embedding cache.
 //
-// Data layout in HBM (DESIGN.md §Layout):
-//   per table t:  bucket_keys[num_buckets][16] int64   one bucket = 128 B = one L2 line
-//                 stamps     [num_buckets][16] uint32  LRU epoch of last use (0 = never used)
-//                 rows       [num_buckets*16][D] fp32  slot s owns rows[s*D .. s*D+D)
+// Data layout in HBM (DESIGN.md §3.2):
+//   per table t:  lines[num_buckets][16] 8-byte words  one bucket = ONE 128-B line (= one L2 line):
+//                     words 0..13   the bucket's 14 keys (HPS_EMPTY_KEY = free slot)
+//                     word  14      recency stamps of slots 0..7, one byte each
+//                     word  15      recency stamps of slots 8..13 (bytes 0..5), bytes 6..7 unused
+//                 rows [num_buckets*14][D] fp32        slot s owns rows[s*D .. s*D+D)
 // A key lives in exactly one bucket: hps_bucket_of(key, num_buckets) (common/hps_hash.h).
+//
+// Recency lives INSIDE the line the probe has to read anyway (round 2 kept 32-bit stamps in a second array: every hit
+// cost a 4-B store into a 277-MB array, and the micro-benchmark tools/micro/probe_width.hip says such a store costs more
+// than the probe itself: 1.1 M probes 30 us, with the store 79 us, with a 1-B store into the probed line 63 us).
+// A stamp is the call counter of the cache in units of 2^age_shift calls, modulo kStampMod = 255 ("stamp8"; the value
+// 255 marks a slot that a group of a running insert kernel owns).  A hit rewrites its
+// slot's stamp only when it differs from the current unit — the comparison is free, the byte came with the keys — so a
+// key that is hit call after call costs one store per 2^age_shift calls.  age = (now8 - stamp8) mod 255; the insert
+// kernel evicts the slot of greatest age and, while it is at it, pulls stamps older than kAgeSaturate units back to
+// exactly that age so that they cannot wrap around and look young.
 #pragma once
 #include <stdint.h>
 
@@ -12,7 +24,13 @@
 
 namespace hps {
 
-constexpr int kBucketSlots = HPS_BUCKET_SLOTS;  // 16
+constexpr int kBucketSlots = HPS_BUCKET_SLOTS;  // 14 keys per bucket line
+constexpr int kLineWords = 16;                   // 8-byte words per bucket line (14 keys + 2 words of stamps)
+constexpr int kProbeLanes = 8;                   // lanes that share one probe: 16 B each
+constexpr uint32_t kStampMod = 255;              // stamps live in [0, 255)
+constexpr uint32_t kStampClaimed = 255;          // stamp byte of a slot owned by a group of the running insert kernel
+constexpr uint32_t kStampFree = 128;             // stamp of the never-used slots of a fresh cache (the warm-up runs in unit 0)
+constexpr uint32_t kAgeSaturate = 192;           // stamps older than this many units are pulled back to it by the insert kernel
 constexpr int kMaxTables = 256;                  // per model
 constexpr int kProbeBlockThreads = 256;
 
@@ -46,14 +64,13 @@ inline constexpr uint32_t AccTableWord(uint32_t t, int what) { return (uint32_t)
 constexpr int32_t kSlotMiss = -1;  // transient, inside the probe kernel only
 
 struct TableCacheDev {
-  int64_t* bucket_keys;
-  uint32_t* stamps;
+  int64_t* lines;  // [num_buckets][kLineWords]
   float* rows;
   uint32_t num_buckets;
   uint32_t dim;
   float default_value;
   uint32_t flags;  // bit0: static cache (no stamp writes, no inserts)
-  uint32_t* claim; // [num_buckets*16] scratch word per slot for the unique-hit count (nullptr until a session needs it)
+  uint32_t* claim; // [num_buckets*14] scratch word per slot for the unique-hit count (nullptr until a session needs it)
 };
 
 // One probe tile: keys [begin, begin + count) of the call's flat key array, all of table `table`.
@@ -72,6 +89,7 @@ struct CallWork {
   uint32_t* tile_cnt;        // [num_tiles*4]
   int64_t* miss_key;         // tile regions: key of the tile's r-th missed representative
   int32_t* sent_i;           // tile regions: global index of every missed key of the tile, as sent
+  int32_t* sent_m;           // tile regions: the same keys' entry m of the tile's miss list (slot[sent_i[r]] == -2 - sent_m[r])
   int32_t* hit_i;            // tile regions: global index of the tile's hit representatives (unique-hit count only)
   int32_t* hit_s;            // tile regions: their slots
   int32_t* rep_of;           // tile regions: m -> m of the call-wide representative of the same (table, key)
@@ -81,6 +99,8 @@ struct CallWork {
   uint32_t* acc;             // accumulator block, layout above
   int64_t* uniq_keys;        // [N] unique missed keys of table t at [key_start[t], key_start[t] + count)
   int64_t* uniq_keys_host;   // the same array in host-mapped pinned memory (the host parameter server reads it)
+  uint32_t* uniq_keys_host32; // not null: the call's keys all fit 32 bits (the request was narrowed) and the host wants
+                              // the unique missed keys as uint32 — half the bytes of the zero-copy stores over PCIe
 };
 
 
@@ -89,8 +109,8 @@ struct CallWork {
 // (model_instance_state.cpp:180-193).
 struct CallDesc {
   uint32_t num_tables;
-  uint32_t epoch;           // LRU epoch of this call (monotonic per cache)
-  uint32_t stamp_mask;      // a hit slot's LRU stamp is rewritten when (hash(slot, epoch) & stamp_mask) == 0: 0 = every hit
+  uint32_t epoch;           // call counter of the cache (monotonic)
+  uint32_t stamp8;          // (epoch >> age_shift) & 255: the recency stamp hits of this call leave in their slots
   uint64_t total_keys;      // N = sum n_t
   const int64_t* keys;      // flat, table-major, device
   const uint32_t* keys32;   // not null: the same keys narrowed to 32 bits (every key of the call is in [0, 2^32); then

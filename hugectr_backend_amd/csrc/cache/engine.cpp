@@ -120,30 +120,10 @@ Status EmbeddingCache::EnsureClaimWords() {
   return Status::Ok();
 }
 
-// LRU epochs: one per lookup call, 32 bits.  Long before the counter wraps (at 10 k lookups/s that is five
-// days) all stamps are folded back so that "smaller = older" keeps holding.  Rare and heavy-handed on purpose:
-// the device is drained, every table's stamps are rewritten, the counter restarts above the kept span.
-constexpr uint32_t kEpochRenormAt = 0xF0000000u;
-constexpr uint32_t kEpochKeepSpan = 1u << 30;
-
-uint32_t EmbeddingCache::NextEpoch() {
-  const uint32_t e = epoch_.fetch_add(1, std::memory_order_relaxed) + 1;
-  if (e >= kEpochRenormAt) {
-    std::lock_guard<std::mutex> lk(order_mu_);
-    const uint32_t cur = epoch_.load(std::memory_order_relaxed);
-    if (cur >= kEpochRenormAt) {
-      (void)hipSetDevice(cfg_.device_id_);
-      (void)hipDeviceSynchronize();
-      const uint32_t keep_from = cur - kEpochKeepSpan;
-      for (const TableCacheDev& tb : h_tables_)
-        (void)LaunchCacheRenorm(tb.stamps, (uint64_t)tb.num_buckets * kBucketSlots, keep_from, nullptr);
-      (void)hipDeviceSynchronize();
-      epoch_.store(kEpochKeepSpan + 2, std::memory_order_relaxed);
-    }
-    return epoch_.fetch_add(1, std::memory_order_relaxed) + 1;
-  }
-  return e;
-}
+// The call counter of the cache: one tick per lookup call (and per background insert), 32 bits, wraps freely.  What the
+// kernels see of it is Stamp8(): the counter in units of 2^age_shift calls modulo kStampMod (device_types.h).  At the
+// 32-bit wrap the stamps jump once (2^32 is not a multiple of 255 units): a blip in the eviction order, nothing else.
+uint32_t EmbeddingCache::NextEpoch() { return epoch_.fetch_add(1, std::memory_order_relaxed) + 1; }
 
 void EmbeddingCache::BeginRead(hipStream_t stream) {
   order_mu_.lock();
@@ -189,6 +169,20 @@ void EmbeddingCache::ForgetFetch(hipEvent_t fetch_done) {
   std::lock_guard<std::mutex> lk(fetch_mu_);
   if (last_fetch_ == fetch_done) { last_fetch_ = nullptr; last_fetch_stream_ = nullptr; }
 }
+void EmbeddingCache::LaneEnter(hipStream_t stream) {
+  lane_mu_.lock();
+  if (last_lane_ != nullptr && last_lane_stream_ != stream) (void)hipStreamWaitEvent(stream, last_lane_, 0);
+}
+void EmbeddingCache::LaneLeave(hipStream_t stream, hipEvent_t done) {
+  (void)hipEventRecord(done, stream);
+  last_lane_ = done;
+  last_lane_stream_ = stream;
+  lane_mu_.unlock();
+}
+void EmbeddingCache::ForgetLane(hipEvent_t done) {
+  std::lock_guard<std::mutex> lk(lane_mu_);
+  if (last_lane_ == done) { last_lane_ = nullptr; last_lane_stream_ = nullptr; }
+}
 void EmbeddingCache::BeginWrite(hipStream_t stream) {
   order_mu_.lock();
   if (has_write_) (void)hipStreamWaitEvent(stream, last_write_, 0);
@@ -221,6 +215,10 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   static_ = p.embedding_cache_type == EmbeddingCacheType::Static;
+  if (const char* e = std::getenv("HPS_LRU_AGE_SHIFT")) {   // A/B switch: recency unit = 2^shift calls (default 4 calls)
+    const long v = std::strtol(e, nullptr, 10);
+    if (v >= 0 && v <= 8) age_shift_ = (uint32_t)v;
+  }
 
   cfg_.num_emb_table_ = T;
   cfg_.use_gpu_embedding_cache_ = true;
@@ -241,12 +239,11 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
       return Error(Code::kUnsupported, "model '", model, "' table ", t, ": cache of ", slots,
                    " slots exceeds the 2^31-slot limit of one table");
     TableCacheDev& tb = h_tables_[t];
-    int64_t* dk = nullptr; uint32_t* ds = nullptr; float* dr = nullptr;
-    HPS_RETURN_IF_ERROR(DevAlloc(&dk, slots)); allocations_.push_back(dk);
-    HPS_RETURN_IF_ERROR(DevAlloc(&ds, slots)); allocations_.push_back(ds);
+    int64_t* dl = nullptr; float* dr = nullptr;
+    HPS_RETURN_IF_ERROR(DevAlloc(&dl, buckets * (size_t)kLineWords)); allocations_.push_back(dl);
     HPS_RETURN_IF_ERROR(DevAlloc(&dr, slots * (size_t)D)); allocations_.push_back(dr);
-    HIP_TRY(LaunchCacheClear(dk, ds, slots, nullptr));
-    tb.bucket_keys = dk; tb.stamps = ds; tb.rows = dr;
+    HIP_TRY(LaunchCacheClear(dl, buckets, kStampFree, nullptr));
+    tb.lines = dl; tb.rows = dr;
     tb.num_buckets = (uint32_t)buckets;
     tb.dim = D;
     tb.default_value = p.default_value_for_each_table[t];
@@ -268,6 +265,7 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
     HPS_RETURN_IF_ERROR(SyncDirectIndex(tables));
   }
 
+  epoch_.store((1u << age_shift_) - 1u);
   if (!p.init_ec) return Status::Ok();
 
   // ---- warm-up: the first `capacity` rows of each table in file order ----
@@ -293,7 +291,7 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   HPS_RETURN_IF_ERROR(DevAlloc(&d_rows, chunk_rows * maxD));
   std::vector<int64_t> hk;
   std::vector<float> hr;
-  const uint32_t epoch = 1;
+  const uint32_t epoch = 0;   // unit 0; lookups start in unit 1 (below), so that the warm rows are evictable from the first call
   Status st = Status::Ok();
   for (size_t t = 0; t < T && st.ok(); ++t) {
     const HostTable& ht = *tables[t];
@@ -326,7 +324,7 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
       for (size_t u = 0; u <= T; ++u) md.useg_start[u] = u > t ? m : 0;
       md.chunk_lo[t] = 0; md.chunk_hi[t] = (uint32_t)m; md.stage_off[t] = 0;
       if (hipMemcpy(d_md, &md, sizeof md, hipMemcpyHostToDevice) != hipSuccess) { st = Error(Code::kInternal, "cache warm-up: H2D copy failed"); break; }
-      const hipError_t e = LaunchCacheInsert(d_warm, (uint32_t)T, d_md, m, d_zero_ks, d_keys, d_rows, nullptr, epoch,
+      const hipError_t e = LaunchCacheInsert(d_warm, (uint32_t)T, d_md, m, d_zero_ks, d_keys, d_rows, nullptr, Stamp8(epoch),
                                              d_stats, cu_count_, nullptr);
       if (e != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         st = Error(Code::kInternal, "cache warm-up: insert kernel failed: ", hipGetErrorString(e));
@@ -339,8 +337,8 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   AddStatLines(lines.data());
   (void)hipFree(d_keys); (void)hipFree(d_rows); (void)hipFree(d_md); (void)hipFree(d_zero_ks); (void)hipFree(d_stats);
   (void)hipFree(d_warm);
-  epoch_.store(1);
-  if (const char* e = std::getenv("HPS_TEST_EPOCH_START")) epoch_.store((uint32_t)std::strtoul(e, nullptr, 0));  // test hook: epoch wrap
+  epoch_.store((1u << age_shift_) - 1u);
+  if (const char* e = std::getenv("HPS_TEST_EPOCH_START")) epoch_.store((uint32_t)std::strtoul(e, nullptr, 0));  // test hook: counter wrap
   return st;
 }
 
@@ -501,7 +499,7 @@ Status EmbeddingCache::FinishDirectInsert() {
   if (e != hipSuccess) return Error(Code::kInternal, "direct background fetch launch failed: ", hipGetErrorString(e));
   HIP_TRY(hipStreamSynchronize(I.stream));
   BeginWrite(I.stream);
-  e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, I.unique_total, I.d_key_start, I.d_keys, I.d_staging, I.d_found, epoch,
+  e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, I.unique_total, I.d_key_start, I.d_keys, I.d_staging, I.d_found, Stamp8(epoch),
                         I.d_acc, cu_count_, I.stream);
   EndWrite(I.stream);
   if (e != hipSuccess) return Error(Code::kInternal, "direct background insert launch failed: ", hipGetErrorString(e));
@@ -530,12 +528,13 @@ Status EmbeddingCache::Query(uint32_t table, const int64_t* h_keys, size_t n, in
 Status EmbeddingCache::DumpKeys(uint32_t table, std::vector<int64_t>* keys) {
   if (table >= num_tables()) return Error(Code::kInvalidArg, "table index out of range");
   HIP_TRY(hipSetDevice(cfg_.device_id_));
-  const size_t slots = (size_t)h_tables_[table].num_buckets * kBucketSlots;
-  std::vector<int64_t> all(slots);
+  const size_t words = (size_t)h_tables_[table].num_buckets * kLineWords;
+  std::vector<int64_t> all(words);
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(all.data(), h_tables_[table].bucket_keys, slots * sizeof(int64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(all.data(), h_tables_[table].lines, words * sizeof(int64_t), hipMemcpyDeviceToHost));
   keys->clear();
-  for (int64_t k : all) if (k != HPS_EMPTY_KEY) keys->push_back(k);
+  for (size_t i = 0; i < words; ++i)
+    if (i % kLineWords < (size_t)kBucketSlots && all[i] != HPS_EMPTY_KEY) keys->push_back(all[i]);
   return Status::Ok();
 }
 
@@ -552,11 +551,12 @@ void LookupSession::Release() {
   cache_->ForgetReader(ev_read_);  // our reader event may still be registered with the cache
   cache_->ForgetReader(ev_probe_);
   cache_->ForgetFetch(ev_fetch_);
+  for (hipEvent_t e : ev_lane_) if (e) { cache_->ForgetLane(e); (void)hipEventDestroy(e); }
   auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
   auto dfree = [](void* p) { if (p) (void)hipFree(p); };
   hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_block_); dfree(d_block_); hfree(h_acc_); dfree(d_mode_);
   hfree(h_md_); dfree(d_md_);
-  dfree(work_.slot); dfree(work_.tile_cnt); dfree(work_.miss_key); dfree(work_.sent_i); dfree(work_.hit_i); dfree(work_.hit_s);
+  dfree(work_.slot); dfree(work_.tile_cnt); dfree(work_.miss_key); dfree(work_.sent_i); dfree(work_.sent_m); dfree(work_.hit_i); dfree(work_.hit_s);
   dfree(work_.rep_of); dfree(work_.uidx_of); dfree(work_.set); dfree(work_.uniq_keys);
   hfree(h_mode_);
   hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
@@ -595,6 +595,8 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   for (hipEvent_t* e : {&ev_copy_, &ev_done_, &ev_read_, &ev_fetch_, &ev_probe_, &ev_keys_})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   for (hipEvent_t* e : {&ev_t0_, &ev_t1_, &ev_f0_, &ev_f1_, &ev_c1_, &ev_g0_, &ev_g1_, &ev_s0_, &ev_s1_, &ev_i0_, &ev_i1_}) HIP_TRY(hipEventCreate(e));
+  for (hipEvent_t& e : ev_lane_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (const char* e = std::getenv("HPS_EXCLUSIVE_KERNELS")) exclusive_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switches
   if (const char* e = std::getenv("HPS_XCD_WALK")) xcd_walk_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_PROBE_VARIANT")) probe_variant_ = (int)std::strtol(e, nullptr, 10);
@@ -647,6 +649,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HPS_RETURN_IF_ERROR(DevAlloc(&w.tile_cnt, max_tiles_ * 4));
   HPS_RETURN_IF_ERROR(DevAlloc(&w.miss_key, regions));
   HPS_RETURN_IF_ERROR(DevAlloc(&w.sent_i, regions));
+  HPS_RETURN_IF_ERROR(DevAlloc(&w.sent_m, regions));
   HPS_RETURN_IF_ERROR(DevAlloc(&w.rep_of, regions));
   HPS_RETURN_IF_ERROR(DevAlloc(&w.uidx_of, regions));
   w.hit_i = w.hit_s = nullptr;  // allocated with the first call whose policy needs the unique-key count
@@ -660,6 +663,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   void* dv = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&dv, h_uniq_keys_, 0));
   w.uniq_keys_host = (int64_t*)dv;
+  w.uniq_keys_host32 = nullptr;   // set per call (LookupDevice)
   uniq_miss_.assign(T, 0);
   if (cache_->direct()) {
     // the device sizes the staging layout itself (hps_missdesc_build), so the buffer must hold the worst case:
@@ -951,7 +955,7 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   c.key_start[T] = N;
   c.total_keys = N;
   c.epoch = cache_->NextEpoch();
-  c.stamp_mask = stamp_mask_;
+  c.stamp8 = cache_->Stamp8(c.epoch);
   if (++call_tag_ == 0) {  // 2^32 calls later: entries of the first calls would look like this call's
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemsetAsync(work_.set, 0, (work_.set_mask + 1) * sizeof(unsigned long long), stream_));
@@ -1077,22 +1081,29 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   CallWork wk = work_;
   // device-driven tier with synchronous insertion: nobody on the host reads the unique keys — spare the PCIe writes
   if (use_direct && params_.hit_rate_threshold >= 1.0f) wk.uniq_keys_host = nullptr;
+  // a narrowed request (every key below 2^32, checked while staging) gets its unique missed keys back as uint32
+  uniq_narrow_ = !use_direct && keys_narrow_ && d_keys_flat == d_keys_ && narrow_publish_;
+  wk.uniq_keys_host32 = uniq_narrow_ ? reinterpret_cast<uint32_t*>(wk.uniq_keys_host) : nullptr;
   // (Tried and withdrawn: K_M without the zero-copy host stores — 12 us of its 23 inside a busy link — and a publish kernel
   //  for the keys on the second stream next to K_G.  The persistent K_G owns every CU by the time the publish kernel is
   //  released, so the counts reached the host after the gather: 0.38 instead of 0.22 ms.)
 
   // ---- K_P: tile dedup + probe;  K_M: call-wide unique misses (+ unique hits) ----
   cache_->BeginRead(stream_);
+  if (exclusive_) cache_->LaneEnter(stream_);
   if (timing_) (void)hipEventRecord(ev_t0_, stream_);
   hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, exact, stream_);
   if (e == hipSuccess) e = LaunchMissUnique(d_call_, cache_->device_tables(), wk, exact, stream_);
   if (timing_) (void)hipEventRecord(ev_t1_, stream_);
+  if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[0]);
   // other sessions' probes chain behind ours: behind K_P, and behind K_M too when it still reads the claim words
   (void)hipEventRecord(ev_probe_, stream_);
   auto gather = [&]() -> hipError_t {
+    if (exclusive_) cache_->LaneEnter(stream_);
     if (timing_) (void)hipEventRecord(ev_g0_, stream_);
     const hipError_t ge = LaunchGatherHits(d_call_, cache_->device_tables(), (uint32_t)T, N, w.slot, gather_blocks, all128, xcd_walk_, stream_);
     if (timing_) (void)hipEventRecord(ev_g1_, stream_);
+    if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[1]);
     return ge;
   };
   bool read_open = true;
@@ -1195,7 +1206,12 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
       std::vector<std::vector<int64_t>> job(T);
       for (size_t t = 0; t < T; ++t) {
         if (!table_async_[t]) continue;
-        job[t].assign(h_uniq_keys_ + c.key_start[t], h_uniq_keys_ + c.key_start[t] + uniq_miss_[t]);
+        if (uniq_narrow_) {
+          const uint32_t* k32 = reinterpret_cast<const uint32_t*>(h_uniq_keys_) + c.key_start[t];
+          job[t].assign(k32, k32 + uniq_miss_[t]);
+        } else {
+          job[t].assign(h_uniq_keys_ + c.key_start[t], h_uniq_keys_ + c.key_start[t] + uniq_miss_[t]);
+        }
       }
       ps_->SubmitAsyncInsert(cache_, std::move(job));
     }
@@ -1250,7 +1266,9 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
   uint64_t N2 = 0;
   HPS_RETURN_IF_ERROR(PrepareCall(d_keys_flat, nullptr, n.data(), T, /*probe_only=*/true, &N2));
   const uint32_t epoch = h_call_->epoch;
-  const CallWork& w = work_;
+  CallWork w = work_;
+  w.uniq_keys_host = nullptr;     // direct-only path: nobody on the host reads the unique keys — spare the PCIe stores
+  w.uniq_keys_host32 = nullptr;
   const int cu = cache_->cu_count();
   // bottom MLP first: it needs nothing from the lookup and leaves the stream before the cache is read-locked
   const void* d_bottom = nullptr;
@@ -1284,8 +1302,8 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
     if (est_bytes > (2u << 20)) HIP_TRY(hipStreamSynchronize(stream_));
   }
   cache_->BeginWrite(stream_);
-  e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, N, d_call_->key_start, w.uniq_keys, d_staging_, d_found_, epoch,
-                        d_acc_, cu, stream_);
+  e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, N, d_call_->key_start, w.uniq_keys, d_staging_, d_found_,
+                        cache_->Stamp8(epoch), d_acc_, cu, stream_);
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
@@ -1317,12 +1335,9 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
     if (timing_) (void)hipEventRecord(ev_f1_, fs);
     cache_->EndFetch(fs, ev_fetch_);
   }
-  if (timing_) (void)hipEventRecord(ev_s0_, stream_);
-  if (e == hipSuccess) e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, d_staging_, stream_);
-  if (timing_) (void)hipEventRecord(ev_s1_, stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "direct miss path launch failed: ", hipGetErrorString(e));
-  // Keep the window in which other sessions' probes wait for our writer event down to the insert kernel: drain the
-  // stream first, so the event is recorded behind the insert alone and not behind a millisecond of PCIe fetch.
+  // Keep the window in which other sessions' kernels wait for our scatter (lane) and our writer event down to those two
+  // kernels: drain the stream first, so that their events are not recorded behind a millisecond of PCIe fetch.
   // Small requests skip the drain (their fetch is a few tens of microseconds, less than the host round trip):
   // the estimate is this call's unique-miss count when known, else the previous call's.
   {
@@ -1331,11 +1346,19 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
     const uint64_t est_bytes = (uint64_t)last_unique_ * row_bytes;
     if (est_bytes > (2u << 20)) HIP_TRY(hipStreamSynchronize(stream_));
   }
+  if (exclusive_) cache_->LaneEnter(stream_);
+  if (timing_) (void)hipEventRecord(ev_s0_, stream_);
+  e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, d_staging_, stream_);
+  if (timing_) (void)hipEventRecord(ev_s1_, stream_);
+  if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[2]);
+  if (e != hipSuccess) return Error(Code::kInternal, "direct miss path launch failed: ", hipGetErrorString(e));
   cache_->BeginWrite(stream_);
+  if (exclusive_) cache_->LaneEnter(stream_);
   if (timing_) (void)hipEventRecord(ev_i0_, stream_);
   e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, max_unique, d_call_->key_start, work_.uniq_keys,
-                        d_staging_, d_found_, epoch, d_acc_, cu, stream_);
+                        d_staging_, d_found_, cache_->Stamp8(epoch), d_acc_, cu, stream_);
   if (timing_) (void)hipEventRecord(ev_i1_, stream_);
+  if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[3]);
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
@@ -1438,8 +1461,9 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       for (uint32_t r = lo; r < hi; r += rows_per_piece) {
         const uint32_t re = std::min(hi, r + rows_per_piece);
         const size_t off = md.stage_off[t] + (size_t)(r - lo) * D;
-        jobs.push_back({tables_[t].get(), h_uniq_keys_ + c.key_start[t] + r, re - r, h_staging_ + off, D,
-                        params_.default_value_for_each_table[t], h_found_ + md.useg_start[t] + (r - lo)});
+        jobs.push_back({tables_[t].get(), uniq_narrow_ ? nullptr : h_uniq_keys_ + c.key_start[t] + r, re - r, h_staging_ + off, D,
+                        params_.default_value_for_each_table[t], h_found_ + md.useg_start[t] + (r - lo),
+                        uniq_narrow_ ? reinterpret_cast<const uint32_t*>(h_uniq_keys_) + c.key_start[t] + r : nullptr});
         piece_begin = std::min(piece_begin, off);
         piece_end = std::max(piece_end, off + (size_t)(re - r) * D);
         if (piece_end - piece_begin >= kPieceFloats) HPS_RETURN_IF_ERROR(flush());
@@ -1458,23 +1482,27 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     const auto tt0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tt0).count(); };
     float tr[6] = {0, 0, 0, 0, 0, 0};
+    // Other sessions' kernels wait for our scatter (the lane) and their probes for our writer event.  Let the PCIe copies
+    // (and this call's own hit gather) drain first, so that those waits cover the scatter and the insert kernel alone
+    // (tens of microseconds) and not the millisecond of H2D queued ahead of them on this stream.
+    // (a chunk read in place has nothing queued ahead of its scatter: no drain, one host wait for the whole call)
+    if (!in_place) HIP_TRY(hipStreamSynchronize(stream_));
+    tr[0] = since();
+    if (exclusive_) cache_->LaneEnter(stream_);
     if (timing_) (void)hipEventRecord(ev_s0_, stream_);
     hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, rows_src, stream_);
-    tr[0] = since();
     if (timing_) (void)hipEventRecord(ev_s1_, stream_);
-    if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
-    // Other sessions' probes wait for our writer event.  Let the PCIe copy and the scatter drain first,
-    // so that the window in which the cache is "being written" is the insert kernel alone (tens of
-    // microseconds) and not insert + the millisecond of H2D queued ahead of it on this stream.
-    // (a chunk read in place has nothing queued ahead but its own scatter: no drain, one host wait for the whole call)
-    if (!in_place) HIP_TRY(hipStreamSynchronize(stream_));
+    if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[2]);
     tr[1] = since();
+    if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
     cache_->BeginWrite(stream_);
     tr[2] = since();
+    if (exclusive_) cache_->LaneEnter(stream_);
     if (timing_) (void)hipEventRecord(ev_i0_, stream_);
     e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, uq, d_call_->key_start, work_.uniq_keys,
-                          rows_src, found_src, epoch, d_acc_, cu, stream_);
+                          rows_src, found_src, cache_->Stamp8(epoch), d_acc_, cu, stream_);
     if (timing_) (void)hipEventRecord(ev_i1_, stream_);
+    if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[3]);
     cache_->EndWrite(stream_);
     tr[3] = since();
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
@@ -1490,7 +1518,7 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     }
     tr[4] = since();
     if (kTrace && tr[4] > 3.0f)
-      fprintf(stderr, "[hps tail] scatter-enqueued %.2f  drained %.2f  write-lock %.2f  insert-enqueued %.2f  done %.2f ms (fetch %.2f ms before)\n",
+      fprintf(stderr, "[hps tail] drained %.2f  scatter-enqueued %.2f  write-lock %.2f  insert-enqueued %.2f  done %.2f ms (fetch %.2f ms before)\n",
               tr[0], tr[1], tr[2], tr[3], tr[4], phase_ms_[1]);
     if (timing_) {
       (void)hipEventElapsedTime(&last_scatter_ms_, ev_s0_, ev_s1_);

@@ -109,7 +109,18 @@ class EmbeddingCache {
   void BeginFetch(hipStream_t stream);
   void EndFetch(hipStream_t stream, hipEvent_t fetch_done);
   void ForgetFetch(hipEvent_t fetch_done);
+  // One HBM-bound kernel group at a time per cache (the "lane"): probe pair, hit gather, miss scatter and insert of all
+  // sessions are chained through events.  Two such kernels side by side only share the memory system — each takes as
+  // long as both together — and a short one (a scatter of 10 us of work) that starts under another session's 220-us
+  // gather is scheduled into the gather's last free wave slots and takes until its end.  Enqueue side only, like the
+  // read/write brackets; lock order: order mutex, then lane mutex.
+  void LaneEnter(hipStream_t stream);
+  void LaneLeave(hipStream_t stream, hipEvent_t done);
+  void ForgetLane(hipEvent_t done);
   uint32_t NextEpoch();
+  // recency stamp the kernels write for call counter `epoch` (device_types.h)
+  uint32_t Stamp8(uint32_t epoch) const { return (epoch >> age_shift_) % kStampMod; }
+  uint32_t age_shift_ = 2;   // recency unit = 2^age_shift calls (HPS_LRU_AGE_SHIFT)
 
   std::string model_;
   EmbeddingCacheConfig cfg_;
@@ -125,6 +136,9 @@ class EmbeddingCache {
   std::vector<hipEvent_t> readers_;
   hipEvent_t last_reader_ = nullptr;        // most recent probe/gather of any session (probes are chained)
   hipStream_t last_reader_stream_ = nullptr;
+  std::mutex lane_mu_;
+  hipEvent_t last_lane_ = nullptr;
+  hipStream_t last_lane_stream_ = nullptr;
   std::mutex fetch_mu_;
   hipEvent_t last_fetch_ = nullptr;         // most recent direct PCIe fetch of any session (fetches are chained)
   hipStream_t last_fetch_stream_ = nullptr;
@@ -217,7 +231,8 @@ class LookupSession {
   void set_split_probe(bool b) { split_probe_ = b; }
   void set_xcd_walk(bool b) { xcd_walk_ = b; }
   void set_chain_gather(bool b) { chain_gather_ = b; }
-  void set_stamp_every(uint32_t n) { uint32_t m = 1; while (m < n) m <<= 1; stamp_mask_ = m - 1; }
+  void set_narrow_publish(bool b) { narrow_publish_ = b; }
+  void set_exclusive_kernels(bool b) { exclusive_ = b; }
   float last_key_stage_ms() const { return key_stage_ms_; }
   float last_scatter_ms() const { return last_scatter_ms_; }   // miss-scatter kernel of the last call (last chunk)
   float last_insert_ms() const { return last_insert_ms_; }     // cache-insert kernel of the last call (last chunk)
@@ -307,7 +322,10 @@ class LookupSession {
   bool split_call_ = false;      // the call in progress gathers its hits on stream_ while the miss path runs (copies go down copy_stream_)
   bool split_probe_ = true;      // host-gather tier: start the miss path behind the probe, gather the hits meanwhile (§3.4c);
                                  // HPS_SPLIT_PROBE=0 / session option split_probe=0: gather first, then the counts
-  uint32_t stamp_mask_ = 0;      // LRU stamps rewritten for one hit in (stamp_mask_ + 1); option "stamp_every" (default 1: every hit, exact recency)
+  bool exclusive_ = true;        // the HBM-bound kernels of this session take the cache's lane (option "exclusive_kernels")
+  hipEvent_t ev_lane_[4] = {nullptr, nullptr, nullptr, nullptr};   // probe pair, hit gather, miss scatter, insert
+  bool narrow_publish_ = true;   // a narrowed request's unique missed keys come back to the host as uint32 (option "narrow_publish")
+  bool uniq_narrow_ = false;     // this call: h_uniq_keys_ holds uint32 keys
   bool chain_gather_ = false;    // other sessions' probes queue behind this session's gather as well as its probe
   bool xcd_walk_ = true;         // K_G: each XCD sweeps its own eighth of the key range (HPS_XCD_WALK=0: plain grid stride)
   MissDesc* h_md_ = nullptr;      // pinned
@@ -386,6 +404,7 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
     size_t stride;
     float default_value;
     uint8_t* found;  // optional
+    const uint32_t* keys32 = nullptr;  // when `keys` is null: the same keys as uint32 (widened task by task)
   };
   Status FetchMulti(const std::vector<FetchJob>& jobs);
 

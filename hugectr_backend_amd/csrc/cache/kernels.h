@@ -27,10 +27,11 @@ hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tabl
 hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w,
                                  const uint32_t* d_table_mode, hipStream_t stream);
 
-// d_stats: kStatLines lines of kAccStride words (insert statistics, see device_types.h)
+// d_stats: kStatLines lines of kAccStride words (insert statistics, see device_types.h); now8: the current recency unit
+// ((epoch >> age_shift) & 255, EmbeddingCache::Stamp8)
 hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const MissDesc* d_md, uint64_t total_unique,
                              const uint64_t* d_key_start, const int64_t* d_uniq_keys, const float* d_staging,
-                             const uint8_t* d_found, uint32_t epoch, uint32_t* d_stats, int cu_count,
+                             const uint8_t* d_found, uint32_t now8, uint32_t* d_stats, int cu_count,
                              hipStream_t stream);
 
 // control words over the compute queue (kernels.hip): call block host -> HBM (bytes rounded up to 16), accumulator words
@@ -38,10 +39,8 @@ hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const Mi
 hipError_t LaunchPull16(const void* src_host_devptr, void* dst, size_t bytes, hipStream_t stream);
 hipError_t LaunchPushWords(const uint32_t* src, uint32_t* dst_host_devptr, uint32_t words, uint32_t* seq_host_devptr, uint32_t seq,
                            hipStream_t stream);
-hipError_t LaunchCacheClear(int64_t* d_keys, uint32_t* d_stamps, uint64_t slots, hipStream_t stream);
-
-// stamps > keep_from -> stamp - keep_from + 1 ; other used stamps -> 1 ; 0 stays 0
-hipError_t LaunchCacheRenorm(uint32_t* d_stamps, uint64_t slots, uint32_t keep_from, hipStream_t stream);
+// every key slot of the bucket lines EMPTY, every recency stamp = stamp8
+hipError_t LaunchCacheClear(int64_t* d_lines, uint64_t num_buckets, uint32_t stamp8, hipStream_t stream);
 
 hipError_t LaunchCacheQuery(const TableCacheDev& tb, const int64_t* d_keys, uint64_t n, int32_t* d_slot,
                             hipStream_t stream);

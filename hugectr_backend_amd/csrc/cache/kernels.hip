@@ -13,9 +13,10 @@
 //   K_C2 hps_cache_insert      unique missed (key,row) -> bucket, LRU victim claimed by CAS
 //   K_D  hps_miss_fill_default async-insert mode: missed rows = default vector
 //
-// Work decomposition of every row mover: one 16-lane group per key (4 keys per wave at a time).  A 16-lane group
-// reads one 128-B key bucket with a single 8-B load per lane and moves a D=128 row as 2 x 16 B per lane
-// (two fully coalesced 256-B segments), so every HBM request is a whole number of 64/128-B lines.
+// Work decomposition of every row mover: one 16-lane group per key (4 keys per wave at a time), a D=128 row as
+// 2 x 16 B per lane (two fully coalesced 256-B segments).  A bucket line (14 keys + 14 one-byte recency stamps =
+// 128 B, device_types.h) is read by an 8-lane group with a single 16-B load per lane: tools/micro/probe_width.hip
+// measures 30.7 us for 1.1 M random lines that way against 39.0 us with sixteen 8-B loads.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,6 +28,12 @@
 namespace hps {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+// recency stamp of slot v from the two stamp words of a bucket line
+__device__ __forceinline__ uint32_t stamp_of(uint64_t a, uint64_t b, uint32_t v) {
+  return (uint32_t)((v < 8 ? a : b) >> (8u * (v & 7u))) & 0xFFu;
+}
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
@@ -108,8 +115,9 @@ __device__ __forceinline__ uint32_t lds_append(uint32_t* sh_count, bool take) {
 //   2. kDedup: tile-local input dedup — 32-bit LDS CAS claims a set entry with the key's tile-local index;
 //      a key that finds an equal key there takes that key as its representative.  Under the Zipf-like
 //      distributions of recommender traffic a third to a half of a tile's keys are duplicates.
-//   3. representatives only: 16-lane group per key, kU independent 128-B bucket lines in flight per group
-//      (the probe is latency-bound: bytes in flight decide its speed, not bandwidth)
+//   3. representatives only: 8-lane group per key, kU independent 128-B bucket lines in flight per group (the probe
+//      is bound by the rate of random line requests, not by their bytes: 64-B granules are no faster,
+//      tools/micro/probe_width.hip); a hit whose slot's recency stamp is not the current unit's rewrites that byte
 //   4. every key takes its representative's result: slot[i] >= 0, or -2 - m with m the representative's position in
 //      the tile's miss list; the lists the later kernels walk (missed representatives' keys, missed keys as sent,
 //      kClaim: hit representatives) are compacted in the tile's own region — no global atomic in this kernel.
@@ -138,8 +146,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   const uint32_t* __restrict__ keys32 = call->keys32;   // wave-uniform: one of the three loads below
   const uint8_t* __restrict__ keys24 = call->keys24;
   const int64_t* __restrict__ keys = call->keys + td.begin;
-  const uint32_t epoch = call->epoch;
-  const uint32_t stamp_mask = call->stamp_mask;
+  const uint32_t stamp8 = call->stamp8;
   constexpr int kPerThread = kTileKeys / kThreads;
 
   if (tid < 4) sh_cnt[tid] = 0;
@@ -193,31 +200,31 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   // ---- 3. one bucket probe per representative ----
   const uint32_t nrep = sh_cnt[0];
   const int lane = lane_id();
-  const int g16 = (int)(tid >> 4), gw = lane >> 4, lig = lane & 15;
-  for (uint32_t r0 = (uint32_t)g16 * kU; r0 < nrep; r0 += (kThreads / 16) * kU) {
+  const int g8 = (int)(tid >> 3), gw = lane >> 3, lig = lane & 7;
+  for (uint32_t r0 = (uint32_t)g8 * kU; r0 < nrep; r0 += (kThreads / kProbeLanes) * kU) {
     uint32_t jj[kU], bb[kU];
-    int64_t bk[kU];
+    u64x2 ln[kU];   // lanes 0..6: two keys each; lane 7: the two stamp words
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const uint32_t r = r0 + u < nrep ? r0 + u : r0;
       jj[u] = sh_list[r];
       bb[u] = sh_bkt[jj[u]];
-      bk[u] = tb.bucket_keys[(uint64_t)bb[u] * kBucketSlots + lig];
+      ln[u] = *reinterpret_cast<const u64x2*>(tb.lines + (uint64_t)bb[u] * kLineWords + lig * 2);
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int64_t key = sh_key[jj[u]];
-      const bool match = bk[u] == key && key != HPS_EMPTY_KEY;
-      const uint32_t m16 = (uint32_t)(__ballot(match) >> (gw * 16)) & 0xFFFFu;
-      if (lig == 0 && r0 + u < nrep) {
+      const bool live = lig < 7 && key != HPS_EMPTY_KEY;
+      const uint32_t m0 = (uint32_t)(__ballot(live && (int64_t)ln[u].x == key) >> (gw * 8)) & 0xFFu;
+      const uint32_t m1 = (uint32_t)(__ballot(live && (int64_t)ln[u].y == key) >> (gw * 8)) & 0xFFu;
+      if (lig == 7 && r0 + u < nrep) {   // the lane that holds the stamps finishes the probe
         int32_t s = kSlotMiss;
-        if (m16) {
-          s = (int32_t)(bb[u] * kBucketSlots + (uint32_t)__builtin_ctz(m16));
-          if (!(tb.flags & 1u)) {
-            // the LRU stamp is rewritten for a sample of the hits (hashed on slot and epoch; stamp_mask 3 = one in
-            // four): a blind 4-B store per hit is a read-modify-write of a whole DRAM sector
-            if (((((uint32_t)s * 0x9E3779B1u + epoch * 0x85EBCA6Bu) >> 13) & stamp_mask) == 0u) tb.stamps[(uint32_t)s] = epoch;
-          }
+        if (m0 | m1) {
+          const uint32_t v = m0 ? 2u * (uint32_t)__builtin_ctz(m0) : 2u * (uint32_t)__builtin_ctz(m1) + 1u;
+          s = (int32_t)(bb[u] * kBucketSlots + v);
+          // recency: one byte of the line just read, rewritten only when it is not already this unit's stamp
+          if (!(tb.flags & 1u) && stamp_of(ln[u].x, ln[u].y, v) != stamp8)
+            reinterpret_cast<uint8_t*>(tb.lines + (uint64_t)bb[u] * kLineWords + kBucketSlots)[v] = (uint8_t)stamp8;
           if (kClaim) tb.claim[(uint32_t)s] = (uint32_t)(td.begin + jj[u]);
         }
         sh_slot[jj[u]] = s;
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
     const int32_t s = j < n ? sh_slot[sh_rep[j]] : 0;
     if (j < n) w.slot[td.begin + j] = s;
     const uint32_t pos = lds_append(&sh_cnt[2], s < 0);
-    if (s < 0) w.sent_i[region + pos] = (int32_t)(td.begin + j);
+    if (s < 0) { w.sent_i[region + pos] = (int32_t)(td.begin + j); w.sent_m[region + pos] = -2 - s; }
   }
   __syncthreads();
   if (tid == 0) {
@@ -334,7 +341,9 @@ __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __
         const uint32_t u = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         w.uidx_of[m] = (int32_t)u;
         w.uniq_keys[ks + u] = key;
-        if (w.uniq_keys_host) w.uniq_keys_host[ks + u] = key;  // zero-copy store into pinned host memory (host-gather tier)
+        // zero-copy store into pinned host memory (host-gather tier), at 4 bytes when the request's keys were narrowed
+        if (w.uniq_keys_host32) w.uniq_keys_host32[ks + u] = (uint32_t)key;
+        else if (w.uniq_keys_host) w.uniq_keys_host[ks + u] = key;
       }
     }
   }
@@ -366,40 +375,78 @@ __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __
   if (lane == 0 && S) atomicAdd(&w.acc[AccTableWord(t, kAccSentMiss)], S);
 }
 
-// index of a missed key's row in its table's unique-miss segment (slot <= -2)
-__device__ __forceinline__ uint32_t miss_uidx(const CallWork& w, int32_t slot) {
-  const uint32_t m = (uint32_t)(-2 - slot);
-  return (uint32_t)w.uidx_of[(uint32_t)w.rep_of[m]];
-}
-
 // ------------------------------------------------------------------------------------------------
-// K_C1: missed rows staging -> output.  One workgroup per tile walks the tile's list of missed keys (as sent),
-// a 16-lane group per key; tiles without misses leave at once.
+// K_C1: missed rows staging -> output.  One workgroup per tile walks the tile's list of missed keys (as sent); tiles
+// without misses leave at once.  Two phases per pass of up to 256 list entries:
+//   resolve  one THREAD per entry: (sent_i, sent_m) -> rep_of[m] -> uidx_of[rep] — the dependent loads of all entries of
+//            the pass are in flight together (round 2 walked the chain once per 16-lane group and row: a tile's ~50 misses
+//            cost four rounds of four dependent loads each, 31 us for 85 MB)
+//   copy     one 16-lane group per row, kRows rows in flight per group, all addresses known
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hps_miss_scatter_kernel(const CallDesc* __restrict__ call,
                                                                 const TableCacheDev* __restrict__ tables,
                                                                 const MissDesc* __restrict__ md, const CallWork w,
                                                                 const float* __restrict__ staging) {
+  __shared__ int32_t sh_i[256];
+  __shared__ uint32_t sh_u[256];
   const uint32_t tile = blockIdx.x;
   const uint32_t S = w.tile_cnt[tile * 4 + kTileCntSentMiss];
-  if (S == 0) return;
+  if (S == 0 || blockIdx.y * 256u >= S) return;
   const uint32_t t = w.tiles[tile].table;
   const uint32_t lo = md->chunk_lo[t], hi = md->chunk_hi[t];
   if (hi == lo) return;  // table served in async mode, or nothing of it in this chunk
   const uint32_t D = tables[t].dim;
   const uint64_t stage_off = md->stage_off[t];
   const bool vec = call->vec_ok[t] != 0 && (stage_off & 3) == 0;  // staging rows are packed (offset multiple of D)
+  const bool fast = vec && D == 128;
   float* __restrict__ out = call->out[t];
   const uint64_t ks = call->key_start[t];
   const uint32_t region = tile * (uint32_t)kTileKeys;
-  const int lig = (int)(threadIdx.x & 15);
+  const int lig = (int)(threadIdx.x & 15), g = (int)(threadIdx.x >> 4);
+  constexpr int kRows = 4;
   // gridDim.y workgroups share a tile's list (few tiles = a small request: one workgroup per tile would copy its rows
   // one after the other)
-  for (uint32_t r = blockIdx.y * 16 + (threadIdx.x >> 4); r < S; r += 16 * gridDim.y) {
-    const int32_t i = w.sent_i[region + r];
-    const uint32_t u = miss_uidx(w, w.slot[i]);
-    if (u < lo || u >= hi) continue;  // other chunk of this call
-    copy_row<true>(staging + stage_off + (uint64_t)(u - lo) * D, out + ((uint64_t)i - ks) * D, D, lig, vec);
+  for (uint32_t base = blockIdx.y * 256u; base < S; base += 256u * gridDim.y) {
+    const uint32_t cnt = S - base < 256u ? S - base : 256u;
+    if (threadIdx.x < cnt) {
+      const int32_t i = w.sent_i[region + base + threadIdx.x];
+      const uint32_t m = (uint32_t)w.sent_m[region + base + threadIdx.x];
+      const uint32_t u = (uint32_t)w.uidx_of[(uint32_t)w.rep_of[m]];
+      sh_i[threadIdx.x] = i;
+      sh_u[threadIdx.x] = (u >= lo && u < hi) ? u - lo : 0xFFFFFFFFu;   // other chunk of this call
+    }
+    __syncthreads();
+    for (uint32_t q0 = (uint32_t)g * kRows; q0 < cnt; q0 += 16 * kRows) {
+      if (fast) {
+        f4 v[kRows][2];
+        float* dst[kRows];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+          const uint32_t q = q0 + r;
+          dst[r] = nullptr;
+          if (q < cnt && sh_u[q] != 0xFFFFFFFFu) {
+            const float* src = staging + stage_off + (uint64_t)sh_u[q] * 128u;
+            dst[r] = out + ((uint64_t)sh_i[q] - ks) * 128u;
+            v[r][0] = *reinterpret_cast<const f4*>(src + lig * 4);
+            v[r][1] = *reinterpret_cast<const f4*>(src + 64 + lig * 4);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+          if (dst[r]) {
+            __builtin_nontemporal_store(v[r][0], reinterpret_cast<f4*>(dst[r] + lig * 4));
+            __builtin_nontemporal_store(v[r][1], reinterpret_cast<f4*>(dst[r] + 64 + lig * 4));
+          }
+        }
+      } else {
+        for (int r = 0; r < kRows; ++r) {
+          const uint32_t q = q0 + r;
+          if (q >= cnt || sh_u[q] == 0xFFFFFFFFu) continue;
+          copy_row<true>(staging + stage_off + (uint64_t)sh_u[q] * D, out + ((uint64_t)sh_i[q] - ks) * D, D, lig, vec);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -508,23 +555,48 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------------
-// K_C2: insert unique missed (key,row) pairs.  One 16-lane group per key.  The group loads the
-// bucket's keys and LRU stamps; if the key is already resident the row is refreshed in place;
-// otherwise the victim is the slot with the smallest stamp that was not used in this epoch (empty
-// slots carry stamp 0 and therefore go first).  Two groups of the same launch may want the same
-// victim: the slot is claimed by atomicCAS(stamp: old -> epoch); the loser learns the new stamp from
-// the CAS return value and moves to its next candidate.  Inserts never run concurrently with another
-// kernel on the same cache (EmbeddingCache orders them with events), so plain loads of keys/stamps
-// at kernel entry are coherent; only slots claimed inside this launch change under us, and those
-// changes are observed through the CAS.
-// `found[f]`==0 (key unknown to every parameter-server tier) -> not cached.
+// K_C2: insert unique missed (key,row) pairs.  One 16-lane group per key.  The group reads the key's bucket line (lanes
+// 0..7 and their mirrors 8..15: 16 B each — 14 keys and the two stamp words).  Key already resident: the row is refreshed
+// in place.  Otherwise the victim is a free slot, else the slot of greatest age; a slot whose stamp is the current
+// unit's (hit or written within the last 2^age_shift calls) is never taken.
+// Ownership inside one launch: a writer claims slot v by a 64-bit compare-and-swap on the stamp WORD that holds v's
+// byte: old word -> same word with byte v = kStampClaimed.  Only slots whose stamp is neither the current unit's nor
+// kStampClaimed are claimed, so a claim always changes the word; a second group that read the same line loses its CAS,
+// learns the new word from the return value and picks again.  The owner writes key and row and then turns the byte into
+// the current stamp.  Every update of a bucket line in this kernel is a device-scope atomic (CAS, atomic store of the
+// key, atomicAnd of the stamp): no line is left dirty in one XCD's L2 while another XCD updates a neighbouring word of
+// it.  Inserts never run concurrently with another kernel on the same cache (EmbeddingCache orders them with events);
+// the plain loads at a group's start may be older than the launch's latest claims, and every decision taken on them is
+// validated by the CAS.  While it rewrites a stamp word the claim also pulls stamps older than kAgeSaturate units
+// back to exactly that age (they would wrap around and look young).
+// `found[f]`==0 (key unknown to every parameter-server tier) -> not cached, and dropped if resident.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t age_of(uint32_t now8, uint32_t st) {   // st in [0, kStampMod)
+  const uint32_t d = now8 + kStampMod - st;
+  return d >= kStampMod ? d - kStampMod : d;
+}
+
+__device__ __forceinline__ uint64_t saturate_stamps(uint64_t word, uint32_t now8) {
+  uint64_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    uint32_t st = (uint32_t)(word >> (8 * k)) & 0xFFu;
+    if (st != kStampClaimed && age_of(now8, st) > kAgeSaturate) st = (now8 + kStampMod - kAgeSaturate) % kStampMod;
+    r |= (uint64_t)st << (8 * k);
+  }
+  return r;
+}
+
+__device__ __forceinline__ uint64_t group_bcast64(uint64_t v, int src_lane) {
+  return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src_lane, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src_lane, 64);
+}
+
 __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheDev* __restrict__ tables, uint32_t T,
                                                                 const MissDesc* __restrict__ md,
                                                                 const uint64_t* __restrict__ key_start,
                                                                 const int64_t* __restrict__ uniq_keys,
                                                                 const float* __restrict__ staging,
-                                                                const uint8_t* __restrict__ found, uint32_t epoch,
+                                                                const uint8_t* __restrict__ found, uint32_t now8,
                                                                 uint32_t* __restrict__ stats /* kStatLines lines of kAccStride words */) {
   const uint64_t total = md->useg_start[T];
   const int lane = lane_id();
@@ -541,62 +613,93 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
     const uint32_t D = tb.dim;
     const float* row = staging + md->stage_off[t] + (uint64_t)(u - md->chunk_lo[t]) * D;
     const uint32_t b = hps_bucket_of(key, tb.num_buckets);
-    const uint64_t base = (uint64_t)b * kBucketSlots;
-    const int64_t bk = tb.bucket_keys[base + lig];
-    uint32_t st = tb.stamps[base + lig];
+    unsigned long long* line = reinterpret_cast<unsigned long long*>(tb.lines) + (uint64_t)b * kLineWords;
+    const u64x2 ln = *reinterpret_cast<const u64x2*>(line + (lig & 7) * 2);
+    const bool klane = lig < 7;
+    const uint32_t p0 = (uint32_t)(__ballot(klane && (int64_t)ln.x == key) >> (g * 16)) & 0x7Fu;
+    const uint32_t p1 = (uint32_t)(__ballot(klane && (int64_t)ln.y == key) >> (g * 16)) & 0x7Fu;
+    const uint32_t e0 = (uint32_t)(__ballot(klane && (int64_t)ln.x == HPS_EMPTY_KEY) >> (g * 16)) & 0x7Fu;
+    const uint32_t e1 = (uint32_t)(__ballot(klane && (int64_t)ln.y == HPS_EMPTY_KEY) >> (g * 16)) & 0x7Fu;
+    uint64_t sw[2];   // the two stamp words, from the group's lane 7, in every lane
+    sw[0] = group_bcast64(ln.x, g * 16 + 7);
+    sw[1] = group_bcast64(ln.y, g * 16 + 7);
+    uint32_t empty = 0;   // bit v: slot v holds no key
+    for (int k = 0; k < 7; ++k) empty |= (((e0 >> k) & 1u) << (2 * k)) | (((e1 >> k) & 1u) << (2 * k + 1));
+    const int present = (p0 | p1) ? (p0 ? 2 * __builtin_ctz(p0) : 2 * __builtin_ctz(p1) + 1) : -1;
+    const bool unknown = found && !found[f];   // the key exists in no parameter-server tier (any more)
+    if (unknown && present < 0) continue;
 
-    const uint32_t present = (uint32_t)(__ballot(bk == key) >> (g * 16)) & 0xFFFFu;
-    if (found && !found[f]) {
-      // the key exists in no parameter-server tier (any more): never cache it, and if a refresh finds it still
-      // resident, drop it so that later lookups fall through to the default value instead of a stale row
-      if (present) {
-        const int v = __builtin_ctz(present);
-        uint32_t old = epoch;
-        if (lig == v && st != epoch) old = atomicCAS(&tb.stamps[base + v], st, epoch);
-        if (lig == v && st != epoch && old == st) { tb.bucket_keys[base + v] = HPS_EMPTY_KEY; tb.stamps[base + v] = 0; }
-      }
-      continue;
-    }
-    int victim = -1;
-    if (present) {
-      // Already resident (another session inserted it after our probe): refresh the row in place, but
-      // only after claiming the slot like any other writer — a second group of this launch may be
-      // about to evict exactly this slot, and an unclaimed refresh would interleave its row with the
-      // evictor's key (key/row mismatch = poisoned slot).  Losing the claim just skips the refresh.
-      const int v = __builtin_ctz(present);
-      uint32_t old = epoch;
-      if (lig == v && st != epoch) old = atomicCAS(&tb.stamps[base + v], st, epoch);
-      old = __shfl(old, g * 16 + v, 64);
-      const uint32_t expect = __shfl(st, g * 16 + v, 64);
-      if (expect != epoch && old == expect) victim = v;
-    } else {
-      for (int tries = 0; tries < kBucketSlots; ++tries) {
-        // min over the group of (stamp, lane) among slots not used in this epoch
-        uint64_t cand = (st != epoch) ? (((uint64_t)st << 4) | (uint64_t)lig) : ~0ull;
-        for (int off = 8; off > 0; off >>= 1) {
-          const uint32_t lo = __shfl_xor((uint32_t)cand, off, 16);
-          const uint32_t hi = __shfl_xor((uint32_t)(cand >> 32), off, 16);
-          const uint64_t o = ((uint64_t)hi << 32) | lo;
-          cand = o < cand ? o : cand;
+    // claim(v): group-uniform; true when this group now owns slot v (its stamp byte reads kStampClaimed)
+    // (a CAS also fails when another group claimed a DIFFERENT slot of the same word meanwhile: try again as long as
+    //  slot v's own byte is what it was)
+    auto claim = [&](int v) -> bool {
+      const int wi = v >> 3, sh = 8 * (v & 7);
+      for (;;) {
+        const unsigned long long old = sw[wi];
+        const unsigned long long want = (saturate_stamps(old, now8) & ~(0xFFull << sh)) | ((unsigned long long)kStampClaimed << sh);
+        unsigned long long got = 0;
+        if (lig == 0) got = atomicCAS(line + kBucketSlots + wi, old, want);
+        got = group_bcast64(got, g * 16);
+        if (got == old) {
+          sw[wi] = want;
+          // the bucket's other stamp word is looked after too (one more CAS, only when something in it is about to wrap)
+          const unsigned long long other = sw[wi ^ 1], sat = saturate_stamps(other, now8);
+          if (sat != other) {
+            if (lig == 0) atomicCAS(line + kBucketSlots + (wi ^ 1), other, sat);   // losing it to a concurrent claim is fine
+            sw[wi ^ 1] = sat;   // (a stale view at worst: every later decision on it is validated by its own CAS)
+          }
+          return true;
         }
-        if (cand == ~0ull) break;  // whole bucket is in use by this epoch
-        const int v = (int)(cand & 15);
-        uint32_t old = 0;
-        if (lig == v) old = atomicCAS(&tb.stamps[base + v], st, epoch);
-        old = __shfl(old, g * 16 + v, 64);
-        const uint32_t expect = __shfl(st, g * 16 + v, 64);
-        if (lig == v) st = (old == expect) ? epoch : old;
-        if (old == expect) { victim = v; break; }
+        sw[wi] = got;
+        if (((got ^ old) >> sh) & 0xFFull) return false;   // somebody else took slot v
       }
-      if (victim >= 0 && lig == victim) tb.bucket_keys[base + victim] = key;
+    };
+    int victim = -1;
+    bool owned = false;   // victim's stamp byte reads kStampClaimed and has to be turned into now8 at the end
+    if (present >= 0) {
+      // Already resident (another session inserted it after our probe, or a refresh): rewrite the row in place — or drop
+      // the slot when the key is unknown now — but only as the slot's owner: a second group of this launch may be about
+      // to evict exactly this slot, and an unowned write would interleave with the evictor's (key/row mismatch = poisoned
+      // slot).  A slot stamped in the current unit is taken by nobody, so it needs no claim; losing the claim skips the write.
+      const uint32_t st = stamp_of(sw[0], sw[1], (uint32_t)present);
+      if (st == now8) victim = present;
+      else if (st != kStampClaimed && claim(present)) { victim = present; owned = true; }
+    } else {
+      for (int tries = 0; tries < kBucketSlots + 2 && victim < 0; ++tries) {
+        // lane v rates slot v; 16-lane maximum of (age << 4 | 15 - v): the greatest age, the lowest slot among equals
+        // (a free slot counts as age 256; a slot used in the current unit or owned by another group of this launch as none)
+        uint32_t cand = 0;
+        if (lig < kBucketSlots) {
+          const uint32_t st = stamp_of(sw[0], sw[1], (uint32_t)lig);
+          if (st != now8 && st != kStampClaimed) cand = ((((empty >> lig) & 1u) ? 256u : age_of(now8, st)) << 4) | (15u - (uint32_t)lig);
+        }
+        for (int off = 8; off > 0; off >>= 1) {
+          const uint32_t o = (uint32_t)__shfl_xor((int)cand, off, 16);
+          cand = o > cand ? o : cand;
+        }
+        const int best = cand ? 15 - (int)(cand & 15u) : -1;
+        if (best < 0) break;  // whole bucket is in use by the current unit
+        if (claim(best)) { victim = best; owned = true; }
+      }
     }
     if (victim < 0) {
-      n_dropped += (lig == 0);  // bucket full of this epoch's keys (or lost the claim)
+      n_dropped += (lig == 0);  // bucket full of the current unit's keys (or lost the claim)
       continue;
     }
-    float* dst = tb.rows + (base + (uint64_t)victim) * D;
-    copy_row<false>(row, dst, D, lig, (D & 3u) == 0 && (md->stage_off[t] & 3) == 0);
-    if (lig == 0) { if (present) ++n_refreshed; else ++n_inserted; }
+    if (unknown) {
+      // drop it, so that later lookups fall through to the default value instead of a stale row
+      if (lig == 0) __hip_atomic_store(line + victim, (unsigned long long)HPS_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (present < 0 && lig == 0) __hip_atomic_store(line + victim, (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float* dst = tb.rows + ((uint64_t)b * kBucketSlots + (uint64_t)victim) * D;
+      copy_row<false>(row, dst, D, lig, (D & 3u) == 0 && (md->stage_off[t] & 3) == 0);
+      if (lig == 0) { if (present >= 0) ++n_refreshed; else ++n_inserted; }
+    }
+    // kStampClaimed (all ones) AND now8 = now8; the other bytes of the word keep whatever they hold by now
+    if (owned && lig == 0) {
+      const int sh = 8 * (victim & 7);
+      atomicAnd(line + kBucketSlots + (victim >> 3), ~(0xFFull << sh) | ((unsigned long long)now8 << sh));
+    }
   }
   // one atomic per block and counter, spread over kStatLines lines of the accumulator block: atomics on one
   // 128-B line serialise at ~90 per microsecond, and 2,048 blocks x 3 counters on one line cost 70 us
@@ -615,35 +718,29 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
   }
 }
 
-// LRU epochs are 32-bit and advance once per lookup call; long before they wrap, every stamp is folded back:
-// stamps younger than `keep_from` keep their order in [1, span], everything older becomes 1, never-used stays 0.
-__global__ void hps_cache_renorm_kernel(uint32_t* stamps, uint64_t slots, uint32_t keep_from) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t s = stamps[i];
-    if (s != 0) stamps[i] = s > keep_from ? s - keep_from + 1u : 1u;
-  }
-}
-
-// Utility: fill bucket keys with EMPTY and stamps with 0.
-__global__ void hps_cache_clear_kernel(int64_t* keys, uint32_t* stamps, uint64_t slots) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
-    keys[i] = HPS_EMPTY_KEY;
-    stamps[i] = 0;
-  }
+// Utility: every key slot EMPTY, every stamp `stamp8` (the warm-up runs in unit 0: 0x80 leaves the free slots claimable).
+__global__ void hps_cache_clear_kernel(int64_t* lines, uint64_t num_buckets, uint32_t stamp8) {
+  const uint64_t words = num_buckets * kLineWords;
+  const uint64_t sw = 0x0101010101010101ull * (uint64_t)(stamp8 & 0xFFu);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x)
+    lines[i] = (i % kLineWords) < (uint64_t)kBucketSlots ? HPS_EMPTY_KEY : (int64_t)sw;
 }
 
 // Utility for tests / refresh: per-key residency (slot index or -1), no side effects.
 __global__ void hps_cache_query_kernel(TableCacheDev tb, const int64_t* __restrict__ keys, uint64_t n,
                                        int32_t* __restrict__ slot) {
   const int lane = lane_id();
-  const int g = lane >> 4, lig = lane & 15;
-  const uint64_t groups_total = (uint64_t)gridDim.x * (blockDim.x / 16);
-  for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4); i < n; i += groups_total) {
+  const int gw = lane >> 3, lig = lane & 7;
+  const uint64_t groups_total = (uint64_t)gridDim.x * (blockDim.x / kProbeLanes);
+  for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x / kProbeLanes) + (threadIdx.x >> 3); i < n; i += groups_total) {
     const int64_t key = keys[i];
     const uint32_t b = hps_bucket_of(key, tb.num_buckets);
-    const int64_t bk = tb.bucket_keys[(uint64_t)b * kBucketSlots + lig];
-    const uint32_t m16 = (uint32_t)(__ballot(bk == key && key != HPS_EMPTY_KEY) >> (g * 16)) & 0xFFFFu;
-    if (lig == 0) slot[i] = m16 ? (int32_t)(b * kBucketSlots + (uint32_t)__builtin_ctz(m16)) : -1;
+    const u64x2 ln = *reinterpret_cast<const u64x2*>(tb.lines + (uint64_t)b * kLineWords + lig * 2);
+    const bool live = lig < 7 && key != HPS_EMPTY_KEY;
+    const uint32_t m0 = (uint32_t)(__ballot(live && (int64_t)ln.x == key) >> (gw * 8)) & 0xFFu;
+    const uint32_t m1 = (uint32_t)(__ballot(live && (int64_t)ln.y == key) >> (gw * 8)) & 0xFFu;
+    if (lig == 0)
+      slot[i] = (m0 | m1) ? (int32_t)(b * kBucketSlots + (m0 ? 2u * (uint32_t)__builtin_ctz(m0) : 2u * (uint32_t)__builtin_ctz(m1) + 1u)) : -1;
   }
 }
 
@@ -738,14 +835,14 @@ hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_
 
 hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const MissDesc* d_md, uint64_t total_unique,
                              const uint64_t* d_key_start, const int64_t* d_uniq_keys, const float* d_staging,
-                             const uint8_t* d_found, uint32_t epoch, uint32_t* d_stats, int cu_count,
+                             const uint8_t* d_found, uint32_t now8, uint32_t* d_stats, int cu_count,
                              hipStream_t stream) {
   if (total_unique == 0) return hipSuccess;
   uint64_t want = (total_unique + 15) / 16;
   const uint64_t cap = (uint64_t)cu_count * 8;
   if (want > cap) want = cap;
   hipLaunchKernelGGL(hps_cache_insert_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_tables, T, d_md,
-                     d_key_start, d_uniq_keys, d_staging, d_found, epoch, d_stats);
+                     d_key_start, d_uniq_keys, d_staging, d_found, now8 & 0xFFu, d_stats);
   return hipGetLastError();
 }
 
@@ -782,26 +879,18 @@ hipError_t LaunchPushWords(const uint32_t* src, uint32_t* dst_host_devptr, uint3
   return hipGetLastError();
 }
 
-hipError_t LaunchCacheClear(int64_t* d_keys, uint32_t* d_stamps, uint64_t slots, hipStream_t stream) {
-  uint64_t want = (slots + 255) / 256;
+hipError_t LaunchCacheClear(int64_t* d_lines, uint64_t num_buckets, uint32_t stamp8, hipStream_t stream) {
+  uint64_t want = (num_buckets * kLineWords + 255) / 256;
   if (want > 4096) want = 4096;
   if (want == 0) want = 1;
-  hipLaunchKernelGGL(hps_cache_clear_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_keys, d_stamps, slots);
-  return hipGetLastError();
-}
-
-hipError_t LaunchCacheRenorm(uint32_t* d_stamps, uint64_t slots, uint32_t keep_from, hipStream_t stream) {
-  uint64_t want = (slots + 255) / 256;
-  if (want > 4096) want = 4096;
-  if (want == 0) want = 1;
-  hipLaunchKernelGGL(hps_cache_renorm_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_stamps, slots, keep_from);
+  hipLaunchKernelGGL(hps_cache_clear_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_lines, num_buckets, stamp8);
   return hipGetLastError();
 }
 
 hipError_t LaunchCacheQuery(const TableCacheDev& tb, const int64_t* d_keys, uint64_t n, int32_t* d_slot,
                             hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  uint64_t want = (n + 15) / 16;
+  uint64_t want = (n + 31) / 32;
   if (want > 8192) want = 8192;
   hipLaunchKernelGGL(hps_cache_query_kernel, dim3((uint32_t)want), dim3(256), 0, stream, tb, d_keys, n, d_slot);
   return hipGetLastError();

@@ -124,7 +124,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
     HIP_TRY(hipStreamSynchronize(I.stream));  // copies done: keep the writer window = the insert kernel only
     BeginWrite(I.stream);
     const hipError_t e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, uq, I.d_ks, I.d_keys, I.d_rows, I.d_found,
-                                           epoch, I.d_stats, cu_count_, I.stream);
+                                           Stamp8(epoch), I.d_stats, cu_count_, I.stream);
     EndWrite(I.stream);
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(I.stream));
@@ -514,7 +514,11 @@ Status HierParameterServer::FetchMulti(const std::vector<FetchJob>& jobs) {
   auto body = [&](size_t ti) {
     const Task& k = tasks[ti];
     const FetchJob& J = jobs[k.job];
-    J.table->Fetch(J.keys + k.begin, k.end - k.begin, J.out + k.begin * J.stride, J.stride, J.default_value,
+    int64_t wide[256];   // tasks are at most 256 keys
+    const int64_t* keys = J.keys ? J.keys + k.begin : wide;
+    if (!J.keys)
+      for (size_t i = k.begin; i < k.end; ++i) wide[i - k.begin] = (int64_t)(uint64_t)J.keys32[i];
+    J.table->Fetch(keys, k.end - k.begin, J.out + k.begin * J.stride, J.stride, J.default_value,
                    J.found ? J.found + k.begin : nullptr);
   };
   if (tasks.size() <= 1) { if (!tasks.empty()) body(0); }

@@ -26,9 +26,9 @@ HPS_HD uint64_t hps_mix64(uint64_t x) {
 // always resolved through the slow path, so results stay exact.
 #define HPS_EMPTY_KEY ((int64_t)0x8000000000000000ull)
 
-// GPU cache geometry: one bucket = 16 keys = 128 B = one L2 line, probed by a
-// 16-lane group with one 8-byte load per lane.
-#define HPS_BUCKET_SLOTS 16
+// GPU cache geometry: one bucket = one 128-B line = 14 keys + 14 one-byte recency
+// stamps, probed by an 8-lane group with one 16-byte load per lane.
+#define HPS_BUCKET_SLOTS 14
 
 // bucket index for a key in a table of `num_buckets` buckets (mul-shift range
 // reduction on the high half of the mixed key; no 64-bit modulo on the GPU).

@@ -63,7 +63,7 @@ typedef struct hps_table_info {
 
 typedef struct hps_cache_table_info {
   uint32_t embedding_vecsize;
-  uint64_t num_buckets;     /* 16-key buckets */
+  uint64_t num_buckets;     /* buckets of 14 keys (one 128-B line each) */
   uint64_t capacity_rows;   /* ceil(gpucacheper * rows) */
 } hps_cache_table_info_t;
 

