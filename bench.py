@@ -202,6 +202,24 @@ def make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, hit, nbatches):
     return out
 
 
+def plan_replicas(n_rep, ndev, base="criteo_dlrm"):
+    """Replica g -> (device, model).  N GPUs: ONE model deployed on devices 0..N-1 (deployed_device_list), one cache per
+    device, as the reference does (model_state.cpp:395-420).  Fewer GPUs than replicas (development box): replica g runs on
+    device g % ndev, and the j-th extra replica of a device deploys the model again as <base>_dup<j> (the engine keys its
+    caches by (model, device)).  Returns (models, model of each replica, {model: its deployed_device_list})."""
+    models, rep_model, seen = [], [], {}
+    for g in range(n_rep):
+        d = g % ndev
+        j = seen.get(d, 0)
+        seen[d] = j + 1
+        name = base if j == 0 else f"{base}_dup{j}"
+        rep_model.append(name)
+        if name not in models:
+            models.append(name)
+    deployed = {m: sorted({g % ndev for g in range(n_rep) if rep_model[g] == m}) for m in models}
+    return models, rep_model, deployed
+
+
 class Runner:
     """Drives the lookup sessions of one deployment (server + cache): one host thread per session, each step one call of
     the hot path on one batch, per-step statistics from the engine (HIP events on the session's stream)."""
@@ -267,6 +285,7 @@ def summarize(rec, N, D, dt, steps):
     return {
         "lookups_per_s": steps * N / dt, "ms_per_step": dt / steps * 1e3,
         "p50_call_ms": float(np.percentile(a[:, 0], 50)), "p99_call_ms": float(np.percentile(a[:, 0], 99)),
+        "max_call_ms": float(a[:, 0].max()),
         "probe_ms": probe, "gather_ms": gather, "scatter_ms": scatter, "insert_ms": float(a[:, 4].mean()),
         "frac_of_hbm_peak_1032B_per_lookup": N * (8 + 8 * D) / (hbm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if hbm_ms > 0 else None,
         "measured_hit_rate": 1.0 - float(a[:, 5].mean()) / N,
@@ -282,124 +301,105 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        # share the host cores between the ranks' parameter-server pools
-        os.environ.setdefault("HCTR_DEFAULT_CONCURRENCY", str(max(2, effective_cpus() // world)))
+    # N GPUs = the reference's arrangement (docs/architecture.md:11,29; hps_backend/src/model_state.cpp:395-420;
+    # backend.cpp:68-69): ONE process with ONE parameter server (one copy of the host tier) and one embedding cache per
+    # GPU of deployed_device_list, the lookup sessions of every GPU driven by host threads of that process.  Under
+    # torch.distributed.run rank 0 is that process; the other ranks take no part in the replicas measurement (they wait
+    # at a gloo barrier) and come in only for the sharded-table leg, where each rank owns one GPU (RCCL inside the engine).
+    n_rep = max(world, a.gpus, 1)
     if a.direct < 0:
-        # the host-gather tier needs host cores (its gather runs on ~14 threads per GPU); with fewer, or with several
-        # replicas sharing one host, the device-driven tier, which needs none, is the one to run
-        a.direct = 0 if (world == 1 and effective_cpus() >= 12) else 1
+        # the host-gather tier needs host cores (its gather runs on ~14 threads per GPU); with fewer per GPU the
+        # device-driven tier, which needs none, is the one to run
+        a.direct = 0 if effective_cpus() >= 12 * n_rep else 1
 
     # HIP spreads a process's streams over 4 hardware queues by default; two lookup sessions whose streams land on the
     # same queue run strictly one after the other.  Must be in the environment before HIP starts.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    if n_rep > 1 and not a.direct:
+        # host-gather tier on N GPUs: the serving pool of the one process gathers for all of them (default: at most 64 threads)
+        os.environ.setdefault("HPS_SERVING_THREADS", str(max(1, min(effective_cpus() - 3, 64 * n_rep))))
+    dist = None
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        # CPU rendezvous only: nothing of the data path goes through torch.distributed
+        dist.init_process_group("gloo", timeout=datetime.timedelta(hours=6))
+    if rank != 0:
+        idle_rank(a, dist, rank, world, local_rank)
+        return
     from hugectr_backend_amd.gpu_wait import wait_for_gpu
     wait_for_gpu(30.0)   # a device that another process has just released can be invisible for a moment
     import torch
-    import torch.distributed as dist
     from hugectr_backend_amd import build as hb
     ndev = torch.cuda.device_count()
     assert ndev > 0, "bench.py needs an MI355X"
-    # one rank per GPU over RCCL ("nccl" on ROCm).  Only when fewer GPUs than ranks are visible (the 1-GPU
-    # development box) do the ranks share devices and rendezvous over gloo, to exercise the same control flow.
-    shared_gpu = world > ndev
-    dev = local_rank % ndev
-    local_rank = dev
+    # replica g runs on device g.  Only when fewer GPUs than replicas are visible (the 1-GPU development box) do replicas
+    # share devices — each extra replica of a device then deploys the model a second time under its own name (own tables,
+    # own cache), which exercises the same multi-cache code path.
+    devs = [g % ndev for g in range(n_rep)]
+    shared_gpu = n_rep > ndev
+    dev = devs[0]
     torch.cuda.set_device(dev)
-    coll_dev = "cpu" if shared_gpu else "cuda"
     numa_note = None
-    if world > 1 and not shared_gpu and hasattr(os, "sched_setaffinity"):
-        # threads created from here on (the engine's pools, the table loaders) inherit the mask
-        try:
-            pr = torch.cuda.get_device_properties(dev)
-            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-            cpus = gpu_local_cpus(bdf, os.sched_getaffinity(0))
-            if cpus:
-                os.sched_setaffinity(0, cpus)
-                numa_note = f"rank bound to the {len(cpus)} CPUs local to GPU {bdf}"
-        except Exception as e:  # noqa: BLE001
-            numa_note = f"no NUMA binding ({e!r})"
-    if world > 1:
-        if shared_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-    if rank == 0:
-        hb.build()
-    if world > 1:
-        dist.barrier()  # the other ranks load the libraries only after rank 0 has (re)built them
+    hb.build()
     from hugectr_backend_amd import hps
 
     T, R, D, B = a.tables, a.rows, a.dim, a.batch
-    # host-memory guard: every rank keeps the full tables in its parameter server (replicas).  If the box
-    # cannot hold them for all ranks, rows/table shrinks and the workload string says so.
+    N = T * B
+    K, W = a.steps, a.warmup
+    blocks = a.blocks if a.blocks > 0 else int(min(12, max(1, -(-240 // max(K, 1)))))
+    nb = W + K * blocks
+    if a.distinct_batches > 0:
+        nb = min(nb, a.distinct_batches)
+    # one model per replica that has to share a device with an earlier one (development box only); on an N-GPU node
+    # there is ONE model deployed on N devices
+    models, rep_model, _ = plan_replicas(n_rep, ndev)
+    model = models[0]
+    # host-memory guard: the host tier exists ONCE whatever the number of GPUs (one parameter server per process); what
+    # grows with N is the timed region's key batches.  Only if the box cannot hold that do rows/table shrink, and the
+    # workload string says so.
     rows_requested = R
-    budget = int(host_memory_budget() * 0.85 / world) - (12 << 30)
-    if world > 1:
-        bt = torch.tensor([budget], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(bt, op=dist.ReduceOp.MIN)
-        budget = int(bt.item())
-    per_row = T * (4 * D + 64) + T * 56 + 2 * (4 * D + 48)   # tables + index, the oracle's index of every table, its copy of two
+    budget = int(host_memory_budget() * 0.85) - (12 << 30) - n_rep * nb * N * 8
+    per_row = len(models) * T * (4 * D + 64) + T * 56 + 2 * (4 * D + 48)   # tables + index, the oracle's index of every table, its copy of two
     if R * per_row > budget:
         R = max(B, int(budget // per_row))
     setup_note = ""
-    if world > 1:
-        # setup-time guard: N ranks generate and pin N copies of the tables on the host cores they share.  A probe
-        # table measures this rank's generation rate under that contention; if the full tables would take longer
-        # than --setup-seconds, rows/table shrinks for every rank (same batch, same hit rate; the workload says so).
-        probe_rows = min(R, 1_000_000)
-        pcfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8},
-                "models": [{"model": "probe", "sparse_files": ["synthetic://probe"], "num_of_worker_buffer_in_pool": 1,
-                            "embedding_vecsize_per_table": [D], "maxnum_catfeature_query_per_table_per_sample": [1],
-                            "default_value_for_each_table": [0.0], "deployed_device_list": [local_rank],
-                            "max_batch_size": 1, "gpucache": False}]}
-        pps = hps.HierParameterServer.create_from_dict(pcfg, load_tables=False)
-        dist.barrier()
-        tp = time.time()
-        pps.load_table_synthetic("probe", 0, SEED, 0, probe_rows)
-        est = (time.time() - tp) / probe_rows * R * T * (1.6 if a.direct else 1.0)   # + page-locking
-        del pps
-        et = torch.tensor([est], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        est = float(et.item())
-        if est > a.setup_seconds:
-            R = max(B, int(R * a.setup_seconds / est) // 1000 * 1000)
-            setup_note = f"; setup-time guard ({est:.0f} s estimated for the full tables on this box's shared host cores)"
-    N = T * B
-    model = "criteo_dlrm"
     threshold = 1.0 if a.mode == "sync" else 0.5
     cfg = {
         "supportlonglong": True,
         "volatile_db": {"type": "hash_map", "num_partitions": 8},
         "models": [{
-            "model": model,
+            "model": m,
             "sparse_files": [f"synthetic://t{t}" for t in range(T)],
             "num_of_worker_buffer_in_pool": max(3, a.sessions),
             "embedding_vecsize_per_table": [D] * T,
             "maxnum_catfeature_query_per_table_per_sample": [1] * T,
             "default_value_for_each_table": [0.0] * T,
-            "deployed_device_list": [local_rank],
+            "deployed_device_list": plan_replicas(n_rep, ndev)[2][m],
             "max_batch_size": B,
             "gpucache": True,
             "gpucacheper": a.cache_frac,
             "hit_rate_threshold": threshold,
             "ps_direct_access": bool(a.direct),
-        }],
+        } for m in models],
     }
 
     def setup():
+        """One parameter server: the host tables are generated once, then one cache per (model, device)."""
         t_setup = time.time()
         ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
-        for t in range(T):
-            ps.load_table_synthetic(model, t, SEED, 0, R)
+        for m in models:
+            for t in range(T):
+                ps.load_table_synthetic(m, t, SEED, 0, R)
         t_tables = time.time() - t_setup
-        ps.create_embedding_cache_per_model(model)
-        cache = ps.get_embedding_cache(model, local_rank)
+        for m in models:
+            ps.create_embedding_cache_per_model(m)
+        caches = [ps.get_embedding_cache(rep_model[g], devs[g]) for g in range(n_rep)]
         t_cache = time.time() - t_setup - t_tables
-        return ps, cache, t_tables, t_cache
+        return ps, caches, t_tables, t_cache
 
     # ps_direct_access pins the whole host tier (hipHostMalloc).  Where the box refuses that much page-locked
-    # memory, every rank falls back to the host-gather tier of the same library (never to a CPU path) and the
+    # memory, the run falls back to the host-gather tier of the same library (never to a CPU path) and the
     # result line says so in config.ps_tier.
     direct_note = None
     made = None
@@ -408,66 +408,79 @@ def main():
             made = setup()
         except Exception as e:  # noqa: BLE001
             direct_note = f"ps_direct_access unavailable on this box ({str(e)[:160]})"
-            sys.stderr.write(f"[bench rank {rank}] {direct_note}; falling back to the host-gather tier\n")
-        ok = 1 if made is not None else 0
-        if world > 1:
-            okt = torch.tensor([ok], dtype=torch.int64, device=coll_dev)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            ok = int(okt.item())
-        if not ok:
-            made = None
+            sys.stderr.write(f"[bench] {direct_note}; falling back to the host-gather tier\n")
             import gc
             gc.collect()
             a.direct = 0
-            cfg["models"][0]["ps_direct_access"] = False
-            direct_note = direct_note or "ps_direct_access unavailable on another rank"
+            for mc in cfg["models"]:
+                mc["ps_direct_access"] = False
     if made is None:
         made = setup()
-    ps, cache, t_tables, t_cache = made
-    sessions = [hps.LookupSession.create(ps, model, cache) for _ in range(a.sessions)]
+    ps, caches, t_tables, t_cache = made
+    cache = caches[0]
     split = (a.split_probe != 0) and not a.direct     # host-gather tier only
-    for s in sessions:
-        s.set_option("timing", 1)
-        s.set_option("probe_variant", a.probe_variant)
-        s.set_option("xcd_walk", a.xcd_walk)
-        s.set_option("split_probe", 1 if split else 0)
-        s.set_option("narrow_keys", a.narrow_keys)
-        s.set_option("chain_gather", a.chain_gather)
-
-    # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
     C = int(np.ceil(a.cache_frac * R))
-    resident = []
-    for t in range(T):
-        k = np.arange(C, dtype=np.int64)
-        resident.append(k[cache.query(t, k) >= 0])
-    resident_frac = float(np.mean([r.size / C for r in resident]))
+    cdf_h = torch.from_numpy(zipf_cdf(C, a.zipf))
 
-    # ---- timed region layout: W warm-up steps, then `blocks` blocks of exactly K steps, every step a fresh batch ----
-    K, W = a.steps, a.warmup
-    blocks = a.blocks if a.blocks > 0 else int(min(12, max(1, -(-240 // max(K, 1)))))
-    nb = W + K * blocks
-    if a.distinct_batches > 0:
-        nb = min(nb, a.distinct_batches)
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(SEED + rank)
-    cdf_d = torch.from_numpy(zipf_cdf(C, a.zipf)).cuda()
-    resident_d = [torch.from_numpy(r).cuda() for r in resident]
-    run = Runner(torch, hps, sessions, T, B, D, dev)
-    # The reference's contract (docs/architecture.md:308-323; hps.cc:586-597): the keys of a request are in HOST memory.
-    # Generated on the device (fast), then moved to ordinary pageable numpy arrays, one per batch.
-    host_batches = []
-    for i in range(0, nb, 16):
-        for bt_ in make_batches_gpu(torch, gen, resident_d, cdf_d, R, C, B, a.hit, min(16, nb - i)):
-            arr = bt_.cpu().numpy()
-            host_batches.append((arr, run.pack_host(arr)))
-    torch.cuda.synchronize()
+    class Replica:
+        """One GPU's share of the deployment: its cache, its lookup sessions, its output buffers, its key batches."""
+
+    reps = []
+    for g in range(n_rep):
+        rp = Replica()
+        rp.g, rp.dev, rp.model, rp.cache = g, devs[g], rep_model[g], caches[g]
+        with torch.cuda.device(rp.dev):
+            rp.sessions = [hps.LookupSession.create(ps, rp.model, rp.cache) for _ in range(a.sessions)]
+            for s in rp.sessions:
+                s.set_option("timing", 1)
+                s.set_option("probe_variant", a.probe_variant)
+                s.set_option("xcd_walk", a.xcd_walk)
+                s.set_option("split_probe", 1 if split else 0)
+                s.set_option("narrow_keys", a.narrow_keys)
+                s.set_option("chain_gather", a.chain_gather)
+            # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
+            resident = []
+            for t in range(T):
+                k = np.arange(C, dtype=np.int64)
+                resident.append(k[rp.cache.query(t, k) >= 0])
+            rp.resident_frac = float(np.mean([r.size / C for r in resident]))
+            # ---- timed region layout: W warm-up steps, then `blocks` blocks of exactly K steps, every step a fresh batch ----
+            gen = torch.Generator(device=f"cuda:{rp.dev}")
+            gen.manual_seed(SEED + g)
+            rp.cdf_d = cdf_h.cuda()
+            rp.resident_d = [torch.from_numpy(r).cuda() for r in resident]
+            rp.run = Runner(torch, hps, rp.sessions, T, B, D, rp.dev)
+            # The reference's contract (docs/architecture.md:308-323; hps.cc:586-597): the keys of a request are in HOST
+            # memory.  Generated on the device (fast), then moved to ordinary pageable numpy arrays, one per batch.
+            rp.host_batches = []
+            for i in range(0, nb, 16):
+                for bt_ in make_batches_gpu(torch, gen, rp.resident_d, rp.cdf_d, R, C, B, a.hit, min(16, nb - i)):
+                    arr = bt_.cpu().numpy()
+                    rp.host_batches.append((arr, rp.run.pack_host(arr)))
+            torch.cuda.synchronize()
+            if g > 0:
+                del rp.resident_d, rp.cdf_d
+        rp.rec = []
+        reps.append(rp)
+    sessions, run, host_batches = reps[0].sessions, reps[0].run, reps[0].host_batches
+    resident_d, cdf_d, resident_frac = reps[0].resident_d, reps[0].cdf_d, reps[0].resident_frac
     ncpu = effective_cpus()
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        # every replica lives in this process: the barrier between blocks is the join of their threads plus a
+        # synchronisation of every device (no other process takes part in the measurement)
+        for d in sorted(set(devs)):
+            torch.cuda.synchronize(d)
+
+    def run_all(count, first, record):
+        """`count` steps on EVERY replica, concurrently (each replica's sessions share its steps); returns when all are done."""
+        if n_rep == 1:
+            reps[0].run.run(reps[0].host_batches, count, first, "host", record=reps[0].rec if record else None)
+            return
+        th = [threading.Thread(target=rp.run.run, args=(rp.host_batches, count, first, "host"),
+                               kwargs={"record": rp.rec if record else None}) for rp in reps]
+        [x.start() for x in th]
+        [x.join() for x in th]
 
     # no collector pass of the interpreter inside the timed region (a full pass over a torch process's objects takes tens of
     # milliseconds and holds the GIL the session threads need between two calls)
@@ -475,32 +488,60 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
-    run.run(host_batches, W, 0, "host")
+    run_all(W, 0, False)
     if a.mode == "async":
-        cache.wait_async()
-    block_s, rec = [], []
+        for c in caches:
+            c.wait_async()
+    block_s = []
     thr0 = cpu_throttle_stat()
     ct0, wall0 = cpu_times(), time.perf_counter()
     for blk in range(blocks):
         barrier()
         t0 = time.perf_counter()
-        run.run(host_batches, K, W + blk * K, "host", record=rec)
+        run_all(K, W + blk * K, True)
         barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        block_s.append(el)
+        block_s.append(time.perf_counter() - t0)   # until the LAST replica has finished its K steps (= max over GPUs)
     thr1 = cpu_throttle_stat()
     ct1, wall1 = cpu_times(), time.perf_counter()
     gc.enable()
     elapsed = float(np.median(block_s))
-    main_rec = list(rec)
+    main_rec = [r for rp in reps for r in rp.rec]
+    per_gpu = None
+    if n_rep > 1:
+        per_gpu = []
+        for rp in reps:
+            m_ = summarize(rp.rec, N, D, elapsed, K)
+            per_gpu.append({"replica": rp.g, "device": rp.dev, "model": rp.model,
+                            "p50_call_ms": m_["p50_call_ms"], "p99_call_ms": m_["p99_call_ms"],
+                            "probe_ms": m_["probe_ms"], "gather_ms": m_["gather_ms"], "scatter_ms": m_["scatter_ms"],
+                            "insert_ms": m_["insert_ms"], "measured_hit_rate": m_["measured_hit_rate"],
+                            "frac_of_hbm_peak_1032B_per_lookup": m_["frac_of_hbm_peak_1032B_per_lookup"],
+                            "resident_fraction_after_warmup": rp.resident_frac})
+        # every other replica's answer to one whole batch against the rows as they sit in the host tier (keys are 0..R-1 in
+        # file order: the expected row of key k is row k); replica 0 gets the full set of checks further down
+        if a.mode == "sync":
+            views = [ps.table_data(rp_.model, t) for rp_ in reps[:1] for t in range(T)] if len(models) == 1 else None
+            for rp in reps[1:]:
+                q = rp.host_batches[0][0]
+                rp.sessions[0].lookup_packed(rp.host_batches[0][1], rp.run.vptrs[0], rp.run.counts)
+                torch.cuda.synchronize(rp.dev)
+                got = rp.run.outs[0].cpu().numpy().reshape(N, D)
+                okr = True
+                for t in range(T):
+                    tk, tr = views[t] if views else ps.table_data(rp.model, t)
+                    qt = q[t * B:(t + 1) * B]
+                    okr &= bool(np.array_equal(tr[qt].view(np.uint32), got[t * B:(t + 1) * B].view(np.uint32)))
+                per_gpu[rp.g]["parity_full_batch_vs_direct_row_index"] = okr
+                del got
+        # the other replicas' sessions and batches are released before the checks (their caches go with the server)
+        for rp in reps[1:]:
+            for s in rp.sessions:
+                s.close()
+            rp.sessions, rp.host_batches, rp.run = [], [], None
 
     # ---- extra legs (outside the timed region; per-GPU numbers of this rank) --------------------------------
     extra = {}
-    if not a.no_extra_legs and world == 1:
+    if not a.no_extra_legs and n_rep == 1:
         gen2 = torch.Generator(device="cuda")
         gen2.manual_seed(SEED + 1000 + rank)
 
@@ -630,6 +671,7 @@ def main():
                 s.set_option("narrow_keys", a.narrow_keys)
                 s.set_option("hit_rate_threshold_permille", 1000 if a.mode == "sync" else 500)
     del cdf_d, resident_d
+    reps[0].cdf_d = reps[0].resident_d = None
 
     # ---- untimed checks of one step against the CPU oracle, and the cpu_baseline leg ----
     parity = parity_full = None
@@ -679,7 +721,7 @@ def main():
                     okf &= bool(np.array_equal(tk[qt], qt))
                     okf &= bool(np.array_equal(tr[qt].view(np.uint32), got_all[t * B:(t + 1) * B].view(np.uint32)))
                 parity_full = okf
-            if a.no_cpu_baseline or world > 1:
+            if a.no_cpu_baseline or n_rep > 1:
                 return
             # ---- cpu_baseline: the oracle (a port of the reference's hash_map parameter-server lookup: a hash-map find per
             # key, row copy or default) on the timed region's own batches, ALL tables, all host cores.  The oracle builds its
@@ -745,9 +787,9 @@ def main():
         fetch_ms = float(ph[:, 1].mean()) if ph.size else 0.0
         res = {
             "metric": "embedding lookups/sec, Criteo 26-slot 64K batch",
-            "value": world * K * N / elapsed,
+            "value": n_rep * K * N / elapsed,
             "unit": "lookups/s",
-            "n_gpus": world,
+            "n_gpus": n_rep,
             "steps": K,
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
@@ -758,20 +800,26 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"Criteo DLRM {T} sparse slots, {R} rows/table"
-                            + (f" (requested {rows_requested}; reduced to fit the host memory / setup time of {world} replicas{setup_note})" if R != rows_requested else "")
-                            + f" x {D}-dim, {B} batch ({N} keys), "
+                            + (f" (requested {rows_requested}; reduced to fit this box's host memory{setup_note})" if R != rows_requested else "")
+                            + f" x {D}-dim, {B} batch ({N} keys) per GPU and step, "
                             f"gpucacheper {a.cache_frac}, 95% cache hit (resident-draw probability {a.hit}; see measured_hit_rate), "
-                            f"zipf {a.zipf} within the resident set, {a.mode} insert, {a.sessions} lookup sessions, "
+                            f"zipf {a.zipf} within the resident set, {a.mode} insert, {a.sessions} lookup sessions per GPU, "
                             f"keys on host (pageable int64 arrays handed to hps_session_lookup, the reference's LookupSession::lookup contract), "
                             f"output rows in HBM",
-                "parallelism": "replicas" if world > 1 else "single",
+                "parallelism": "single" if n_rep == 1 else
+                               (f"replicas: ONE process, ONE parameter server (host tier built once, {t_tables:.0f} s), one embedding cache + "
+                                f"{a.sessions} lookup sessions per GPU on devices {devs}, no data-path collective "
+                                "(the reference's arrangement: docs/architecture.md:11,29; model_state.cpp:395-420)"
+                                + ("; replicas SHARE devices on this box (fewer GPUs than replicas): each extra replica of a device "
+                                   "deploys the model again under its own name" if shared_gpu else "")),
+                "host_cpus_per_gpu": ncpu / n_rep,
                 "ps_tier": "device-driven (ps_direct_access)" if a.direct else
                            ("host gather" + (f" [{direct_note}]" if direct_note else "")),
-                "timed_region": f"{blocks} blocks of exactly {K} steps (barrier + synchronize on both sides, max over ranks), every step a "
-                                f"fresh batch; value = the MEDIAN block",
+                "timed_region": f"{blocks} blocks of exactly {K} steps per GPU (every device synchronised on both sides; a block ends when "
+                                f"the last GPU has finished its {K} steps = max over GPUs), every step a fresh batch; value = the MEDIAN block",
             },
             "block_ms": [b * 1e3 for b in block_s],
-            "value_min_max_over_blocks": [world * K * N / max(block_s), world * K * N / min(block_s)],
+            "value_min_max_over_blocks": [n_rep * K * N / max(block_s), n_rep * K * N / min(block_s)],
             "p50_batch_latency_ms": float(np.percentile(lat, 50)),
             "p99_batch_latency_ms": float(np.percentile(lat, 99)),
             # GPU side of a batch (HIP events on the session's stream: probe start to the last kernel of the call)
@@ -791,6 +839,7 @@ def main():
                      "hypervisor_steal_ms_in_timed_region": (ct1[0] - ct0[0]) * 1e3 if ct0[0] is not None and ct1[0] is not None else None,
                      "process_cpus_busy_in_timed_region": (ct1[1] - ct0[1]) / max(wall1 - wall0, 1e-9)},
             "resident_fraction_after_warmup": resident_frac,
+            "per_gpu": per_gpu,
             "roofline": {
                 "bound": "hbm",
                 # every lookup priced at 1,032 algorithmic bytes over ALL HBM-side kernels of the lookup
@@ -833,7 +882,8 @@ def main():
             "extra_legs": extra or None,
             "cpu_baseline": cpu,
             "parity_vs_oracle_bit_exact": parity,
-            "parity_full_batch_vs_direct_row_index": parity_full,
+            "parity_full_batch_vs_direct_row_index": parity_full if per_gpu is None or parity_full is None else
+                                                     bool(parity_full and all(p.get("parity_full_batch_vs_direct_row_index", True) for p in per_gpu)),
             "checker_note": checker_note,
             "setup_seconds": {"host_tables": t_tables, "gpu_cache_warmup": t_cache},
             "cache_counters": cache.counters(),
@@ -843,9 +893,9 @@ def main():
 
     # ---- one GPU: legs that need the headline's memory back (its tables are 133 GB): the plugin boundary driven by the
     #      native load generator, then the other parameter-server tier ----
-    if world == 1 and not a.no_extra_legs:
+    if n_rep == 1 and not a.no_extra_legs:
         import gc
-        del sessions, cache, ps, made, run, host_batches
+        del sessions, cache, caches, ps, made, run, host_batches, reps
         gc.collect()
         torch.cuda.empty_cache()
         if not a.no_triton_leg:
@@ -858,36 +908,60 @@ def main():
                 sys.stderr.write(f"[bench] device-driven tier leg stopped: {e!r}\n")
             res["extra_legs"] = dict(res["extra_legs"] or {}, device_driven_tier=dleg)
 
-    # ---- BASELINE config 3 leg (N > 1 only): ONE table sharded over the ranks, RCCL all-to-all of keys and rows ----
-    # Runs after the headline measurement is complete and its resources are released; a watchdog prints the headline
-    # line and ends every rank if the leg does not finish (a collective that hangs cannot be caught any other way).
-    if world > 1 and not a.no_sharded_leg:
+    # ---- BASELINE config 3 leg (only under torch.distributed.run with N > 1 ranks): ONE table sharded over the ranks, one
+    # rank per GPU, RCCL send/recv inside the engine.  Runs after the headline measurement is complete and its resources are
+    # released (the barrier below is what the idle ranks have been waiting at); a watchdog prints the headline line and ends
+    # the rank if the leg does not finish (a collective that hangs cannot be caught any other way).
+    if world > 1:
         import gc
-        del sessions, cache, ps, made, run, host_batches
+        del sessions, cache, caches, ps, made, run, host_batches, reps
         gc.collect()
-        torch.cuda.empty_cache()
-
-        def give_up():
-            if rank == 0:
+        for d in sorted(set(devs)):
+            with torch.cuda.device(d):
+                torch.cuda.empty_cache()
+        dist.barrier()
+        if not a.no_sharded_leg:
+            def give_up():
                 res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3={"error": f"no result within {a.sharded_timeout} s"})
                 print(json.dumps(res), flush=True)
-            os._exit(0)
+                os._exit(0)
 
-        dog = threading.Timer(a.sharded_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            leg3 = sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev)
-        except Exception as e:  # noqa: BLE001
-            leg3 = {"error": repr(e)[:300]}
-        dog.cancel()
-        if rank == 0:
+            dog = threading.Timer(a.sharded_timeout, give_up)
+            dog.daemon = True
+            dog.start()
+            try:
+                leg3 = sharded_leg(a, torch, dist, hps, rank, world, local_rank % ndev, world > ndev)
+            except Exception as e:  # noqa: BLE001
+                leg3 = {"error": repr(e)[:300]}
+            dog.cancel()
             res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3=leg3)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
+    print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def idle_rank(a, dist, rank, world, local_rank):
+    """Ranks 1..N-1 under torch.distributed.run.  The replicas measurement is rank 0's alone (one process serves every GPU,
+    as the reference does), so these ranks wait for it at a barrier; afterwards each takes its own GPU for the sharded-table
+    leg (BASELINE config 3), where one process per GPU is the arrangement."""
+    dist.barrier()
+    if not a.no_sharded_leg:
+        dog = threading.Timer(a.sharded_timeout, lambda: os._exit(0))
+        dog.daemon = True
+        dog.start()
+        try:
+            from hugectr_backend_amd.gpu_wait import wait_for_gpu
+            wait_for_gpu(30.0)
+            import torch
+            from hugectr_backend_amd import hps
+            ndev = torch.cuda.device_count()
+            sharded_leg(a, torch, dist, hps, rank, world, local_rank % ndev, world > ndev)
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"[bench rank {rank}] sharded leg stopped: {e!r}\n")
+        dog.cancel()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def triton_abi_leg(a, hb, T, R, D, B):
@@ -967,7 +1041,7 @@ def other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
     return out
 
 
-def sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev):
+def sharded_leg(a, torch, dist, hps, rank, world, local_rank, shared_gpu):
     """One table of Rt rows x D sharded over the P ranks (owner = mix64(key) mod P), every rank resident at 100 % in
     its own HBM; per step every rank looks up N/P uniform keys through the engine's sharded session
     (csrc/cache/shard_session.cpp: bucket by owner into fixed-capacity blocks, RCCL send/recv group of the keys, padded
@@ -975,6 +1049,8 @@ def sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev):
     Global lookups/s = N x steps / time."""
     from hugectr_backend_amd.sharded import ShardedLookup
     P, D = world, a.dim
+    coll_dev = "cpu"   # the process group is gloo: it carries the RCCL unique id, the barriers and the checks, nothing else
+    torch.cuda.set_device(local_rank)
     N = a.tables * a.batch
     n_local = N // P
     budget = int(host_memory_budget() * 0.6)          # this rank's share is checked against the minimum over ranks
@@ -1000,7 +1076,9 @@ def sharded_leg(a, torch, dist, hps, rank, world, local_rank, coll_dev):
     ps.create_embedding_cache_per_model(model)
     cache = ps.get_embedding_cache(model, local_rank)
     sess = hps.LookupSession.create(ps, model, cache)
-    sl = ShardedLookup(sess, max_local_keys=n_local)   # backend nccl: the engine's native RCCL session (no torch collectives per step)
+    # own GPU per rank: the engine's native RCCL session (no torch collective per step); ranks sharing the development box's
+    # one GPU: the torch.distributed variant over gloo (control flow only)
+    sl = ShardedLookup(sess, max_local_keys=n_local, native=not shared_gpu)
     t_setup = time.time() - t0
     gen = torch.Generator(device="cuda")
     gen.manual_seed(SEED + 77 + rank)

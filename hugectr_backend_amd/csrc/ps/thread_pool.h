@@ -70,7 +70,7 @@ class ThreadPool {
     std::atomic<uint32_t> n{0}, grain{1};
     uint32_t gen = 0;                                                  // owner only
   };
-  static constexpr int kFastSlots = 4;
+  static constexpr int kFastSlots = 16;   // two sessions per GPU on an 8-GPU node fork-join side by side
   FastLoop fast_[kFastSlots];
   // claims and runs grains of slot `L` while its generation is `gen`; returns the number of tasks this thread ran
   static uint32_t RunFast(FastLoop& L, uint32_t gen);

@@ -32,3 +32,18 @@ def test_gpu_local_cpus_binds_only_on_multi_node_hosts(tmp_path):
     unknown = _fake_sysfs(tmp_path / "unk", 2, -1, "0-127\n")
     assert bench.gpu_local_cpus("0000:05:00.0", allowed, unknown) is None
     assert bench.gpu_local_cpus("0000:99:00.0", allowed, two) is None
+
+
+def test_replica_plan_one_model_on_n_devices_and_duplicates_on_a_small_box():
+    # 8 GPUs: one model, deployed_device_list 0..7 (the reference's arrangement: one cache per device, one server)
+    models, rep_model, deployed = bench.plan_replicas(8, 8)
+    assert models == ["criteo_dlrm"] and rep_model == ["criteo_dlrm"] * 8 and deployed == {"criteo_dlrm": list(range(8))}
+    # 2 replicas, 1 GPU: the second replica is a second deployment of the model on device 0
+    models, rep_model, deployed = bench.plan_replicas(2, 1)
+    assert models == ["criteo_dlrm", "criteo_dlrm_dup1"] and rep_model == models
+    assert deployed == {"criteo_dlrm": [0], "criteo_dlrm_dup1": [0]}
+    # 4 replicas, 2 GPUs
+    models, rep_model, deployed = bench.plan_replicas(4, 2)
+    assert rep_model == ["criteo_dlrm", "criteo_dlrm", "criteo_dlrm_dup1", "criteo_dlrm_dup1"]
+    assert deployed == {"criteo_dlrm": [0, 1], "criteo_dlrm_dup1": [0, 1]}
+    assert bench.plan_replicas(1, 1) == (["criteo_dlrm"], ["criteo_dlrm"], {"criteo_dlrm": [0]})

@@ -496,6 +496,13 @@ def test_host_keys_staged_in_pieces_and_pinned_in_place():
             s.set_option("keys_pinned_check", check)
             out = s.lookup(pinned.numpy(), nk).cpu().numpy()
             assert np.array_equal(_bits(out), _bits(ref))
+            if check == 1 and sum(nk) > 200_000:
+                # the DMA-in-place branch was taken: page-locked keys are never read by host threads (an order of magnitude
+                # slower than pageable memory: round 2's 87-ms calls) — they cross PCIe as they are, 8 bytes each, and the
+                # host side of the staging is the pointer check plus one enqueue
+                st = s.last_stats()
+                assert st.key_bytes == 8 and st.keys_narrowed == 0
+                assert st.key_stage_ms < 1.0, st.key_stage_ms
         s.set_option("keys_pinned_check", 1)
         # per-table pointers that are NOT one flat array (each table from its own allocation)
         parts, off = [], 0
