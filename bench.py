@@ -77,6 +77,8 @@ def parse_args():
                          "while the misses are fetched (DESIGN.md 3.4c); 0: gather first")
     ap.add_argument("--no-direct-leg", action="store_true",
                     help="one GPU, host-gather headline: skip the device-driven-tier leg measured afterwards")
+    ap.add_argument("--no-wide-leg", action="store_true",
+                    help="one GPU: skip the leg with keys offset by 2^40 (8 bytes per key over PCIe) at 95 %% hit")
     ap.add_argument("--no-triton-leg", action="store_true",
                     help="one GPU: skip the leg through TRITONBACKEND_ModelInstanceExecute (tools/triton_abi_bench.cpp)")
     ap.add_argument("--triton-timeout", type=float, default=240.0)
@@ -899,7 +901,17 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         if not a.no_triton_leg:
-            res["extra_legs"] = dict(res["extra_legs"] or {}, triton_abi=triton_abi_leg(a, hb, T, R, D, B))
+            res["extra_legs"] = dict(res["extra_legs"] or {}, triton_abi=triton_abi_leg(a, hb, T, R, D, B),
+                                     c1_cpu_ps_triton=c1_leg(a, hb), c4_two_models_triton=c4_leg(a, hb))
+        if not a.no_wide_leg:
+            try:
+                wleg = wide_keys_leg(a, torch, hps, T, R, D, B, N, dev, cfg)
+            except Exception as e:  # noqa: BLE001
+                wleg = {"error": repr(e)[:300]}
+                sys.stderr.write(f"[bench] wide-keys leg stopped: {e!r}\n")
+            res["extra_legs"] = dict(res["extra_legs"] or {}, wide_keys_95=wleg)
+            gc.collect()
+            torch.cuda.empty_cache()
         if not a.direct and not a.no_direct_leg:
             try:
                 dleg = other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg)
@@ -964,19 +976,16 @@ def idle_rank(a, dist, rank, world, local_rank):
     dist.destroy_process_group()
 
 
-def triton_abi_leg(a, hb, T, R, D, B):
-    """The same workload through the plugin boundary: tools/triton_abi_bench.cpp (native, two threads) drives
-    TRITONBACKEND_ModelInstanceExecute of libtriton_hps.so through the mock Triton core — what perf_analyzer does to the
-    reference (.gitlab-ci.yml:70).  Own process: it loads the model through TRITONBACKEND_ModelInitialize itself."""
+def run_abi_driver(hb, args, timeout):
+    """tools/triton_abi_bench.cpp (native): plays tritonserver through the mock core and drives
+    TRITONBACKEND_ModelInstanceExecute of libtriton_hps.so — what perf_analyzer does to the reference (.gitlab-ci.yml:70).
+    Own process: it loads its models through TRITONBACKEND_ModelInitialize itself."""
     import subprocess
     exe = hb.LIB / "triton_abi_bench.bin"
     if not exe.exists():
         return {"error": "tools/triton_abi_bench.cpp was not built"}
-    cmd = [str(exe), "--lib-dir", str(hb.LIB), "--tables", str(T), "--rows", str(R), "--dim", str(D), "--batch", str(B),
-           "--cache-frac", str(a.cache_frac), "--hit", str(a.hit), "--zipf", str(a.zipf), "--instances", str(a.sessions),
-           "--steps", "20", "--blocks", "12", "--warmup", "5", "--direct", str(int(bool(a.direct)))]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=a.triton_timeout)
+        r = subprocess.run([str(exe), "--lib-dir", str(hb.LIB), *map(str, args)], capture_output=True, text=True, timeout=timeout)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if not line:
             return {"error": f"rc={r.returncode}: {r.stderr[-300:]}"}
@@ -987,16 +996,50 @@ def triton_abi_leg(a, hb, T, R, D, B):
         return {"error": repr(e)[:300]}
 
 
-def other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
-    """The headline workload on a ps_direct_access deployment of the same model (own server: page-locked tables, device
-    index): two sessions, fresh batches of host keys, exact rows."""
+def triton_abi_leg(a, hb, T, R, D, B):
+    """The headline workload through the plugin boundary (two instances, pageable KEYS, device OUTPUT0)."""
+    return run_abi_driver(hb, ["--tables", T, "--rows", R, "--dim", D, "--batch", B, "--cache-frac", a.cache_frac, "--hit", a.hit,
+                               "--zipf", a.zipf, "--instances", a.sessions, "--steps", 20, "--blocks", 12, "--warmup", 5,
+                               "--direct", int(bool(a.direct))], a.triton_timeout)
+
+
+def c1_leg(a, hb):
+    """BASELINE config 1 — the reference's own CI performance smoke (.gitlab-ci.yml:70: perf_analyzer against the hps backend):
+    one table 1,048,576 x 16, 4,096-key requests, CPU parameter server only (gpucache=false, KIND_CPU instance, OUTPUT0 in host
+    memory), through TRITONBACKEND_ModelInstanceExecute."""
+    out = run_abi_driver(hb, ["--tables", 1, "--rows", 1 << 20, "--dims", 16, "--batch", 4096, "--gpucache", 0, "--uniform", 1,
+                              "--instances", 1, "--steps", 500, "--blocks", 6, "--warmup", 200], 120.0)
+    out["config"] = "BASELINE configs[0]: 1 table 1,048,576 x 16 fp32, 4,096 uniform keys per request, gpucache=false, one KIND_CPU instance"
+    return out
+
+
+def c4_leg(a, hb):
+    """BASELINE config 4 — two W&D models (README.md:148-152: D = [1,16], keys per sample [2,26]) served side by side on one GPU,
+    batch 1,024 = 28,672 keys per request, one instance each, synchronous insertion (exact rows), hit rate swept."""
+    res = {}
+    for hit in (0.5, 0.9, 0.99):
+        res[f"target_hit_{hit}"] = run_abi_driver(
+            hb, ["--models", 2, "--dims", "1,16", "--per-sample", "2,26", "--rows", 1_000_000, "--batch", 1024, "--instances", 1,
+                 "--cache-frac", 0.2, "--hit", hit, "--zipf", a.zipf, "--steps", 100, "--blocks", 6, "--warmup", 50,
+                 "--direct", int(bool(a.direct))], 120.0)
+    return {"config": "BASELINE configs[3]: two W&D models (2 tables each, 1,000,000 rows x [1,16] fp32, keys/sample [2,26], batch 1,024 = "
+                      "28,672 keys per request), one GPU instance each, concurrent Execute, sync insert, pageable KEYS, device OUTPUT0",
+            "results": res}
+
+
+def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0, check_rows=False):
+    """The headline workload on a deployment of its own (own server, the headline's has been released): two sessions, fresh
+    batches of host keys every step, exact rows.  direct: the parameter-server tier; key0: the tables' keys are
+    key0 .. key0+R-1 (key0 = 2^40: keys that need all 8 bytes over PCIe — the reference takes int64 keys, hps.cc:573)."""
     model = cfg["models"][0]["model"]
     cfg = json.loads(json.dumps(cfg))
-    cfg["models"][0]["ps_direct_access"] = True
+    cfg["models"] = cfg["models"][:1]
+    cfg["models"][0]["ps_direct_access"] = bool(direct)
+    cfg["models"][0]["deployed_device_list"] = [dev]
     t0 = time.time()
     ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
     for t in range(T):
-        ps.load_table_synthetic(model, t, SEED, 0, R)
+        ps.load_table_synthetic(model, t, SEED, key0, R)
     ps.create_embedding_cache_per_model(model)
     cache = ps.get_embedding_cache(model, dev)
     t_setup = time.time() - t0
@@ -1006,17 +1049,18 @@ def other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
         s.set_option("probe_variant", a.probe_variant)
         s.set_option("xcd_walk", a.xcd_walk)
         s.set_option("narrow_keys", a.narrow_keys)
+        s.set_option("split_probe", 1 if (a.split_probe != 0 and not direct) else 0)
     C = int(np.ceil(a.cache_frac * R))
     resident = []
     for t in range(T):
         k = np.arange(C, dtype=np.int64)
-        resident.append(torch.from_numpy(k[cache.query(t, k) >= 0]).cuda())
+        resident.append(torch.from_numpy(k[cache.query(t, k + key0) >= 0]).cuda())
     gen = torch.Generator(device="cuda")
-    gen.manual_seed(SEED + 555)
+    gen.manual_seed(SEED + 555 + (key0 & 0xFFFF) + (key0 >> 32))
     cdf_d = torch.from_numpy(zipf_cdf(C, a.zipf)).cuda()
     run = Runner(torch, hps, sessions, T, B, D, dev)
     steps = 40
-    hb_ = [(x.cpu().numpy(),) for x in make_batches_gpu(torch, gen, resident, cdf_d, R, C, B, a.hit, steps + 8)]
+    hb_ = [((x + key0).cpu().numpy(),) for x in make_batches_gpu(torch, gen, resident, cdf_d, R, C, B, a.hit, steps + 8)]
     hb_ = [(x[0], run.pack_host(x[0])) for x in hb_]
     rec = []
     run.run(hb_, 8, 0, "host")
@@ -1026,18 +1070,59 @@ def other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
     out = summarize(rec, N, D, dt, steps)
+    out.update({"sessions": len(sessions), "steps": steps, "setup_seconds": t_setup,
+                "key_bytes_over_pcie_mean": float(np.mean([r[11] for r in rec]))})
+    if check_rows:
+        # the last batch again, every row against the table as it sits in the host tier (file order = key order: row of key k
+        # is row k - key0)
+        q = hb_[-1][0]
+        sessions[0].lookup_packed(hb_[-1][1], run.vptrs[0], run.counts)
+        torch.cuda.synchronize()
+        got = run.outs[0].cpu().numpy().reshape(N, D)
+        ok = True
+        for t in range(T):
+            tk, tr = ps.table_data(model, t)
+            qt = q[t * B:(t + 1) * B]
+            ok &= bool(np.array_equal(tk[qt - key0], qt))
+            ok &= bool(np.array_equal(tr[qt - key0].view(np.uint32), got[t * B:(t + 1) * B].view(np.uint32)))
+        out["parity_full_batch_vs_direct_row_index"] = ok
+    for s in sessions:
+        s.close()
+    return out, rec
+
+
+def other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
+    """The headline workload on a ps_direct_access deployment of the same model (own server: page-locked tables, device
+    index): two sessions, fresh batches of host keys, exact rows."""
+    out, rec = fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct=True)
     f_ms = float(np.mean([r[8][1] for r in rec]))
     uniq = float(np.mean([r[6] for r in rec]))
     out.update({
-        "sessions": len(sessions), "steps": steps, "setup_seconds": t_setup,
         "roofline_pcie": {"bound": "pcie", "kernel": "hps_ps_fetch_direct_kernel", "avg_kernel_ms": f_ms,
                           "achieved": uniq * 4 * D / (f_ms * 1e-3) / 1e9 if f_ms > 0 else None, "peak": PCIE_PEAK_GBS, "unit": "GB/s",
                           "frac": uniq * 4 * D / (f_ms * 1e-3) / 1e9 / PCIE_PEAK_GBS if f_ms > 0 else None},
         "note": "same workload (host keys), two sessions, exact rows; the GPU resolves the misses through a device index of the "
                 "page-locked host tables and reads the rows over PCIe itself (no host threads on the miss path)",
     })
-    for s in sessions:
-        s.close()
+    return out
+
+
+def wide_keys_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
+    """The headline workload with keys that need all 64 bits on the wire: tables keyed 2^40 .. 2^40+R-1, same recipe, same
+    tier and session options as the headline, 95 % hit, every step a fresh batch."""
+    key0 = 1 << 40
+    out, rec = fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct=bool(a.direct), key0=key0, check_rows=True)
+    uniq = float(np.mean([r[6] for r in rec]))
+    bytes_step = uniq * 4 * D + N * out["key_bytes_over_pcie_mean"]
+    out.update({
+        "key0": key0,
+        "pcie_bytes_per_step": bytes_step,
+        "pcie_GBps": bytes_step / (out["ms_per_step"] * 1e-3) / 1e9,
+        "pcie_frac_of_63": bytes_step / (out["ms_per_step"] * 1e-3) / 1e9 / PCIE_PEAK_GBS,
+        "note": "keys 2^40 + (the headline's key distribution): nothing can be narrowed, KEYS cross PCIe at 8 bytes each "
+                "(13.6 MB per step next to ~42 MB of missed rows); the step is PCIe-bound, so the floor is the headline's time x "
+                "(rows + 8-byte keys) / (rows + 3-byte keys)",
+    })
     return out
 
 
@@ -1090,12 +1175,14 @@ def sharded_leg(a, torch, dist, hps, rank, world, local_rank, shared_gpu):
     dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    lat = []
+    lat, tim = [], []
     for i in range(steps):
         ts = time.perf_counter()
         out = sl.lookup(batches[i % 8])
         torch.cuda.current_stream().synchronize()
         lat.append((time.perf_counter() - ts) * 1e3)
+        if getattr(sl, "last_timing", None):
+            tim.append((sl.last_timing["keys_exchange_ms"], sl.last_timing["lookup_ms"], sl.last_timing["rows_exchange_ms"]))
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -1126,6 +1213,19 @@ def sharded_leg(a, torch, dist, hps, rank, world, local_rank, shared_gpu):
         "exchange": "native RCCL session (hps_shard_session_*)" if sl._native else "torch.distributed all_to_all (ranks share a GPU)",
         "block_capacity_keys": getattr(sl, "last_capacity", None), "attempts_last_step": sl.last_attempts,
     }
+    if tim and getattr(sl, "last_capacity", None):
+        # the two RCCL send/recv groups on their own (HIP events on the session's stream, this rank): every peer pair moves one
+        # block over its own xGMI link, so the per-link rate is block bytes / group time
+        tm = np.mean(np.array(tim), axis=0)
+        cap = sl.last_capacity
+        res["rccl_groups"] = {
+            "keys_exchange_ms": float(tm[0]), "local_lookup_ms": float(tm[1]), "rows_exchange_ms": float(tm[2]),
+            "row_block_bytes_per_peer": cap * 4 * D, "key_block_bytes_per_peer": (cap + 2) * 8,
+            "rows_GBps_per_link": cap * 4 * D / (tm[2] * 1e-3) / 1e9 if tm[2] > 0 else None,
+            "rows_frac_of_153_GBps_link": cap * 4 * D / (tm[2] * 1e-3) / 1e9 / 153.0 if tm[2] > 0 else None,
+            "keys_GBps_per_link": (cap + 2) * 8 / (tm[0] * 1e-3) / 1e9 if tm[0] > 0 else None,
+            "padding_fraction_of_row_blocks": 1.0 - (n_local / P) / cap,
+        }
     sess.close()
     return res
 

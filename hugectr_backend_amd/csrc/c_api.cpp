@@ -25,10 +25,10 @@ struct hps_server { std::shared_ptr<HierParameterServer> ps; std::vector<std::st
 // parameter server and its model, so LookupSessionBase::create(params, cache) needs nothing else.  `cache` is null for a
 // model that runs without GPU cache (the reference hands out a cache object with use_gpu_embedding_cache = false there).
 struct hps_cache { std::shared_ptr<HierParameterServer> ps; std::string model; int device; std::shared_ptr<EmbeddingCache> cache; };
-struct hps_session { std::shared_ptr<HierParameterServer> ps; std::unique_ptr<LookupSession> s; };
+struct hps_session { std::shared_ptr<HierParameterServer> ps; std::shared_ptr<LookupSession> s; };   // shared: a sharded session built on it keeps it alive
 struct hps_dense { std::unique_ptr<DenseInteraction> d; };
 struct hps_shard_group { std::shared_ptr<LocalShardGroup> g; };
-struct hps_shard_session { std::unique_ptr<ShardedSession> s; };
+struct hps_shard_session { std::shared_ptr<HierParameterServer> ps; std::unique_ptr<ShardedSession> s; };   // (s goes first)
 
 namespace {
 // Runs when the library is loaded.  HIP maps a process's streams onto 4 hardware queues unless told otherwise; lookup
@@ -504,8 +504,8 @@ int hps_shard_session_create(hps_session_t* session, uint32_t rank, uint32_t wor
     std::unique_ptr<ShardTransport> tr;
     HPS_RETURN_IF_ERROR(MakeRcclTransport(rank, world, unique_id128, session->s->device(), &tr));
     std::unique_ptr<ShardedSession> ss;
-    HPS_RETURN_IF_ERROR(ShardedSession::Create(session->s.get(), std::move(tr), (size_t)max_local_keys, &ss));
-    *out = new hps_shard_session{std::move(ss)};
+    HPS_RETURN_IF_ERROR(ShardedSession::Create(session->s, std::move(tr), (size_t)max_local_keys, &ss));
+    *out = new hps_shard_session{session->ps, std::move(ss)};
     return Status::Ok();
   });
 }
@@ -527,8 +527,8 @@ int hps_shard_session_create_local(hps_session_t* session, hps_shard_group_t* gr
     std::unique_ptr<ShardTransport> tr;
     HPS_RETURN_IF_ERROR(MakeLocalTransport(group->g, rank, &tr));
     std::unique_ptr<ShardedSession> ss;
-    HPS_RETURN_IF_ERROR(ShardedSession::Create(session->s.get(), std::move(tr), (size_t)max_local_keys, &ss));
-    *out = new hps_shard_session{std::move(ss)};
+    HPS_RETURN_IF_ERROR(ShardedSession::Create(session->s, std::move(tr), (size_t)max_local_keys, &ss));
+    *out = new hps_shard_session{session->ps, std::move(ss)};
     return Status::Ok();
   });
 }
@@ -537,6 +537,27 @@ int hps_shard_session_lookup(hps_shard_session_t* shard, const int64_t* d_keys, 
   return Guard([&]() -> Status {
     if (!shard) return Error(Code::kInvalidArg, "null argument");
     return shard->s->Lookup(d_keys, (size_t)n, d_out);
+  });
+}
+
+int hps_shard_session_lookup_host(hps_shard_session_t* shard, const int64_t* h_keys, uint64_t n, float* d_out) {
+  return Guard([&]() -> Status {
+    if (!shard) return Error(Code::kInvalidArg, "null argument");
+    return shard->s->LookupHost(h_keys, (size_t)n, d_out);
+  });
+}
+
+int hps_shard_session_last_timing(hps_shard_session_t* shard, float* keys_exchange_ms, float* lookup_ms, float* rows_exchange_ms,
+                                  uint64_t* keys_received, int32_t* key_bytes) {
+  return Guard([&]() -> Status {
+    if (!shard) return Error(Code::kInvalidArg, "null argument");
+    const ShardCallStats& st = shard->s->last_stats();
+    if (keys_exchange_ms) *keys_exchange_ms = st.keys_exchange_ms;
+    if (lookup_ms) *lookup_ms = st.lookup_ms;
+    if (rows_exchange_ms) *rows_exchange_ms = st.rows_exchange_ms;
+    if (keys_received) *keys_received = st.received;
+    if (key_bytes) *key_bytes = st.key_bytes;
+    return Status::Ok();
   });
 }
 

@@ -40,7 +40,9 @@ struct HsaApi {
 };
 
 // one pass over the engines of one direction; returns how many took a copy
-int WakeDirection(const HsaApi& api, void* dst, hsa_agent_t dst_agent, const void* src, hsa_agent_t src_agent, size_t bytes) {
+// *stuck is set when a copy did not finish within the bound: the engine may still write `dst` / signal `sig`, so the caller
+// must give up the scratch buffers (and this function the signal) instead of freeing memory under a DMA in flight
+int WakeDirection(const HsaApi& api, void* dst, hsa_agent_t dst_agent, const void* src, hsa_agent_t src_agent, size_t bytes, bool* stuck) {
   uint32_t mask = 0;
   const hsa_status_t st = api.engine_status(dst_agent, src_agent, &mask);
   if (st != HSA_STATUS_SUCCESS && st != HSA_STATUS_ERROR_OUT_OF_RESOURCES) return 0;
@@ -54,6 +56,7 @@ int WakeDirection(const HsaApi& api, void* dst, hsa_agent_t dst_agent, const voi
         HSA_STATUS_SUCCESS) {
       // bounded wait (10^9 ticks of the HSA system clock, seconds): a copy of a few KB that does not finish is left alone
       if (api.signal_wait(sig, HSA_SIGNAL_CONDITION_LT, 1, 1000000000ull, HSA_WAIT_STATE_BLOCKED) < 1) ++woken;
+      else { *stuck = true; break; }   // signal and buffers are leaked on purpose (a few KB, once per process)
     }
     (void)api.signal_destroy(sig);
   }
@@ -87,18 +90,21 @@ std::string WakeCopyEngines(int device) {
   hsa_amd_pointer_info_t di, hi;
   di.size = hi.size = sizeof(hsa_amd_pointer_info_t);
   int up = 0, down = 0;
+  bool stuck = false;
   if (api.pointer_info(d, &di, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS &&
       api.pointer_info(h, &hi, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS &&
       di.type != HSA_EXT_POINTER_TYPE_UNKNOWN && hi.type != HSA_EXT_POINTER_TYPE_UNKNOWN) {
-    up = WakeDirection(api, d, di.agentOwner, h, hi.agentOwner, bytes);
-    down = WakeDirection(api, h, hi.agentOwner, d, di.agentOwner, bytes);
+    up = WakeDirection(api, d, di.agentOwner, h, hi.agentOwner, bytes, &stuck);
+    if (!stuck) down = WakeDirection(api, h, hi.agentOwner, d, di.agentOwner, bytes, &stuck);
   }
   const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  (void)hipFree(d);
-  (void)hipHostFree(h);
+  if (!stuck) {
+    (void)hipFree(d);
+    (void)hipHostFree(h);
+  }
   (void)hipSetDevice(prev);
   std::ostringstream os;
-  os << up << " engines host->device, " << down << " device->host, " << ms << " ms";
+  os << up << " engines host->device, " << down << " device->host, " << ms << " ms" << (stuck ? " (a copy did not finish: scratch buffers abandoned)" : "");
   return report = os.str();
 }
 

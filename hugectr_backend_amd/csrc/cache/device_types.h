@@ -61,7 +61,8 @@ inline constexpr uint32_t AccTableWord(uint32_t t, int what) { return (uint32_t)
 //   >= 0   cache slot of the key's row
 //   <= -2  missed: -2 - m, m = position of the key's tile representative in the tile regions (miss_key[m]);
 //          its row in the miss staging is uidx_of[rep_of[m]] once the miss-unique kernel has run
-constexpr int32_t kSlotMiss = -1;  // transient, inside the probe kernel only
+//   -1     padding (CallDesc::skip_empty_keys): nothing to read, nothing to write
+constexpr int32_t kSlotMiss = -1;  // also the probe's transient "not found yet" of a representative
 
 struct TableCacheDev {
   int64_t* lines;  // [num_buckets][kLineWords]
@@ -111,6 +112,8 @@ struct CallDesc {
   uint32_t num_tables;
   uint32_t epoch;           // call counter of the cache (monotonic)
   uint32_t stamp8;          // (epoch >> age_shift) & 255: the recency stamp hits of this call leave in their slots
+  uint32_t skip_empty_keys; // 1: a key equal to HPS_EMPTY_KEY is padding of the sharded exchange — no probe, no row, no list
+                            // entry, slot = -1 (0: it is a key like any other, in no table by construction: default vector)
   uint64_t total_keys;      // N = sum n_t
   const int64_t* keys;      // flat, table-major, device
   const uint32_t* keys32;   // not null: the same keys narrowed to 32 bits (every key of the call is in [0, 2^32); then

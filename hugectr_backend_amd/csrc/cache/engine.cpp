@@ -219,6 +219,10 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 0 && v <= 8) age_shift_ = (uint32_t)v;
   }
+  if (const char* e = std::getenv("HPS_LRU_INSERT_AGE")) {
+    const long v = std::strtol(e, nullptr, 10);
+    if (v >= 0 && v < (long)kAgeSaturate) insert_age_ = (uint32_t)v;
+  }
 
   cfg_.num_emb_table_ = T;
   cfg_.use_gpu_embedding_cache_ = true;
@@ -324,7 +328,8 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
       for (size_t u = 0; u <= T; ++u) md.useg_start[u] = u > t ? m : 0;
       md.chunk_lo[t] = 0; md.chunk_hi[t] = (uint32_t)m; md.stage_off[t] = 0;
       if (hipMemcpy(d_md, &md, sizeof md, hipMemcpyHostToDevice) != hipSuccess) { st = Error(Code::kInternal, "cache warm-up: H2D copy failed"); break; }
-      const hipError_t e = LaunchCacheInsert(d_warm, (uint32_t)T, d_md, m, d_zero_ks, d_keys, d_rows, nullptr, Stamp8(epoch),
+      const hipError_t e = LaunchCacheInsert(d_warm, (uint32_t)T, d_md, m, d_zero_ks, d_keys, d_rows, nullptr, Stamp8(epoch) * 0x101u,   // warm-up rows enter as if they had just been hit
+                                             
                                              d_stats, cu_count_, nullptr);
       if (e != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         st = Error(Code::kInternal, "cache warm-up: insert kernel failed: ", hipGetErrorString(e));
@@ -499,7 +504,7 @@ Status EmbeddingCache::FinishDirectInsert() {
   if (e != hipSuccess) return Error(Code::kInternal, "direct background fetch launch failed: ", hipGetErrorString(e));
   HIP_TRY(hipStreamSynchronize(I.stream));
   BeginWrite(I.stream);
-  e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, I.unique_total, I.d_key_start, I.d_keys, I.d_staging, I.d_found, Stamp8(epoch),
+  e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, I.unique_total, I.d_key_start, I.d_keys, I.d_staging, I.d_found, InsertStamps(epoch),
                         I.d_acc, cu_count_, I.stream);
   EndWrite(I.stream);
   if (e != hipSuccess) return Error(Code::kInternal, "direct background insert launch failed: ", hipGetErrorString(e));
@@ -560,7 +565,7 @@ void LookupSession::Release() {
   dfree(work_.rep_of); dfree(work_.uidx_of); dfree(work_.set); dfree(work_.uniq_keys);
   hfree(h_mode_);
   hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
-  for (hipEvent_t e : {ev_done_, ev_read_, ev_fetch_, ev_t0_, ev_t1_, ev_f0_, ev_f1_, ev_c1_, ev_probe_, ev_copy_, ev_keys_,
+  for (hipEvent_t e : {ev_done_, ev_read_, ev_fetch_, ev_t0_, ev_t1_, ev_f0_, ev_f1_, ev_c1_, ev_probe_, ev_copy_,
                        ev_g0_, ev_g1_, ev_s0_, ev_s1_, ev_i0_, ev_i1_})
     if (e) (void)hipEventDestroy(e);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
@@ -592,7 +597,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HIP_TRY(hipSetDevice(device_));
   HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&ev_copy_, &ev_done_, &ev_read_, &ev_fetch_, &ev_probe_, &ev_keys_})
+  for (hipEvent_t* e : {&ev_copy_, &ev_done_, &ev_read_, &ev_fetch_, &ev_probe_})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   for (hipEvent_t* e : {&ev_t0_, &ev_t1_, &ev_f0_, &ev_f1_, &ev_c1_, &ev_g0_, &ev_g1_, &ev_s0_, &ev_s1_, &ev_i0_, &ev_i1_}) HIP_TRY(hipEventCreate(e));
   for (hipEvent_t& e : ev_lane_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -810,10 +815,20 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     }
     // (page-locked keys are DMA'd in place, never narrowed: host threads read that memory an order of magnitude slower
     //  than ordinary memory on the MI355X boxes — 0.41 against 2.66 G lookups/s in bench.py's pinned-keys legs)
-    const bool try_narrow = !direct_dma && narrow_keys_ && narrow_backoff_ == 0 && N >= 4 * kTaskKeys;
+    bool try_narrow = !direct_dma && narrow_keys_ && narrow_backoff_ == 0 && N >= 4 * kTaskKeys;
     if (narrow_backoff_ > 0) --narrow_backoff_;
-    const bool try_pack24 = try_narrow && pack24_keys_ && narrow24_backoff_ == 0;
+    bool try_pack24 = try_narrow && pack24_keys_ && narrow24_backoff_ == 0;
     if (narrow24_backoff_ > 0) --narrow24_backoff_;
+    if (try_narrow) {
+      // A look at a few keys of every task before any copying: traffic whose keys are wide (hashed 64-bit ids, negative
+      // keys) shows it in the first sample, and the call goes straight to the width that can work instead of paying for a
+      // failed 4-MB group, a stream synchronisation and a restage (the optimistic check while copying still catches the
+      // request with one wide key among narrow ones).
+      uint64_t sample = 0;
+      for (const Task& tk : tasks) sample |= (uint64_t)tk.src[0] | (uint64_t)tk.src[tk.n / 2] | (uint64_t)tk.src[tk.n - 1];
+      if (sample >> 32) { try_narrow = try_pack24 = false; NarrowFailed(false); }
+      else if (sample >> 24) { if (try_pack24) NarrowFailed(true); try_pack24 = false; }
+    }
     // stage(width): the keys leave at `width` bytes each — 8 as they are, 4 as uint32, 3 packed little-endian.  A narrower
     // width is optimistic: every task ORs its keys together while it copies, and the first group that saw a key too wide
     // ends the attempt (the caller restages at the next width; `seen` tells it which one can work).
@@ -855,18 +870,19 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
       HPS_RETURN_IF_ERROR(stage(3));
       staged = keys_narrow_;
       if (!staged) {
-        narrow24_backoff_ = 256;   // keys of more than 24 bits in this traffic
+        NarrowFailed(true);   // keys of more than 24 bits in this traffic
         HIP_TRY(hipStreamSynchronize(stream_));   // groups already in flight read the staging buffer we are about to rewrite
-      }
+      } else narrow24_streak_ = 0;
     }
     if (!staged && try_narrow && (seen >> 32) == 0) {
       seen = 0;
       HPS_RETURN_IF_ERROR(stage(4));
       staged = keys_narrow_;
       if (!staged) HIP_TRY(hipStreamSynchronize(stream_));
+      else narrow_streak_ = 0;
     }
     if (!staged) {
-      if (try_narrow) narrow_backoff_ = 256;   // wide (or negative) keys in this traffic: plain copies for the next calls
+      if (try_narrow) NarrowFailed(false);   // wide (or negative) keys in this traffic: plain copies for the next calls
       if (direct_dma) HIP_TRY(hipMemcpyAsync(d_keys_, base, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
       else HPS_RETURN_IF_ERROR(stage(8));
     }
@@ -908,6 +924,20 @@ Status LookupSession::lookup_from_device(const int64_t* d_keys_flat, float* cons
   keys_narrow_ = false;
   key_bytes_ = 8;
   return TimedLookupDevice(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
+}
+
+Status LookupSession::lookup_from_device_padded(const int64_t* d_keys_flat, float* const* d_vectors_per_table,
+                                                const size_t* num_keys_per_table, size_t num_tables) {
+  skip_empty_next_ = true;
+  const Status st = lookup_from_device(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
+  skip_empty_next_ = false;
+  return st;
+}
+
+void LookupSession::discount_padding(uint64_t padding_keys) {
+  if (!cache_ || padding_keys == 0) return;
+  std::lock_guard<std::mutex> lk(cache_->stat_mu_);
+  cache_->counters_.keys -= std::min<uint64_t>(padding_keys, cache_->counters_.keys);
 }
 
 Status LookupSession::LookupHostTier(const void* const* h_keys_per_table, float* const* h_vectors_per_table,
@@ -956,6 +986,7 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   c.total_keys = N;
   c.epoch = cache_->NextEpoch();
   c.stamp8 = cache_->Stamp8(c.epoch);
+  c.skip_empty_keys = skip_empty_next_ ? 1u : 0u;
   if (++call_tag_ == 0) {  // 2^32 calls later: entries of the first calls would look like this call's
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemsetAsync(work_.set, 0, (work_.set_mask + 1) * sizeof(unsigned long long), stream_));
@@ -986,6 +1017,12 @@ Status LookupSession::PushWords(uint32_t words) {
   return Status::Ok();
 }
 
+static inline void SpinPause() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
+
 Status LookupSession::WaitPushed() {
   if (!zc_control_) { HIP_TRY(hipEventSynchronize(ev_done_)); return Status::Ok(); }
   const uint32_t want = push_seq_;
@@ -994,7 +1031,7 @@ Status LookupSession::WaitPushed() {
   const auto t0 = std::chrono::steady_clock::now();
   for (uint32_t i = 1;; ++i) {
     if (__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) == want) return Status::Ok();
-    __builtin_ia32_pause();
+    SpinPause();
     if ((i & 511u) == 0) {
       const hipError_t q = hipEventQuery(ev_done_);
       if (q != hipSuccess && q != hipErrorNotReady) return Error(Code::kInternal, "lookup stream failed: ", hipGetErrorString(q));
@@ -1005,7 +1042,7 @@ Status LookupSession::WaitPushed() {
   // the push kernel has retired: its stores are on their way; give the last one the time to land
   for (uint32_t i = 0; i < (1u << 24); ++i) {
     if (__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) == want) return Status::Ok();
-    __builtin_ia32_pause();
+    SpinPause();
   }
   return Error(Code::kInternal, "accumulator push did not arrive");
 }
@@ -1303,7 +1340,7 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
   }
   cache_->BeginWrite(stream_);
   e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, N, d_call_->key_start, w.uniq_keys, d_staging_, d_found_,
-                        cache_->Stamp8(epoch), d_acc_, cu, stream_);
+                        cache_->InsertStamps(epoch), d_acc_, cu, stream_);
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
@@ -1356,7 +1393,7 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   if (exclusive_) cache_->LaneEnter(stream_);
   if (timing_) (void)hipEventRecord(ev_i0_, stream_);
   e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, max_unique, d_call_->key_start, work_.uniq_keys,
-                        d_staging_, d_found_, cache_->Stamp8(epoch), d_acc_, cu, stream_);
+                        d_staging_, d_found_, cache_->InsertStamps(epoch), d_acc_, cu, stream_);
   if (timing_) (void)hipEventRecord(ev_i1_, stream_);
   if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[3]);
   cache_->EndWrite(stream_);
@@ -1500,7 +1537,7 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     if (exclusive_) cache_->LaneEnter(stream_);
     if (timing_) (void)hipEventRecord(ev_i0_, stream_);
     e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, uq, d_call_->key_start, work_.uniq_keys,
-                          rows_src, found_src, cache_->Stamp8(epoch), d_acc_, cu, stream_);
+                          rows_src, found_src, cache_->InsertStamps(epoch), d_acc_, cu, stream_);
     if (timing_) (void)hipEventRecord(ev_i1_, stream_);
     if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[3]);
     cache_->EndWrite(stream_);

@@ -120,6 +120,13 @@ class EmbeddingCache {
   uint32_t NextEpoch();
   // recency stamp the kernels write for call counter `epoch` (device_types.h)
   uint32_t Stamp8(uint32_t epoch) const { return (epoch >> age_shift_) % kStampMod; }
+  // what the insert kernel gets: the current unit in byte 0, the stamp of a newly inserted key in byte 1 (insert_age_ units
+  // in the past: scan-resistant insertion — a key seen once must be seen again before it outranks keys that were hit)
+  uint32_t InsertStamps(uint32_t epoch) const {
+    const uint32_t now8 = Stamp8(epoch);
+    return now8 | (((now8 + kStampMod - insert_age_) % kStampMod) << 8);
+  }
+  uint32_t insert_age_ = 64;  // recency units (HPS_LRU_INSERT_AGE; 0 = plain LRU insertion), < kAgeSaturate
   uint32_t age_shift_ = 2;   // recency unit = 2^age_shift calls (HPS_LRU_AGE_SHIFT)
 
   std::string model_;
@@ -220,7 +227,13 @@ class LookupSession {
   size_t max_keys() const { return max_keys_; }
   size_t num_tables() const { return tables_.size(); }
   uint32_t table_dim(size_t t) const { return tables_[t]->dim(); }
-  int64_t any_key_of_table(size_t t) const { return tables_[t]->size() ? tables_[t]->keys()[0] : 0; }
+  float table_default(size_t t) const { return params_.default_value_for_each_table[t]; }
+  // lookup_from_device for the padded key array of the sharded exchange: keys equal to HPS_EMPTY_KEY are padding (no probe,
+  // no row written, no statistics); `padding` of the `num_keys` are such keys as far as the caller knows (0 if unknown:
+  // the cache's key counter then includes them)
+  Status lookup_from_device_padded(const int64_t* d_keys_flat, float* const* d_vectors_per_table, const size_t* num_keys_per_table,
+                                   size_t num_tables);
+  void discount_padding(uint64_t padding_keys);
   // last call's numbers
   uint64_t last_miss_count() const { return last_misses_; }
   uint64_t last_unique_miss_count() const { return last_unique_; }
@@ -237,7 +250,7 @@ class LookupSession {
   float last_scatter_ms() const { return last_scatter_ms_; }   // miss-scatter kernel of the last call (last chunk)
   float last_insert_ms() const { return last_insert_ms_; }     // cache-insert kernel of the last call (last chunk)
   void set_keys_pinned_check(bool b) { keys_pinned_hint_ = b ? 1 : 0; }
-  void set_narrow_keys(int mode) { narrow_keys_ = mode != 0; pack24_keys_ = mode == 1; narrow_backoff_ = 0; narrow24_backoff_ = 0; }   // 0 off, 1 uint32 + 3-byte packing, 2 uint32 only
+  void set_narrow_keys(int mode) { narrow_keys_ = mode != 0; pack24_keys_ = mode == 1; narrow_backoff_ = narrow24_backoff_ = 0; narrow_streak_ = narrow24_streak_ = 0; }   // 0 off, 1 uint32 + 3-byte packing, 2 uint32 only
   bool last_keys_narrow() const { return keys_narrow_; }
   int last_key_bytes() const { return key_bytes_; }   // bytes per key the last host-keys call moved over PCIe: 8, 4 or 3
   float last_gpu_call_ms() const { return last_gpu_call_ms_; }  // first kernel to last of the last call (HIP events)
@@ -274,15 +287,22 @@ class LookupSession {
   hipStream_t copy_stream_ = nullptr;  // second H2D queue for the missed-row pieces
   hipEvent_t ev_copy_ = nullptr;
   hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr,
-             ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr, ev_probe_ = nullptr, ev_keys_ = nullptr;
+             ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr, ev_probe_ = nullptr;
   float last_gpu_call_ms_ = 0.f;
   float stage_pool_ms_ = 0.f, stage_enqueue_ms_ = 0.f;   // key staging: time in the pool loops / in the H2D enqueues
   float key_stage_ms_ = 0.f;      // host side of lookup(): staging the keys and enqueueing their H2D copies
   bool narrow_keys_ = true;       // option "narrow_keys": stage pageable keys as uint32 when they all fit
   bool pack24_keys_ = true;       // ... and at 3 bytes each when they all fit 24 bits (option value 2 turns only this off)
   bool keys_narrow_ = false;      // this call's staged keys are uint32
+  bool skip_empty_next_ = false;  // the call being prepared treats HPS_EMPTY_KEY as padding (lookup_from_device_padded)
   int narrow_backoff_ = 0;        // calls left before narrowing is tried again after a wide key was seen
   int narrow24_backoff_ = 0;      // the same for the 3-byte packing after a key of 25..32 bits
+  int narrow_streak_ = 0, narrow24_streak_ = 0;   // failed attempts in a row: the pause doubles with each, 256 .. 65,536 calls
+  void NarrowFailed(bool pack24) {
+    int& streak = pack24 ? narrow24_streak_ : narrow_streak_;
+    (pack24 ? narrow24_backoff_ : narrow_backoff_) = 256 << (streak < 8 ? streak : 8);
+    if (streak < 8) ++streak;
+  }
   int key_bytes_ = 8;
   int keys_pinned_hint_ = 1;      // 1: flat key arrays in page-locked memory are DMA'd in place (option "keys_pinned_check")
   Status TimedLookupDevice(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T);

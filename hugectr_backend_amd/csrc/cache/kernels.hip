@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   const uint8_t* __restrict__ keys24 = call->keys24;
   const int64_t* __restrict__ keys = call->keys + td.begin;
   const uint32_t stamp8 = call->stamp8;
+  const bool skip_empty = call->skip_empty_keys != 0;
   constexpr int kPerThread = kTileKeys / kThreads;
 
   if (tid < 4) sh_cnt[tid] = 0;
@@ -181,7 +182,9 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   for (int q = 0; q < kPerThread; ++q) {
     const uint32_t j = tid + (uint32_t)q * kThreads;
     uint32_t rep = j;
-    if (kDedup && j < n) {
+    const bool pad = skip_empty && k[q] == HPS_EMPTY_KEY;   // padding of the sharded exchange: represents nothing
+    if (pad && j < n) sh_slot[j] = kSlotMiss;
+    if (kDedup && j < n && !pad) {
       uint32_t e = hlo[q] & (uint32_t)(kTileSet - 1);
       for (;;) {
         const uint32_t prev = atomicCAS(&sh_set[e], 0xFFFFFFFFu, j);
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
         e = (e + 1) & (uint32_t)(kTileSet - 1);
       }
     }
-    const bool is_rep = j < n && rep == j;
+    const bool is_rep = j < n && rep == j && !pad;
     if (j < n) sh_rep[j] = (uint16_t)rep;
     const uint32_t pos = lds_append(&sh_cnt[0], is_rep);
     if (is_rep) sh_list[pos] = (uint16_t)j;
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
     const uint32_t j = tid + (uint32_t)q * kThreads;
-    const bool is_rep = j < n && sh_rep[j] == (uint16_t)j;
+    const bool is_rep = j < n && sh_rep[j] == (uint16_t)j && !(skip_empty && k[q] == HPS_EMPTY_KEY);
     const int32_t s = is_rep ? sh_slot[j] : 0;
     const bool miss = is_rep && s < 0;
     const uint32_t pos = lds_append(&sh_cnt[1], miss);
@@ -258,9 +261,9 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   for (int q = 0; q < kPerThread; ++q) {
     const uint32_t j = tid + (uint32_t)q * kThreads;
     const int32_t s = j < n ? sh_slot[sh_rep[j]] : 0;
-    if (j < n) w.slot[td.begin + j] = s;
-    const uint32_t pos = lds_append(&sh_cnt[2], s < 0);
-    if (s < 0) { w.sent_i[region + pos] = (int32_t)(td.begin + j); w.sent_m[region + pos] = -2 - s; }
+    if (j < n) w.slot[td.begin + j] = s;   // (padding: its own kSlotMiss)
+    const uint32_t pos = lds_append(&sh_cnt[2], s <= -2);
+    if (s <= -2) { w.sent_i[region + pos] = (int32_t)(td.begin + j); w.sent_m[region + pos] = -2 - s; }
   }
   __syncthreads();
   if (tid == 0) {
@@ -596,8 +599,12 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
                                                                 const uint64_t* __restrict__ key_start,
                                                                 const int64_t* __restrict__ uniq_keys,
                                                                 const float* __restrict__ staging,
-                                                                const uint8_t* __restrict__ found, uint32_t now8,
+                                                                const uint8_t* __restrict__ found, uint32_t stamps,
                                                                 uint32_t* __restrict__ stats /* kStatLines lines of kAccStride words */) {
+  // stamps: byte 0 = the current recency unit (what a hit of this call writes), byte 1 = the stamp a NEWLY inserted key
+  // gets — the current unit minus the cache's insert age (EmbeddingCache::InsertStamps): a key that was asked for once
+  // enters the bucket older than the keys that have been hit, and is the first to go unless it is asked for again
+  const uint32_t now8 = stamps & 0xFFu, ins8 = (stamps >> 8) & 0xFFu;
   const uint64_t total = md->useg_start[T];
   const int lane = lane_id();
   const int g = lane >> 4, lig = lane & 15;
@@ -698,7 +705,8 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
     // kStampClaimed (all ones) AND now8 = now8; the other bytes of the word keep whatever they hold by now
     if (owned && lig == 0) {
       const int sh = 8 * (victim & 7);
-      atomicAnd(line + kBucketSlots + (victim >> 3), ~(0xFFull << sh) | ((unsigned long long)now8 << sh));
+      const unsigned long long st = (present >= 0 || unknown) ? now8 : ins8;
+      atomicAnd(line + kBucketSlots + (victim >> 3), ~(0xFFull << sh) | (st << sh));
     }
   }
   // one atomic per block and counter, spread over kStatLines lines of the accumulator block: atomics on one
@@ -835,14 +843,14 @@ hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_
 
 hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const MissDesc* d_md, uint64_t total_unique,
                              const uint64_t* d_key_start, const int64_t* d_uniq_keys, const float* d_staging,
-                             const uint8_t* d_found, uint32_t now8, uint32_t* d_stats, int cu_count,
+                             const uint8_t* d_found, uint32_t stamps, uint32_t* d_stats, int cu_count,
                              hipStream_t stream) {
   if (total_unique == 0) return hipSuccess;
   uint64_t want = (total_unique + 15) / 16;
   const uint64_t cap = (uint64_t)cu_count * 8;
   if (want > cap) want = cap;
   hipLaunchKernelGGL(hps_cache_insert_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_tables, T, d_md,
-                     d_key_start, d_uniq_keys, d_staging, d_found, now8 & 0xFFu, d_stats);
+                     d_key_start, d_uniq_keys, d_staging, d_found, stamps & 0xFFFFu, d_stats);
   return hipGetLastError();
 }
 

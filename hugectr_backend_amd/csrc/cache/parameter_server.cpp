@@ -124,7 +124,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
     HIP_TRY(hipStreamSynchronize(I.stream));  // copies done: keep the writer window = the insert kernel only
     BeginWrite(I.stream);
     const hipError_t e = LaunchCacheInsert(d_tables_, (uint32_t)T, I.d_md, uq, I.d_ks, I.d_keys, I.d_rows, I.d_found,
-                                           Stamp8(epoch), I.d_stats, cu_count_, I.stream);
+                                           InsertStamps(epoch), I.d_stats, cu_count_, I.stream);
     EndWrite(I.stream);
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(I.stream));

@@ -13,15 +13,18 @@ size_t ShardBucketWorkspaceBytes(uint64_t n, uint32_t num_shards);
 hipError_t LaunchShardBucket(const int64_t* d_keys, uint64_t n, uint32_t num_shards, int64_t* d_keys_sorted, int32_t* d_perm,
                              uint64_t* d_totals, void* d_workspace, hipStream_t stream);
 // Fixed-capacity exchange (shard_session.cpp): d_send = P blocks of (2 + cap) int64 — [0] keys in the block (<= cap),
-// [1] overflow flag of this rank, then the keys in input order; d_pos[i] = owner(i) * cap + rank of key i in its block;
-// d_totals[s] = keys owned by shard s (uint64, may exceed cap: then the flag is set and the call has to be retried)
-hipError_t LaunchShardBucketPadded(const int64_t* d_keys, uint64_t n, uint32_t num_shards, uint64_t cap, int64_t* d_send,
+// [1] the largest block this rank needed (> cap: it overflowed), then the keys in input order; d_keys: int64 (key_bytes 8) or
+// uint32 (key_bytes 4); d_pos[i] = owner(i) * cap + rank of key i in its block, 0xFFFFFFFF for the cache's reserved key
+// (HPS_EMPTY_KEY: never sent, answered with the default vector); d_totals[s] = keys owned by shard s (uint64, may exceed cap)
+hipError_t LaunchShardBucketPadded(const void* d_keys, uint32_t key_bytes, uint64_t n, uint32_t num_shards, uint64_t cap, int64_t* d_send,
                                    uint32_t* d_pos, uint64_t* d_totals, void* d_workspace, hipStream_t stream);
-// received blocks -> contiguous [P][cap] keys (unused slots = pad_key); d_flags[0] |= 1 if any peer overflowed
-hipError_t LaunchShardPrepare(const int64_t* d_recv, uint32_t num_shards, uint64_t cap, int64_t pad_key, int64_t* d_keys_pad,
-                              uint32_t* d_flags, hipStream_t stream);
-// d_out[i] = d_rows[d_pos[i]]
-hipError_t LaunchShardGatherBack(const float* d_rows, const uint32_t* d_pos, uint64_t n, uint32_t dim, float* d_out, hipStream_t stream);
+// received blocks -> contiguous [P][cap] keys (unused slots = HPS_EMPTY_KEY, skipped by the probe);
+// d_flags[0] = max(d_flags[0], largest block any peer needed), d_flags[1] += keys received
+hipError_t LaunchShardPrepare(const int64_t* d_recv, uint32_t num_shards, uint64_t cap, int64_t* d_keys_pad, uint32_t* d_flags,
+                              hipStream_t stream);
+// d_out[i] = d_rows[d_pos[i]], or the default vector where d_pos[i] == 0xFFFFFFFF
+hipError_t LaunchShardGatherBack(const float* d_rows, const uint32_t* d_pos, uint64_t n, uint32_t dim, float* d_out, float default_value,
+                                 hipStream_t stream);
 hipError_t LaunchShardUnpermute(const float* d_rows, const int32_t* d_perm, uint64_t n, uint32_t dim, float* d_out,
                                 hipStream_t stream);
 

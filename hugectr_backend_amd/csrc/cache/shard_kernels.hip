@@ -1,7 +1,8 @@
 // Kernels of the table-sharded (model-parallel) lookup — BASELINE config 3, a north-star addition (the
 // reference itself is replicas-only).  Rows of one table are partitioned over P ranks by
 // owner(key) = mix64(key) mod P; a rank buckets its local keys by owner, exchanges keys and rows with RCCL
-// all-to-all (done by the host layer, hugectr_backend_amd/sharded.py) and restores the input order.
+// send/recv groups (csrc/cache/shard_session.cpp; the torch.distributed variant in hugectr_backend_amd/sharded.py serves
+// host-tier shards over gloo) and restores the input order.
 //
 //   hps_shard_hist      per-block histogram of owners (1024 keys per block)
 //   hps_shard_scan      exclusive scan -> write offset of every (shard, block) pair; totals per shard
@@ -20,6 +21,26 @@ constexpr int kShardBlock = 1024;
 constexpr int kMaxShards = 64;
 
 __device__ __forceinline__ uint32_t owner_of(int64_t key, uint32_t P) { return (uint32_t)(hps_mix64((uint64_t)key) % P); }
+// keys of the padded exchange arrive as int64 or, when a host request was narrowed while it was staged, as uint32
+__device__ __forceinline__ int64_t load_key(const void* keys, uint32_t key_bytes, uint64_t i) {
+  return key_bytes == 4 ? (int64_t)(uint64_t)reinterpret_cast<const uint32_t*>(keys)[i] : reinterpret_cast<const int64_t*>(keys)[i];
+}
+constexpr uint32_t kNoOwner = 0xFFFFFFFFu;
+constexpr uint32_t kPosDefault = 0xFFFFFFFFu;   // pos[] of a key that is never sent (the cache's reserved key): default vector
+
+__global__ __launch_bounds__(kShardBlock) void hps_shard_hist_padded_kernel(const void* __restrict__ keys, uint32_t key_bytes, uint64_t n,
+                                                                           uint32_t P, uint32_t* __restrict__ hist /*[blocks][P]*/) {
+  __shared__ uint32_t sh[kMaxShards];
+  if (threadIdx.x < P) sh[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * kShardBlock + threadIdx.x;
+  if (i < n) {
+    const int64_t key = load_key(keys, key_bytes, i);
+    if (key != HPS_EMPTY_KEY) atomicAdd(&sh[owner_of(key, P)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < P) hist[(uint64_t)blockIdx.x * P + threadIdx.x] = sh[threadIdx.x];
+}
 
 __global__ __launch_bounds__(kShardBlock) void hps_shard_hist_kernel(const int64_t* __restrict__ keys, uint64_t n, uint32_t P,
                                                                     uint32_t* __restrict__ hist /*[blocks][P]*/) {
@@ -107,34 +128,35 @@ __global__ __launch_bounds__(64) void hps_shard_scan_padded_kernel(const uint32_
                                                                    uint64_t* __restrict__ offsets /*[blocks][P]: rank of the block's first key inside its shard*/,
                                                                    int64_t* __restrict__ send, uint64_t stride, uint64_t cap,
                                                                    uint64_t* __restrict__ totals) {
-  __shared__ uint32_t any_over;
-  if (threadIdx.x == 0) any_over = 0;
+  __shared__ unsigned long long need;   // the largest block this rank would have liked to send
+  if (threadIdx.x == 0) need = 0;
   __syncthreads();
   const uint32_t s = threadIdx.x;
   uint64_t run = 0;
   if (s < P) {
     for (uint32_t b = 0; b < blocks; ++b) { offsets[(uint64_t)b * P + s] = run; run += hist[(uint64_t)b * P + s]; }
     totals[s] = run;
-    if (run > cap) atomicOr(&any_over, 1u);
+    atomicMax(&need, (unsigned long long)run);
   }
   __syncthreads();
   if (s < P) {
     send[(uint64_t)s * stride] = (int64_t)(run < cap ? run : cap);
-    send[(uint64_t)s * stride + 1] = (int64_t)any_over;
+    send[(uint64_t)s * stride + 1] = (int64_t)need;   // > cap: this rank overflowed; the group retries with the largest need seen
   }
 }
 
 // stable scatter into the padded send blocks; pos[i] = where key i's row will sit in the returned padded row layout
-__global__ __launch_bounds__(kShardBlock) void hps_shard_scatter_padded_kernel(const int64_t* __restrict__ keys, uint64_t n, uint32_t P,
+__global__ __launch_bounds__(kShardBlock) void hps_shard_scatter_padded_kernel(const void* __restrict__ keys, uint32_t key_bytes, uint64_t n, uint32_t P,
                                                                               const uint64_t* __restrict__ offsets,
                                                                               int64_t* __restrict__ send, uint64_t stride, uint64_t cap,
                                                                               uint32_t* __restrict__ pos) {
   __shared__ uint32_t wave_cnt[kShardBlock / 64][kMaxShards];
   const uint64_t i = (uint64_t)blockIdx.x * kShardBlock + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool valid = i < n;
-  const int64_t key = valid ? keys[i] : 0;
-  const uint32_t own = valid ? owner_of(key, P) : 0xFFFFFFFFu;
+  const bool inb = i < n;
+  const int64_t key = inb ? load_key(keys, key_bytes, i) : 0;
+  const bool valid = inb && key != HPS_EMPTY_KEY;   // the cache's reserved key never travels: its answer is the default vector
+  const uint32_t own = valid ? owner_of(key, P) : kNoOwner;
   for (uint32_t s = lane; s < P; s += 64) wave_cnt[wave][s] = 0;
   __syncthreads();
   uint32_t rank_in_wave = 0;
@@ -150,30 +172,41 @@ __global__ __launch_bounds__(kShardBlock) void hps_shard_scatter_padded_kernel(c
     const uint64_t r = offsets[(uint64_t)blockIdx.x * P + own] + before + rank_in_wave;   // rank inside the shard's block
     if (r < cap) send[(uint64_t)own * stride + 2 + r] = key;
     pos[i] = (uint32_t)((uint64_t)own * cap + (r < cap ? r : cap - 1));   // overflowed keys: a valid slot; the call is retried
+  } else if (inb) {
+    pos[i] = kPosDefault;
   }
 }
 
-// received blocks -> one contiguous padded key array [P][cap] for the local lookup (unused slots: pad_key, a key the
-// local shard holds, so that they hit the cache); flags[0] |= any peer's overflow flag
+// received blocks -> one contiguous padded key array [P][cap] for the local lookup.  Unused slots carry HPS_EMPTY_KEY, which
+// the probe kernel skips when the call says so (CallDesc::skip_empty_keys): no bucket probe, no row, no statistics.
+// flags[0] = the largest block any rank of the group needed (> cap: the call is repeated with that capacity);
+// flags[1] = keys received (the local lookup's real size)
 __global__ __launch_bounds__(256) void hps_shard_prepare_kernel(const int64_t* __restrict__ recv, uint32_t P, uint64_t stride, uint64_t cap,
-                                                                int64_t pad_key, int64_t* __restrict__ keys_pad, uint32_t* __restrict__ flags) {
+                                                                int64_t* __restrict__ keys_pad, uint32_t* __restrict__ flags) {
   const uint64_t total = (uint64_t)P * cap;
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t p = e / cap, j = e - p * cap;
     const uint64_t cnt = (uint64_t)recv[p * stride];
-    keys_pad[e] = j < cnt ? recv[p * stride + 2 + j] : pad_key;
+    keys_pad[e] = j < cnt ? recv[p * stride + 2 + j] : HPS_EMPTY_KEY;
   }
-  if (blockIdx.x == 0 && threadIdx.x < P && recv[(uint64_t)threadIdx.x * stride + 1] != 0) atomicOr(&flags[0], 1u);
+  if (blockIdx.x == 0 && threadIdx.x < P) {
+    atomicMax(&flags[0], (uint32_t)recv[(uint64_t)threadIdx.x * stride + 1]);
+    atomicAdd(&flags[1], (uint32_t)recv[(uint64_t)threadIdx.x * stride]);
+  }
 }
 
 // out[i] = rows[pos[i]]   (16-lane group per row, 16 B per lane; input order restored by construction)
 __global__ __launch_bounds__(256) void hps_shard_gather_back_kernel(const float* __restrict__ rows, const uint32_t* __restrict__ pos,
-                                                                    uint64_t n, uint32_t D, float* __restrict__ out, int vec) {
+                                                                    uint64_t n, uint32_t D, float* __restrict__ out, int vec, float default_value) {
   const int lig = threadIdx.x & 15;
   const uint64_t groups_total = (uint64_t)gridDim.x * 16;
   for (uint64_t i = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4); i < n; i += groups_total) {
-    const float* src = rows + (uint64_t)pos[i] * D;
     float* dst = out + i * D;
+    if (pos[i] == kPosDefault) {   // the reserved key: in no table by construction (docs/hierarchical_parameter_server.md:244-246)
+      for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = default_value;
+      continue;
+    }
+    const float* src = rows + (uint64_t)pos[i] * D;
     if (vec) {
       for (uint32_t c = (uint32_t)lig * 4; c < D; c += 64)
         __builtin_nontemporal_store(*reinterpret_cast<const f4s*>(src + c), reinterpret_cast<f4s*>(dst + c));
@@ -204,36 +237,38 @@ hipError_t LaunchShardBucket(const int64_t* d_keys, uint64_t n, uint32_t P, int6
   return hipGetLastError();
 }
 
-hipError_t LaunchShardBucketPadded(const int64_t* d_keys, uint64_t n, uint32_t P, uint64_t cap, int64_t* d_send, uint32_t* d_pos,
+hipError_t LaunchShardBucketPadded(const void* d_keys, uint32_t key_bytes, uint64_t n, uint32_t P, uint64_t cap, int64_t* d_send, uint32_t* d_pos,
                                    uint64_t* d_totals, void* d_workspace, hipStream_t stream) {
+  if (key_bytes != 8 && key_bytes != 4) return hipErrorInvalidValue;
   if (P == 0 || P > (uint32_t)kMaxShards || cap == 0) return hipErrorInvalidValue;
   const uint64_t stride = cap + 2;
   uint32_t blocks = (uint32_t)((n + kShardBlock - 1) / kShardBlock);
   uint32_t* hist = reinterpret_cast<uint32_t*>(d_workspace);
   uint64_t* offsets = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_workspace) + (((size_t)(blocks ? blocks : 1) * P * sizeof(uint32_t) + 15) & ~(size_t)15));
-  if (blocks) hipLaunchKernelGGL(hps_shard_hist_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, n, P, hist);
+  if (blocks) hipLaunchKernelGGL(hps_shard_hist_padded_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, key_bytes, n, P, hist);
   hipLaunchKernelGGL(hps_shard_scan_padded_kernel, dim3(1), dim3(64), 0, stream, hist, blocks, P, offsets, d_send, stride, cap, d_totals);
   if (blocks)
-    hipLaunchKernelGGL(hps_shard_scatter_padded_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, n, P, offsets, d_send,
+    hipLaunchKernelGGL(hps_shard_scatter_padded_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, key_bytes, n, P, offsets, d_send,
                        stride, cap, d_pos);
   return hipGetLastError();
 }
 
-hipError_t LaunchShardPrepare(const int64_t* d_recv, uint32_t P, uint64_t cap, int64_t pad_key, int64_t* d_keys_pad, uint32_t* d_flags,
+hipError_t LaunchShardPrepare(const int64_t* d_recv, uint32_t P, uint64_t cap, int64_t* d_keys_pad, uint32_t* d_flags,
                               hipStream_t stream) {
   uint64_t want = ((uint64_t)P * cap + 255) / 256;
   if (want > 2048) want = 2048;
   if (want == 0) want = 1;
-  hipLaunchKernelGGL(hps_shard_prepare_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_recv, P, cap + 2, cap, pad_key, d_keys_pad, d_flags);
+  hipLaunchKernelGGL(hps_shard_prepare_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_recv, P, cap + 2, cap, d_keys_pad, d_flags);
   return hipGetLastError();
 }
 
-hipError_t LaunchShardGatherBack(const float* d_rows, const uint32_t* d_pos, uint64_t n, uint32_t D, float* d_out, hipStream_t stream) {
+hipError_t LaunchShardGatherBack(const float* d_rows, const uint32_t* d_pos, uint64_t n, uint32_t D, float* d_out, float default_value,
+                                 hipStream_t stream) {
   if (n == 0) return hipSuccess;
   uint64_t want = (n + 15) / 16;
   if (want > 2048) want = 2048;
   const int vec = ((D & 3u) == 0 && ((uintptr_t)d_rows & 15u) == 0 && ((uintptr_t)d_out & 15u) == 0) ? 1 : 0;
-  hipLaunchKernelGGL(hps_shard_gather_back_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_rows, d_pos, n, D, d_out, vec);
+  hipLaunchKernelGGL(hps_shard_gather_back_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_rows, d_pos, n, D, d_out, vec, default_value);
   return hipGetLastError();
 }
 

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstring>
 
+#include "../ps/thread_pool.h"
+#include "key_pack.h"
 #include "shard_kernels.h"
 
 namespace hps {
@@ -31,6 +33,7 @@ struct RcclApi {
   int (*GetUniqueId)(UniqueId*) = nullptr;
   int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(Comm) = nullptr;
+  int (*CommAbort)(Comm) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
@@ -48,6 +51,7 @@ struct RcclApi {
       a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
       a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
       a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+      a.CommAbort = (decltype(a.CommAbort))dlsym(h, "ncclCommAbort");   // optional
       a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
       a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
       a.Send = (decltype(a.Send))sym("ncclSend");
@@ -75,11 +79,15 @@ class RcclTransport : public ShardTransport {
  public:
   RcclTransport(uint32_t rank, uint32_t world, RcclApi::Comm comm) : rank_(rank), world_(world), comm_(comm) {}
   ~RcclTransport() override { if (comm_) (void)RcclApi::Get().CommDestroy(comm_); }
+  void Abort() override {
+    if (comm_ && RcclApi::Get().CommAbort) { (void)RcclApi::Get().CommAbort(comm_); comm_ = nullptr; }
+  }
   uint32_t rank() const override { return rank_; }
   uint32_t size() const override { return world_; }
   const char* name() const override { return "rccl"; }
   Status AllToAll(const void* d_send, void* d_recv, size_t bytes, hipStream_t stream) override {
     RcclApi& api = RcclApi::Get();
+    if (!comm_) return Error(Code::kUnavailable, "the RCCL communicator of this sharded session was aborted");
     // one group = one fused launch: P sends and P receives progress together over the xGMI links
     RCCL_TRY(api, api.GroupStart());
     for (uint32_t p = 0; p < world_; ++p) {
@@ -130,29 +138,37 @@ class LocalShardGroup {
     for (hipEvent_t e : done_) if (e) (void)hipEventDestroy(e);
   }
   uint32_t world() const { return world_; }
-  // generation barrier over the P calling threads
-  void Arrive() {
+  // generation barrier over the P calling threads; false: some rank gave up (Abort) — nobody waits for it any more
+  bool Arrive() {
     std::unique_lock<std::mutex> lk(mu_);
+    if (aborted_) return false;
     const uint64_t gen = gen_;
     if (++arrived_ == world_) { arrived_ = 0; ++gen_; cv_.notify_all(); }
-    else cv_.wait(lk, [&] { return gen_ != gen; });
+    else cv_.wait(lk, [&] { return gen_ != gen || aborted_; });
+    return !aborted_;
+  }
+  void Abort() {
+    std::lock_guard<std::mutex> lk(mu_);
+    aborted_ = true;
+    cv_.notify_all();
   }
   Status Exchange(uint32_t rank, const void* d_send, void* d_recv, size_t bytes, hipStream_t stream) {
+    const auto gone = [] { return Error(Code::kUnavailable, "sharded lookup: another rank of the in-process group failed; the group is unusable"); };
     if (!ready_[rank]) {
       HIP_TRY(hipEventCreateWithFlags(&ready_[rank], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&done_[rank], hipEventDisableTiming));
     }
     send_[rank] = d_send;
     HIP_TRY(hipEventRecord(ready_[rank], stream));   // my blocks are complete once my stream gets here
-    Arrive();
+    if (!Arrive()) return gone();
     for (uint32_t p = 0; p < world_; ++p) {          // pull my block out of every peer's send buffer
       HIP_TRY(hipStreamWaitEvent(stream, ready_[p], 0));
       HIP_TRY(hipMemcpyAsync((char*)d_recv + (size_t)p * bytes, (const char*)send_[p] + (size_t)rank * bytes, bytes, hipMemcpyDeviceToDevice, stream));
     }
     HIP_TRY(hipEventRecord(done_[rank], stream));
-    Arrive();
+    if (!Arrive()) return gone();
     for (uint32_t p = 0; p < world_; ++p) HIP_TRY(hipStreamWaitEvent(stream, done_[p], 0));   // peers are done reading my send buffer
-    Arrive();   // nobody re-records an event another rank has not waited on yet
+    if (!Arrive()) return gone();   // nobody re-records an event another rank has not waited on yet
     return Status::Ok();
   }
 
@@ -164,6 +180,7 @@ class LocalShardGroup {
   std::condition_variable cv_;
   uint32_t arrived_ = 0;
   uint64_t gen_ = 0;
+  bool aborted_ = false;
 };
 
 namespace {
@@ -174,8 +191,11 @@ class LocalTransport : public ShardTransport {
   uint32_t size() const override { return g_->world(); }
   const char* name() const override { return "in-process"; }
   Status AllToAll(const void* d_send, void* d_recv, size_t bytes, hipStream_t stream) override {
-    return g_->Exchange(rank_, d_send, d_recv, bytes, stream);
+    const Status st = g_->Exchange(rank_, d_send, d_recv, bytes, stream);
+    if (!st.ok()) g_->Abort();   // a HIP call of mine failed in the middle of the rendezvous: release the others
+    return st;
   }
+  void Abort() override { g_->Abort(); }
 
  private:
   std::shared_ptr<LocalShardGroup> g_;
@@ -194,27 +214,27 @@ Status MakeLocalTransport(std::shared_ptr<LocalShardGroup> group, uint32_t rank,
 // =================================================================================================
 // ShardedSession
 // =================================================================================================
-Status ShardedSession::Create(LookupSession* session, std::unique_ptr<ShardTransport> transport, size_t max_local_keys,
+Status ShardedSession::Create(std::shared_ptr<LookupSession> session, std::unique_ptr<ShardTransport> transport, size_t max_local_keys,
                               std::unique_ptr<ShardedSession>* out) {
   if (!session || !transport) return Error(Code::kInvalidArg, "null argument");
   if (!session->uses_gpu_cache()) return Error(Code::kUnsupported, "the native sharded lookup needs a GPU-cache session");
   if (session->num_tables() != 1) return Error(Code::kUnsupported, "the sharded lookup handles one table per session, the model has ", session->num_tables());
   if (max_local_keys == 0) return Error(Code::kInvalidArg, "max_local_keys is 0");
+  if (max_local_keys >= 0xFFFFFFFFull) return Error(Code::kInvalidArg, "max_local_keys must be below 2^32 - 1");
   std::unique_ptr<ShardedSession> s(new ShardedSession());
-  s->session_ = session;
   s->P_ = transport->size();
   s->transport_ = std::move(transport);
   s->stream_ = session->stream();
   s->device_ = session->device();
   s->dim_ = session->table_dim(0);
+  s->default_value_ = session->table_default(0);
   s->max_local_ = max_local_keys;
-  s->pad_key_ = session->any_key_of_table(0);
   if (s->P_ == 0 || s->P_ > 64) return Error(Code::kUnsupported, "1..64 shards are supported, got ", s->P_);
   // the local lookup sees P blocks of `cap` keys: the session's request capacity bounds the block size
   s->cap_max_ = session->max_keys() / s->P_;
   const double mean = (double)max_local_keys / s->P_;
   // start at mean + 8 sigma of a binomial split (hashed owners) + a little: uniform traffic never overflows; skewed
-  // traffic (one hot key = one owner) overflows once and the capacity doubles
+  // traffic (one hot key = one owner) overflows once and the capacity becomes what was needed
   uint64_t cap = (uint64_t)std::ceil(mean + 8.0 * std::sqrt(mean) + 64.0);
   cap = std::min<uint64_t>(std::max<uint64_t>(cap, 1), std::min<uint64_t>(s->cap_max_, max_local_keys));
   if (s->cap_max_ == 0)
@@ -229,76 +249,173 @@ Status ShardedSession::Create(LookupSession* session, std::unique_ptr<ShardTrans
     *p = (std::remove_reference_t<decltype(**p)>*)v;
     return Status::Ok();
   };
-  HPS_RETURN_IF_ERROR(dev(&s->d_send_, P * (cap_alloc + 2)));
-  HPS_RETURN_IF_ERROR(dev(&s->d_recv_, P * (cap_alloc + 2)));
+  HPS_RETURN_IF_ERROR(dev(&s->d_send_, P * std::max<uint64_t>(cap_alloc + 2, 4)));   // (4 words per peer: VerifyGeometry)
+  HPS_RETURN_IF_ERROR(dev(&s->d_recv_, P * std::max<uint64_t>(cap_alloc + 2, 4)));
   HPS_RETURN_IF_ERROR(dev(&s->d_keys_pad_, P * cap_alloc));
   HPS_RETURN_IF_ERROR(dev(&s->d_rows_pad_, P * cap_alloc * D));
   HPS_RETURN_IF_ERROR(dev(&s->d_rows_back_, P * cap_alloc * D));
   HPS_RETURN_IF_ERROR(dev(&s->d_pos_, max_local_keys));
   HPS_RETURN_IF_ERROR(dev(&s->d_flags_, 4));
   HPS_RETURN_IF_ERROR(dev(&s->d_totals_, P));
+  HPS_RETURN_IF_ERROR(dev(&s->d_keys_in_, max_local_keys));
   {
     void* v = nullptr;
     HIP_TRY(hipMalloc(&v, ShardBucketWorkspaceBytes(max_local_keys, s->P_) + 64));
     s->d_ws_ = v;
     HIP_TRY(hipHostMalloc(&v, 4 * sizeof(uint32_t), hipHostMallocDefault));
     s->h_flags_ = (uint32_t*)v;
-    HIP_TRY(hipHostMalloc(&v, P * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&v, std::max<size_t>(P, 4) * sizeof(uint64_t), hipHostMallocDefault));
     s->h_totals_ = (uint64_t*)v;
+    HIP_TRY(hipHostMalloc(&v, max_local_keys * sizeof(int64_t), hipHostMallocDefault));
+    s->h_keys_in_ = (int64_t*)v;
   }
+  for (hipEvent_t& e : s->ev_) HIP_TRY(hipEventCreate(&e));
   s->cap_max_ = cap_alloc;
+  s->session_ = std::move(session);
   *out = std::move(s);
   return Status::Ok();
 }
 
 ShardedSession::~ShardedSession() {
   (void)hipSetDevice(device_);
-  if (stream_) (void)hipStreamSynchronize(stream_);
+  if (stream_ && session_) (void)hipStreamSynchronize(stream_);   // (the stream belongs to the session, alive through session_)
   for (void* p : {(void*)d_send_, (void*)d_recv_, (void*)d_keys_pad_, (void*)d_rows_pad_, (void*)d_rows_back_, (void*)d_pos_, (void*)d_flags_,
-                  (void*)d_totals_, d_ws_})
+                  (void*)d_totals_, (void*)d_keys_in_, d_ws_})
     if (p) (void)hipFree(p);
   if (h_flags_) (void)hipHostFree(h_flags_);
   if (h_totals_) (void)hipHostFree(h_totals_);
+  if (h_keys_in_) (void)hipHostFree(h_keys_in_);
+  for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
 }
 
-Status ShardedSession::Attempt(const int64_t* d_keys, size_t n, float* d_out, uint64_t cap, bool* overflow) {
+Status ShardedSession::Attempt(const void* d_keys, uint32_t key_bytes, size_t n, float* d_out, uint64_t cap, uint64_t* need) {
   const uint64_t stride = cap + 2;
   const size_t D = dim_;
   HIP_TRY(hipMemsetAsync(d_flags_, 0, 4 * sizeof(uint32_t), stream_));
-  HIP_TRY(LaunchShardBucketPadded(d_keys, n, P_, cap, d_send_, d_pos_, d_totals_, d_ws_, stream_));
+  HIP_TRY(LaunchShardBucketPadded(d_keys, key_bytes, n, P_, cap, d_send_, d_pos_, d_totals_, d_ws_, stream_));
+  HIP_TRY(hipEventRecord(ev_[0], stream_));
   HPS_RETURN_IF_ERROR(transport_->AllToAll(d_send_, d_recv_, stride * sizeof(int64_t), stream_));
-  HIP_TRY(LaunchShardPrepare(d_recv_, P_, cap, pad_key_, d_keys_pad_, d_flags_, stream_));
-  // the local lookup: one table, P * cap keys, rows in the same padded layout (its own kernels follow ours on the stream)
+  HIP_TRY(hipEventRecord(ev_[1], stream_));
+  HIP_TRY(LaunchShardPrepare(d_recv_, P_, cap, d_keys_pad_, d_flags_, stream_));
+  // the local lookup: one table, P * cap keys, rows in the same padded layout (its own kernels follow ours on the stream);
+  // the padding is skipped by the probe
   float* rows = d_rows_pad_;
   const size_t nk = (size_t)P_ * cap;
-  HPS_RETURN_IF_ERROR(session_->lookup_from_device(d_keys_pad_, &rows, &nk, 1));
+  HPS_RETURN_IF_ERROR(session_->lookup_from_device_padded(d_keys_pad_, &rows, &nk, 1));
+  HIP_TRY(hipEventRecord(ev_[2], stream_));
   HPS_RETURN_IF_ERROR(transport_->AllToAll(d_rows_pad_, d_rows_back_, cap * D * sizeof(float), stream_));
-  HIP_TRY(LaunchShardGatherBack(d_rows_back_, d_pos_, n, dim_, d_out, stream_));
-  HIP_TRY(hipMemcpyAsync(h_flags_, d_flags_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipEventRecord(ev_[3], stream_));
+  HIP_TRY(LaunchShardGatherBack(d_rows_back_, d_pos_, n, dim_, d_out, default_value_, stream_));
+  HIP_TRY(hipMemcpyAsync(h_flags_, d_flags_, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipMemcpyAsync(h_totals_, d_totals_, P_ * sizeof(uint64_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipStreamSynchronize(stream_));
-  *overflow = h_flags_[0] != 0;
+  *need = h_flags_[0];
+  stats_.received = h_flags_[1];
+  session_->discount_padding(nk - std::min<uint64_t>(nk, h_flags_[1]));
+  (void)hipEventElapsedTime(&stats_.keys_exchange_ms, ev_[0], ev_[1]);
+  (void)hipEventElapsedTime(&stats_.lookup_ms, ev_[1], ev_[2]);
+  (void)hipEventElapsedTime(&stats_.rows_exchange_ms, ev_[2], ev_[3]);
   return Status::Ok();
 }
 
-Status ShardedSession::Lookup(const int64_t* d_keys, size_t n, float* d_out) {
-  if (n > max_local_) return Error(Code::kInvalidArg, "sharded lookup: ", n, " keys exceed max_local_keys = ", max_local_);
-  if (n && (!d_keys || !d_out)) return Error(Code::kInvalidArg, "null argument");
-  HIP_TRY(hipSetDevice(device_));
+// Every rank must have been created with the same geometry: one exchange of (max_local_keys, first capacity, row width,
+// block limit) per peer at the start of the first collective call, compared on the host.  A mismatch would otherwise show up
+// as mismatched send/recv sizes — a hang.
+Status ShardedSession::VerifyGeometry() {
+  uint64_t* mine = h_totals_;
+  mine[0] = max_local_; mine[1] = cap_; mine[2] = dim_; mine[3] = cap_max_;
+  for (uint32_t p = 0; p < P_; ++p)
+    HIP_TRY(hipMemcpyAsync(d_send_ + (size_t)p * 4, mine, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+  HPS_RETURN_IF_ERROR(transport_->AllToAll(d_send_, d_recv_, 4 * sizeof(uint64_t), stream_));
+  std::vector<uint64_t> got((size_t)P_ * 4);
+  HIP_TRY(hipMemcpyAsync(got.data(), d_recv_, got.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, stream_));
+  HIP_TRY(hipStreamSynchronize(stream_));
+  for (uint32_t p = 0; p < P_; ++p)
+    if (memcmp(&got[(size_t)p * 4], mine, 4 * sizeof(uint64_t)) != 0)
+      return Error(Code::kInvalidArg, "sharded session: rank ", p, " was created with max_local_keys ", got[(size_t)p * 4], ", first capacity ",
+                   got[(size_t)p * 4 + 1], ", row width ", got[(size_t)p * 4 + 2], ", block limit ", got[(size_t)p * 4 + 3], "; this rank (",
+                   transport_->rank(), ") with ", mine[0], ", ", mine[1], ", ", mine[2], ", ", mine[3], " — they must agree");
+  verified_ = true;
+  return Status::Ok();
+}
+
+Status ShardedSession::Run(const void* d_keys, uint32_t key_bytes, size_t n, float* d_out) {
   stats_.attempts = 0;
+  if (!verified_) {
+    const Status st = VerifyGeometry();
+    if (!st.ok()) { transport_->Abort(); return st; }
+  }
   for (;;) {
-    bool overflow = false;
+    uint64_t need = 0;
     ++stats_.attempts;
-    HPS_RETURN_IF_ERROR(Attempt(d_keys, n, d_out, cap_, &overflow));
+    const Status st = Attempt(d_keys, key_bytes, n, d_out, cap_, &need);
+    if (!st.ok()) {
+      transport_->Abort();   // this rank is out of the collective: nobody may wait for it
+      return st;
+    }
     stats_.capacity = cap_;
     stats_.sent.assign(h_totals_, h_totals_ + P_);
-    if (!overflow) return Status::Ok();
-    // some rank's block was too small: every rank saw the flag (it travels with the keys), every rank doubles
-    if (cap_ >= cap_max_)
-      return Error(Code::kInvalidArg, "sharded lookup: a shard received more than ", cap_max_,
-                   " keys from one rank; raise the model's max_batch_size (request capacity / shards bounds the block size)");
-    cap_ = std::min<uint64_t>(cap_max_, cap_ * 2);
+    if (need <= cap_) return Status::Ok();
+    // some rank's block was too small.  Every rank has seen the same maximum (each rank's largest need travels in every
+    // block header it sends), so every rank picks the same new capacity and the second attempt fits.
+    if (need > cap_max_) {
+      transport_->Abort();
+      return Error(Code::kInvalidArg, "sharded lookup: one rank has ", need, " keys for one shard, more than the block limit of ", cap_max_,
+                   " keys; raise the model's max_batch_size (request capacity / shards bounds the block size)");
+    }
+    cap_ = std::min<uint64_t>(cap_max_, need + need / 16 + 64);   // a little headroom: the next call's hot key may be hotter
   }
+}
+
+// A call that is refused before it reaches the exchange still leaves the other ranks inside theirs: every refusal goes
+// through here, which takes this rank's endpoint out of the group so that nobody waits for it.
+Status ShardedSession::Refuse(Status st) {
+  transport_->Abort();
+  return st;
+}
+
+Status ShardedSession::Lookup(const int64_t* d_keys, size_t n, float* d_out) {
+  if (n > max_local_) return Refuse(Error(Code::kInvalidArg, "sharded lookup: ", n, " keys exceed max_local_keys = ", max_local_));
+  if (n && (!d_keys || !d_out)) return Refuse(Error(Code::kInvalidArg, "null argument"));
+  if (hipSetDevice(device_) != hipSuccess) return Refuse(Error(Code::kInternal, "hipSetDevice(", device_, ") failed"));
+  stats_.key_bytes = 8;
+  return Run(d_keys, 8, n, d_out);
+}
+
+Status ShardedSession::LookupHost(const int64_t* h_keys, size_t n, float* d_out) {
+  if (n > max_local_) return Refuse(Error(Code::kInvalidArg, "sharded lookup: ", n, " keys exceed max_local_keys = ", max_local_));
+  if (n && (!h_keys || !d_out)) return Refuse(Error(Code::kInvalidArg, "null argument"));
+  if (hipSetDevice(device_) != hipSuccess) return Refuse(Error(Code::kInternal, "hipSetDevice(", device_, ") failed"));
+  // stage + narrow, as LookupSession::lookup does for a replica's request: 32 K-key tasks on the serving pool copy the keys
+  // into page-locked memory as uint32 while OR-ing them together; a key that does not fit ends the attempt and the
+  // request goes as it is (8 bytes per key)
+  constexpr size_t kTaskKeys = 32768;
+  const size_t tasks = (n + kTaskKeys - 1) / kTaskKeys;
+  uint32_t width = 4;
+  {
+    uint64_t sample = 0;
+    for (size_t t = 0; t < tasks; ++t) sample |= (uint64_t)h_keys[t * kTaskKeys] | (uint64_t)h_keys[std::min(n, (t + 1) * kTaskKeys) - 1];
+    if (sample >> 32) width = 8;
+  }
+  for (;;) {
+    std::atomic<uint64_t> high{0};
+    auto body = [&](size_t t) {
+      const size_t b = t * kTaskKeys, e = std::min(n, b + kTaskKeys);
+      if (width == 8) memcpy(h_keys_in_ + b, h_keys + b, (e - b) * sizeof(int64_t));
+      else {
+        const uint64_t h = PackKeys32(h_keys + b, e - b, reinterpret_cast<uint32_t*>(h_keys_in_) + b);
+        if (h >> 32) high.fetch_or(h, std::memory_order_relaxed);
+      }
+    };
+    if (tasks <= 2) for (size_t t = 0; t < tasks; ++t) body(t);
+    else ThreadPool::Serving().ParallelFor(tasks, body);
+    if (width == 4 && high.load() != 0) { width = 8; continue; }
+    break;
+  }
+  if (n && hipMemcpyAsync(d_keys_in_, h_keys_in_, n * width, hipMemcpyHostToDevice, stream_) != hipSuccess)
+    return Refuse(Error(Code::kInternal, "sharded lookup: key upload failed"));
+  stats_.key_bytes = (int)width;
+  return Run(d_keys_in_, width, n, d_out);
 }
 
 }  // namespace hps

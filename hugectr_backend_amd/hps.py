@@ -133,6 +133,9 @@ def _load() -> C.CDLL:
         "hps_shard_unique_id": (C.c_int, [P]),
         "hps_shard_session_create": (C.c_int, [P, u32, u32, P, u64, C.POINTER(P)]),
         "hps_shard_group_create_local": (C.c_int, [u32, C.POINTER(P)]),
+        "hps_shard_session_lookup_host": (C.c_int, [P, P, u64, P]),
+        "hps_shard_session_last_timing": (C.c_int, [P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                                    C.POINTER(u64), C.POINTER(C.c_int32)]),
         "hps_shard_group_destroy": (None, [P]),
         "hps_shard_session_create_local": (C.c_int, [P, P, u32, u64, C.POINTER(P)]),
         "hps_shard_session_lookup": (C.c_int, [P, P, u64, P]),
@@ -161,7 +164,8 @@ EXPORTED_SYMBOLS = [
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
     "hps_server_table_data", "hps_cache_on_device", "hps_wake_copy_engines", "hps_session_create_from_cache",
     "hps_shard_unique_id", "hps_shard_session_create", "hps_shard_group_create_local", "hps_shard_group_destroy",
-    "hps_shard_session_create_local", "hps_shard_session_lookup", "hps_shard_session_last_stats", "hps_shard_session_destroy",
+    "hps_shard_session_create_local", "hps_shard_session_lookup", "hps_shard_session_lookup_host", "hps_shard_session_last_timing",
+    "hps_shard_session_last_stats", "hps_shard_session_destroy",
     "hps_server_host_tier_stats", "hps_server_host_tier_keys", "hps_cache_num_tables", "hps_cache_table_info",
     "hps_cache_counters", "hps_cache_query", "hps_cache_wait_async", "hps_cache_release", "hps_session_create",
     "hps_session_destroy", "hps_session_lookup", "hps_session_lookup_device", "hps_session_last_stats",

@@ -103,12 +103,26 @@ class ShardedLookup:
             out = torch.empty(max(n, 1) * self.dim, dtype=torch.float32, device=d_keys.device)
         torch.cuda.current_stream(d_keys.device).synchronize()   # the engine works on the session's own stream
         hps._check(hps.LIB.hps_shard_session_lookup(self._native, d_keys.data_ptr(), n, out.data_ptr()))
+        return self._native_stats(out, n)
+
+    def lookup_host(self, h_keys: np.ndarray, out):
+        """Keys in host memory (the reference's lookup contract): staged and, when they fit, narrowed by the engine."""
+        h_keys = np.ascontiguousarray(h_keys, dtype=np.int64)
+        hps._check(hps.LIB.hps_shard_session_lookup_host(self._native, h_keys.ctypes.data, h_keys.size, out.data_ptr()))
+        return self._native_stats(out, h_keys.size)
+
+    def _native_stats(self, out, n):
         cap, att = C.c_uint64(0), C.c_uint32(0)
         sent = (C.c_uint64 * self.P)()
         hps._check(hps.LIB.hps_shard_session_last_stats(self._native, C.byref(cap), C.byref(att), sent, self.P))
         self.last_sent = [int(x) for x in sent]
         self.last_attempts = int(att.value)
         self.last_capacity = int(cap.value)
+        t = [C.c_float(0), C.c_float(0), C.c_float(0)]
+        recv, kb = C.c_uint64(0), C.c_int32(0)
+        hps._check(hps.LIB.hps_shard_session_last_timing(self._native, C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(recv), C.byref(kb)))
+        self.last_timing = {"keys_exchange_ms": t[0].value, "lookup_ms": t[1].value, "rows_exchange_ms": t[2].value,
+                            "keys_received": int(recv.value), "key_bytes": int(kb.value)}
         return out[: n * self.dim]
 
     def close(self):

@@ -217,18 +217,25 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
  * this session's misses the reference's way — host threads gather, hipMemcpyAsync ships — e.g. to compare the two tiers
  * on one deployment), "split_probe" (0/1: read the miss counts back before / after the hit gather), and the kernel A/B
  * switches "probe_variant" (U + 100*no_dedup, U in {2,4,8}), "xcd_walk" (0/1), "keys_pinned_check" (0/1: DMA flat
- * page-locked key arrays in place instead of staging them), "narrow_keys" (0/1: pageable keys that all fit 32 bits
- * cross PCIe as uint32) */
+ * page-locked key arrays in place instead of staging them), "narrow_keys" (pageable keys cross PCIe at the width the
+ * request needs — 0: always 8 bytes; 1 (default): 3 bytes each when every key is in [0, 2^24), uint32 when in [0, 2^32);
+ * 2: uint32 only.  A width that fails is not tried again for 256 calls, doubling with every failure in a row up to
+ * 65,536) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 /* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------
  * One table, rows partitioned by owner(key) = mix64(key) mod num_shards, one process per GPU.  The native sharded
  * session drives the whole exchange itself — RCCL (ncclSend/ncclRecv groups over xGMI) on the lookup session's stream,
- * fixed-capacity blocks, no count exchange and no host round trip inside a call (csrc/cache/shard_session.h):
+ * fixed-capacity blocks, no count exchange and no device->host read-back between the two exchanges (csrc/cache/shard_session.h):
  *
  *   hps_shard_unique_id(id)                     on rank 0; distribute the 128 bytes to the other ranks (any side channel)
- *   hps_shard_session_create(session, rank, world, id, max_local_keys, &shard)     collective
+ *   hps_shard_session_create(session, rank, world, id, max_local_keys, &shard)     collective (ncclCommInitRank)
  *   hps_shard_session_lookup(shard, d_keys, n, d_out)                              collective, blocking
+ * Every rank passes the same max_local_keys (verified at the first lookup).  The session handle may be destroyed before
+ * the sharded session (the engine keeps what it needs alive).  A rank that fails inside a collective call aborts its side
+ * of the transport so that in-process peers return an error instead of waiting; RCCL peers already inside a send/recv
+ * kernel cannot be reached — bound the call with a watchdog.  The key INT64_MIN (the cache's reserved value) is in no
+ * table: it is answered with the default vector without travelling.
  *
  * `session` is the lookup session of a ONE-table GPU-cache model that holds this rank's shard
  * (hps_server_load_table_synthetic_shard, or files holding only the rank's rows); its request capacity
@@ -247,7 +254,15 @@ int hps_shard_session_create_local(hps_session_t* session, hps_shard_group_t* gr
                                    hps_shard_session_t** out);
 /* d_keys: n int64 on the session's device (this rank's keys); d_out: n x D fp32 rows in input order. */
 int hps_shard_session_lookup(hps_shard_session_t* shard, const int64_t* d_keys, uint64_t n, float* d_out);
-/* last call: keys per exchange block, attempts (2+ = a block overflowed and the capacity was doubled), keys sent to each rank */
+/* The reference's contract for a lookup (keys in HOST memory, docs/architecture.md:308-323): staged through page-locked memory,
+ * as uint32 when every key of the request fits 32 bits, else 8 bytes each. */
+int hps_shard_session_lookup_host(hps_shard_session_t* shard, const int64_t* h_keys, uint64_t n, float* d_out);
+/* last call, last attempt: time of the key exchange, of the local lookup and of the row exchange (HIP events on the session's
+ * stream), keys this rank's shard was asked for, bytes per key of a host request over PCIe (8 for device keys) */
+int hps_shard_session_last_timing(hps_shard_session_t* shard, float* keys_exchange_ms, float* lookup_ms, float* rows_exchange_ms,
+                                  uint64_t* keys_received, int32_t* key_bytes);
+/* last call: keys per exchange block, attempts (2 = a block overflowed and the call was repeated with the capacity that was
+ * needed — every rank learns the largest block any rank wanted from the block headers), keys sent to each rank */
 int hps_shard_session_last_stats(hps_shard_session_t* shard, uint64_t* capacity, uint32_t* attempts, uint64_t* sent_per_rank,
                                  uint32_t world);
 void hps_shard_session_destroy(hps_shard_session_t* shard);

@@ -220,7 +220,8 @@ def test_native_sharded_session_logical_shards_in_one_process(P):
     [t.join(timeout=300) for t in th]
     assert not errs, errs
     assert all(a[0] == 1 for a in attempts)                 # uniform keys fit the first capacity
-    assert all(a[3] >= 2 for a in attempts)                 # the skewed round was repeated on every rank alike
+    assert all(a[3] == 2 for a in attempts)                 # the skewed round was repeated ONCE, on every rank alike
+    assert all(a[4] == 1 for a in attempts)                 # ... and the capacity it found is kept
     for h in shards:
         hps.LIB.hps_shard_session_destroy(h)
     hps.LIB.hps_shard_group_destroy(grp)
@@ -252,3 +253,124 @@ def test_native_sharded_session_over_rccl_single_rank():
         assert np.array_equal(_bits(out.cpu().numpy()), _bits(O.np_lookup(tables, q, [n], [2.0])))
     hps.LIB.hps_shard_session_destroy(h)
     sess.close()
+
+
+@pytest.mark.gpu
+def test_native_sharded_session_zipf_skew_host_keys_and_reserved_key():
+    """P = 4 logical shards, keys in HOST memory (hps_shard_session_lookup_host: staged + narrowed to uint32 when they fit),
+    drawn Zipf-like so that a handful of keys make up most of a request: the first call overflows its blocks and is repeated
+    ONCE with the capacity the headers reported (never a third attempt); later calls fit.  The cache's reserved key
+    (INT64_MIN) never travels and is answered with the default vector; wide keys make the request cross PCIe at 8 bytes."""
+    import ctypes as C
+    import threading
+    import torch
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    P = 4
+    max_local = 40000
+    tables, made = _native_shards(P, max_local=max_local)
+    keys = tables[0][0]
+    grp = C.c_void_p()
+    hps._check(hps.LIB.hps_shard_group_create_local(P, C.byref(grp)))
+    shards = []
+    for r, (_, sess) in enumerate(made):
+        h = C.c_void_p()
+        hps._check(hps.LIB.hps_shard_session_create_local(sess._h, grp, r, max_local, C.byref(h)))
+        shards.append(h)
+    # the lookup sessions' handles go first: the sharded sessions keep what they need alive
+    for _, sess in made:
+        sess.close()
+    rng = np.random.default_rng(77)
+    ranks = np.argsort(rng.random(keys.size))
+    w = 1.0 / np.arange(1, keys.size + 1) ** 1.6          # the hottest key alone is ~45 % of a request
+    w /= w.sum()
+    rounds = []
+    for it in range(4):
+        per_rank = []
+        for r in range(P):
+            q = keys[ranks[rng.choice(keys.size, size=max_local, p=w)]].astype(np.int64)
+            if it == 2:
+                q[::97] = np.iinfo(np.int64).min            # reserved key
+                q[5::101] = -5 - rng.integers(0, 1 << 40)   # absent (and wide: this request goes at 8 bytes per key)
+            per_rank.append(q)
+        rounds.append(per_rank)
+    errs = []
+    info = [[None] * len(rounds) for _ in range(P)]
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            for it, per_rank in enumerate(rounds):
+                q = per_rank[r]
+                out = torch.empty(q.size * 128, dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                hps._check(hps.LIB.hps_shard_session_lookup_host(shards[r], q.ctypes.data, q.size, out.data_ptr()))
+                att, cap = C.c_uint32(0), C.c_uint64(0)
+                sent = (C.c_uint64 * P)()
+                hps._check(hps.LIB.hps_shard_session_last_stats(shards[r], C.byref(cap), C.byref(att), sent, P))
+                t = [C.c_float(0) for _ in range(3)]
+                recv, kb = C.c_uint64(0), C.c_int32(0)
+                hps._check(hps.LIB.hps_shard_session_last_timing(shards[r], C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(recv), C.byref(kb)))
+                info[r][it] = (att.value, cap.value, kb.value, recv.value, sum(sent), [x.value for x in t])
+                ref = O.np_lookup(tables, q, [q.size], [2.0])
+                if not np.array_equal(_bits(out.cpu().numpy()), _bits(ref)):
+                    errs.append((r, it, "mismatch"))
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, "exception", repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errs, errs
+    for r in range(P):
+        assert info[r][0][0] == 2, info[r][0]                       # skew: one repetition, never more
+        assert all(info[r][it][0] <= 2 for it in range(4))
+        assert info[r][1][0] == 1                                   # the capacity found is kept
+        assert info[r][0][1] == info[0][0][1] and info[r][0][1] > max_local // P   # every rank chose the same capacity
+        assert info[r][0][2] == 4 and info[r][2][2] == 8           # narrowed when the keys fit, 8 bytes with wide keys
+        assert info[r][2][4] == max_local - len(range(0, max_local, 97))           # the reserved key was not sent
+        assert all(x >= 0 for x in info[r][3][5])
+    assert sum(info[r][1][3] for r in range(P)) == P * max_local   # keys received over all ranks = keys sent
+    for h in shards:
+        hps.LIB.hps_shard_session_destroy(h)
+    hps.LIB.hps_shard_group_destroy(grp)
+
+
+@pytest.mark.gpu
+def test_native_sharded_session_a_failing_rank_releases_the_others():
+    """A rank that cannot take part in a collective call (here: more keys than max_local_keys) aborts its endpoint: the
+    other rank's call returns an error instead of waiting for ever, and the group stays unusable."""
+    import ctypes as C
+    import threading
+    import torch
+    from hugectr_backend_amd import hps
+    P = 2
+    tables, made = _native_shards(P)
+    keys = tables[0][0]
+    grp = C.c_void_p()
+    hps._check(hps.LIB.hps_shard_group_create_local(P, C.byref(grp)))
+    shards = []
+    for r, (_, sess) in enumerate(made):
+        h = C.c_void_p()
+        hps._check(hps.LIB.hps_shard_session_create_local(sess._h, grp, r, 1000, C.byref(h)))
+        shards.append(h)
+    rc = [None, None]
+
+    def work(r):
+        torch.cuda.set_device(0)
+        n = 1000 if r == 0 else 1001
+        dq = torch.from_numpy(np.resize(keys, n).astype(np.int64)).cuda()
+        out = torch.empty(n * 128, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        rc[r] = hps.LIB.hps_shard_session_lookup(shards[r], dq.data_ptr(), n, out.data_ptr())
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=60) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for the one that failed"
+    assert rc[1] == hps.ERR_INVALID_ARG and rc[0] not in (0, None)
+    for h in shards:
+        hps.LIB.hps_shard_session_destroy(h)
+    hps.LIB.hps_shard_group_destroy(grp)
+    for _, sess in made:
+        sess.close()

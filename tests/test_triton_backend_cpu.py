@@ -309,3 +309,25 @@ def test_host_tier_smaller_than_the_table_through_the_plugin(tmp_path):
         assert (tmp_path / "pdb" / "hps_wdl" / "sparse_embedding2" / "emb_vector").stat().st_size == tables[1][1].nbytes
     finally:
         srv.shutdown()
+
+
+def test_native_driver_config1_cpu_parameter_server_through_the_plugin():
+    """BASELINE configs[0] — the reference's CI smoke is perf_analyzer against a CPU-only deployment (.gitlab-ci.yml:70): the
+    native load generator (tools/triton_abi_bench.cpp) plays that role here: 1 table x 16 floats, 4,096-key requests,
+    gpucache=false, KIND_CPU instance, OUTPUT0 in host memory, every sampled row checked against the table recipe; and a
+    two-table W&D-shaped CPU model (D = [1,16], keys per sample [2,26]) for the per-table slicing of NUMKEYS / OUTPUT0."""
+    import json
+    import subprocess
+    from hugectr_backend_amd import build as hb
+    exe = hb.LIB / "triton_abi_bench.bin"
+    assert exe.exists()
+    for extra, nkeys, nout in (
+            (["--tables", "1", "--rows", "200000", "--dims", "16", "--batch", "4096", "--uniform", "1"], 4096, 4096 * 16),
+            (["--models", "2", "--rows", "50000", "--dims", "1,16", "--per-sample", "2,26", "--batch", "64"], 64 * 28, 64 * (2 + 26 * 16))):
+        r = subprocess.run([str(exe), "--lib-dir", str(hb.LIB), *extra, "--gpucache", "0", "--instances", "1", "--steps", "20",
+                            "--blocks", "2", "--warmup", "5"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["failed"] == 0 and d["rows_wrong"] == 0 and d["rows_checked_against_recipe"] >= 2048
+        assert d["keys_per_request"] == nkeys and d["floats_per_response"] == nout and d["output_memory"] == "host"
+        assert d["requests_ok_reported_by_backend"] == d["batch_statistics_reports"] == 45

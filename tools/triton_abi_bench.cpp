@@ -11,8 +11,17 @@
 // model loads through the plugin boundary without 133 GB of files.
 //
 // Timing follows bench.py: `blocks` timed blocks of `steps` requests (all instances together), the median block is the
-// result; p50/p99 over every timed request.  One response is checked against the table recipe at the end.
+// result; p50/p99 over every timed request.  One response per model is checked against the table recipe at the end.
 // Prints ONE JSON line.
+//
+// The other BASELINE configurations run through the same driver:
+//   config 1 (.gitlab-ci.yml:70: perf_analyzer against a CPU-only deployment):
+//       --tables 1 --rows 1048576 --dims 16 --batch 4096 --gpucache 0 --uniform 1 --instances 1
+//       gpucache=false model, KIND_CPU instance, OUTPUT0 in host memory, keys uniform over the table
+//   config 4 (README.md:148-152: W&D, D = [1,16], keys per sample [2,26]; two models served side by side on one GPU):
+//       --models 2 --dims 1,16 --per-sample 2,26 --rows 1000000 --batch 1024 --instances 1 --hit 0.9
+// --dims / --per-sample are comma lists (one entry per table; --tables N --dim D is the short form of N equal tables);
+// --models M deploys the model M times (own tables: seed + model index) and drives all of them concurrently.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,6 +47,8 @@ namespace {
 struct Args {
   std::string lib_dir = "hugectr_backend_amd/lib";
   int tables = 26, dim = 128, instances = 2, steps = 20, warmup = 5, blocks = 10, direct = 0, pinned_keys = 0;
+  int models = 1, gpucache = 1, uniform = 0;
+  std::string dims, per_sample;   // comma lists; empty: `tables` tables of `dim` floats, one key per sample
   long rows = 10000000, batch = 65536;
   double cache_frac = 0.2, hit = 0.957, zipf = 1.05, threshold = 1.0;
 };
@@ -84,12 +95,39 @@ int main(int argc, char** argv) {
     else if (k == "--direct") a.direct = atoi(v);
     else if (k == "--pinned-keys") a.pinned_keys = atoi(v);
     else if (k == "--threshold") a.threshold = atof(v);
+    else if (k == "--models") a.models = atoi(v);
+    else if (k == "--gpucache") a.gpucache = atoi(v);
+    else if (k == "--uniform") a.uniform = atoi(v);
+    else if (k == "--dims") a.dims = v;
+    else if (k == "--per-sample") a.per_sample = v;
     else die("unknown option", argv[i]);
   }
   setenv("GPU_MAX_HW_QUEUES", "8", 0);   // two instances' streams on separate hardware queues
-  const int T = a.tables, D = a.dim;
+  auto split = [](const std::string& csv) {
+    std::vector<long> out;
+    size_t b = 0;
+    while (b < csv.size()) {
+      size_t e = csv.find(',', b);
+      if (e == std::string::npos) e = csv.size();
+      out.push_back(atol(csv.substr(b, e - b).c_str()));
+      b = e + 1;
+    }
+    return out;
+  };
+  std::vector<long> Dt = split(a.dims), Pt = split(a.per_sample);
+  if (Dt.empty()) Dt.assign((size_t)a.tables, a.dim);
+  const int T = (int)Dt.size();
+  if (Pt.empty()) Pt.assign((size_t)T, 1);
+  if ((int)Pt.size() != T) die("--dims and --per-sample must have one entry per table");
   const long R = a.rows, B = a.batch;
-  const size_t N = (size_t)T * (size_t)B;
+  const int M = std::max(1, a.models);
+  std::vector<size_t> key_off((size_t)T + 1, 0), out_off((size_t)T + 1, 0);   // per request: keys / floats before table t
+  for (int t = 0; t < T; ++t) {
+    key_off[(size_t)t + 1] = key_off[(size_t)t] + (size_t)B * (size_t)Pt[(size_t)t];
+    out_off[(size_t)t + 1] = out_off[(size_t)t] + (size_t)B * (size_t)Pt[(size_t)t] * (size_t)Dt[(size_t)t];
+  }
+  const size_t N = key_off[(size_t)T], OUT = out_off[(size_t)T];
+  const bool gpu = a.gpucache != 0;
 
   void* core = dlopen((a.lib_dir + "/libtriton_mock_core.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
   if (!core) die("cannot load the mock core:", dlerror());
@@ -103,56 +141,73 @@ int main(int argc, char** argv) {
   LOAD(mock_instance_get_stats);
 #undef LOAD
 
-  // ---- ps.json + model configuration (what Triton derives from config.pbtxt) ----
+  // ---- ps.json + model configurations (what Triton derives from config.pbtxt) ----
+  const uint64_t kSeed = 20260929ull;
+  std::vector<std::string> names;
+  for (int mi = 0; mi < M; ++mi) names.push_back(M == 1 ? std::string("criteo_dlrm") : "model_" + std::to_string(mi));
   char tmpl[] = "/tmp/hps_abi_bench_XXXXXX";
   if (!mkdtemp(tmpl)) die("mkdtemp failed");
   const std::string ps_path = std::string(tmpl) + "/ps.json";
   {
-    std::string j = "{\"supportlonglong\": true, \"volatile_db\": {\"type\": \"hash_map\", \"num_partitions\": 8}, \"models\": [{";
-    j += "\"model\": \"criteo_dlrm\", \"sparse_files\": [";
-    for (int t = 0; t < T; ++t) j += (t ? ", \"synthetic://" : "\"synthetic://") + std::to_string(R) + "\"";
-    j += "], \"num_of_worker_buffer_in_pool\": " + std::to_string(std::max(3, a.instances));
-    auto list = [&](const char* key, const std::string& v) {
-      j += std::string(", \"") + key + "\": [";
-      for (int t = 0; t < T; ++t) j += (t ? ", " : "") + v;
-      j += "]";
-    };
-    list("embedding_vecsize_per_table", std::to_string(D));
-    list("maxnum_catfeature_query_per_table_per_sample", "1");
-    list("default_value_for_each_table", "0.0");
-    char buf[256];
-    snprintf(buf, sizeof buf, ", \"deployed_device_list\": [0], \"max_batch_size\": %ld, \"gpucache\": true, \"gpucacheper\": %.6f, "
-             "\"hit_rate_threshold\": %.6f, \"ps_direct_access\": %s}]}", B, a.cache_frac, a.threshold, a.direct ? "true" : "false");
-    j += buf;
+    std::string j = "{\"supportlonglong\": true, \"volatile_db\": {\"type\": \"hash_map\", \"num_partitions\": 8}, \"models\": [";
+    for (int mi = 0; mi < M; ++mi) {
+      j += std::string(mi ? ", {" : "{") + "\"model\": \"" + names[(size_t)mi] + "\", \"sparse_files\": [";
+      for (int t = 0; t < T; ++t)
+        j += (t ? ", \"synthetic://" : "\"synthetic://") + std::to_string(R) + "?seed=" + std::to_string(kSeed + (uint64_t)mi) + "\"";
+      j += "], \"num_of_worker_buffer_in_pool\": " + std::to_string(std::max(3, a.instances));
+      auto list = [&](const char* key, const std::vector<long>* v, const char* all) {
+        j += std::string(", \"") + key + "\": [";
+        for (int t = 0; t < T; ++t) j += (t ? ", " : "") + (v ? std::to_string((*v)[(size_t)t]) : std::string(all));
+        j += "]";
+      };
+      list("embedding_vecsize_per_table", &Dt, "");
+      list("maxnum_catfeature_query_per_table_per_sample", &Pt, "");
+      list("default_value_for_each_table", nullptr, "0.0");
+      char buf[320];
+      snprintf(buf, sizeof buf, ", \"deployed_device_list\": [0], \"max_batch_size\": %ld, \"gpucache\": %s, \"gpucacheper\": %.6f, "
+               "\"hit_rate_threshold\": %.6f, \"ps_direct_access\": %s}", B, gpu ? "true" : "false", a.cache_frac, a.threshold,
+               (a.direct && gpu) ? "true" : "false");
+      j += buf;
+    }
+    j += "]}";
     FILE* f = fopen(ps_path.c_str(), "w");
     if (!f) die("cannot write", ps_path.c_str());
     fputs(j.c_str(), f);
     fclose(f);
   }
   const std::string backend_cfg = "{\"cmdline\": {\"auto-complete-config\": \"true\", \"ps\": \"" + ps_path + "\"}}";
-  const std::string model_cfg =
-      "{\"name\": \"criteo_dlrm\", \"backend\": \"hps\", \"max_batch_size\": " + std::to_string(B) +
-      ", \"input\": [{\"name\": \"KEYS\", \"data_type\": \"TYPE_INT64\", \"dims\": [-1]}, {\"name\": \"NUMKEYS\", \"data_type\": "
-      "\"TYPE_INT32\", \"dims\": [-1]}], \"output\": [{\"name\": \"OUTPUT0\", \"data_type\": \"TYPE_FP32\", \"dims\": [-1]}], "
-      "\"instance_group\": [{\"count\": " + std::to_string(a.instances) + ", \"kind\": \"KIND_GPU\", \"gpus\": [0]}]}";
 
   const double t_load0 = now_s();
   mock_server_t* srv = nullptr;
   if (m.mock_server_create((a.lib_dir + "/libtriton_hps.so").c_str(), "hps", backend_cfg.c_str(), 0, 0, &srv) != 0)
     die("TRITONBACKEND_Initialize failed:", m.mock_last_error());
-  mock_model_t* model = nullptr;
-  if (m.mock_model_load(srv, "criteo_dlrm", 1, model_cfg.c_str(), &model) != 0) die("ModelInitialize failed:", m.mock_last_error());
-  std::vector<mock_instance_t*> inst(a.instances);
-  for (int i = 0; i < a.instances; ++i)
-    if (m.mock_instance_create(model, ("criteo_dlrm_0_" + std::to_string(i)).c_str(), 2, 0, &inst[i]) != 0)
-      die("ModelInstanceInitialize failed:", m.mock_last_error());
+  std::vector<mock_model_t*> model((size_t)M, nullptr);
+  std::vector<mock_instance_t*> inst;   // worker w serves model w / instances, instance w % instances
+  for (int mi = 0; mi < M; ++mi) {
+    const std::string model_cfg =
+        "{\"name\": \"" + names[(size_t)mi] + "\", \"backend\": \"hps\", \"max_batch_size\": " + std::to_string(B) +
+        ", \"input\": [{\"name\": \"KEYS\", \"data_type\": \"TYPE_INT64\", \"dims\": [-1]}, {\"name\": \"NUMKEYS\", \"data_type\": "
+        "\"TYPE_INT32\", \"dims\": [-1]}], \"output\": [{\"name\": \"OUTPUT0\", \"data_type\": \"TYPE_FP32\", \"dims\": [-1]}], "
+        "\"instance_group\": [{\"count\": " + std::to_string(a.instances) + ", \"kind\": \"" + (gpu ? "KIND_GPU" : "KIND_CPU") +
+        "\", \"gpus\": [" + (gpu ? "0" : "") + "]}]}";
+    if (m.mock_model_load(srv, names[(size_t)mi].c_str(), 1, model_cfg.c_str(), &model[(size_t)mi]) != 0)
+      die("ModelInitialize failed:", m.mock_last_error());
+    for (int i = 0; i < a.instances; ++i) {
+      mock_instance_t* h = nullptr;
+      if (m.mock_instance_create(model[(size_t)mi], (names[(size_t)mi] + "_0_" + std::to_string(i)).c_str(), gpu ? 2 : 1, 0, &h) != 0)
+        die("ModelInstanceInitialize failed:", m.mock_last_error());
+      inst.push_back(h);
+    }
+  }
+  const int W = (int)inst.size();   // workers = models x instances
   const double load_s = now_s() - t_load0;
 
-  // ---- key batches: per table B keys; with probability `hit` a Zipf-ranked key of the warmed range [0, C), else uniform
-  //      from the cold range [C, R) — bench.py's generator, on host threads ----
+  // ---- key batches: per table n_t keys; with probability `hit` a Zipf-ranked key of the warmed range [0, C), else uniform
+  //      from the cold range [C, R) — bench.py's generator, on host threads (--uniform 1: uniform over [0, R)) ----
   const long C = (long)std::ceil(a.cache_frac * (double)R);
-  std::vector<double> cdf((size_t)C);
-  {
+  std::vector<double> cdf;
+  if (!a.uniform) {
+    cdf.resize((size_t)C);
     double acc = 0;
     for (long i = 0; i < C; ++i) { acc += 1.0 / std::pow((double)(i + 1), a.zipf); cdf[(size_t)i] = acc; }
     for (long i = 0; i < C; ++i) cdf[(size_t)i] /= acc;
@@ -176,14 +231,17 @@ int main(int argc, char** argv) {
           const long job = next.fetch_add(1);   // one (batch, table) slice per job
           if (job >= (long)nbatch * T) return;
           const long b = job / T, t = job % T;
-          int64_t* dst = keys_all + (size_t)b * N + (size_t)t * (size_t)B;
+          const long nt = (long)(key_off[(size_t)t + 1] - key_off[(size_t)t]);
+          int64_t* dst = keys_all + (size_t)b * N + key_off[(size_t)t];
           uint64_t s = mix(0x5EEDull * 1315423911ull + (uint64_t)job);
-          for (long i = 0; i < B; ++i) {
+          for (long i = 0; i < nt; ++i) {
             s = mix(s + (uint64_t)i);
             const double u = (double)(s >> 11) * (1.0 / 9007199254740992.0);
             const uint64_t s2 = mix(s ^ 0xABCDEFull);
             const double v = (double)(s2 >> 11) * (1.0 / 9007199254740992.0);
-            if (u < a.hit || R <= C) {
+            if (a.uniform) {
+              dst[i] = std::min((long)(v * (double)R), R - 1);
+            } else if (u < a.hit || R <= C) {
               const long rank = (long)(std::lower_bound(cdf.begin(), cdf.end(), v) - cdf.begin());
               dst[i] = std::min(rank, C - 1);
             } else {
@@ -194,10 +252,13 @@ int main(int argc, char** argv) {
       });
     for (auto& x : th) x.join();
   }
-  std::vector<int32_t> numkeys((size_t)T, (int32_t)B);
-  std::vector<float*> d_out(a.instances, nullptr);
-  for (int i = 0; i < a.instances; ++i)
-    if (hipMalloc((void**)&d_out[i], N * (size_t)D * sizeof(float)) != hipSuccess) die("hipMalloc of OUTPUT0 failed");
+  std::vector<int32_t> numkeys((size_t)T);
+  for (int t = 0; t < T; ++t) numkeys[(size_t)t] = (int32_t)(key_off[(size_t)t + 1] - key_off[(size_t)t]);
+  std::vector<float*> out_buf((size_t)W, nullptr);   // device memory for GPU instances, host memory for CPU instances
+  for (int i = 0; i < W; ++i) {
+    if (gpu) { if (hipMalloc((void**)&out_buf[(size_t)i], OUT * sizeof(float)) != hipSuccess) die("hipMalloc of OUTPUT0 failed"); }
+    else if (!(out_buf[(size_t)i] = (float*)malloc(OUT * sizeof(float)))) die("out of memory for OUTPUT0");
+  }
 
   // ---- stall watchdog: a thread that does nothing but sleep 200 us at a time and notes every wake-up that comes more than
   //      2 ms late.  A late wake-up that coincides with a slow request means the whole process stood still (CPU quota of an
@@ -217,17 +278,17 @@ int main(int argc, char** argv) {
   std::vector<std::pair<double, double>> slow_requests;   // (start since dog_t0 [s], duration [ms]) of requests over 5 ms
   std::mutex slow_mu;
 
-  // ---- request loop ----
+  // ---- request loop: `count` requests shared by all workers (every model takes its share of the batches) ----
   std::atomic<long> next{0};
   std::atomic<int> failed{0};
-  std::vector<std::vector<double>> lat(a.instances);
-  std::vector<long> last_batch(a.instances, -1);
+  std::vector<std::vector<double>> lat((size_t)W);
+  std::vector<long> last_batch((size_t)W, -1);
   auto run = [&](long first, long count, bool record) {
     next.store(0);
     std::vector<std::thread> th;
-    for (int w = 0; w < a.instances; ++w)
+    for (int w = 0; w < W; ++w)
       th.emplace_back([&, w] {
-        (void)hipSetDevice(0);
+        if (gpu) (void)hipSetDevice(0);
         const int64_t kshape[2] = {1, (int64_t)N}, nshape[2] = {1, (int64_t)T};
         for (;;) {
           const long i = next.fetch_add(1);
@@ -238,9 +299,9 @@ int main(int argc, char** argv) {
                                           a.pinned_keys ? 1 : 0, 0);
           m.mock_request_add_input_buffer(rq, "NUMKEYS", 8 /*INT32*/, nshape, 2, numkeys.data(), (uint64_t)T * sizeof(int32_t), 0, 0);
           m.mock_request_add_requested_output(rq, "OUTPUT0");
-          m.mock_request_set_output_buffer(rq, d_out[w], N * (size_t)D * sizeof(float), 2 /*GPU*/, 0);
+          m.mock_request_set_output_buffer(rq, out_buf[(size_t)w], OUT * sizeof(float), gpu ? 2 /*GPU*/ : 0 /*CPU*/, 0);
           const double t0 = now_s();
-          const int rc = m.mock_instance_execute(inst[w], &rq, 1);
+          const int rc = m.mock_instance_execute(inst[(size_t)w], &rq, 1);
           const double dt = now_s() - t0;
           if (rc != 0 || m.mock_request_error_code(rq) != -1 || m.mock_request_response_count(rq) != 1 ||
               m.mock_request_release_count(rq) != 1) {
@@ -248,42 +309,48 @@ int main(int argc, char** argv) {
               fprintf(stderr, "request %ld failed: rc=%d code=%d %s\n", b, rc, m.mock_request_error_code(rq),
                       m.mock_request_error_message(rq) ? m.mock_request_error_message(rq) : "");
           }
-          if (record) lat[w].push_back(dt * 1e3);
+          if (record) lat[(size_t)w].push_back(dt * 1e3);
           if (record && dt > 0.005) { std::lock_guard<std::mutex> lk(slow_mu); slow_requests.emplace_back(t0 - dog_t0, dt * 1e3); }
-          last_batch[w] = b;
+          last_batch[(size_t)w] = b;
           m.mock_request_delete(rq);
         }
       });
     for (auto& x : th) x.join();
   };
   run(0, a.warmup, false);
-  (void)hipDeviceSynchronize();
+  if (gpu) (void)hipDeviceSynchronize();
   std::vector<double> block_s;
   for (int blk = 0; blk < a.blocks; ++blk) {
     const double t0 = now_s();
     run(a.warmup + (long)blk * a.steps, a.steps, true);
-    (void)hipDeviceSynchronize();
+    if (gpu) (void)hipDeviceSynchronize();
     block_s.push_back(now_s() - t0);
   }
 
   dog_stop.store(true);
   dog.join();
 
-  // ---- one response against the table recipe: every key of [0, R) exists, row(t, k) is a pure function ----
+  // ---- the last response of every worker against the table recipe: every key of [0, R) exists, row(t, k) is
+  //      a pure function of (seed of the model, t, k) ----
   long bad = 0, checked = 0;
-  {
-    const int w = 0;
-    const long b = last_batch[w];
-    std::vector<float> row((size_t)D);
-    for (int s = 0; s < 2048 && b >= 0; ++s) {
-      const size_t i = (size_t)(mix(77 + (uint64_t)s) % N);
-      const uint32_t t = (uint32_t)(i / (size_t)B);
+  for (int w = 0; w < W; ++w) {
+    const long b = last_batch[(size_t)w];
+    const uint64_t seed = kSeed + (uint64_t)(w / a.instances);
+    std::vector<float> row;
+    for (int s = 0; s < 2048 / W + 1 && b >= 0; ++s) {
+      const size_t i = (size_t)(mix(77 + (uint64_t)s + 1000ull * (uint64_t)w) % N);
+      int t = 0;
+      while (i >= key_off[(size_t)t + 1]) ++t;
+      const size_t D = (size_t)Dt[(size_t)t];
       const int64_t key = keys_all[(size_t)b * N + i];
-      if (hipMemcpy(row.data(), d_out[w] + i * (size_t)D, (size_t)D * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { ++bad; continue; }
-      const uint64_t rb = hps_synth_row_base(hps_synth_table_base(20260929ull, t), key);
-      for (int j = 0; j < D; ++j) {
+      const float* src = out_buf[(size_t)w] + out_off[(size_t)t] + (i - key_off[(size_t)t]) * D;
+      row.resize(D);
+      if (gpu) { if (hipMemcpy(row.data(), src, D * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { ++bad; continue; } }
+      else memcpy(row.data(), src, D * sizeof(float));
+      const uint64_t rb = hps_synth_row_base(hps_synth_table_base(seed, (uint32_t)t), key);
+      for (size_t j = 0; j < D; ++j) {
         uint32_t got;
-        memcpy(&got, &row[(size_t)j], 4);
+        memcpy(&got, &row[j], 4);
         if (got != hps_synth_elem_bits(rb, (uint32_t)j)) { ++bad; break; }
       }
       ++checked;
@@ -291,7 +358,7 @@ int main(int argc, char** argv) {
   }
   mock_instance_stats_t st{};
   uint64_t ok_req = 0, reports = 0;
-  for (int i = 0; i < a.instances; ++i) { m.mock_instance_get_stats(inst[i], &st); ok_req += st.success_requests; reports += st.batch_reports; }
+  for (int i = 0; i < W; ++i) { m.mock_instance_get_stats(inst[(size_t)i], &st); ok_req += st.success_requests; reports += st.batch_reports; }
 
   std::vector<double> all;
   for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
@@ -301,14 +368,16 @@ int main(int argc, char** argv) {
   const double med = bs.empty() ? 0 : bs[bs.size() / 2];
   auto pct = [&](double p) { return all.empty() ? 0.0 : all[std::min(all.size() - 1, (size_t)(p * (double)all.size()))]; };
   printf("{\"through\": \"TRITONBACKEND_ModelInstanceExecute (libtriton_hps.so) driven by the mock Triton core, native caller\", "
-         "\"keys_memory\": \"%s\", \"output_memory\": \"device\", \"instances\": %d, \"steps_per_block\": %d, \"blocks\": %d, "
-         "\"lookups_per_s\": %.6g, \"ms_per_step\": %.6g, \"block_ms\": [", a.pinned_keys ? "host, page-locked" : "host, pageable",
-         a.instances, a.steps, a.blocks, med > 0 ? (double)a.steps * (double)N / med : 0.0, med / a.steps * 1e3);
+         "\"keys_memory\": \"%s\", \"output_memory\": \"%s\", \"models\": %d, \"instances\": %d, \"tables\": %d, \"keys_per_request\": %zu, "
+         "\"floats_per_response\": %zu, \"steps_per_block\": %d, \"blocks\": %d, "
+         "\"lookups_per_s\": %.6g, \"requests_per_s\": %.6g, \"ms_per_step\": %.6g, \"block_ms\": [", a.pinned_keys ? "host, page-locked" : "host, pageable",
+         gpu ? "device" : "host", M, a.instances, T, N, OUT, a.steps, a.blocks, med > 0 ? (double)a.steps * (double)N / med : 0.0,
+         med > 0 ? (double)a.steps / med : 0.0, med / a.steps * 1e3);
   for (size_t i = 0; i < block_s.size(); ++i) printf("%s%.4g", i ? ", " : "", block_s[i] * 1e3);
-  printf("], \"p50_request_ms\": %.5g, \"p99_request_ms\": %.5g, \"requests_ok_reported_by_backend\": %llu, \"batch_statistics_reports\": %llu, "
+  printf("], \"p50_request_ms\": %.5g, \"p99_request_ms\": %.5g, \"max_request_ms\": %.5g, \"requests_ok_reported_by_backend\": %llu, \"batch_statistics_reports\": %llu, "
          "\"failed\": %d, \"rows_checked_against_recipe\": %ld, \"rows_wrong\": %ld, \"model_load_seconds\": %.4g, \"ps_tier\": \"%s\", ",
-         pct(0.5), pct(0.99), (unsigned long long)ok_req, (unsigned long long)reports, failed.load(), checked, bad, load_s,
-         a.direct ? "device-driven (ps_direct_access)" : "host gather");
+         pct(0.5), pct(0.99), all.empty() ? 0.0 : all.back(), (unsigned long long)ok_req, (unsigned long long)reports, failed.load(), checked, bad, load_s,
+         !gpu ? "CPU parameter server only (gpucache=false)" : a.direct ? "device-driven (ps_direct_access)" : "host gather");
   // requests over 5 ms, and for each the watchdog gaps that overlap it
   printf("\"slow_requests_ms\": [");
   int coincide = 0;
@@ -323,7 +392,7 @@ int main(int argc, char** argv) {
          "\"slow_requests_with_process_wide_stall\": %d, \"watchdog_late_wakeups_over_2ms\": %zu}\n", coincide, dog_gaps.size());
   fflush(stdout);
   for (auto* i : inst) m.mock_instance_destroy(i);
-  m.mock_model_unload(model);
+  for (auto* mm : model) m.mock_model_unload(mm);
   m.mock_server_destroy(srv);
   return failed.load() || bad ? 1 : 0;
 }
