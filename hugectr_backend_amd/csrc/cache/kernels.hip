@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
       // to evict exactly this slot, and an unowned write would interleave with the evictor's (key/row mismatch = poisoned
       // slot).  A slot stamped in the current unit is taken by nobody, so it needs no claim; losing the claim skips the write.
       const uint32_t st = stamp_of(sw[0], sw[1], (uint32_t)present);
-      if (st == now8) victim = present;
+      if (st == now8 || st == ins8) victim = present;   // nobody takes such a slot in this launch (see the victim search)
       else if (st != kStampClaimed && claim(present)) { victim = present; owned = true; }
     } else {
       for (int tries = 0; tries < kBucketSlots + 2 && victim < 0; ++tries) {
@@ -678,7 +678,10 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
         uint32_t cand = 0;
         if (lig < kBucketSlots) {
           const uint32_t st = stamp_of(sw[0], sw[1], (uint32_t)lig);
-          if (st != now8 && st != kStampClaimed) cand = ((((empty >> lig) & 1u) ? 256u : age_of(now8, st)) << 4) | (15u - (uint32_t)lig);
+          // (ins8: what this launch's own inserts leave behind.  Such a slot must not change hands again inside the launch —
+          //  its first owner's row stores may still be in flight when the second owner's arrive — so the stamp of new keys
+          //  is off limits like the current unit's; a key that was last hit exactly insert-age units ago shares the privilege)
+          if (st != now8 && st != ins8 && st != kStampClaimed) cand = ((((empty >> lig) & 1u) ? 256u : age_of(now8, st)) << 4) | (15u - (uint32_t)lig);
         }
         for (int off = 8; off > 0; off >>= 1) {
           const uint32_t o = (uint32_t)__shfl_xor((int)cand, off, 16);
