@@ -1027,7 +1027,7 @@ def c4_leg(a, hb):
             "results": res}
 
 
-def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0, check_rows=False):
+def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0, check_rows=False, more=None):
     """The headline workload on a deployment of its own (own server, the headline's has been released): two sessions, fresh
     batches of host keys every step, exact rows.  direct: the parameter-server tier; key0: the tables' keys are
     key0 .. key0+R-1 (key0 = 2^40: keys that need all 8 bytes over PCIe — the reference takes int64 keys, hps.cc:573)."""
@@ -1086,6 +1086,15 @@ def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0,
             ok &= bool(np.array_equal(tk[qt - key0], qt))
             ok &= bool(np.array_equal(tr[qt - key0].view(np.uint32), got[t * B:(t + 1) * B].view(np.uint32)))
         out["parity_full_batch_vs_direct_row_index"] = ok
+    if more is not None:
+        try:   # further legs on this deployment while it is up
+            more(out, dict(ps=ps, cache=cache, sessions=sessions, run=run, resident=resident, cdf_d=cdf_d, gen=gen, C=C, model=model))
+        except Exception as e:  # noqa: BLE001
+            out["more_error"] = repr(e)[:300]
+            sys.stderr.write(f"[bench] leg on the fresh deployment stopped: {e!r}\n")
+        finally:
+            run.post_hooks[:] = []
+            run.step_hooks[:] = []
     for s in sessions:
         s.close()
     return out, rec
@@ -1094,7 +1103,68 @@ def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0,
 def other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
     """The headline workload on a ps_direct_access deployment of the same model (own server: page-locked tables, device
     index): two sessions, fresh batches of host keys, exact rows."""
-    out, rec = fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct=True)
+    def c5_fused(out, ctx):
+        """BASELINE config 5 on this deployment: lookup + bottom MLP + interaction as separate steps (OUTPUT0 written and read
+        back) against the fused call (hps_session_lookup_interact_device: the interaction reads cache slots / staged rows,
+        OUTPUT0 never exists); device keys, exact rows, same batches for both, outputs compared bit for bit."""
+        if not (D % 32 == 0 and D <= 512 and T <= 31 and a.mode == "sync"):
+            return
+        from hugectr_backend_amd.dense import DenseInteraction
+        sessions, run = ctx["sessions"], ctx["run"]
+        rngw = np.random.default_rng(SEED)
+        dims, k = [512, 256, D], 13
+        ws, bs = [], []
+        for n_ in dims:
+            ws.append(((rngw.random((k, n_), dtype=np.float32) * 2 - 1) * (1.5 / np.sqrt(k))).astype(np.float32))
+            bs.append(((rngw.random(n_, dtype=np.float32) - 0.3) * 0.2).astype(np.float32))
+            k = n_
+        ops = [DenseInteraction(ws, bs, T, D, device=dev) for _ in sessions]
+        xd = torch.randn(B, 13, device="cuda")
+        outd = [torch.empty((B, ops[0].out_stride), dtype=torch.float16, device="cuda") for _ in sessions]
+
+        def fresh(n_, hit=None):
+            return make_batches_gpu(torch, ctx["gen"], ctx["resident"], ctx["cdf_d"], R, ctx["C"], B, a.hit if hit is None else hit, n_)
+
+        def leg(batches, steps):
+            r = []
+            run.run(batches, 4, 0, "device")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run.run(batches, steps, 4, "device", record=r)
+            torch.cuda.synchronize()
+            return summarize(r, N, D, time.perf_counter() - t0, steps)
+
+        res = {}
+        for name, hit in (("hit_95", None), ("all_hit", 1.1)):
+            bt = fresh(28, hit)
+            run.step_hooks[:] = []
+            run.post_hooks[:] = [lambda si: (ops[si].forward(xd, run.outs[si], B, out=outd[si]),
+                                             torch.cuda.current_stream().synchronize()) for _ in sessions]
+            un = leg(bt, 24)
+            ref = outd[0].clone()
+            last = bt[(4 + 23) % len(bt)]
+            # which batch session 0 saw last is not fixed (two sessions share the steps): recompute one batch on session 0 for the check
+            sessions[0].lookup_device(last, run.nk, out=run.outs[0])
+            ops[0].forward(xd, run.outs[0], B, out=outd[0])
+            torch.cuda.synchronize()
+            ref = outd[0].clone()
+            run.post_hooks[:] = []
+            run.step_hooks[:] = [lambda si, keys: ops[si].lookup_interact(sessions[si], keys, B, xd, out=outd[si]) for _ in sessions]
+            fu = leg(fresh(28, hit), 24)
+            ops[0].lookup_interact(sessions[0], last, B, xd, out=outd[0])
+            torch.cuda.synchronize()
+            same = bool(torch.equal(ref, outd[0]))
+            run.step_hooks[:] = []
+            res[name] = {"separate_steps_samples_per_s": un["lookups_per_s"] / T, "separate_ms_per_step": un["ms_per_step"],
+                         "fused_samples_per_s": fu["lookups_per_s"] / T, "fused_ms_per_step": fu["ms_per_step"],
+                         "fused_over_separate": fu["lookups_per_s"] / un["lookups_per_s"],
+                         "fused_p50_call_ms": fu["p50_call_ms"], "fused_p99_call_ms": fu["p99_call_ms"], "fused_max_call_ms": fu["max_call_ms"],
+                         "outputs_bit_identical": same}
+        out["c5_fused_lookup_interact"] = dict(res, note="BASELINE configs[4]: lookup + bottom MLP 13-512-256-%d + dot interaction per "
+                                               "step, device keys, two sessions; separate = OUTPUT0 written then read by the dense "
+                                               "kernels, fused = one call whose interaction kernel reads cache slots / staged rows" % D)
+
+    out, rec = fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct=True, more=c5_fused)
     f_ms = float(np.mean([r[8][1] for r in rec]))
     uniq = float(np.mean([r[6] for r in rec]))
     out.update({

@@ -37,6 +37,7 @@ ENGINE_SRCS = [
     "ps/thread_pool.cpp",
     "ps/host_table.cpp",
     "ps/volatile_tier.cpp",
+    "ps/update_source.cpp",
     "cache/kernels.hip",
     "cache/shard_kernels.hip",
     "cache/shard_session.cpp",

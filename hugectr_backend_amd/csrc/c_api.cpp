@@ -231,6 +231,38 @@ int hps_server_load_table_synthetic(hps_server_t* sv, const char* model, uint32_
   });
 }
 
+int hps_server_update_source_stats(hps_server_t* sv, uint64_t* out6) {
+  return Guard([&]() -> Status {
+    if (!sv || !out6) return Error(Code::kInvalidArg, "null argument");
+    UpdateSourceStats st;
+    if (!sv->ps->update_source_stats(&st)) return Error(Code::kUnavailable, "no update source is configured (ps.json update_source.type)");
+    out6[0] = st.messages; out6[1] = st.keys; out6[2] = st.dispatches; out6[3] = st.commits; out6[4] = st.dispatch_failures;
+    out6[5] = st.rejected_messages;
+    return Status::Ok();
+  });
+}
+
+int hps_server_update_source_drain(hps_server_t* sv, uint32_t timeout_ms) {
+  return Guard([&]() -> Status {
+    if (!sv) return Error(Code::kInvalidArg, "null argument");
+    return sv->ps->drain_update_source(timeout_ms);
+  });
+}
+
+int hps_update_message_encode(const char* model, uint32_t table, uint32_t dim, const int64_t* keys, const float* rows, uint64_t n,
+                              void* out, uint64_t out_capacity, uint64_t* out_bytes) {
+  return Guard([&]() -> Status {
+    if (!model || !out_bytes || (n && (!keys || !rows))) return Error(Code::kInvalidArg, "null argument");
+    const std::string m = EncodeUpdateMessage(model, table, dim, keys, rows, (size_t)n);
+    *out_bytes = m.size();
+    if (out) {
+      if (out_capacity < m.size()) return Error(Code::kInvalidArg, "buffer of ", out_capacity, " bytes for a message of ", m.size());
+      memcpy(out, m.data(), m.size());
+    }
+    return Status::Ok();
+  });
+}
+
 int hps_server_load_table_synthetic_shard(hps_server_t* sv, const char* model, uint32_t table, uint64_t seed,
                                           int64_t key0, uint64_t R, uint32_t shard, uint32_t num_shards) {
   return Guard([&]() -> Status {

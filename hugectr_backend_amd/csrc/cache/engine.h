@@ -24,6 +24,7 @@
 #include "../common/config.h"
 #include "../common/status.h"
 #include "../ps/host_table.h"
+#include "../ps/update_source.h"
 #include "../ps/thread_pool.h"
 #include "../dense/dense.h"
 #include "device_types.h"
@@ -435,6 +436,16 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
 
   ThreadPool* pool() { return pool_; }
 
+  // ---- online updates (ps.json "update_source", csrc/ps/update_source.h) ----
+  // One chunk of an update message into the database layers (insert-or-overwrite in the host tier, written through to the
+  // persistent store); the keys are remembered until the consumer commits.
+  Status ApplyUpdate(const std::string& model, uint32_t table, uint32_t dim, const int64_t* keys, const float* rows, size_t n);
+  // The consumer committed: rows of updated keys that are RESIDENT in a GPU cache of these models are replaced there
+  // (keys that are not resident stay out: an update is not a request).
+  void OnUpdatesCommitted(const std::set<std::string>& models);
+  bool update_source_stats(UpdateSourceStats* out) const;
+  Status drain_update_source(size_t timeout_ms);
+
  private:
   HierParameterServer() = default;
   Status Build(bool load_tables);
@@ -446,6 +457,9 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   std::mutex mu_;
   std::map<std::string, std::vector<std::shared_ptr<HostTable>>> tables_;
   std::map<std::pair<std::string, int>, std::shared_ptr<EmbeddingCache>> caches_;
+  std::mutex upd_mu_;
+  std::map<std::string, std::vector<std::vector<int64_t>>> updated_keys_;   // model -> per table: keys applied since the last commit
+  std::unique_ptr<UpdateConsumer> updates_;   // last member: its thread stops before anything it uses goes away
 };
 
 }  // namespace hps

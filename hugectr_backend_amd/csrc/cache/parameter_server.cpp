@@ -139,6 +139,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
 // HierParameterServer
 // =================================================================================================
 HierParameterServer::~HierParameterServer() {
+  updates_.reset();   // the consumer thread calls back into this object
   for (auto& kv : caches_) kv.second->WaitAsync();
   caches_.clear();
 }
@@ -177,15 +178,83 @@ Status HierParameterServer::create_from_config(const ParameterServerConfig& cfg,
   if (cfg.persistent_db.type != DatabaseType::Disabled && cfg.persistent_db.type != DatabaseType::RocksDB)
     return Error(Code::kUnsupported, "persistent_db.type = ", ToString(cfg.persistent_db.type),
                  " is not a persistent database (available: disabled, rocks_db)");
-  if (cfg.update_source.type != UpdateSourceType::Null)
-    return Error(Code::kUnsupported, "update_source.type = ", ToString(cfg.update_source.type),
-                 " (Kafka online updates) is not implemented in this build");
+  if (cfg.update_source.type == UpdateSourceType::KafkaMessageQueue)
+    return Error(Code::kUnsupported, "update_source.type = kafka_message_queue: no Kafka client in this build; the consumer "
+                                     "loop is there behind a transport interface (csrc/ps/update_source.h) — available: null, file_tail");
   if (!(cfg.volatile_db.initial_cache_rate >= 0.0) || cfg.volatile_db.initial_cache_rate > 1.0)
     return Error(Code::kInvalidArg, "volatile_db.initial_cache_rate = ", cfg.volatile_db.initial_cache_rate, " is outside [0, 1]");
   if (cfg.volatile_db.overflow_margin == 0) return Error(Code::kInvalidArg, "volatile_db.overflow_margin must be > 0");
   HPS_RETURN_IF_ERROR(ps->Build(load_tables));
+  if (cfg.update_source.type == UpdateSourceType::FileTail) {
+    std::unique_ptr<UpdateTransport> tr;
+    HPS_RETURN_IF_ERROR(MakeFileTailTransport(cfg.update_source.brokers, cfg.update_source.receive_buffer_size, &tr));
+    HierParameterServer* raw = ps.get();   // the consumer is a member: it never outlives the server
+    ps->updates_.reset(new UpdateConsumer(
+        cfg.update_source, std::move(tr),
+        [raw](const std::string& m, uint32_t t, uint32_t d, const int64_t* k, const float* r, size_t n) { return raw->ApplyUpdate(m, t, d, k, r, n); },
+        [raw](const std::set<std::string>& models) { raw->OnUpdatesCommitted(models); }));
+  }
   *out = std::move(ps);
   return Status::Ok();
+}
+
+Status HierParameterServer::ApplyUpdate(const std::string& model, uint32_t table, uint32_t dim, const int64_t* keys, const float* rows, size_t n) {
+  auto tabs = tables_of(model);
+  if (table >= tabs.size()) return Error(Code::kNotFound, "update for model '", model, "' table ", table, ": no such table in this server");
+  if (tabs[table]->dim() != dim)
+    return Error(Code::kInvalidArg, "update for model '", model, "' table ", table, ": rows are ", dim, " wide, the table is ", tabs[table]->dim());
+  HPS_RETURN_IF_ERROR(upsert_table(model, table, keys, rows, n));
+  std::lock_guard<std::mutex> lk(upd_mu_);
+  auto& per_table = updated_keys_[model];
+  if (per_table.size() < tabs.size()) per_table.resize(tabs.size());
+  per_table[table].insert(per_table[table].end(), keys, keys + n);
+  return Status::Ok();
+}
+
+void HierParameterServer::OnUpdatesCommitted(const std::set<std::string>& models) {
+  for (const std::string& model : models) {
+    std::vector<std::vector<int64_t>> keys;
+    {
+      std::lock_guard<std::mutex> lk(upd_mu_);
+      auto it = updated_keys_.find(model);
+      if (it == updated_keys_.end()) continue;
+      keys = std::move(it->second);
+      updated_keys_.erase(it);
+    }
+    std::vector<std::shared_ptr<EmbeddingCache>> caches;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (auto& kv : caches_) if (kv.first.first == model) caches.push_back(kv.second);
+    }
+    for (auto& c : caches) {
+      if (keys.size() != c->num_tables()) continue;
+      // only what is resident: an updated row that nobody has asked for does not displace a row somebody has
+      std::vector<std::vector<int64_t>> resident(keys.size());
+      bool any = false;
+      for (size_t t = 0; t < keys.size(); ++t) {
+        std::vector<int64_t>& k = keys[t];
+        std::sort(k.begin(), k.end());
+        k.erase(std::unique(k.begin(), k.end()), k.end());
+        if (k.empty()) continue;
+        std::vector<int32_t> slots(k.size());
+        if (!c->Query((uint32_t)t, k.data(), k.size(), slots.data()).ok()) continue;
+        for (size_t i = 0; i < k.size(); ++i) if (slots[i] >= 0) resident[t].push_back(k[i]);
+        any |= !resident[t].empty();
+      }
+      if (any) (void)c->InsertKeys(this, resident);
+    }
+  }
+}
+
+bool HierParameterServer::update_source_stats(UpdateSourceStats* out) const {
+  if (!updates_) return false;
+  if (out) *out = updates_->stats();
+  return true;
+}
+
+Status HierParameterServer::drain_update_source(size_t timeout_ms) {
+  if (!updates_) return Error(Code::kUnavailable, "no update source is configured (ps.json update_source.type)");
+  return updates_->Drain(timeout_ms);
 }
 
 // Copies a table's two files into the persistent store directory (created if needed).

@@ -72,6 +72,7 @@ const char* ToString(UpdateSourceType v) {
   switch (v) {
     case UpdateSourceType::Null: return "null";
     case UpdateSourceType::KafkaMessageQueue: return "kafka_message_queue";
+    case UpdateSourceType::FileTail: return "file_tail";
   }
   return "?";
 }
@@ -153,7 +154,8 @@ Status ParseField(UpdateSourceType& v, const Json& j, const char* key, bool requ
   return EnumField<UpdateSourceType>(
       v, j, key, required, false,
       {{UpdateSourceType::Null, {"null", "none"}},
-       {UpdateSourceType::KafkaMessageQueue, {"kafka_message_queue", "kafka_mq", "kafka"}}},
+       {UpdateSourceType::KafkaMessageQueue, {"kafka_message_queue", "kafka_mq", "kafka"}},
+       {UpdateSourceType::FileTail, {"file_tail"}}},
       "UpdateSourceType_t");
 }
 

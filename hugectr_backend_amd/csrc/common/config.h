@@ -20,7 +20,7 @@ enum class DatabaseType { Disabled, HashMap, ParallelHashMap, RedisCluster, Rock
 // triton_helpers.cpp:250-298
 enum class DatabaseOverflowPolicy { EvictRandom, EvictLeastUsed, EvictOldest };
 // triton_helpers.cpp:300-339
-enum class UpdateSourceType { Null, KafkaMessageQueue };
+enum class UpdateSourceType { Null, KafkaMessageQueue, FileTail };   // FileTail: this build's transport (csrc/ps/update_source.h)
 // backend.cpp:479-491
 enum class EmbeddingCacheType { Dynamic, Static, UVM, Stochastic };
 

@@ -11,6 +11,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dense.h"
 
@@ -113,6 +114,122 @@ __global__ __launch_bounds__(kMlpThreads) void hps_dense_mlp_kernel(DenseMlpDesc
         const uint32_t m = i / per_row, c = (i % per_row) * 8;
         if (m_base + m < batch)
           *reinterpret_cast<h8*>(out + (m_base + m) * Nout + c) = *reinterpret_cast<const h8*>(fin + (size_t)m * fstride + c);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Bottom MLP, 128 samples per block (the default when every layer is at most 512 wide).  The 64-row kernel above re-reads
+// the weights from L2 once per 64 samples (340 KB x 1,024 blocks = 350 MB per 64 K batch: 58 us, L2-bound).  Here a wave
+// owns whole COLUMN tiles and feeds all four 32-row M tiles from each weight fragment it loads, so the weights are read once
+// per 128 samples where the layer has at least 8 column tiles (narrower layers split the M tiles over the waves instead of
+// leaving waves idle: a 128-wide layer is read twice).  One LDS buffer holds the activations of all 128 rows; a layer's
+// outputs stay in the accumulators until every wave has finished reading its inputs (barrier), then overwrite them in
+// place — 128 x (512 + 8) f16 = 133 KB, one block per CU.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kMlp2Rows = 128;
+constexpr int kMlp2Threads = 512;   // 8 waves, 256 VGPRs each
+constexpr int kMlp2MaxUnits = 2;    // (column tile, group of M tiles) units a wave may own in one layer: layers up to 512 wide
+
+__global__ __launch_bounds__(kMlp2Threads) void hps_dense_mlp128_kernel(DenseMlpDesc d, const float* __restrict__ x, uint64_t batch,
+                                                                       _Float16* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const uint32_t stride = d.max_dim + kLdsPad;
+  _Float16* act = lds;
+  for (uint64_t m_base = (uint64_t)blockIdx.x * kMlp2Rows; m_base < batch; m_base += (uint64_t)gridDim.x * kMlp2Rows) {
+    // numeric features as f16, zero-padded to in_pad columns and to 128 rows
+    for (uint32_t i = threadIdx.x; i < kMlp2Rows * d.in_pad; i += kMlp2Threads) {
+      const uint32_t m = i / d.in_pad, k = i % d.in_pad;
+      float v = 0.f;
+      if (m_base + m < batch && k < d.in_dim) v = x[(m_base + m) * d.in_dim + k];
+      act[m * stride + k] = (_Float16)v;
+    }
+    __syncthreads();
+    uint32_t K = d.in_pad;
+    for (uint32_t l = 0; l < d.num_layers; ++l) {
+      const uint32_t Nout = d.dims[l];
+      const uint32_t ctiles = Nout / 32;
+      // units: (column tile, group of `mper` consecutive M tiles); at least 8 of them so that every wave has work
+      const uint32_t msplit = ctiles >= 8 ? 1u : (ctiles >= 4 ? 2u : 4u);
+      const uint32_t mper = 4u / msplit;
+      const uint32_t units = ctiles * msplit;
+      const _Float16* __restrict__ W = reinterpret_cast<const _Float16*>(d.weights[l]);
+      const float* __restrict__ bias = d.biases[l];
+      f16x acc[kMlp2MaxUnits][4];
+#pragma unroll
+      for (int u = 0; u < kMlp2MaxUnits; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[u][t] = f16x{0};
+#pragma unroll
+      for (int u = 0; u < kMlp2MaxUnits; ++u) {
+        const uint32_t unit = (uint32_t)wave + 8u * (uint32_t)u;
+        if (unit < units) {
+          const uint32_t nt = unit / msplit, m0 = (unit % msplit) * mper;   // column tile, first M tile of the group
+          const _Float16* wrow = W + ((size_t)nt * (K / 16) * 64 + lane) * 8;
+          const _Float16* a = act + (size_t)(32 * m0 + r) * stride + 8 * h;
+          uint32_t k0 = 0;
+          for (; k0 + 128 <= K; k0 += 128) {
+            h8 bw[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bw[q] = *reinterpret_cast<const h8*>(wrow + (size_t)(k0 / 16 + q) * 512);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                if ((uint32_t)t < mper) {
+                  const h8 fa = *reinterpret_cast<const h8*>(a + (size_t)(32 * t) * stride + k0 + 16 * q);
+                  acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, bw[q], acc[u][t], 0, 0, 0);
+                }
+              }
+            }
+          }
+          for (; k0 < K; k0 += 16) {
+            const h8 b = *reinterpret_cast<const h8*>(wrow + (size_t)(k0 / 16) * 512);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if ((uint32_t)t < mper) {
+                const h8 fa = *reinterpret_cast<const h8*>(a + (size_t)(32 * t) * stride + k0);
+                acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, b, acc[u][t], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();   // every wave has read what it needs of this layer's input: the outputs may take its place
+#pragma unroll
+      for (int u = 0; u < kMlp2MaxUnits; ++u) {
+        const uint32_t unit = (uint32_t)wave + 8u * (uint32_t)u;
+        if (unit < units) {
+          const uint32_t nt = unit / msplit, m0 = (unit % msplit) * mper;
+          const uint32_t n = nt * 32 + r;
+          const float bn = bias[n];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if ((uint32_t)t < mper) {
+#pragma unroll
+              for (int reg = 0; reg < 16; ++reg) {
+                float v = acc[u][t][reg] + bn;
+                v = v > 0.f ? v : 0.f;
+                act[(size_t)(32 * (m0 + t) + acc_row(lane, reg)) * stride + n] = (_Float16)v;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      K = Nout;
+    }
+    {
+      const uint32_t Nout = d.dims[d.num_layers - 1];
+      const uint32_t per_row = Nout / 8;
+      for (uint32_t i = threadIdx.x; i < kMlp2Rows * per_row; i += kMlp2Threads) {
+        const uint32_t m = i / per_row, c = (i % per_row) * 8;
+        if (m_base + m < batch)
+          *reinterpret_cast<h8*>(out + (m_base + m) * Nout + c) = *reinterpret_cast<const h8*>(act + (size_t)m * stride + c);
       }
     }
     __syncthreads();
@@ -242,6 +359,20 @@ __global__ __launch_bounds__(256) void hps_dense_interact_kernel(const float* __
 
 hipError_t LaunchDenseMlp(const DenseMlpDesc& d, const float* d_x, uint64_t batch, void* d_out_f16, int cu_count, hipStream_t stream) {
   if (batch == 0) return hipSuccess;
+  static const bool force64 = [] { const char* e = getenv("HPS_DENSE_MLP_ROWS"); return e && atoi(e) == 64; }();
+  bool fits128 = !force64 && batch > (uint64_t)kMlpRows;
+  for (uint32_t l = 0; l < d.num_layers; ++l) fits128 = fits128 && d.dims[l] / 32 <= 8u * kMlp2MaxUnits;
+  const size_t lds128 = (size_t)kMlp2Rows * (d.max_dim + kLdsPad) * sizeof(_Float16);
+  if (fits128 && lds128 <= (160u << 10)) {
+    uint64_t want = (batch + kMlp2Rows - 1) / kMlp2Rows;
+    if (want > (uint64_t)cu_count) want = (uint64_t)cu_count;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hps_dense_mlp128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds128);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(hps_dense_mlp128_kernel, dim3((uint32_t)want), dim3(kMlp2Threads), lds128, stream, d, d_x, batch,
+                       reinterpret_cast<_Float16*>(d_out_f16));
+    return hipGetLastError();
+  }
   uint64_t want = (batch + kMlpRows - 1) / kMlpRows;
   const size_t lds_bytes = (size_t)kMlpRows * (d.buf_dim[0] + d.buf_dim[1] + 2 * kLdsPad) * sizeof(_Float16);
   uint64_t per_cu = (160u << 10) / lds_bytes;  // resident blocks per CU (160 KB of LDS)

@@ -126,6 +126,9 @@ def _load() -> C.CDLL:
         "hps_session_lookup_device": (C.c_int, [P, P, P, P, C.c_size_t]),
         "hps_session_last_stats": (C.c_int, [P, C.POINTER(LookupStats)]),
         "hps_session_set_option": (C.c_int, [P, cp, C.c_int]),
+        "hps_update_message_encode": (C.c_int, [cp, u32, u32, P, P, u64, P, u64, C.POINTER(u64)]),
+        "hps_server_update_source_stats": (C.c_int, [P, P]),
+        "hps_server_update_source_drain": (C.c_int, [P, u32]),
         "hps_shard_owner": (u32, [i64, u32]),
         "hps_shard_bucket_workspace_bytes": (u64, [u64, u32]),
         "hps_shard_bucket_device": (C.c_int, [P, u64, u32, P, P, P, P, P]),
@@ -162,7 +165,8 @@ EXPORTED_SYMBOLS = [
     "hps_server_create_embedding_cache_per_model", "hps_server_destroy_embedding_cache_per_model",
     "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
-    "hps_server_table_data", "hps_cache_on_device", "hps_wake_copy_engines", "hps_session_create_from_cache",
+    "hps_server_table_data", "hps_update_message_encode", "hps_server_update_source_stats", "hps_server_update_source_drain",
+    "hps_cache_on_device", "hps_wake_copy_engines", "hps_session_create_from_cache",
     "hps_shard_unique_id", "hps_shard_session_create", "hps_shard_group_create_local", "hps_shard_group_destroy",
     "hps_shard_session_create_local", "hps_shard_session_lookup", "hps_shard_session_lookup_host", "hps_shard_session_last_timing",
     "hps_shard_session_last_stats", "hps_shard_session_destroy",
@@ -338,6 +342,14 @@ class HierParameterServer:
         assert rows.size == keys.size * self.table_info(model, table).embedding_vecsize
         _check(LIB.hps_server_upsert(self._h, model.encode(), table, keys.ctypes.data, rows.ctypes.data, keys.size))
 
+    def update_source_stats(self) -> dict:
+        v = (C.c_uint64 * 6)()
+        _check(LIB.hps_server_update_source_stats(self._h, v))
+        return dict(zip(["messages", "keys", "dispatches", "commits", "dispatch_failures", "rejected_messages"], map(int, v)))
+
+    def drain_update_source(self, timeout_ms: int = 10000):
+        _check(LIB.hps_server_update_source_drain(self._h, int(timeout_ms)))
+
     def host_tier_stats(self, model: str, table: int) -> dict:
         st = HostTierStats()
         _check(LIB.hps_server_host_tier_stats(self._h, model.encode(), table, C.byref(st)))
@@ -494,3 +506,15 @@ class LookupSession:
             self.close()
         except Exception:
             pass
+
+
+def encode_update_message(model: str, table: int, keys, rows) -> bytes:
+    """One frame of the online update source's message file (csrc/ps/update_source.h): what a producer appends."""
+    keys = np.ascontiguousarray(keys, dtype=np.int64)
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    dim = rows.size // max(keys.size, 1)
+    n = C.c_uint64(0)
+    _check(LIB.hps_update_message_encode(model.encode(), table, dim, keys.ctypes.data, rows.ctypes.data, keys.size, None, 0, C.byref(n)))
+    buf = (C.c_uint8 * n.value)()
+    _check(LIB.hps_update_message_encode(model.encode(), table, dim, keys.ctypes.data, rows.ctypes.data, keys.size, buf, n.value, C.byref(n)))
+    return bytes(buf)

@@ -156,6 +156,20 @@ int hps_server_table_data(hps_server_t* server, const char* model, uint32_t tabl
 int hps_server_upsert(hps_server_t* server, const char* model, uint32_t table, const int64_t* keys, const float* rows,
                       uint64_t n);
 
+/* ---- online update source (ps.json "update_source"; reference: backend.cpp:262-308, docs/hierarchical_parameter_server.md:
+ * 575-646).  "type": "file_tail" + "brokers": "<path>" starts a consumer thread that follows an append-only file of framed
+ * update messages (csrc/ps/update_source.h), dispatches them in chunks of at most max_batch_size keys to the host tier and the
+ * persistent store (as hps_server_upsert does), commits after at most max_commit_interval messages or poll_timeout_ms without
+ * news — remembering its position in <path>.offset — and replaces the rows of updated keys that are resident in the model's
+ * GPU caches.  "kafka_message_queue" is refused at start-up (no Kafka client in this build).
+ *   hps_update_message_encode   one message frame for a producer to append (out = NULL: only the size)
+ *   hps_server_update_source_stats   out6 = messages, keys, dispatches, commits, dispatch failures, rejected messages
+ *   hps_server_update_source_drain   returns once the source has been found empty twice in a row (tests, tools) */
+int hps_update_message_encode(const char* model, uint32_t table, uint32_t dim, const int64_t* keys, const float* rows, uint64_t n,
+                              void* out, uint64_t out_capacity, uint64_t* out_bytes);
+int hps_server_update_source_stats(hps_server_t* server, uint64_t* out6);
+int hps_server_update_source_drain(hps_server_t* server, uint32_t timeout_ms);
+
 /* Host tier smaller than the table (volatile_db.overflow_margin / overflow_policy / overflow_resolution_target /
  * initial_cache_rate / cache_missed_embeddings, persistent_db.*;  docs/hierarchical_parameter_server.md:460-569). */
 typedef struct hps_host_tier_stats {

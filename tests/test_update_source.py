@@ -1,0 +1,139 @@
+"""Online update source (ps.json "update_source"): the consumer loop of the reference's real-time update path
+(/root/reference/hps_backend/src/backend.cpp:262-308, docs/hierarchical_parameter_server.md:575-646) over this build's
+file-tail transport — messages appended to a file are dispatched to the host tier in chunks, committed, survive a restart
+exactly once; Kafka stays refused."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import make_tables, ps_config
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _server(tmp_path, tables, src, gpucache=False, **kw):
+    from hugectr_backend_amd import hps
+    cfg = ps_config("upd", tables, gpucache=gpucache, **kw)
+    cfg["update_source"] = src
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    for t, (k, r) in enumerate(tables):
+        ps.load_table_arrays("upd", t, k, r)
+    return ps
+
+
+def test_kafka_is_refused_and_file_tail_needs_a_path():
+    from hugectr_backend_amd import hps
+    tables = make_tables([(100, 4)])
+    for src, needle in (({"type": "kafka_message_queue", "brokers": "127.0.0.1:9092"}, "Kafka"),
+                        ({"type": "file_tail", "brokers": ""}, "path")):
+        cfg = ps_config("upd", tables, gpucache=False)
+        cfg["update_source"] = src
+        with pytest.raises(hps.HpsError, match=needle):
+            hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+
+
+def test_messages_reach_the_host_tier_in_chunks_and_are_committed_once(tmp_path):
+    from hugectr_backend_amd import hps
+    rng = np.random.default_rng(5)
+    tables = make_tables([(3000, 8), (500, 16)])
+    path = tmp_path / "updates.bin"
+    src = {"type": "file_tail", "brokers": str(path), "poll_timeout_ms": 50, "max_batch_size": 64, "max_commit_interval": 3,
+           "failure_backoff_ms": 5}
+    ps = _server(tmp_path, tables, src)
+    sess = hps.LookupSession.create(ps, "upd", None)
+    # expected content, updated as the messages are written
+    want = [dict(zip(k.tolist(), map(np.array, r))) for k, r in tables]
+    with open(path, "ab") as f:
+        for i in range(7):
+            t = i % 2
+            k = np.concatenate([rng.choice(tables[t][0], 150), 10_000_000 + rng.integers(0, 1000, 20)]).astype(np.int64)   # overwrite + new keys
+            k = np.unique(k)
+            r = rng.random((k.size, tables[t][1].shape[1]), dtype=np.float32)
+            f.write(hps.encode_update_message("upd", t, k, r))
+            f.flush()
+            for kk, rr in zip(k.tolist(), r):
+                want[t][kk] = rr
+        # a message for a model this server does not hold, and one with the wrong row width: dropped, not fatal
+        f.write(hps.encode_update_message("someone_else", 0, np.arange(3), np.zeros((3, 8), np.float32)))
+        f.write(hps.encode_update_message("upd", 0, np.arange(3), np.zeros((3, 5), np.float32)))
+        # half a frame: the producer is still writing
+        tail = hps.encode_update_message("upd", 1, np.array([42], np.int64), np.full((1, 16), 7.5, np.float32))
+        f.write(tail[:20])
+        f.flush()
+        ps.drain_update_source(10000)
+        st = ps.update_source_stats()
+        assert st["messages"] == 7 and st["rejected_messages"] == 2 and st["commits"] >= 3
+        assert st["dispatches"] >= 7 * 3      # ~170 keys per message in chunks of 64
+        for t in range(2):
+            q = np.array(list(want[t].keys()), dtype=np.int64)
+            nk = [q.size, 0] if t == 0 else [0, q.size]
+            out = sess.lookup(q, nk).reshape(q.size, -1)
+            assert np.array_equal(_bits(out), _bits(np.stack([want[t][int(x)] for x in q])))
+        # the rest of the frame arrives
+        f.write(tail[20:])
+        f.flush()
+        ps.drain_update_source(10000)
+    out = sess.lookup(np.array([42], np.int64), [0, 1])
+    assert np.all(out == 7.5)
+    assert ps.update_source_stats()["messages"] == 8
+    committed = int(open(str(path) + ".offset").read())
+    assert committed == os.path.getsize(path)
+    sess.close()
+    ps.close()
+    # a restarted server resumes behind the last commit: nothing is applied twice, new messages are
+    ps2 = _server(tmp_path, tables, src)
+    with open(path, "ab") as f:
+        f.write(hps.encode_update_message("upd", 0, np.array([7], np.int64), np.full((1, 8), -2.0, np.float32)))
+    ps2.drain_update_source(10000)
+    st = ps2.update_source_stats()
+    assert st["messages"] == 1 and st["keys"] == 1
+    s2 = hps.LookupSession.create(ps2, "upd", None)
+    assert np.all(s2.lookup(np.array([7], np.int64), [1, 0]) == -2.0)
+    s2.close()
+    ps2.close()
+
+
+def test_a_frame_that_cannot_be_a_message_stops_the_source_without_taking_the_server_down(tmp_path):
+    from hugectr_backend_amd import hps
+    tables = make_tables([(200, 4)])
+    path = tmp_path / "updates.bin"
+    path.write_bytes(b"this is not a message frame at all, just text....")
+    ps = _server(tmp_path, tables, {"type": "file_tail", "brokers": str(path), "poll_timeout_ms": 20, "failure_backoff_ms": 5})
+    ps.drain_update_source(10000)
+    assert ps.update_source_stats()["rejected_messages"] >= 1 and ps.update_source_stats()["messages"] == 0
+    sess = hps.LookupSession.create(ps, "upd", None)
+    q = tables[0][0][:10]
+    assert np.array_equal(_bits(sess.lookup(q, [10]).reshape(10, 4)), _bits(tables[0][1][:10]))
+    sess.close()
+
+
+@pytest.mark.gpu
+def test_resident_rows_are_replaced_in_the_gpu_cache_and_absent_keys_stay_out(tmp_path):
+    from hugectr_backend_amd import hps
+    tables = make_tables([(4000, 16)])
+    path = tmp_path / "updates.bin"
+    src = {"type": "file_tail", "brokers": str(path), "poll_timeout_ms": 30, "max_batch_size": 256}
+    ps = _server(tmp_path, tables, src, gpucache=True, gpucacheper=0.25, hit_rate_threshold=1.0)
+    ps.create_embedding_cache_per_model("upd")
+    cache = ps.get_embedding_cache("upd", 0)
+    sess = hps.LookupSession.create(ps, "upd", cache)
+    keys = tables[0][0]
+    res = keys[cache.query(0, keys) >= 0]
+    cold = keys[cache.query(0, keys) < 0]
+    assert res.size > 100 and cold.size > 100
+    upd = np.concatenate([res[:64], cold[:64]])
+    with open(path, "ab") as f:
+        f.write(hps.encode_update_message("upd", 0, upd, np.full((upd.size, 16), 9.0, np.float32)))
+    ps.drain_update_source(10000)
+    # the cold keys were NOT pulled into the cache by the update; the resident ones answer with the new rows from the cache
+    assert np.all(cache.query(0, cold[:64]) < 0) and np.all(cache.query(0, res[:64]) >= 0)
+    before = cache.counters()["misses"]
+    out = sess.lookup(res[:64], [64]).cpu().numpy()
+    assert np.all(out == 9.0) and cache.counters()["misses"] == before
+    out = sess.lookup(cold[:64], [64]).cpu().numpy()     # ... and the host tier has the new rows for the others
+    assert np.all(out == 9.0)
+    sess.close()
