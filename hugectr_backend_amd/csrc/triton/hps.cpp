@@ -223,18 +223,18 @@ TRITONSERVER_Error* TRITONBACKEND_Initialize(TRITONBACKEND_Backend* backend) {
   if (api_version_major != TRITONBACKEND_API_VERSION_MAJOR || api_version_minor < TRITONBACKEND_API_VERSION_MINOR)
     return HPS_TRITON_ERROR(UNSUPPORTED, "Triton backend API version does not support this backend");
 
-  TRITONSERVER_Message* backend_config_message;                                         // hps.cc:88-90
-  RETURN_IF_ERROR(TRITONBACKEND_BackendConfig(backend, &backend_config_message));
-  TRITONBACKEND_ArtifactType artifact_type;
-  const char* location;
-  RETURN_IF_ERROR(TRITONBACKEND_BackendArtifacts(backend, &artifact_type, &location));  // hps.cc:92-98
-  HPS_TRITON_LOG(INFO, "The Hierarchical Parameter Server Backend Repository location: ", location);
+  TRITONSERVER_Message* cfg_msg;                                                        // hps.cc:88-90
+  RETURN_IF_ERROR(TRITONBACKEND_BackendConfig(backend, &cfg_msg));
+  TRITONBACKEND_ArtifactType where_kind;
+  const char* where;
+  RETURN_IF_ERROR(TRITONBACKEND_BackendArtifacts(backend, &where_kind, &where));        // hps.cc:92-98
+  HPS_TRITON_LOG(INFO, "backend artifacts of '", name, "' are at ", where);
 
   // {"cmdline":{"ps":"<path to ps.json>", ...}}                                        // hps.cc:100-125
   const char* buffer;
   size_t byte_size;
-  RETURN_IF_ERROR(TRITONSERVER_MessageSerializeToJson(backend_config_message, &buffer, &byte_size));
-  HPS_TRITON_LOG(INFO, "The HPS configuration: ", std::string(buffer, byte_size));
+  RETURN_IF_ERROR(TRITONSERVER_MessageSerializeToJson(cfg_msg, &buffer, &byte_size));
+  HPS_TRITON_LOG(INFO, "backend configuration as handed over by Triton: ", std::string(buffer, byte_size));
   Json backend_config;
   std::string perr;
   if (!Json::Parse(std::string(buffer, byte_size), &backend_config, &perr))
@@ -270,15 +270,15 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInitialize(TRITONBACKEND_Model* model) {
   uint64_t version;
   RETURN_IF_ERROR(TRITONBACKEND_ModelVersion(model, &version));
   HPS_TRITON_LOG(INFO, "TRITONBACKEND_ModelInitialize: ", name, " (version ", version, ")");
-  TRITONBACKEND_ArtifactType artifact_type;
+  TRITONBACKEND_ArtifactType repo_kind;
   const char* location;
-  RETURN_IF_ERROR(TRITONBACKEND_ModelRepository(model, &artifact_type, &location));
+  RETURN_IF_ERROR(TRITONBACKEND_ModelRepository(model, &repo_kind, &location));
   HPS_TRITON_LOG(INFO, "Repository location: ", location);
   TRITONBACKEND_Backend* backend;
   RETURN_IF_ERROR(TRITONBACKEND_ModelBackend(model, &backend));
-  void* vbackendstate;
-  RETURN_IF_ERROR(TRITONBACKEND_BackendState(backend, &vbackendstate));
-  HPSBackend* backend_state = reinterpret_cast<HPSBackend*>(vbackendstate);
+  void* raw_backend_state;
+  RETURN_IF_ERROR(TRITONBACKEND_BackendState(backend, &raw_backend_state));
+  HPSBackend* backend_state = reinterpret_cast<HPSBackend*>(raw_backend_state);
   if (backend_state == nullptr) return HPS_TRITON_ERROR(INTERNAL, "the hps backend was not initialised");
 
   // a model (or a new version of it) that was not in ps.json when the server started: re-read ps.json
@@ -286,7 +286,7 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInitialize(TRITONBACKEND_Model* model) {
   auto ps = backend_state->HierarchicalParameterServer();
   InferenceParams params;
   if (!ps->model_params(name, &params) || version != model_ps_version) {
-    HPS_TRITON_LOG(INFO, "Parsing the latest Parameter Server json config file for deploying model ", name, " online");
+    HPS_TRITON_LOG(INFO, "model ", name, " version ", version, " is new to the parameter server: reading ps.json again");
     RETURN_IF_ERROR(backend_state->ParseParameterServer(backend_state->ParameterServerJsonFile()));
   }
   if (!ps->model_params(name, &params))                                                 // hps.cc:221-223 (map.at throws there)
@@ -319,15 +319,15 @@ TRITONSERVER_Error* TRITONBACKEND_ModelFinalize(TRITONBACKEND_Model* model) {
   RETURN_IF_ERROR(TRITONBACKEND_ModelName(model, &name));
   TRITONBACKEND_Backend* backend;
   RETURN_IF_ERROR(TRITONBACKEND_ModelBackend(model, &backend));
-  void* vbackendstate;
-  RETURN_IF_ERROR(TRITONBACKEND_BackendState(backend, &vbackendstate));
-  HPSBackend* backend_state = reinterpret_cast<HPSBackend*>(vbackendstate);
+  void* raw_backend_state;
+  RETURN_IF_ERROR(TRITONBACKEND_BackendState(backend, &raw_backend_state));
+  HPSBackend* backend_state = reinterpret_cast<HPSBackend*>(raw_backend_state);
   void* vstate;
   RETURN_IF_ERROR(TRITONBACKEND_ModelState(model, &vstate));
   ModelState* model_state = reinterpret_cast<ModelState*>(vstate);
   if (model_state == nullptr) return nullptr;
   if (backend_state != nullptr) model_state->MarkServingVersion(backend_state->GetModelVersion(name));
-  HPS_TRITON_LOG(INFO, "TRITONBACKEND_ModelFinalize: delete model state");
+  HPS_TRITON_LOG(INFO, "model ", name, ": releasing the model state");
   delete model_state;
   return nullptr;
   });
@@ -349,7 +349,7 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInstanceInitialize(TRITONBACKEND_ModelIns
 
   ModelInstanceState* instance_state;
   RETURN_IF_ERROR(ModelInstanceState::Create(model_state, instance, &instance_state));
-    TRITONSERVER_Error* err = instance_state->LoadHPSInstance();
+  TRITONSERVER_Error* err = instance_state->LoadHPSInstance();
   if (err == nullptr) err = TRITONBACKEND_ModelInstanceSetState(instance, reinterpret_cast<void*>(instance_state));
   if (err != nullptr) { delete instance_state; return err; }
   return nullptr;
@@ -360,7 +360,7 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInstanceFinalize(TRITONBACKEND_ModelInsta
   return NoThrow("TRITONBACKEND_ModelInstanceFinalize", [&]() -> TRITONSERVER_Error* {  // hps.cc:330-344
   void* vstate;
   RETURN_IF_ERROR(TRITONBACKEND_ModelInstanceState(instance, &vstate));
-  HPS_TRITON_LOG(INFO, "TRITONBACKEND_ModelInstanceFinalize: delete instance state");
+  HPS_TRITON_LOG(INFO, "releasing a model instance (lookup session and staging buffers)");
   delete reinterpret_cast<ModelInstanceState*>(vstate);
   return nullptr;
   });

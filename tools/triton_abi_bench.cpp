@@ -290,8 +290,14 @@ int main(int argc, char** argv) {
       th.emplace_back([&, w] {
         if (gpu) (void)hipSetDevice(0);
         const int64_t kshape[2] = {1, (int64_t)N}, nshape[2] = {1, (int64_t)T};
+        // one model: the instances share the requests (whoever is free takes the next, as Triton's scheduler hands them out);
+        // several models: every model's instances get that model's own share, so that all of them are under load all the time
+        const int mi = w / a.instances, wi = w % a.instances;
+        long mine = wi;
         for (;;) {
-          const long i = next.fetch_add(1);
+          long i;
+          if (M == 1) i = next.fetch_add(1);
+          else { i = mine * M + mi; mine += a.instances; }
           if (i >= count) return;
           const long b = first + i;
           mock_request_t* rq = m.mock_request_new(std::to_string(b).c_str(), 0);
