@@ -359,6 +359,10 @@ __global__ __launch_bounds__(256) void hps_dense_interact_kernel(const float* __
 
 hipError_t LaunchDenseMlp(const DenseMlpDesc& d, const float* d_x, uint64_t batch, void* d_out_f16, int cu_count, hipStream_t stream) {
   if (batch == 0) return hipSuccess;
+  // (A 256-row variant that fused the first two layers — the hidden layer produced 128 columns at a time into LDS and consumed
+  //  at once as a K-chunk of layer 2, weights read once per 256 samples: 106 MB of L2 reads per batch instead of 205 — was
+  //  measured at the same 235-240 us per forward as this one and withdrawn: below ~200 MB the kernel is no longer bound by the
+  //  weight reads but by the serial chain of barriers and LDS round trips of one resident block per CU.)
   static const bool force64 = [] { const char* e = getenv("HPS_DENSE_MLP_ROWS"); return e && atoi(e) == 64; }();
   bool fits128 = !force64 && batch > (uint64_t)kMlpRows;
   for (uint32_t l = 0; l < d.num_layers; ++l) fits128 = fits128 && d.dims[l] / 32 <= 8u * kMlp2MaxUnits;
