@@ -131,12 +131,17 @@ UpdateSourceStats UpdateConsumer::stats() const {
 }
 
 Status UpdateConsumer::Drain(size_t timeout_ms) {
-  std::unique_lock<std::mutex> lk(mu_);
-  const uint64_t seen = idle_polls_;
-  // two idle polls: the one in progress when the call started may have begun before the producer's last append
-  if (!cv_.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return idle_polls_ >= seen + 2; }))
-    return Error(Code::kUnavailable, "update source: still busy after ", timeout_ms, " ms");
-  return Status::Ok();
+  // two idle polls: the one in progress when the call started may have begun before the producer's last append.
+  // (Polled, not waited for on the condition variable: wait_for on the steady clock is pthread_cond_clockwait, which the
+  //  ThreadSanitizer runtime of this toolchain does not know — it then believes the mutex stays locked through the wait.)
+  uint64_t seen;
+  { std::lock_guard<std::mutex> lk(mu_); seen = idle_polls_; }
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+  for (;;) {
+    { std::lock_guard<std::mutex> lk(mu_); if (idle_polls_ >= seen + 2) return Status::Ok(); }
+    if (std::chrono::steady_clock::now() >= deadline) return Error(Code::kUnavailable, "update source: still busy after ", timeout_ms, " ms");
+    usleep(1000);
+  }
 }
 
 void UpdateConsumer::Run() {
@@ -164,7 +169,6 @@ void UpdateConsumer::Run() {
       commit();
       usleep((useconds_t)std::max<size_t>(1, p_.failure_backoff_ms) * 1000);
       { std::lock_guard<std::mutex> lk(mu_); ++idle_polls_; }
-      cv_.notify_all();
       continue;
     }
     if (msgs.empty()) {
@@ -175,7 +179,6 @@ void UpdateConsumer::Run() {
         commit();
         waited_ms = 0;
         { std::lock_guard<std::mutex> lk(mu_); ++idle_polls_; }
-        cv_.notify_all();
       }
       continue;
     }

@@ -14,7 +14,6 @@
 //   model name bytes | count x int64 keys | count x dim fp32 rows
 #pragma once
 #include <atomic>
-#include <condition_variable>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -88,7 +87,6 @@ class UpdateConsumer {
   std::thread thread_;
   std::atomic<bool> stop_{false};
   mutable std::mutex mu_;
-  std::condition_variable cv_;
   UpdateSourceStats stats_;
   uint64_t idle_polls_ = 0;   // polls that found nothing with nothing pending (Drain waits for one to pass)
 };

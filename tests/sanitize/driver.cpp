@@ -5,11 +5,16 @@
 //   driver parse     configuration parser on valid / truncated / hostile inputs
 //   driver table     load, duplicates, sentinel key, synthetic + sharded generation, lookups checked against a std::map
 //   driver threads   concurrent Fetch from several threads while another thread upserts and reloads; pool stress
+#include <unistd.h>
+
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <random>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -19,6 +24,7 @@
 #include "common/hps_hash.h"
 #include "ps/host_table.h"
 #include "ps/thread_pool.h"
+#include "ps/update_source.h"
 
 using namespace hps;
 
@@ -261,6 +267,92 @@ static int run_keypack() {
   return 0;
 }
 
+// Online update source: a producer appends framed messages to a file (sometimes half a frame at a time) while the consumer
+// thread follows it and upserts into a table that three reader threads are fetching from; at the end every key the producer
+// wrote answers with its last row.
+static int run_updates() {
+  ThreadPool pool(4, 50);
+  const uint32_t D = 8;
+  const size_t R = 20000;
+  HostTable tb("t", D, 8);
+  CHECK(tb.LoadSynthetic(5, 0, 0, R, &pool).ok());
+  char tmpl[] = "/tmp/hps_updates_XXXXXX";
+  const int fd = mkstemp(tmpl);
+  CHECK(fd >= 0);
+  UpdateSourceParams up;
+  up.type = UpdateSourceType::FileTail;
+  up.brokers = tmpl;
+  up.poll_timeout_ms = 20;
+  up.max_batch_size = 100;
+  up.max_commit_interval = 4;
+  up.failure_backoff_ms = 1;
+  std::unique_ptr<UpdateTransport> tr;
+  CHECK(MakeFileTailTransport(tmpl, 1 << 20, &tr).ok());
+  std::atomic<size_t> commits{0};
+  std::map<int64_t, float> want;   // producer's view: key -> value every float of its row has
+  {
+    UpdateConsumer consumer(up, std::move(tr),
+                            [&](const std::string& m, uint32_t t, uint32_t d, const int64_t* k, const float* r, size_t n) -> Status {
+                              if (m != "m" || t != 0 || d != D) return Error(Code::kNotFound, "not mine");
+                              return tb.Upsert(k, r, n);
+                            },
+                            [&](const std::set<std::string>&) { commits.fetch_add(1); });
+    std::atomic<bool> stop{false};
+    std::atomic<int> bad{0};
+    auto reader = [&](int seed) {
+      std::mt19937_64 rng(seed);
+      std::vector<int64_t> q(256);
+      std::vector<float> out(q.size() * D);
+      std::vector<uint8_t> found(q.size());
+      while (!stop.load()) {
+        for (auto& k : q) k = (int64_t)(rng() % R);
+        tb.Fetch(q.data(), q.size(), out.data(), D, 0.f, found.data());
+        for (size_t i = 0; i < q.size(); ++i) if (!found[i]) bad.fetch_add(1);   // the table's own keys never disappear
+      }
+    };
+    std::vector<std::thread> th;
+    for (int i = 0; i < 3; ++i) th.emplace_back(reader, 7 + i);
+    std::mt19937_64 rng(3);
+    for (int msg = 0; msg < 40; ++msg) {
+      std::vector<int64_t> k(1 + rng() % 300);
+      for (auto& x : k) x = (int64_t)(rng() % (2 * R));   // half overwrite, half new keys
+      std::sort(k.begin(), k.end());
+      k.erase(std::unique(k.begin(), k.end()), k.end());
+      std::vector<float> r(k.size() * D, (float)(msg + 1));
+      for (int64_t x : k) want[x] = (float)(msg + 1);
+      const std::string frame = EncodeUpdateMessage(msg % 7 == 6 ? "other" : "m", 0, D, k.data(), r.data(), k.size());
+      if (msg % 7 == 6) for (int64_t x : k) want.erase(x);   // a message for another model changes nothing here: its keys are not checked
+      const size_t cut = msg % 3 == 0 ? frame.size() / 2 : frame.size();
+      CHECK(write(fd, frame.data(), cut) == (ssize_t)cut);
+      if (cut < frame.size()) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(3));
+        CHECK(write(fd, frame.data() + cut, frame.size() - cut) == (ssize_t)(frame.size() - cut));
+      }
+    }
+    CHECK(consumer.Drain(20000).ok());
+    stop.store(true);
+    for (auto& t : th) t.join();
+    CHECK(bad.load() == 0);
+    const UpdateSourceStats st = consumer.stats();
+    CHECK(st.messages == 40 - 5 && st.rejected_messages == 5 && st.commits >= 1 && commits.load() >= 1);
+  }
+  close(fd);
+  // every key whose last writer was a message for "m" carries that message's value
+  std::vector<int64_t> q;
+  std::vector<float> expect;
+  for (auto& kv : want) { q.push_back(kv.first); expect.push_back(kv.second); }
+  std::vector<float> out(q.size() * D);
+  std::vector<uint8_t> found(q.size());
+  tb.Fetch(q.data(), q.size(), out.data(), D, -1.f, found.data());
+  int wrong = 0;
+  for (size_t i = 0; i < q.size(); ++i)
+    if (!found[i] || out[i * D] != expect[i] || out[i * D + D - 1] != expect[i]) ++wrong;
+  CHECK(wrong == 0);
+  unlink(tmpl);
+  unlink((std::string(tmpl) + ".offset").c_str());
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "all";
   int rc = 0;
@@ -269,6 +361,7 @@ int main(int argc, char** argv) {
   if (what == "parse" || what == "all") rc |= run_parse();
   if (what == "table" || what == "all") rc |= run_table();
   if (what == "threads" || what == "all") rc |= run_threads();
+  if (what == "updates" || what == "all") rc |= run_updates();
   printf("%s: %s\n", what.c_str(), rc ? "FAILED" : "ok");
   return rc;
 }

@@ -12,7 +12,7 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 SRC = ROOT / "hugectr_backend_amd" / "csrc"
-UNITS = ["common/json.cpp", "common/config.cpp", "ps/thread_pool.cpp", "ps/host_table.cpp", "ps/volatile_tier.cpp"]
+UNITS = ["common/json.cpp", "common/config.cpp", "ps/thread_pool.cpp", "ps/host_table.cpp", "ps/volatile_tier.cpp", "ps/update_source.cpp"]
 
 
 def _build_cmd(out: Path, san: str):
@@ -48,13 +48,13 @@ def _run(binary, what, env_extra):
         report[-3000:]
 
 
-@pytest.mark.parametrize("what", ["parse", "table", "threads", "tiered", "keypack"])
+@pytest.mark.parametrize("what", ["parse", "table", "threads", "tiered", "keypack", "updates"])
 def test_host_side_under_asan_ubsan(binaries, what):
     # leak checking is off: the HIP runtime library keeps process-lifetime allocations of its own
     _run(binaries["asan"], what, {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
 
 
-@pytest.mark.parametrize("what", ["threads", "tiered"])
+@pytest.mark.parametrize("what", ["threads", "tiered", "updates"])
 def test_host_side_under_tsan(binaries, what):
     _run(binaries["tsan"], what, {"TSAN_OPTIONS": "halt_on_error=0:report_signal_unsafe=0"})
 
