@@ -475,6 +475,8 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       s->s->set_probe_variant(value);
     } else if (n == "exclusive_kernels") {
       s->s->set_exclusive_kernels(value != 0);
+    } else if (n == "fused_unique") {
+      s->s->set_fused_unique(value != 0);
     } else if (n == "narrow_publish") {
       s->s->set_narrow_publish(value != 0);
     } else if (n == "chain_gather") {

@@ -602,6 +602,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   for (hipEvent_t* e : {&ev_t0_, &ev_t1_, &ev_f0_, &ev_f1_, &ev_c1_, &ev_g0_, &ev_g1_, &ev_s0_, &ev_s1_, &ev_i0_, &ev_i1_}) HIP_TRY(hipEventCreate(e));
   for (hipEvent_t& e : ev_lane_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char* e = std::getenv("HPS_EXCLUSIVE_KERNELS")) exclusive_ = std::strtol(e, nullptr, 10) != 0;
+  if (const char* e = std::getenv("HPS_FUSED_UNIQUE")) fused_unique_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switches
   if (const char* e = std::getenv("HPS_XCD_WALK")) xcd_walk_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_PROBE_VARIANT")) probe_variant_ = (int)std::strtol(e, nullptr, 10);
@@ -1129,8 +1130,9 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   cache_->BeginRead(stream_);
   if (exclusive_) cache_->LaneEnter(stream_);
   if (timing_) (void)hipEventRecord(ev_t0_, stream_);
-  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, exact, stream_);
-  if (e == hipSuccess) e = LaunchMissUnique(d_call_, cache_->device_tables(), wk, exact, stream_);
+  const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_, exact);
+  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, exact, tail, stream_);
+  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), wk, exact, stream_);
   if (timing_) (void)hipEventRecord(ev_t1_, stream_);
   if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[0]);
   // other sessions' probes chain behind ours: behind K_P, and behind K_M too when it still reads the claim words
@@ -1313,8 +1315,9 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
 
   cache_->BeginRead(stream_);   // ---- read lock: held (order mutex + reader event) until the interaction is enqueued ----
   if (timing_) (void)hipEventRecord(ev_t0_, stream_);
-  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), w, probe_variant_, false, stream_);
-  if (e == hipSuccess) e = LaunchMissUnique(d_call_, cache_->device_tables(), w, false, stream_);
+  const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_, false);
+  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), w, probe_variant_, false, tail, stream_);
+  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), w, false, stream_);
   if (timing_) (void)hipEventRecord(ev_t1_, stream_);
   (void)hipEventRecord(ev_probe_, stream_);
   if (e == hipSuccess) e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_acc_, d_md_, /*clear_stats=*/false, nullptr, stream_);

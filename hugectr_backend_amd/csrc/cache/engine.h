@@ -247,6 +247,7 @@ class LookupSession {
   void set_chain_gather(bool b) { chain_gather_ = b; }
   void set_narrow_publish(bool b) { narrow_publish_ = b; }
   void set_exclusive_kernels(bool b) { exclusive_ = b; }
+  void set_fused_unique(bool b) { fused_unique_ = b; }
   float last_key_stage_ms() const { return key_stage_ms_; }
   float last_scatter_ms() const { return last_scatter_ms_; }   // miss-scatter kernel of the last call (last chunk)
   float last_insert_ms() const { return last_insert_ms_; }     // cache-insert kernel of the last call (last chunk)
@@ -343,6 +344,7 @@ class LookupSession {
   bool split_call_ = false;      // the call in progress gathers its hits on stream_ while the miss path runs (copies go down copy_stream_)
   bool split_probe_ = true;      // host-gather tier: start the miss path behind the probe, gather the hits meanwhile (§3.4c);
                                  // HPS_SPLIT_PROBE=0 / session option split_probe=0: gather first, then the counts
+  bool fused_unique_ = true;     // the call-wide unique misses are found in the probe kernel's tail (option "fused_unique", HPS_FUSED_UNIQUE)
   bool exclusive_ = true;        // the HBM-bound kernels of this session take the cache's lane (option "exclusive_kernels")
   hipEvent_t ev_lane_[4] = {nullptr, nullptr, nullptr, nullptr};   // probe pair, hit gather, miss scatter, insert
   bool narrow_publish_ = true;   // a narrowed request's unique missed keys come back to the host as uint32 (option "narrow_publish")

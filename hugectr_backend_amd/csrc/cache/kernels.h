@@ -11,8 +11,11 @@ uint32_t GatherGridBlocks(uint64_t N, int cu_count);
 
 // K_P: one workgroup per tile of w.tiles.  variant = U + 100 * no_dedup (U in {2,4,8}).  claim: hit representatives
 // mark their slot's claim word (tables[t].claim must be allocated) so that K_M can count the call's unique hit keys.
+// tail: the tile's first wave also does K_M's work (call-wide unique misses) — then LaunchMissUnique must NOT follow.  Only for
+// variants with tile dedup and without claim (ProbeTailAvailable).
+bool ProbeTailAvailable(int variant, bool claim);
 hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
-                            hipStream_t stream);
+                            bool tail, hipStream_t stream);
 // K_M: call-wide unique missed keys per table (+ exact: unique hit keys) into w.acc / w.uniq_keys / w.rep_of / w.uidx_of
 hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, bool exact,
                             hipStream_t stream);

@@ -109,6 +109,11 @@ __device__ __forceinline__ uint32_t lds_append(uint32_t* sh_count, bool take) {
   return base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
 }
 
+// position of a (table, key) in a session's call-wide miss set (K_P's tail / K_M)
+__device__ __forceinline__ uint64_t set_hash(int64_t key, uint32_t t) {
+  return hps_mix64((uint64_t)key ^ ((uint64_t)(t + 1) * 0xD6E8FEB86659FD93ull));
+}
+
 // ------------------------------------------------------------------------------------------------
 // K_P: probe, one workgroup per tile (<= kTileKeys consecutive keys of one table).
 //   1. keys -> LDS (coalesced), one hash per key: high half = cache bucket, low bits = LDS set position
@@ -126,13 +131,13 @@ __device__ __forceinline__ uint32_t lds_append(uint32_t* sh_count, bool take) {
 // index there (K_M counts those).  Plain stores, no atomics.
 // Algorithmic bytes per key: 8 (key) + 4 (slot); overhead: one 128-B bucket line per tile-unique key.
 // ------------------------------------------------------------------------------------------------
-template <bool kDedup, bool kClaim, int kU, int kThreads>
+template <bool kDedup, bool kClaim, int kU, int kThreads, bool kTail>
 __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc* __restrict__ call,
                                                                             const TableCacheDev* __restrict__ tables,
                                                                             const CallWork w) {
   __shared__ int64_t sh_key[kTileKeys];
   __shared__ uint32_t sh_bkt[kTileKeys];
-  __shared__ uint32_t sh_set[kDedup ? kTileSet : 1];
+  __shared__ __attribute__((aligned(8))) uint32_t sh_set[kDedup ? kTileSet : 1];   // (kTail: reused as the tile's missed keys, int64)
   __shared__ uint16_t sh_rep[kTileKeys];
   __shared__ int32_t sh_slot[kTileKeys];
   __shared__ uint16_t sh_list[kTileKeys];
@@ -246,7 +251,11 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
     const bool miss = is_rep && s < 0;
     const uint32_t pos = lds_append(&sh_cnt[1], miss);
     if (miss) {
-      w.miss_key[region + pos] = k[q];
+      if (kTail) {
+        reinterpret_cast<int64_t*>(sh_set)[pos] = k[q];   // the set is dead since step 2; the tail writes miss_key itself
+      } else {
+        w.miss_key[region + pos] = k[q];
+      }
       sh_slot[j] = -2 - (int32_t)(region + pos);
     }
     if (kClaim) {
@@ -271,6 +280,71 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
     w.tile_cnt[tile * 4 + kTileCntSentMiss] = sh_cnt[2];
     w.tile_cnt[tile * 4 + kTileCntRepHit] = kClaim ? sh_cnt[3] : 0u;
   }
+  // ---- 5. (kTail) call-wide unique misses: what hps_miss_unique_kernel does in a launch of its own, done here by the tile's
+  // first wave while the other waves retire.  Round 3: the separate kernel cost 15-17 us per call in the timed region for a few
+  // microseconds of dependent accesses per tile (launch gap, tile_cnt / miss_key round trips); the price of folding it in is
+  // the hand-off inside a launch: a loser reads the WINNER's key, which another workgroup wrote moments ago.  The lane that
+  // publishes a set entry therefore writes its key itself, as a device-scope store (write-through past the XCD's L2), and
+  // waits for that store before the compare-and-swap; the loser's read is a device-scope load whose address comes out of the
+  // entry.  No fence: a device-scope release / acquire fence on gfx950 writes back / invalidates the whole L2 of the XCD —
+  // tried first: 500 us instead of 45 for this kernel.  Not with kClaim: the unique-hit count needs every tile's claim
+  // stores, i.e. the kernel boundary.
+  if (kTail && !kClaim) {
+    if (tid >= 64) return;
+    const uint32_t M = sh_cnt[1], S = sh_cnt[2];
+    if ((M | S) == 0) return;
+    const uint32_t t = td.table;
+    const unsigned long long tag = (unsigned long long)w.call_tag << 32;
+    const uint64_t ks = call->key_start[t];
+    const int64_t* sh_mk = reinterpret_cast<const int64_t*>(sh_set);
+    for (uint32_t r0 = 0; r0 < M; r0 += 64) {
+      const uint32_t r = r0 + (uint32_t)lane;
+      const bool active = r < M;
+      const uint32_t m = region + r;
+      bool winner = false;
+      uint32_t rep = m;
+      int64_t key = 0;
+      if (active) {
+        key = sh_mk[r];
+        __hip_atomic_store(&w.miss_key[m], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the keys are out before any of this wave's entries can be seen
+      if (active) {
+        uint64_t h = set_hash(key, t) & w.set_mask;
+        unsigned long long cur = __hip_atomic_load(&w.set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+          if ((cur & 0xFFFFFFFF00000000ull) != tag) {  // free: left by an earlier call
+            const unsigned long long prev = atomicCAS(&w.set[h], cur, tag | m);
+            if (prev == cur) { winner = true; break; }
+            cur = prev;
+            continue;
+          }
+          const uint32_t pm = (uint32_t)cur;
+          const int64_t other = __hip_atomic_load(&w.miss_key[pm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (other == key && w.tiles[pm / (uint32_t)kTileKeys].table == t) { rep = pm; break; }
+          h = (h + 1) & w.set_mask;
+          cur = __hip_atomic_load(&w.set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      const uint64_t bal = __ballot(winner);
+      uint32_t base = 0;
+      if (bal) {
+        if (lane == 0) base = atomicAdd(&w.acc[AccTableWord(t, kAccUniqMiss)], (uint32_t)__popcll(bal));
+        base = uniform_u32(base);
+      }
+      if (active) {
+        w.rep_of[m] = (int32_t)rep;
+        if (winner) {
+          const uint32_t u = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+          w.uidx_of[m] = (int32_t)u;
+          w.uniq_keys[ks + u] = key;
+          if (w.uniq_keys_host32) w.uniq_keys_host32[ks + u] = (uint32_t)key;
+          else if (w.uniq_keys_host) w.uniq_keys_host[ks + u] = key;
+        }
+      }
+    }
+    if (lane == 0 && S) atomicAdd(&w.acc[AccTableWord(t, kAccSentMiss)], S);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -284,10 +358,6 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
 // kExact: also counts the tile's hit representatives that still own their slot's claim word (one per distinct
 // slot over the whole call): the call's unique hit keys per table.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t set_hash(int64_t key, uint32_t t) {
-  return hps_mix64((uint64_t)key ^ ((uint64_t)(t + 1) * 0xD6E8FEB86659FD93ull));
-}
-
 template <bool kExact>
 __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __restrict__ call,
                                                                const TableCacheDev* __restrict__ tables, const CallWork w) {
@@ -777,16 +847,24 @@ static inline uint32_t ListSubBlocks(uint32_t tiles) {
   return k < 1 ? 1u : (k > 16 ? 16u : k);
 }
 
+bool ProbeTailAvailable(int variant, bool claim) { return !claim && (variant / 100) % 10 == 0; }
+
 hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
-                            hipStream_t stream) {
+                            bool tail, hipStream_t stream) {
   if (w.num_tiles == 0) return hipSuccess;
+  if (tail && !ProbeTailAvailable(variant, claim)) return hipErrorInvalidValue;
   // variant = U + 100 * no_dedup + 1000 * wide   (U in {2,4,8}: bucket lines in flight per 16-lane group; wide: 512 threads
   // per tile instead of 256 — twice the groups probing per workgroup, 32 waves per CU at 4 workgroups)
   const int U = variant % 100;
   const bool dedup = (variant / 100) % 10 == 0;
   const bool wide = (variant / 1000) % 10 != 0;
-#define HPS_PT(DD, CC, UU, TT)                                                                                  \
-  hipLaunchKernelGGL((hps_probe_tile_kernel<DD, CC, UU, TT>), dim3(w.num_tiles), dim3(TT), 0, stream, d_call, d_tables, w)
+#define HPS_PT(DD, CC, UU, TT)                                                                                         \
+  do {                                                                                                                 \
+    if (tail && DD && !CC)                                                                                             \
+      hipLaunchKernelGGL((hps_probe_tile_kernel<DD, false, UU, TT, DD && !CC>), dim3(w.num_tiles), dim3(TT), 0, stream, d_call, d_tables, w); \
+    else                                                                                                               \
+      hipLaunchKernelGGL((hps_probe_tile_kernel<DD, CC, UU, TT, false>), dim3(w.num_tiles), dim3(TT), 0, stream, d_call, d_tables, w);        \
+  } while (0)
 #define HPS_PT_T(DD, CC, UU)                      \
   do {                                            \
     if (wide) HPS_PT(DD, CC, UU, 512);            \

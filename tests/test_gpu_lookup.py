@@ -626,3 +626,39 @@ def test_pageable_keys_below_2_to_24_cross_pcie_at_three_bytes():
     out = s.lookup(q3, nk).cpu().numpy()
     assert s.last_stats().key_bytes == 8 and s.last_stats().keys_narrowed == 0
     assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q3, nk, [0.0] * 3)))
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_call_wide_unique_misses_with_the_same_missed_keys_in_every_tile(fused):
+    """The call-wide dedup of missed keys — in the probe kernel's tail (default: a loser reads the winner's key, which another
+    workgroup of the same launch wrote) or in the separate hps_miss_unique launch: requests whose tiles all miss the SAME few
+    keys (absent ones and non-resident ones), so that nearly every missed representative is a loser of some other tile's
+    entry.  Many calls on one session (set entries of earlier calls are stale, never cleared); the unique-miss count must be
+    exactly the number of distinct missed keys and the rows exact, call after call."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(1234 + fused)
+    tables = make_tables([(30000, 32), (30000, 8), (30000, 128)])
+    ps, cache, s = _mk(f"fuq{fused}", tables, maxcat=[1, 1, 1], gpucacheper=0.05, hit_rate_threshold=1.0, defaults=[0.25, 0.5, 0.75],
+                       max_batch=40000)
+    s.set_option("fused_unique", fused)
+    for it in range(60):
+        nk, parts = [], []
+        for t, (keys, _) in enumerate(tables):
+            n = int(rng.integers(9000, 40000))                    # 9 .. 40 tiles of this table
+            pool_cold = rng.choice(keys, size=int(rng.integers(1, 120)), replace=False)      # mostly non-resident (cache = 5 %)
+            pool_absent = -7 - rng.integers(0, 1 << 45, size=int(rng.integers(1, 60)))      # in no table
+            pool = np.concatenate([pool_cold, pool_absent])
+            q = rng.choice(pool, size=n, replace=True)
+            nk.append(n)
+            parts.append(q.astype(np.int64))
+        q = np.concatenate(parts)
+        resident = [tk[cache.query(t, tk) >= 0] for t, (tk, _) in enumerate(tables)]
+        uc = O.np_unique_counts(q, nk, resident)
+        out = s.lookup(q, nk).cpu().numpy()
+        ref = O.np_lookup(tables, q, nk, [0.25, 0.5, 0.75])
+        assert np.array_equal(_bits(out), _bits(ref)), it
+        st = s.last_stats()
+        assert st.unique_misses == sum(m for _, m in uc), (it, st.unique_misses, uc)
+    c = cache.counters()
+    assert c["inserted"] + c["refreshed"] + c["dropped"] > 0
+    s.close()
