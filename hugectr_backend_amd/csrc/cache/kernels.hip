@@ -675,20 +675,31 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
   // gets — the current unit minus the cache's insert age (EmbeddingCache::InsertStamps): a key that was asked for once
   // enters the bucket older than the keys that have been hit, and is the first to go unless it is asked for again
   const uint32_t now8 = stamps & 0xFFu, ins8 = (stamps >> 8) & 0xFFu;
-  const uint64_t total = md->useg_start[T];
+  // per-table words of the call in LDS: the table of a flat index is a binary search over the unique-segment starts, and from
+  // global memory that search alone was five dependent round trips in front of every key's bucket line (the kernel is a chain
+  // of dependent accesses per key: 45 us for 84 K keys)
+  extern __shared__ __attribute__((aligned(16))) char ins_smem[];
+  uint64_t* sh_us = reinterpret_cast<uint64_t*>(ins_smem);            // [T + 1] unique-segment starts
+  uint64_t* sh_ks = sh_us + (T + 1);                                   // [T] key_start
+  uint64_t* sh_so = sh_ks + T;                                         // [T] stage_off
+  uint32_t* sh_lo = reinterpret_cast<uint32_t*>(sh_so + T);            // [T] chunk_lo
+  for (uint32_t t = threadIdx.x; t <= T; t += blockDim.x) sh_us[t] = md->useg_start[t];
+  for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) { sh_ks[t] = key_start[t]; sh_so[t] = md->stage_off[t]; sh_lo[t] = md->chunk_lo[t]; }
+  __syncthreads();
+  const uint64_t total = sh_us[T];
   const int lane = lane_id();
   const int g = lane >> 4, lig = lane & 15;
   const uint64_t groups_total = (uint64_t)gridDim.x * 16;
   uint32_t n_dropped = 0, n_inserted = 0, n_refreshed = 0;  // counted by each group's lane 0
   for (uint64_t f = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4); f < total; f += groups_total) {
-    const int t = find_table(md->useg_start, (int)T, f);
+    const int t = find_table(sh_us, (int)T, f);
+    const uint32_t u = sh_lo[t] + (uint32_t)(f - sh_us[t]);
+    const int64_t key = uniq_keys[sh_ks[t] + u];          // (independent of the table descriptor: both loads go out together)
     const TableCacheDev tb = tables[t];
     if (tb.flags & 1u) continue;  // static cache: never insert
-    const uint32_t u = md->chunk_lo[t] + (uint32_t)(f - md->useg_start[t]);
-    const int64_t key = uniq_keys[key_start[t] + u];
     if (key == HPS_EMPTY_KEY) continue;
     const uint32_t D = tb.dim;
-    const float* row = staging + md->stage_off[t] + (uint64_t)(u - md->chunk_lo[t]) * D;
+    const float* row = staging + sh_so[t] + (uint64_t)(u - sh_lo[t]) * D;
     const uint32_t b = hps_bucket_of(key, tb.num_buckets);
     unsigned long long* line = reinterpret_cast<unsigned long long*>(tb.lines) + (uint64_t)b * kLineWords;
     const u64x2 ln = *reinterpret_cast<const u64x2*>(line + (lig & 7) * 2);
@@ -772,7 +783,7 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
     } else {
       if (present < 0 && lig == 0) __hip_atomic_store(line + victim, (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       float* dst = tb.rows + ((uint64_t)b * kBucketSlots + (uint64_t)victim) * D;
-      copy_row<false>(row, dst, D, lig, (D & 3u) == 0 && (md->stage_off[t] & 3) == 0);
+      copy_row<false>(row, dst, D, lig, (D & 3u) == 0 && (sh_so[t] & 3) == 0);
       if (lig == 0) { if (present >= 0) ++n_refreshed; else ++n_inserted; }
     }
     // kStampClaimed (all ones) AND now8 = now8; the other bytes of the word keep whatever they hold by now
@@ -930,7 +941,8 @@ hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const Mi
   uint64_t want = (total_unique + 15) / 16;
   const uint64_t cap = (uint64_t)cu_count * 8;
   if (want > cap) want = cap;
-  hipLaunchKernelGGL(hps_cache_insert_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_tables, T, d_md,
+  const size_t lds = (size_t)(T + 1) * 8 + (size_t)T * (8 + 8 + 4) + 16;
+  hipLaunchKernelGGL(hps_cache_insert_kernel, dim3((uint32_t)want), dim3(256), lds, stream, d_tables, T, d_md,
                      d_key_start, d_uniq_keys, d_staging, d_found, stamps & 0xFFFFu, d_stats);
   return hipGetLastError();
 }
