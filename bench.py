@@ -882,7 +882,8 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 # every lookup priced at 1,032 algorithmic bytes over ALL HBM-side kernels of the lookup
-                "kernel": "hps_probe_tile_kernel + hps_miss_unique_kernel + hps_gather_hits_kernel + hps_miss_scatter_kernel",
+                "kernel": "hps_probe_tile_kernel (tile dedup + probe + call-wide unique misses in its tail) + hps_gather_hits_kernel + "
+                          "hps_miss_scatter_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

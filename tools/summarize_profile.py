@@ -47,12 +47,14 @@ def main(d, out):
     kernels = ("hps_probe_tile", "hps_miss_unique", "hps_gather_hits", "hps_miss_scatter", "hps_cache_insert")
     res["pmc_by_kernel"] = {k: v for k, v in ((k, pmc_of(k)) for k in kernels) if v}
     # SURVEY 8(d)'s lookup = probe + unique + gather + scatter (the insert is cache maintenance, reported on its own)
+    # (hps_miss_unique is a launch of its own only when the unique-hit count is needed: since round 3 its work is the tail of
+    #  hps_probe_tile and its bytes are counted there)
     call = [res["pmc_by_kernel"].get(k, {}) for k in kernels[:4]]
-    if all("hbm_bytes_per_launch_fetch_doubled" in c for c in call[:3]):
+    if all("hbm_bytes_per_launch_fetch_doubled" in res["pmc_by_kernel"].get(k, {}) for k in ("hps_probe_tile", "hps_gather_hits")):
         res["pmc"] = {
             "hbm_bytes_per_call_fetch_doubled": sum(c.get("hbm_bytes_per_launch_fetch_doubled", 0.0) for c in call),
             "hbm_bytes_per_call_raw": sum(c.get("hbm_bytes_per_launch_raw", 0.0) for c in call),
-            "note": "sum over hps_probe_tile + hps_miss_unique + hps_gather_hits + hps_miss_scatter, one launch of each per "
+            "note": "sum over hps_probe_tile (+ hps_miss_unique where it is a launch of its own) + hps_gather_hits + hps_miss_scatter, one launch of each per "
                     "lookup call, one session; FETCH_SIZE and WRITE_SIZE from separate --pmc passes, both in KiB; on gfx950 "
                     "FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM) — the bulk of "
                     "the reads are 16 B/lane row segments and 128-B bucket lines"}
