@@ -703,14 +703,7 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
     const uint32_t b = hps_bucket_of(key, tb.num_buckets);
     unsigned long long* line = reinterpret_cast<unsigned long long*>(tb.lines) + (uint64_t)b * kLineWords;
     const u64x2 ln = *reinterpret_cast<const u64x2*>(line + (lig & 7) * 2);
-    // the staged row is fetched together with the bucket line (its address is known already): one round trip less in the
-    // per-key chain line -> claim -> row -> stores
-    const bool fast_row = D == 128 && (sh_so[t] & 3) == 0;
-    f4 rv0 = {0.f, 0.f, 0.f, 0.f}, rv1 = rv0;
-    if (fast_row) {
-      rv0 = *reinterpret_cast<const f4*>(row + lig * 4);
-      rv1 = *reinterpret_cast<const f4*>(row + 64 + lig * 4);
-    }
+    // (fetching the staged row here, together with the bucket line, instead of after the claim was measured: 40 us either way)
     const bool klane = lig < 7;
     const uint32_t p0 = (uint32_t)(__ballot(klane && (int64_t)ln.x == key) >> (g * 16)) & 0x7Fu;
     const uint32_t p1 = (uint32_t)(__ballot(klane && (int64_t)ln.y == key) >> (g * 16)) & 0x7Fu;
@@ -791,12 +784,7 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
     } else {
       if (present < 0 && lig == 0) __hip_atomic_store(line + victim, (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       float* dst = tb.rows + ((uint64_t)b * kBucketSlots + (uint64_t)victim) * D;
-      if (fast_row) {
-        *reinterpret_cast<f4*>(dst + lig * 4) = rv0;
-        *reinterpret_cast<f4*>(dst + 64 + lig * 4) = rv1;
-      } else {
-        copy_row<false>(row, dst, D, lig, (D & 3u) == 0 && (sh_so[t] & 3) == 0);
-      }
+      copy_row<false>(row, dst, D, lig, (D & 3u) == 0 && (sh_so[t] & 3) == 0);
       if (lig == 0) { if (present >= 0) ++n_refreshed; else ++n_inserted; }
     }
     // kStampClaimed (all ones) AND now8 = now8; the other bytes of the word keep whatever they hold by now
