@@ -69,9 +69,9 @@ def parse_args():
     ap.add_argument("--direct", type=int, default=-1,
                     help="parameter-server tier of the miss path.  0: host threads gather the missed rows and "
                          "hipMemcpyAsync ships them (the reference's arrangement); 1: ps_direct_access (the GPU resolves "
-                         "misses itself out of pinned host memory, no host threads); -1 (default): host gather when this "
-                         "rank has at least 12 CPUs to itself, else device-driven — on one GPU the other tier is measured "
-                         "right after the headline and reported under extra_legs")
+                         "misses itself out of pinned host memory, no host threads); -1 (default): host gather when there are "
+                         "at least 12 CPUs per GPU and at most four GPUs, else device-driven — on one GPU the other tier is "
+                         "measured right after the headline and reported under extra_legs")
     ap.add_argument("--split-probe", type=int, default=-1,
                     help="1 / -1 (default): the miss counts are read back right behind the probe and the hit rows are gathered "
                          "while the misses are fetched (DESIGN.md 3.4c); 0: gather first")
@@ -310,9 +310,11 @@ def main():
     # at a gloo barrier) and come in only for the sharded-table leg, where each rank owns one GPU (RCCL inside the engine).
     n_rep = max(world, a.gpus, 1)
     if a.direct < 0:
-        # the host-gather tier needs host cores (its gather runs on ~14 threads per GPU); with fewer per GPU the
-        # device-driven tier, which needs none, is the one to run
-        a.direct = 0 if effective_cpus() >= 12 * n_rep else 1
+        # the host-gather tier needs host cores (its gather runs on ~13 threads per GPU) and host DRAM bandwidth (every missed
+        # row is read by a host thread, written to the staging buffer and read again by the DMA engine: ~3 x 47 GB/s per GPU at
+        # this workload's PCIe-bound rate — beyond four GPUs that is more than a two-socket host delivers); the device-driven
+        # tier needs no host thread and reads every missed row once
+        a.direct = 0 if (effective_cpus() >= 12 * n_rep and n_rep <= 4) else 1
 
     # HIP spreads a process's streams over 4 hardware queues by default; two lookup sessions whose streams land on the
     # same queue run strictly one after the other.  Must be in the environment before HIP starts.

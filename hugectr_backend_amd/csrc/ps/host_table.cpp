@@ -5,11 +5,13 @@
 #include <immintrin.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -68,10 +70,45 @@ Status FileSize(const std::string& path, size_t* out) {
 
 }  // namespace
 
+// Several GPUs read a page-locked host tier at once (ps_direct_access, one process, one copy of the tables: DESIGN.md §5).
+// By default HIP places page-locked memory on the NUMA node next to the CURRENT device: on a two-socket node every GPU of the
+// other socket would read all of its missed rows across the socket link, and one socket's DRAM channels would serve all of
+// them.  With more than one GPU and more than one NUMA node the tables are interleaved over the nodes instead
+// (hipHostMallocNumaUser + MPOL_INTERLEAVE around the allocation; HPS_HOST_NUMA_INTERLEAVE=0/1 overrides).  One GPU: unchanged.
+static bool InterleavePinnedTables() {
+  static const bool on = [] {
+    if (const char* e = std::getenv("HPS_HOST_NUMA_INTERLEAVE")) return std::strtol(e, nullptr, 10) != 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    struct stat st;
+    return ndev > 1 && stat("/sys/devices/system/node/node1", &st) == 0;
+  }();
+  return on;
+}
+
 void* HostTable::DataAlloc(size_t bytes) {
   if (!pinned_) return SlabAlloc(bytes);
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+  unsigned flags = hipHostMallocMapped | hipHostMallocPortable;
+  bool policy_set = false;
+  if (InterleavePinnedTables()) {
+    unsigned long mask[16];   // every node the kernel lists
+    unsigned long maxnode = 0;
+    for (int n = 0; n < 1024; ++n) {
+      struct stat st;
+      char path[64];
+      snprintf(path, sizeof path, "/sys/devices/system/node/node%d", n);
+      if (stat(path, &st) != 0) break;
+      maxnode = (unsigned long)n + 1;
+    }
+    memset(mask, 0, sizeof mask);
+    for (unsigned long n = 0; n < maxnode && n < sizeof(mask) * 8; ++n) mask[n / (8 * sizeof(long))] |= 1ul << (n % (8 * sizeof(long)));
+    policy_set = maxnode > 1 && syscall(SYS_set_mempolicy, 3 /*MPOL_INTERLEAVE*/, mask, maxnode + 1) == 0;
+    if (policy_set) flags |= hipHostMallocNumaUser;
+  }
+  const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 64, flags);
+  if (policy_set) (void)syscall(SYS_set_mempolicy, 0 /*MPOL_DEFAULT*/, nullptr, 0);
+  if (e != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
   }
