@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--mode", choices=["sync", "async"], default="sync",
                     help="sync: exact rows (threshold 1.0); async: misses return default, inserted in background")
     ap.add_argument("--distinct-batches", type=int, default=0, help="0: one fresh batch per step")
-    ap.add_argument("--probe-variant", type=int, default=1004, help="probe kernel variant U + 100*no_dedup + 1000*wide (tools/kbench.py)")
+    ap.add_argument("--probe-variant", type=int, default=1002, help="probe kernel variant U + 100*no_dedup + 1000*wide (tools/kbench.py)")
     ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
     ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
     ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys narrower when every key of the request fits: 1 = 3-byte packing or uint32, 2 = uint32 only, 0 = off")

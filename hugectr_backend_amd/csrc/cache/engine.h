@@ -371,7 +371,8 @@ class LookupSession {
   bool last_async_ = false;
   float last_gpu_ms_ = 0.f;
   float phase_ms_[4] = {0, 0, 0, 0};
-  int probe_variant_ = 1004;  // K_P: U + 100 * no_dedup + 1000 * wide (512 threads per tile); tools/kbench.py: 38 us against 51 for 4
+  int probe_variant_ = 1002;  // K_P: U + 100 * no_dedup + 1000 * wide (512 threads per tile).  Two bucket lines in flight per 8-lane
+                              // group: 43 us against 46.5 (U = 4) and 45 (U = 1) alone, 50 against 56 us in the timed region (tools/kbench.py)
   bool force_host_gather_ = false;  // option "host_gather": host-thread gather + H2D even on a ps_direct_access cache
   bool timing_ = false;
 };

@@ -884,7 +884,8 @@ hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_table
   } while (0)
 #define HPS_PT_U(DD, CC)                          \
   do {                                            \
-    if (U == 2) HPS_PT_T(DD, CC, 2);              \
+    if (U == 1) HPS_PT_T(DD, CC, 1);              \
+    else if (U == 2) HPS_PT_T(DD, CC, 2);         \
     else if (U == 8) HPS_PT_T(DD, CC, 8);         \
     else HPS_PT_T(DD, CC, 4);                     \
   } while (0)

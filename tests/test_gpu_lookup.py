@@ -442,7 +442,7 @@ def test_policy_hit_rate_is_over_unique_keys():
     assert st.misses == 300 + 5000
 
 
-@pytest.mark.parametrize("variant", [2, 4, 8, 102, 104, 108, 1004, 1008, 1102])
+@pytest.mark.parametrize("variant", [1, 2, 4, 8, 102, 104, 108, 1001, 1002, 1004, 1008, 1102])
 @pytest.mark.parametrize("xcd_walk", [0, 1])
 def test_probe_variants_and_gather_walks_agree(variant, xcd_walk):
     """Every variant of the probe kernel (bucket lines in flight per group; with and without the tile-local input
