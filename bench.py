@@ -894,6 +894,10 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_call": alg,
                 "kernel_ms_per_call": hbm_ms,
+                "kernel_times": "each kernel's own start/stop timestamps (hipExtLaunchKernel events on the session's stream), averaged over "
+                                "the timed region's calls — the launch durations rocprofv3 reports for the same command "
+                                "(profiles/round3/ab_kernel_timestamps_vs_event_pairs_vs_rocprofv3.txt); HPS_KERNEL_TIMESTAMPS=0 gives "
+                                "hipEventRecord pairs around the launches instead (+5..8 us of queue hand-offs per kernel)",
                 "probe_ms": probe, "gather_ms": gather, "scatter_ms": scatter,
                 "insert_ms_not_counted": m["insert_ms"],
                 "frac_probe_plus_gather": alg / ((probe + gather) * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -603,6 +603,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   for (hipEvent_t& e : ev_lane_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char* e = std::getenv("HPS_EXCLUSIVE_KERNELS")) exclusive_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_FUSED_UNIQUE")) fused_unique_ = std::strtol(e, nullptr, 10) != 0;
+  if (const char* e = std::getenv("HPS_KERNEL_TIMESTAMPS")) kernel_stamps_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switches
   if (const char* e = std::getenv("HPS_XCD_WALK")) xcd_walk_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_PROBE_VARIANT")) probe_variant_ = (int)std::strtol(e, nullptr, 10);
@@ -1129,19 +1130,20 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   // ---- K_P: tile dedup + probe;  K_M: call-wide unique misses (+ unique hits) ----
   cache_->BeginRead(stream_);
   if (exclusive_) cache_->LaneEnter(stream_);
-  if (timing_) (void)hipEventRecord(ev_t0_, stream_);
+  Mark(ev_t0_);
   const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_, exact);
-  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, exact, tail, stream_);
-  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), wk, exact, stream_);
-  if (timing_) (void)hipEventRecord(ev_t1_, stream_);
+  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, exact, tail, stream_, Kt(ev_t0_, tail ? ev_t1_ : nullptr));
+  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), wk, exact, stream_, Kt(nullptr, ev_t1_));
+  Mark(ev_t1_);
   if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[0]);
   // other sessions' probes chain behind ours: behind K_P, and behind K_M too when it still reads the claim words
   (void)hipEventRecord(ev_probe_, stream_);
   auto gather = [&]() -> hipError_t {
     if (exclusive_) cache_->LaneEnter(stream_);
-    if (timing_) (void)hipEventRecord(ev_g0_, stream_);
-    const hipError_t ge = LaunchGatherHits(d_call_, cache_->device_tables(), (uint32_t)T, N, w.slot, gather_blocks, all128, xcd_walk_, stream_);
-    if (timing_) (void)hipEventRecord(ev_g1_, stream_);
+    Mark(ev_g0_);
+    const hipError_t ge = LaunchGatherHits(d_call_, cache_->device_tables(), (uint32_t)T, N, w.slot, gather_blocks, all128, xcd_walk_, stream_,
+                                           Kt(ev_g0_, ev_g1_));
+    Mark(ev_g1_);
     if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[1]);
     return ge;
   };
@@ -1314,11 +1316,11 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
   HPS_RETURN_IF_ERROR(dense->BottomMlp(d_dense_features, batch, stream_, &d_bottom));
 
   cache_->BeginRead(stream_);   // ---- read lock: held (order mutex + reader event) until the interaction is enqueued ----
-  if (timing_) (void)hipEventRecord(ev_t0_, stream_);
+  Mark(ev_t0_);
   const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_, false);
-  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), w, probe_variant_, false, tail, stream_);
-  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), w, false, stream_);
-  if (timing_) (void)hipEventRecord(ev_t1_, stream_);
+  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), w, probe_variant_, false, tail, stream_, Kt(ev_t0_, tail ? ev_t1_ : nullptr));
+  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), w, false, stream_, Kt(nullptr, ev_t1_));
+  Mark(ev_t1_);
   (void)hipEventRecord(ev_probe_, stream_);
   if (e == hipSuccess) e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_acc_, d_md_, /*clear_stats=*/false, nullptr, stream_);
   if (e == hipSuccess) {
@@ -1387,17 +1389,17 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
     if (est_bytes > (2u << 20)) HIP_TRY(hipStreamSynchronize(stream_));
   }
   if (exclusive_) cache_->LaneEnter(stream_);
-  if (timing_) (void)hipEventRecord(ev_s0_, stream_);
-  e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, d_staging_, stream_);
-  if (timing_) (void)hipEventRecord(ev_s1_, stream_);
+  Mark(ev_s0_);
+  e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, d_staging_, stream_, Kt(ev_s0_, ev_s1_));
+  Mark(ev_s1_);
   if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[2]);
   if (e != hipSuccess) return Error(Code::kInternal, "direct miss path launch failed: ", hipGetErrorString(e));
   cache_->BeginWrite(stream_);
   if (exclusive_) cache_->LaneEnter(stream_);
-  if (timing_) (void)hipEventRecord(ev_i0_, stream_);
+  Mark(ev_i0_);
   e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, max_unique, d_call_->key_start, work_.uniq_keys,
-                        d_staging_, d_found_, cache_->InsertStamps(epoch), d_acc_, cu, stream_);
-  if (timing_) (void)hipEventRecord(ev_i1_, stream_);
+                        d_staging_, d_found_, cache_->InsertStamps(epoch), d_acc_, cu, stream_, Kt(ev_i0_, ev_i1_));
+  Mark(ev_i1_);
   if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[3]);
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
@@ -1529,19 +1531,19 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     if (!in_place) HIP_TRY(hipStreamSynchronize(stream_));
     tr[0] = since();
     if (exclusive_) cache_->LaneEnter(stream_);
-    if (timing_) (void)hipEventRecord(ev_s0_, stream_);
-    hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, rows_src, stream_);
-    if (timing_) (void)hipEventRecord(ev_s1_, stream_);
+    Mark(ev_s0_);
+    hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, rows_src, stream_, Kt(ev_s0_, ev_s1_));
+    Mark(ev_s1_);
     if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[2]);
     tr[1] = since();
     if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
     cache_->BeginWrite(stream_);
     tr[2] = since();
     if (exclusive_) cache_->LaneEnter(stream_);
-    if (timing_) (void)hipEventRecord(ev_i0_, stream_);
+    Mark(ev_i0_);
     e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, uq, d_call_->key_start, work_.uniq_keys,
-                          rows_src, found_src, cache_->InsertStamps(epoch), d_acc_, cu, stream_);
-    if (timing_) (void)hipEventRecord(ev_i1_, stream_);
+                          rows_src, found_src, cache_->InsertStamps(epoch), d_acc_, cu, stream_, Kt(ev_i0_, ev_i1_));
+    Mark(ev_i1_);
     if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[3]);
     cache_->EndWrite(stream_);
     tr[3] = since();

@@ -28,6 +28,7 @@
 #include "../ps/thread_pool.h"
 #include "../dense/dense.h"
 #include "device_types.h"
+#include "kernels.h"
 #include "direct_kernels.h"
 
 #include <shared_mutex>
@@ -344,6 +345,12 @@ class LookupSession {
   bool split_call_ = false;      // the call in progress gathers its hits on stream_ while the miss path runs (copies go down copy_stream_)
   bool split_probe_ = true;      // host-gather tier: start the miss path behind the probe, gather the hits meanwhile (§3.4c);
                                  // HPS_SPLIT_PROBE=0 / session option split_probe=0: gather first, then the counts
+  // option "timing": the per-kernel times of a call are the kernels' OWN start / stop timestamps (KTimer, kernels.h), as a
+  // profiler reports them; HPS_KERNEL_TIMESTAMPS=0: hipEventRecord pairs around the launches (they also time two packet
+  // hand-offs per kernel)
+  bool kernel_stamps_ = true;
+  KTimer Kt(hipEvent_t a, hipEvent_t b) const { return (timing_ && kernel_stamps_) ? KTimer{a, b} : KTimer{}; }
+  void Mark(hipEvent_t e) { if (timing_ && !kernel_stamps_) (void)hipEventRecord(e, stream_); }
   bool fused_unique_ = true;     // the call-wide unique misses are found in the probe kernel's tail (option "fused_unique", HPS_FUSED_UNIQUE)
   bool exclusive_ = true;        // the HBM-bound kernels of this session take the cache's lane (option "exclusive_kernels")
   hipEvent_t ev_lane_[4] = {nullptr, nullptr, nullptr, nullptr};   // probe pair, hit gather, miss scatter, insert

@@ -14,18 +14,22 @@ uint32_t GatherGridBlocks(uint64_t N, int cu_count);
 // tail: the tile's first wave also does K_M's work (call-wide unique misses) — then LaunchMissUnique must NOT follow.  Only for
 // variants with tile dedup and without claim (ProbeTailAvailable).
 bool ProbeTailAvailable(int variant, bool claim);
+// KTimer: events that take the KERNEL's own start / stop timestamps (hipExtLaunchKernel): what rocprofv3 reports as the launch's
+// duration.  A pair of hipEventRecord around a launch also measures two packet hand-offs on the queue (6-8 us per kernel on
+// the MI355X box: probe 57 against 51.6 us, gather 249 against 241, scatter 30 against 23 in the same run).
+struct KTimer { hipEvent_t start = nullptr, stop = nullptr; };
 hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
-                            bool tail, hipStream_t stream);
+                            bool tail, hipStream_t stream, KTimer kt = {});
 // K_M: call-wide unique missed keys per table (+ exact: unique hit keys) into w.acc / w.uniq_keys / w.rep_of / w.uidx_of
 hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, bool exact,
-                            hipStream_t stream);
+                            hipStream_t stream, KTimer kt = {});
 
 // K_G: hit rows cache -> output from the slot indices K_P left (d_call carries the output pointers).
 hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream);
+                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream, KTimer kt = {});
 
 hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tables, const MissDesc* d_md, const CallWork& w,
-                             const float* d_staging, hipStream_t stream);
+                             const float* d_staging, hipStream_t stream, KTimer kt = {});
 
 hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w,
                                  const uint32_t* d_table_mode, hipStream_t stream);
@@ -35,7 +39,7 @@ hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_
 hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const MissDesc* d_md, uint64_t total_unique,
                              const uint64_t* d_key_start, const int64_t* d_uniq_keys, const float* d_staging,
                              const uint8_t* d_found, uint32_t stamps, uint32_t* d_stats, int cu_count,
-                             hipStream_t stream);
+                             hipStream_t stream, KTimer kt = {});
 
 // control words over the compute queue (kernels.hip): call block host -> HBM (bytes rounded up to 16), accumulator words
 // HBM -> host followed by a sequence word

@@ -17,6 +17,7 @@
 // 2 x 16 B per lane (two fully coalesced 256-B segments).  A bucket line (14 keys + 14 one-byte recency stamps =
 // 128 B, device_types.h) is read by an 8-lane group with a single 16-B load per lane: tools/micro/probe_width.hip
 // measures 30.7 us for 1.1 M random lines that way against 39.0 us with sixteen 8-B loads.
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -862,7 +863,7 @@ static inline uint32_t ListSubBlocks(uint32_t tiles) {
 bool ProbeTailAvailable(int variant, bool claim) { return !claim && (variant / 100) % 10 == 0; }
 
 hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
-                            bool tail, hipStream_t stream) {
+                            bool tail, hipStream_t stream, KTimer kt) {
   if (w.num_tiles == 0) return hipSuccess;
   if (tail && !ProbeTailAvailable(variant, claim)) return hipErrorInvalidValue;
   // variant = U + 100 * no_dedup + 1000 * wide   (U in {2,4,8}: bucket lines in flight per 16-lane group; wide: 512 threads
@@ -873,9 +874,9 @@ hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_table
 #define HPS_PT(DD, CC, UU, TT)                                                                                         \
   do {                                                                                                                 \
     if (tail && DD && !CC)                                                                                             \
-      hipLaunchKernelGGL((hps_probe_tile_kernel<DD, false, UU, TT, DD && !CC>), dim3(w.num_tiles), dim3(TT), 0, stream, d_call, d_tables, w); \
+      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, false, UU, TT, DD && !CC>), dim3(w.num_tiles), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w); \
     else                                                                                                               \
-      hipLaunchKernelGGL((hps_probe_tile_kernel<DD, CC, UU, TT, false>), dim3(w.num_tiles), dim3(TT), 0, stream, d_call, d_tables, w);        \
+      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, CC, UU, TT, false>), dim3(w.num_tiles), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);        \
   } while (0)
 #define HPS_PT_T(DD, CC, UU)                      \
   do {                                            \
@@ -898,32 +899,32 @@ hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_table
 }
 
 hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, bool exact,
-                            hipStream_t stream) {
+                            hipStream_t stream, KTimer kt) {
   if (w.num_tiles == 0) return hipSuccess;
   const uint32_t blocks = (w.num_tiles + 3) / 4;   // one wave per tile
-  if (exact) hipLaunchKernelGGL(hps_miss_unique_kernel<true>, dim3(blocks), dim3(256), 0, stream, d_call, d_tables, w);
-  else hipLaunchKernelGGL(hps_miss_unique_kernel<false>, dim3(blocks), dim3(256), 0, stream, d_call, d_tables, w);
+  if (exact) hipExtLaunchKernelGGL(hps_miss_unique_kernel<true>, dim3(blocks), dim3(256), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);
+  else hipExtLaunchKernelGGL(hps_miss_unique_kernel<false>, dim3(blocks), dim3(256), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);
   return hipGetLastError();
 }
 
 hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream) {
+                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream, KTimer kt) {
   if (N == 0) return hipSuccess;
   const size_t lds = sizeof(TableLds) * num_tables + sizeof(uint64_t) * (num_tables + 1);
   if (all_128_aligned)
-    hipLaunchKernelGGL((hps_gather_hits_kernel<4, true>), dim3(grid), dim3(kProbeBlockThreads), lds, stream, d_call, d_tables, d_slot,
-                       xcd_walk ? 1u : 0u);
+    hipExtLaunchKernelGGL((hps_gather_hits_kernel<4, true>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
+                          d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
   else
-    hipLaunchKernelGGL((hps_gather_hits_kernel<4, false>), dim3(grid), dim3(kProbeBlockThreads), lds, stream, d_call, d_tables, d_slot,
-                       xcd_walk ? 1u : 0u);
+    hipExtLaunchKernelGGL((hps_gather_hits_kernel<4, false>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
+                          d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
   return hipGetLastError();
 }
 
 hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tables, const MissDesc* d_md, const CallWork& w,
-                             const float* d_staging, hipStream_t stream) {
+                             const float* d_staging, hipStream_t stream, KTimer kt) {
   if (w.num_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(hps_miss_scatter_kernel, dim3(w.num_tiles, ListSubBlocks(w.num_tiles)), dim3(256), 0, stream, d_call, d_tables, d_md,
-                     w, d_staging);
+  hipExtLaunchKernelGGL(hps_miss_scatter_kernel, dim3(w.num_tiles, ListSubBlocks(w.num_tiles)), dim3(256), 0, stream, kt.start, kt.stop, 0,
+                        d_call, d_tables, d_md, w, d_staging);
   return hipGetLastError();
 }
 
@@ -938,14 +939,14 @@ hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_
 hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const MissDesc* d_md, uint64_t total_unique,
                              const uint64_t* d_key_start, const int64_t* d_uniq_keys, const float* d_staging,
                              const uint8_t* d_found, uint32_t stamps, uint32_t* d_stats, int cu_count,
-                             hipStream_t stream) {
+                             hipStream_t stream, KTimer kt) {
   if (total_unique == 0) return hipSuccess;
   uint64_t want = (total_unique + 15) / 16;
   const uint64_t cap = (uint64_t)cu_count * 8;
   if (want > cap) want = cap;
   const size_t lds = (size_t)(T + 1) * 8 + (size_t)T * (8 + 8 + 4) + 16;
-  hipLaunchKernelGGL(hps_cache_insert_kernel, dim3((uint32_t)want), dim3(256), lds, stream, d_tables, T, d_md,
-                     d_key_start, d_uniq_keys, d_staging, d_found, stamps & 0xFFFFu, d_stats);
+  hipExtLaunchKernelGGL(hps_cache_insert_kernel, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, kt.start, kt.stop, 0, d_tables, T, d_md,
+                        d_key_start, d_uniq_keys, d_staging, d_found, stamps & 0xFFFFu, d_stats);
   return hipGetLastError();
 }
 
