@@ -494,6 +494,29 @@ def main():
         [x.start() for x in th]
         [x.join() for x in th]
 
+    # what THIS box's HBM delivers to a plain device-to-device copy (read + write bytes over time): the boxes of the pool differ by
+    # up to 17 % in their HBM-bound kernels with identical code and traffic, and the line should say which kind this one is
+    box_copy_gbs = None
+    try:
+        with torch.cuda.device(dev):
+            xa = torch.empty(1 << 28, dtype=torch.float32, device="cuda")   # 1 GiB
+            xb = torch.empty_like(xa)
+            xa.fill_(1.0)
+            for _ in range(3):
+                xb.copy_(xa)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                xb.copy_(xa)
+            e1.record()
+            torch.cuda.synchronize()
+            box_copy_gbs = 10 * 2 * xa.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del xa, xb
+            torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write(f"[bench] copy-bandwidth probe skipped: {e!r}\n")
+
     # no collector pass of the interpreter inside the timed region (a full pass over a torch process's objects takes tens of
     # milliseconds and holds the GIL the session threads need between two calls)
     import gc
@@ -904,6 +927,9 @@ def main():
                 # the gather kernel alone on its own bytes (4 B slot per key + 8D per hit) — the dominant kernel
                 "frac_gather_own_bytes": (N * 4 + hits * 8 * D) / (gather * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_of_copy_ceiling_6290": achieved / 6290.0,
+                # a 1-GiB device-to-device copy on THIS box right before the timed region (read + write bytes / time)
+                "box_d2d_copy_GBps": box_copy_gbs,
+                "achieved_over_box_copy": achieved / box_copy_gbs if box_copy_gbs else None,
                 # the whole job against the same roofline: at 95 % hit with synchronous insertion the path is bound by PCIe
                 # (every unique missed row + the keys cross the link once), not by HBM
                 "frac_end_to_end": alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
