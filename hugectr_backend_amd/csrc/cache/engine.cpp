@@ -215,7 +215,7 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   static_ = p.embedding_cache_type == EmbeddingCacheType::Static;
-  if (const char* e = std::getenv("HPS_LRU_AGE_SHIFT")) {   // A/B switch: recency unit = 2^shift calls (default 4 calls)
+  if (const char* e = std::getenv("HPS_LRU_AGE_SHIFT")) {   // A/B switch: recency unit = 2^shift calls (default 8 calls)
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 0 && v <= 8) age_shift_ = (uint32_t)v;
   }

@@ -128,8 +128,8 @@ class EmbeddingCache {
     const uint32_t now8 = Stamp8(epoch);
     return now8 | (((now8 + kStampMod - insert_age_) % kStampMod) << 8);
   }
-  uint32_t insert_age_ = 64;  // recency units (HPS_LRU_INSERT_AGE; 0 = plain LRU insertion), < kAgeSaturate
-  uint32_t age_shift_ = 2;   // recency unit = 2^age_shift calls (HPS_LRU_AGE_SHIFT)
+  uint32_t insert_age_ = 32;  // recency units = 256 calls (HPS_LRU_INSERT_AGE; 0 = plain LRU insertion), < kAgeSaturate
+  uint32_t age_shift_ = 3;   // recency unit = 2^age_shift calls (HPS_LRU_AGE_SHIFT): 8 calls; 192 units = 1,536 calls of horizon
 
   std::string model_;
   EmbeddingCacheConfig cfg_;
