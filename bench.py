@@ -494,29 +494,6 @@ def main():
         [x.start() for x in th]
         [x.join() for x in th]
 
-    # what THIS box's HBM delivers to a plain device-to-device copy (read + write bytes over time): the boxes of the pool differ by
-    # up to 17 % in their HBM-bound kernels with identical code and traffic, and the line should say which kind this one is
-    box_copy_gbs = None
-    try:
-        with torch.cuda.device(dev):
-            xa = torch.empty(1 << 28, dtype=torch.float32, device="cuda")   # 1 GiB
-            xb = torch.empty_like(xa)
-            xa.fill_(1.0)
-            for _ in range(3):
-                xb.copy_(xa)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(10):
-                xb.copy_(xa)
-            e1.record()
-            torch.cuda.synchronize()
-            box_copy_gbs = 10 * 2 * xa.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            del xa, xb
-            torch.cuda.empty_cache()
-    except Exception as e:  # noqa: BLE001
-        sys.stderr.write(f"[bench] copy-bandwidth probe skipped: {e!r}\n")
-
     # no collector pass of the interpreter inside the timed region (a full pass over a torch process's objects takes tens of
     # milliseconds and holds the GIL the session threads need between two calls)
     import gc
@@ -573,6 +550,30 @@ def main():
             for s in rp.sessions:
                 s.close()
             rp.sessions, rp.host_batches, rp.run = [], [], None
+
+    # what THIS box's HBM delivers to a plain device-to-device copy (read + write bytes over time): the boxes of the pool differ by
+    # up to 17 % in their HBM-bound kernels with identical code and traffic, and the line should say which kind this one is.
+    # (After the timed region: allocating and freeing the 2 GiB right before it made the first timed block 40 % slower.)
+    box_copy_gbs = None
+    try:
+        with torch.cuda.device(dev):
+            xa = torch.empty(1 << 28, dtype=torch.float32, device="cuda")   # 1 GiB
+            xb = torch.empty_like(xa)
+            xa.fill_(1.0)
+            for _ in range(3):
+                xb.copy_(xa)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                xb.copy_(xa)
+            e1.record()
+            torch.cuda.synchronize()
+            box_copy_gbs = 10 * 2 * xa.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del xa, xb
+            torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write(f"[bench] copy-bandwidth probe skipped: {e!r}\n")
 
     # ---- extra legs (outside the timed region; per-GPU numbers of this rank) --------------------------------
     extra = {}
