@@ -1135,11 +1135,15 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, exact, tail, stream_, Kt(ev_t0_, tail ? ev_t1_ : nullptr));
   if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), wk, exact, stream_, Kt(nullptr, ev_t1_));
   Mark(ev_t1_);
-  if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[0]);
+  // K_G follows K_P at once when the call does not wait for the counts first (no misses lately, or the device-driven tier):
+  // the lane is kept across both — handing it to the other session in between costs two more switches of the GPU between
+  // streams per pair of calls for nothing (every key resident, two sessions: 20 us of idle GPU per step)
+  const bool hold_lane = exclusive_ && !split && e == hipSuccess;
+  if (exclusive_ && !hold_lane) cache_->LaneLeave(stream_, ev_lane_[0]);
   // other sessions' probes chain behind ours: behind K_P, and behind K_M too when it still reads the claim words
   (void)hipEventRecord(ev_probe_, stream_);
   auto gather = [&]() -> hipError_t {
-    if (exclusive_) cache_->LaneEnter(stream_);
+    if (exclusive_ && !hold_lane) cache_->LaneEnter(stream_);
     Mark(ev_g0_);
     const hipError_t ge = LaunchGatherHits(d_call_, cache_->device_tables(), (uint32_t)T, N, w.slot, gather_blocks, all128, xcd_walk_, stream_,
                                            Kt(ev_g0_, ev_g1_));
