@@ -20,6 +20,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -911,7 +912,14 @@ hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_table
                             const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream, KTimer kt) {
   if (N == 0) return hipSuccess;
   const size_t lds = sizeof(TableLds) * num_tables + sizeof(uint64_t) * (num_tables + 1);
-  if (all_128_aligned)
+  static const int gather_u = [] { const char* e = getenv("HPS_GATHER_U"); return e ? atoi(e) : 4; }();
+  if (all_128_aligned && gather_u == 8)
+    hipExtLaunchKernelGGL((hps_gather_hits_kernel<8, true>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
+                          d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
+  else if (all_128_aligned && gather_u == 2)
+    hipExtLaunchKernelGGL((hps_gather_hits_kernel<2, true>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
+                          d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
+  else if (all_128_aligned)
     hipExtLaunchKernelGGL((hps_gather_hits_kernel<4, true>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
                           d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
   else
