@@ -219,6 +219,10 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 0 && v <= 8) age_shift_ = (uint32_t)v;
   }
+  if (const char* e = std::getenv("HPS_LRU_ADMIT")) {
+    const long v = std::strtol(e, nullptr, 10);
+    if (v >= 0 && v <= 15) admit_log2_ = (uint32_t)v;
+  }
   if (const char* e = std::getenv("HPS_LRU_INSERT_AGE")) {
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 0 && v < (long)kAgeSaturate) insert_age_ = (uint32_t)v;

@@ -124,10 +124,13 @@ class EmbeddingCache {
   uint32_t Stamp8(uint32_t epoch) const { return (epoch >> age_shift_) % kStampMod; }
   // what the insert kernel gets: the current unit in byte 0, the stamp of a newly inserted key in byte 1 (insert_age_ units
   // in the past: scan-resistant insertion — a key seen once must be seen again before it outranks keys that were hit)
+  // bits 16..23: the call counter's low byte, bits 24..27: admit_log2_ (the insert kernel's admission rule, kernels.hip)
   uint32_t InsertStamps(uint32_t epoch) const {
     const uint32_t now8 = Stamp8(epoch);
-    return now8 | (((now8 + kStampMod - insert_age_) % kStampMod) << 8);
+    return now8 | (((now8 + kStampMod - insert_age_) % kStampMod) << 8) | ((epoch & 0xFFu) << 16) | ((admit_log2_ & 15u) << 24);
   }
+  uint32_t admit_log2_ = 4;   // HPS_LRU_ADMIT: a new key does not take a slot hit more recently than the insert age, except one
+                              // new key in 2^this (0 = every new key takes the bucket's oldest slot, rounds 1-3's behaviour)
   uint32_t insert_age_ = 32;  // recency units = 256 calls (HPS_LRU_INSERT_AGE; 0 = plain LRU insertion), < kAgeSaturate
   uint32_t age_shift_ = 3;   // recency unit = 2^age_shift calls (HPS_LRU_AGE_SHIFT): 8 calls; 192 units = 1,536 calls of horizon
 

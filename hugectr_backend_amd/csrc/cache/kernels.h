@@ -34,7 +34,7 @@ hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tabl
 hipError_t LaunchMissFillDefault(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w,
                                  const uint32_t* d_table_mode, hipStream_t stream);
 
-// d_stats: kStatLines lines of kAccStride words (insert statistics, see device_types.h); stamps: the current recency unit in byte 0, the stamp of newly inserted keys in byte 1 (EmbeddingCache::InsertStamps)
+// d_stats: kStatLines lines of kAccStride words (insert statistics, see device_types.h); stamps: the current recency unit in byte 0, the stamp of newly inserted keys in byte 1, the call counter's low byte in byte 2, the admission parameter in bits 24..27 (EmbeddingCache::InsertStamps)
 // ((epoch >> age_shift) & 255, EmbeddingCache::Stamp8)
 hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const MissDesc* d_md, uint64_t total_unique,
                              const uint64_t* d_key_start, const int64_t* d_uniq_keys, const float* d_staging,

@@ -666,7 +666,9 @@ __device__ __forceinline__ uint64_t group_bcast64(uint64_t v, int src_lane) {
   return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src_lane, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src_lane, 64);
 }
 
-__global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheDev* __restrict__ tables, uint32_t T,
+// (register budget: 6 waves per SIMD = 80 VGPRs, no scratch; left alone the compiler takes 83 = 5 waves: 37.0 -> 35.8 us;
+//  8 waves = 64 VGPRs + 60 B of scratch: 42 us — profiles/round3/ab_probe_tile_sizes_and_insert_registers.txt)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void hps_cache_insert_kernel(const TableCacheDev* __restrict__ tables, uint32_t T,
                                                                 const MissDesc* __restrict__ md,
                                                                 const uint64_t* __restrict__ key_start,
                                                                 const int64_t* __restrict__ uniq_keys,
@@ -677,6 +679,12 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
   // gets — the current unit minus the cache's insert age (EmbeddingCache::InsertStamps): a key that was asked for once
   // enters the bucket older than the keys that have been hit, and is the first to go unless it is asked for again
   const uint32_t now8 = stamps & 0xFFu, ins8 = (stamps >> 8) & 0xFFu;
+  // Admission (bits 24..27 = k > 0, insert age > 0): the new key's nominal age is the insert age, and plain LRU logic says a
+  // key that would be the OLDEST of its bucket is its own victim — so a slot that was hit more recently than the insert age
+  // is not given up for a key seen once (the key's row has been served; it just stays out of the cache).  One newcomer in
+  // 2^k is let through regardless, chosen by (key hash ^ call counter, bits 16..23): a key that keeps being asked for gets in
+  // within 2^k calls even when all 14 keys of its bucket are hit all the time.
+  const uint32_t ins_age = age_of(now8, ins8), adm_k = (stamps >> 24) & 15u, call8 = (stamps >> 16) & 0xFFu;
   // per-table words of the call in LDS: the table of a flat index is a binary search over the unique-segment starts, and from
   // global memory that search alone was five dependent round trips in front of every key's bucket line (the kernel is a chain
   // of dependent accesses per key: 45 us for 84 K keys)
@@ -745,6 +753,7 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
         if (((got ^ old) >> sh) & 0xFFull) return false;   // somebody else took slot v
       }
     };
+    const bool guarded = adm_k != 0 && ins_age != 0 && ((((uint32_t)(hps_mix64((uint64_t)key) >> 8)) ^ call8) & ((1u << adm_k) - 1u)) != 0;
     int victim = -1;
     bool owned = false;   // victim's stamp byte reads kStampClaimed and has to be turned into now8 at the end
     if (present >= 0) {
@@ -765,14 +774,17 @@ __global__ __launch_bounds__(256) void hps_cache_insert_kernel(const TableCacheD
           // (ins8: what this launch's own inserts leave behind.  Such a slot must not change hands again inside the launch —
           //  its first owner's row stores may still be in flight when the second owner's arrive — so the stamp of new keys
           //  is off limits like the current unit's; a key that was last hit exactly insert-age units ago shares the privilege)
-          if (st != now8 && st != ins8 && st != kStampClaimed) cand = ((((empty >> lig) & 1u) ? 256u : age_of(now8, st)) << 4) | (15u - (uint32_t)lig);
+          if (st != now8 && st != ins8 && st != kStampClaimed) {
+            const uint32_t a = ((empty >> lig) & 1u) ? 256u : age_of(now8, st);
+            if (!(guarded && a < ins_age)) cand = (a << 4) | (15u - (uint32_t)lig);
+          }
         }
         for (int off = 8; off > 0; off >>= 1) {
           const uint32_t o = (uint32_t)__shfl_xor((int)cand, off, 16);
           cand = o > cand ? o : cand;
         }
         const int best = cand ? 15 - (int)(cand & 15u) : -1;
-        if (best < 0) break;  // whole bucket is in use by the current unit
+        if (best < 0) break;  // whole bucket is in use by the current unit (or hit more recently than the newcomer's nominal age)
         if (claim(best)) { victim = best; owned = true; }
       }
     }
@@ -957,7 +969,7 @@ hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const Mi
   if (want > cap) want = cap;
   const size_t lds = (size_t)(T + 1) * 8 + (size_t)T * (8 + 8 + 4) + 16;
   hipExtLaunchKernelGGL(hps_cache_insert_kernel, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, kt.start, kt.stop, 0, d_tables, T, d_md,
-                        d_key_start, d_uniq_keys, d_staging, d_found, stamps & 0xFFFFu, d_stats);
+                        d_key_start, d_uniq_keys, d_staging, d_found, stamps, d_stats);
   return hipGetLastError();
 }
 

@@ -59,6 +59,14 @@ def _native_libs():
     hps_oracle.build()
 
 
+@pytest.fixture
+def plain_lru(monkeypatch):
+    """Caches created inside the test take every new key (HPS_LRU_ADMIT=0): for tests that watch the insert kernel's mechanics
+    (what was missed is resident afterwards) rather than the default admission rule, which keeps a key seen once out of a
+    bucket whose keys were all hit lately."""
+    monkeypatch.setenv("HPS_LRU_ADMIT", "0")
+
+
 def make_tables(spec, seed=20260929, key_space_mult=3, rng=None):
     """spec: list of (R, D).  Keys are a random subset of [0, key_space_mult*R) in random order."""
     from oracle import hps_oracle as O

@@ -182,6 +182,7 @@ def test_direct_reload_drops_vanished_keys():
     assert np.array_equal(_bits(out), _bits(ref))
 
 
+@pytest.mark.usefixtures("plain_lru")   # watches the insert mechanics: every missed key is taken in (conftest.py)
 def test_direct_async_mode_uses_background_inserter():
     """hit rate above the threshold: defaults now, insertion in the background (host inserter), as in the host path."""
     from oracle import hps_oracle as O

@@ -42,6 +42,7 @@ def _queries(rng, tables, num_keys, miss_frac=0.2):
     return np.concatenate(parts) if parts else np.zeros(0, np.int64)
 
 
+@pytest.mark.usefixtures("plain_lru")   # watches the insert mechanics: every missed key is taken in (conftest.py)
 def test_wdl_shape_sync_exact():
     """W&D request shape of the reference sample: D=[1,16], 10 samples, keys/sample [2,26] -> 4180 floats
     (samples/Hierarchical_Parameter_Server_Deployment.ipynb:738-747,793-795)."""
@@ -138,6 +139,7 @@ def test_device_resident_keys_path():
     assert np.array_equal(_bits(out), _bits(ref))
 
 
+@pytest.mark.usefixtures("plain_lru")   # watches the insert mechanics: every missed key is taken in (conftest.py)
 def test_async_insert_mode_returns_default_then_converges():
     """hit rate >= hit_rate_threshold -> missed keys return the default vector now and are inserted in the
     background (docs/architecture.md:32,65-67)."""
@@ -295,6 +297,7 @@ def test_call_counter_wrap(monkeypatch):
     assert cache.counters()["inserted"] > inserted_before  # eviction/insertion keeps working after the wrap
 
 
+@pytest.mark.usefixtures("plain_lru")   # watches the insert mechanics: every missed key is taken in (conftest.py)
 @pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
 def test_insertion_policy_is_decided_per_table(direct):
     """hit_rate_threshold between two tables' hit rates: the hot table answers in async-insert mode (defaults for its
@@ -662,3 +665,43 @@ def test_call_wide_unique_misses_with_the_same_missed_keys_in_every_tile(fused):
     c = cache.counters()
     assert c["inserted"] + c["refreshed"] + c["dropped"] > 0
     s.close()
+
+
+def test_admission_rule_keeps_recently_hit_keys_and_lets_new_keys_in_once_they_aged(monkeypatch):
+    """Default insertion policy (kernels.hip, hps_cache_insert_kernel): a new key's nominal age is the insert age, so it never
+    takes a slot that was hit more recently than that — its row is served exactly, it just stays out of the cache; once
+    the bucket's keys have gone unhit for longer than the insert age, new keys replace them.  Here: recency unit = 1 call,
+    insert age 4 calls, no bypass (HPS_LRU_ADMIT=15: one new key in 32,768 would be let through regardless)."""
+    from oracle import hps_oracle as O
+    monkeypatch.setenv("HPS_LRU_AGE_SHIFT", "0")
+    monkeypatch.setenv("HPS_LRU_INSERT_AGE", "4")
+    monkeypatch.setenv("HPS_LRU_ADMIT", "15")
+    tables = make_tables([(8000, 32)])
+    keys, rows = tables[0]
+    ps, cache, s = _mk("admit", tables, maxcat=[1], gpucacheper=0.5, defaults=[0.0], max_batch=8192)
+    resident0 = keys[cache.query(0, keys) >= 0]
+    cold = keys[cache.query(0, keys) < 0]
+    s.lookup(resident0.astype(np.int64), [resident0.size])                                  # every resident key is hit ...
+    q = cold[:400].astype(np.int64)                                                         # ... one call before 400 new keys arrive
+    out = s.lookup(q, [q.size]).cpu().numpy()
+    assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, [q.size], [0.0])))      # rows exact whatever is admitted
+    c1 = cache.counters()
+    assert (cache.query(0, resident0) >= 0).sum() >= resident0.size - 1                    # nobody hit a call ago was given up
+    in1 = int((cache.query(0, cold[:400]) >= 0).sum())
+    assert 0 < in1 < 400 and c1["dropped"] >= 400 - in1 - 1                                # free slots taken, full buckets refuse
+    for _ in range(6):                                                                      # six calls go by; the residents are not asked for
+        s.lookup(resident0[:1].astype(np.int64), [1])
+    q2 = cold[400:800].astype(np.int64)
+    out2 = s.lookup(q2, [q2.size]).cpu().numpy()
+    assert np.array_equal(_bits(out2), _bits(O.np_lookup(tables, q2, [q2.size], [0.0])))
+    assert (cache.query(0, q2) >= 0).mean() > 0.97                                         # older than the insert age: replaced
+    # plain LRU insertion for comparison (HPS_LRU_ADMIT=0): the same two calls evict keys that were hit a call ago
+    monkeypatch.setenv("HPS_LRU_ADMIT", "0")
+    ps0, cache0, s0 = _mk("admit0", tables, maxcat=[1], gpucacheper=0.5, defaults=[0.0], max_batch=8192)
+    r0 = keys[cache0.query(0, keys) >= 0]
+    c0 = keys[cache0.query(0, keys) < 0]
+    s0.lookup(r0.astype(np.int64), [r0.size])
+    q = c0[:400].astype(np.int64)
+    out = s0.lookup(q, [q.size]).cpu().numpy()
+    assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, [q.size], [0.0])))
+    assert (cache0.query(0, q) >= 0).mean() > 0.97 and (cache0.query(0, r0) >= 0).sum() < r0.size - 20

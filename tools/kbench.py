@@ -62,30 +62,36 @@ def main():
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1)
     cdf = torch.from_numpy(B.zipf_cdf(C, a.zipf)).cuda()
-    batches = B.make_batches_gpu(torch, gen, resident, cdf, R, C, Bn, a.hit, a.iters)
+    variants = [(int(v), int(b)) for v in a.variants.split(",") for b in a.xcd.split(",")]
+    # with misses in the batches every batch is used ONCE (a replayed batch finds its cold keys inserted): one batch per
+    # variant and step, the variants taking turns
+    fresh = a.hit < 1.0
+    batches = B.make_batches_gpu(torch, gen, resident, cdf, R, C, Bn, a.hit, a.iters * (a.rounds * len(variants) + 1) if fresh else a.iters)
     out = torch.empty(N * D, dtype=torch.float32, device="cuda")
     nk = [Bn] * T
     print(f"setup {time.time() - t0:.1f}s", flush=True)
-    variants = [(int(v), int(b)) for v in a.variants.split(",") for b in a.xcd.split(",")]
     res = {v: [] for v in variants}
-    for v, x in variants:  # warm
+    for i, (v, x) in enumerate(variants):  # warm
         s.set_option("probe_variant", v)
         s.set_option("xcd_walk", x)
-        s.lookup_device(batches[0], nk, out=out)
+        s.lookup_device(batches[i % a.iters], nk, out=out)
+    nxt = a.iters   # (fresh: the first a.iters batches warmed the variants up)
     for r in range(a.rounds):
         for v, x in variants:
             s.set_option("probe_variant", v)
             s.set_option("xcd_walk", x)
-            for b in batches:
+            for b in (batches[nxt:nxt + a.iters] if fresh else batches):
                 s.lookup_device(b, nk, out=out)
                 st = s.last_stats()
-                res[(v, x)].append((st.probe_gather_ms, st.hit_gather_ms))
+                res[(v, x)].append((st.probe_gather_ms, st.hit_gather_ms, st.scatter_ms, st.insert_ms))
+            nxt += a.iters if fresh else 0
     alg = N * (8 + 8 * D)
     for v, x in variants:
         arr = np.array(res[(v, x)])
         p, g = float(np.median(arr[:, 0])), float(np.median(arr[:, 1]))
         print(f"variant {v:4d} xcd_walk={x}: probe median {p * 1e3:7.1f} us (min {arr[:, 0].min() * 1e3:7.1f})  gather median {g * 1e3:7.1f} us "
-              f"(min {arr[:, 1].min() * 1e3:7.1f})  frac(probe+gather) {alg / ((p + g) * 1e-3) / 8e12:.3f}  n={arr.shape[0]}")
+              f"(min {arr[:, 1].min() * 1e3:7.1f})  scatter median {np.median(arr[:, 2]) * 1e3:6.1f}  insert median {np.median(arr[:, 3]) * 1e3:6.1f} us  "
+              f"frac(probe+gather) {alg / ((p + g) * 1e-3) / 8e12:.3f}  n={arr.shape[0]}")
 
 
 if __name__ == "__main__":
