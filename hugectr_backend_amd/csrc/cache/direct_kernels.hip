@@ -89,53 +89,118 @@ __device__ __forceinline__ int find_table_d(const uint64_t* ks, int T, uint64_t 
   return lo;
 }
 
-// One 16-lane group per unique missed key: the group reads 16 consecutive index slots (128 B) per probe step,
-// then moves the row host -> staging with 16-B loads per lane (two coalesced 256-B PCIe read bursts for D=128).
+// One 16-lane group per unique missed key, kRows keys per group and step: the group reads 16 consecutive index slots
+// (128 B) per key and probe step, then moves the rows host -> staging with 16-B loads per lane (two coalesced 256-B PCIe
+// read bursts per D=128 row).  Round 3 (last session): a group used to walk ONE key at a time through a chain of dependent
+// accesses — table search over md in global memory, key, index line (HBM), row (PCIe, a few microseconds) — so a group had
+// a row on the link for about half of its time, and the kernel moved 41-43 GB/s of the 53-55 the link delivers (fetch
+// 0.9 ms for 37.5 MB, with or without other kernels next to it).  Now the per-table words sit in LDS, the kRows index
+// lines of a step are in flight together, and so are its kRows rows (2 x kRows 16-B loads per lane).
+template <int kRows>
 __global__ __launch_bounds__(256) void hps_ps_fetch_direct_kernel(const PsIndexDev* __restrict__ index, uint32_t T,
                                                                   const MissDesc* __restrict__ md,
                                                                   const uint64_t* __restrict__ key_start,
                                                                   const int64_t* __restrict__ uniq_keys,
                                                                   float* __restrict__ staging, uint8_t* __restrict__ found) {
-  const uint64_t total = md->useg_start[T];
+  extern __shared__ __attribute__((aligned(16))) char fd_smem[];
+  uint64_t* sh_us = reinterpret_cast<uint64_t*>(fd_smem);   // [T + 1] unique-segment starts
+  uint64_t* sh_ks = sh_us + (T + 1);                         // [T] key_start
+  uint64_t* sh_so = sh_ks + T;                               // [T] stage_off
+  PsIndexDev* sh_ix = reinterpret_cast<PsIndexDev*>(sh_so + T);   // [T]
+  for (uint32_t t = threadIdx.x; t <= T; t += blockDim.x) sh_us[t] = md->useg_start[t];
+  for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) { sh_ks[t] = key_start[t]; sh_so[t] = md->stage_off[t]; sh_ix[t] = index[t]; }
+  __syncthreads();
+  const uint64_t total = sh_us[T];
   const int lane = threadIdx.x & 63, g = lane >> 4, lig = lane & 15;
   const uint64_t groups_total = (uint64_t)gridDim.x * 16;
-  for (uint64_t f = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4); f < total; f += groups_total) {
-    const int t = find_table_d(md->useg_start, (int)T, f);
-    const PsIndexDev ix = index[t];
-    const uint32_t u = (uint32_t)(f - md->useg_start[t]);
-    const int64_t key = uniq_keys[key_start[t] + u];
-    const uint32_t D = ix.dim;
-    float* dst = staging + md->stage_off[t] + (uint64_t)u * D;
-    int64_t row = -1;
-    if (key == HPS_EMPTY_KEY) {
-      row = ix.has_sentinel ? (int64_t)ix.sentinel_row : -1;
-    } else if (ix.keys != nullptr) {
-      const uint64_t h = idx_hash(key) & ix.mask;
-      uint64_t blk = h >> 4;
-      const uint64_t nblk = (ix.mask + 1) >> 4;
-      uint32_t first_lane = (uint32_t)(h & 15);
-      for (uint64_t step = 0; step < nblk; ++step) {
-        const uint64_t s = (blk << 4) + lig;
-        const int64_t k = ix.keys[s];
-        const uint32_t hit = (uint32_t)(__ballot(k == key) >> (g * 16)) & 0xFFFFu;
-        if (hit) { row = (int64_t)ix.rows[(blk << 4) + (uint32_t)__builtin_ctz(hit)]; break; }
-        const uint32_t empty = (uint32_t)(__ballot(k == HPS_EMPTY_KEY && (uint32_t)lig >= first_lane) >> (g * 16)) & 0xFFFFu;
-        if (empty) break;  // an empty slot ends the probe sequence: the key is not in the table
-        blk = blk + 1 == nblk ? 0 : blk + 1;
-        first_lane = 0;
+  for (uint64_t f0 = ((uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4)) * kRows; f0 < total; f0 += groups_total * kRows) {
+    int tt[kRows];
+    int64_t key[kRows], row[kRows], k0[kRows];
+    uint64_t blk[kRows];
+    float* dst[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const uint64_t f = f0 + r < total ? f0 + r : f0;   // (a group's last step may be short: its spare rows repeat the first)
+      tt[r] = find_table_d(sh_us, (int)T, f);
+      const uint32_t u = (uint32_t)(f - sh_us[tt[r]]);
+      key[r] = uniq_keys[sh_ks[tt[r]] + u];
+      dst[r] = staging + sh_so[tt[r]] + (uint64_t)u * sh_ix[tt[r]].dim;
+    }
+    // first index block of every key: the kRows 128-B lines are in flight together
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const PsIndexDev& ix = sh_ix[tt[r]];
+      blk[r] = (idx_hash(key[r]) & ix.mask) >> 4;
+      k0[r] = (ix.keys != nullptr && key[r] != HPS_EMPTY_KEY) ? ix.keys[(blk[r] << 4) + lig] : HPS_EMPTY_KEY;
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const PsIndexDev& ix = sh_ix[tt[r]];
+      row[r] = -1;
+      if (key[r] == HPS_EMPTY_KEY) {
+        row[r] = ix.has_sentinel ? (int64_t)ix.sentinel_row : -1;
+      } else if (ix.keys != nullptr) {
+        const uint64_t nblk = (ix.mask + 1) >> 4;
+        uint32_t first_lane = (uint32_t)((idx_hash(key[r]) & ix.mask) & 15);
+        int64_t k = k0[r];
+        for (uint64_t step = 0; step < nblk; ++step) {
+          const uint32_t hit = (uint32_t)(__ballot(k == key[r]) >> (g * 16)) & 0xFFFFu;
+          if (hit) { row[r] = (int64_t)ix.rows[(blk[r] << 4) + (uint32_t)__builtin_ctz(hit)]; break; }
+          const uint32_t empty = (uint32_t)(__ballot(k == HPS_EMPTY_KEY && (uint32_t)lig >= first_lane) >> (g * 16)) & 0xFFFFu;
+          if (empty) break;  // an empty slot ends the probe sequence: the key is not in the table
+          blk[r] = blk[r] + 1 == nblk ? 0 : blk[r] + 1;
+          first_lane = 0;
+          k = ix.keys[(blk[r] << 4) + lig];
+        }
       }
     }
-    if (row >= 0) {
-      const float* src = ix.host_rows + (uint64_t)row * D;  // pinned host memory, read over PCIe
-      if ((D & 3u) == 0) {
-        for (uint32_t c = (uint32_t)lig * 4; c < D; c += 64) *reinterpret_cast<f4d*>(dst + c) = *reinterpret_cast<const f4d*>(src + c);
-      } else {
-        for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = src[c];
+    // rows: pinned host memory, read over PCIe
+    bool fast = true;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) fast = fast && sh_ix[tt[r]].dim == 128u;
+    if (fast) {
+      f4d v[kRows][2];
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        if (row[r] >= 0) {
+          const float* src = sh_ix[tt[r]].host_rows + (uint64_t)row[r] * 128u;
+          v[r][0] = *reinterpret_cast<const f4d*>(src + lig * 4);
+          v[r][1] = *reinterpret_cast<const f4d*>(src + 64 + lig * 4);
+        } else {
+          const float dv = sh_ix[tt[r]].default_value;
+          v[r][0] = f4d{dv, dv, dv, dv};
+          v[r][1] = v[r][0];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        if (f0 + r < total) {
+          *reinterpret_cast<f4d*>(dst[r] + lig * 4) = v[r][0];
+          *reinterpret_cast<f4d*>(dst[r] + 64 + lig * 4) = v[r][1];
+        }
       }
     } else {
-      for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = ix.default_value;
+      for (int r = 0; r < kRows; ++r) {
+        if (f0 + r >= total) continue;
+        const PsIndexDev& ix = sh_ix[tt[r]];
+        const uint32_t D = ix.dim;
+        if (row[r] >= 0) {
+          const float* src = ix.host_rows + (uint64_t)row[r] * D;
+          if ((D & 3u) == 0) {
+            for (uint32_t c = (uint32_t)lig * 4; c < D; c += 64) *reinterpret_cast<f4d*>(dst[r] + c) = *reinterpret_cast<const f4d*>(src + c);
+          } else {
+            for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[r][c] = src[c];
+          }
+        } else {
+          for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[r][c] = ix.default_value;
+        }
+      }
     }
-    if (lig == 0) found[f] = row >= 0 ? 1 : 0;
+    if (lig == 0) {
+#pragma unroll
+      for (int r = 0; r < kRows; ++r)
+        if (f0 + r < total) found[f0 + r] = row[r] >= 0 ? 1 : 0;
+    }
   }
 }
 
@@ -163,21 +228,41 @@ hipError_t LaunchPsFetchDirect(const PsIndexDev* d_index, uint32_t T, const Miss
                                const int64_t* d_uniq_keys, float* d_staging, uint8_t* d_found, uint64_t max_unique,
                                int grid_blocks, hipStream_t stream) {
   if (max_unique == 0) return hipSuccess;
-  uint64_t want = (max_unique + 15) / 16;
-  // Grid = rows in flight over PCIe (16 per block), not chip occupancy: ~512 rows in flight saturate the link
-  // (tools/micro/pcie_contention.hip), each group also spends part of its time in the index probe, and every
-  // extra wave only costs the HBM-bound kernels of the other sessions running underneath.
+  // Grid = rows in flight over PCIe, not chip occupancy.  Round 3 (last session), 37.5 MB of missed rows per call out of a
+  // 133-GB page-locked host tier, two sessions (profiles/round3/ab_direct_fetch_grid.txt): 32 blocks x 16 groups x 4 rows in
+  // flight move 43 GB/s and leave the other session's probe and gather alone (59 / 214 us); 64 blocks saturate the link
+  // (0.70 ms = 53.6 GB/s) but the probe next to them takes 151 us and the gather 241, and the step is no shorter; one
+  // row per group needs 128 blocks for the same rate and disturbs more (probe 190 us).  HPS_DIRECT_FETCH_BLOCKS /
+  // HPS_DIRECT_FETCH_ROWS (1, 2, 4, 8) for A/B.
   static const int max_blocks = [] {
     const char* e = getenv("HPS_DIRECT_FETCH_BLOCKS");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 128;
+    return v > 0 ? v : 32;
   }();
+  static const int rows_in_flight = [] {
+    const char* e = getenv("HPS_DIRECT_FETCH_ROWS");   // keys (index lines, then rows) in flight per 16-lane group
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 4;
+  }();
+  const uint64_t per_block = 16ull * (uint64_t)(rows_in_flight >= 8 ? 8 : rows_in_flight >= 4 ? 4 : rows_in_flight >= 2 ? 2 : 1);
+  uint64_t want = (max_unique + per_block - 1) / per_block;
   // grid_blocks > 0: the caller's own bound (the background inserter runs a small grid: it is in no hurry, and
   // fewer PCIe reads in flight disturb the probe kernels of the foreground lookups less)
   const uint64_t cap = (uint64_t)(grid_blocks > 0 ? grid_blocks : max_blocks);
   if (want > cap) want = cap;
-  hipLaunchKernelGGL(hps_ps_fetch_direct_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_index, T, d_md, d_key_start,
-                     d_uniq_keys, d_staging, d_found);
+  const size_t lds = (size_t)(T + 1) * 8 + (size_t)T * (8 + 8 + sizeof(PsIndexDev)) + 16;
+  if (rows_in_flight >= 8)
+    hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<8>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
+                       d_uniq_keys, d_staging, d_found);
+  else if (rows_in_flight >= 4)
+    hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<4>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
+                       d_uniq_keys, d_staging, d_found);
+  else if (rows_in_flight >= 2)
+    hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<2>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
+                       d_uniq_keys, d_staging, d_found);
+  else
+    hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<1>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
+                       d_uniq_keys, d_staging, d_found);
   return hipGetLastError();
 }
 

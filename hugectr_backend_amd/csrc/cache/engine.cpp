@@ -504,7 +504,7 @@ Status EmbeddingCache::FinishDirectInsert() {
   // not part of the foreground fetch chain: a small grid that takes its time must not hold up a lookup's fetch
   if (e == hipSuccess)
     e = LaunchPsFetchDirect(d_index_, (uint32_t)T, I.d_md, I.d_key_start, I.d_keys, I.d_staging, I.d_found, I.unique_total,
-                            /*grid_blocks=*/32, I.stream);
+                            /*grid_blocks=*/8, I.stream);
   if (e != hipSuccess) return Error(Code::kInternal, "direct background fetch launch failed: ", hipGetErrorString(e));
   HIP_TRY(hipStreamSynchronize(I.stream));
   BeginWrite(I.stream);
@@ -606,6 +606,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   for (hipEvent_t* e : {&ev_t0_, &ev_t1_, &ev_f0_, &ev_f1_, &ev_c1_, &ev_g0_, &ev_g1_, &ev_s0_, &ev_s1_, &ev_i0_, &ev_i1_}) HIP_TRY(hipEventCreate(e));
   for (hipEvent_t& e : ev_lane_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char* e = std::getenv("HPS_EXCLUSIVE_KERNELS")) exclusive_ = std::strtol(e, nullptr, 10) != 0;
+  if (const char* e = std::getenv("HPS_DIRECT_SPLIT")) direct_split_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_FUSED_UNIQUE")) fused_unique_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_KERNEL_TIMESTAMPS")) kernel_stamps_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switches
@@ -1115,9 +1116,11 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   // probe, and the hit rows are gathered by K_G while the host threads gather the missed rows and the DMA engine
   // uploads them — HBM-bound and PCIe-bound halves of one call side by side.  Otherwise K_G runs before the counts
   // are read (a call that missed nothing then needs no second synchronisation).
-  // (device-driven tier: measured and left un-split.  With K_G on the session's stream and the staging layout + fetch
-  //  kernel on the second one, config 2 dropped from 1.85 to 1.70 G lookups/s: the fetch kernel then shares the memory
-  //  system with its own session's K_G as well as the other session's kernels.)
+  // (device-driven tier: its own split, direct_split_ — staging layout + fetch kernel on the second stream next to K_G on
+  //  the session's stream, HandleMissesDirect.  Round 1 measured this arrangement 8 % slower with the fetch kernel of the
+  //  time, 2,048 single-row groups that shared the memory system with K_G; with round 3's small fetch grid it is 4 % faster:
+  //  1.74 / 1.75 -> 1.83 / 1.81 G lookups/s, profiles/round3/ab_direct_fetch_grid.txt.  Putting the fetch kernel into the
+  //  lane instead — nothing next to it at all — gave 1.34 against 1.59 G.)
   const bool split = split_probe_ && !use_direct && last_misses_ > 0;
   const int cu = cache_->cu_count();
   const uint32_t gather_blocks = GatherGridBlocks(N, cu);
@@ -1375,7 +1378,13 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   const size_t T = tables_.size();
   const int cu = cache_->cu_count();
   const uint64_t max_unique = counts_known ? (uint64_t)last_unique_ : N;
+  // direct_split_: staging layout + PCIe fetch on the session's second stream, released by the probe alone — they run next
+  // to this call's own hit gather; the scatter waits for both
   hipStream_t fs = stream_;
+  if (direct_split_ && !counts_known) {
+    fs = copy_stream_;
+    HIP_TRY(hipStreamWaitEvent(fs, ev_probe_, 0));
+  }
   hipError_t e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_acc_, d_md_, /*clear_stats=*/false, d_table_mode, fs);
   if (e == hipSuccess) {
     cache_->BeginFetch(fs);
@@ -1384,6 +1393,7 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
                             d_found_, max_unique, 0, fs);
     if (timing_) (void)hipEventRecord(ev_f1_, fs);
     cache_->EndFetch(fs, ev_fetch_);
+    if (fs != stream_) (void)hipStreamWaitEvent(stream_, ev_fetch_, 0);
   }
   if (e != hipSuccess) return Error(Code::kInternal, "direct miss path launch failed: ", hipGetErrorString(e));
   // Keep the window in which other sessions' kernels wait for our scatter (lane) and our writer event down to those two

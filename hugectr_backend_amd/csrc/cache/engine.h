@@ -357,6 +357,7 @@ class LookupSession {
   bool fused_unique_ = true;     // the call-wide unique misses are found in the probe kernel's tail (option "fused_unique", HPS_FUSED_UNIQUE)
   bool exclusive_ = true;        // the HBM-bound kernels of this session take the cache's lane (option "exclusive_kernels")
   hipEvent_t ev_lane_[4] = {nullptr, nullptr, nullptr, nullptr};   // probe pair, hit gather, miss scatter, insert
+  bool direct_split_ = true;     // device-driven tier: the fetch kernel runs next to the call's own hit gather (HPS_DIRECT_SPLIT=0: behind it)
   bool narrow_publish_ = true;   // a narrowed request's unique missed keys come back to the host as uint32 (option "narrow_publish")
   bool uniq_narrow_ = false;     // this call: h_uniq_keys_ holds uint32 keys
   bool chain_gather_ = false;    // other sessions' probes queue behind this session's gather as well as its probe
