@@ -42,7 +42,7 @@ constexpr int kProbeBlockThreads = 256;
 // ~0.09 G/s: tools/micro/atomic_rate.hip).
 constexpr int kTileKeys = 1024;
 constexpr int kTileSet = 2048;   // LDS set entries of the tile-local input dedup (load <= 0.5)
-enum : int { kTileCntRepMiss = 0, kTileCntSentMiss = 1, kTileCntRepHit = 2 };
+enum : int { kTileCntRepMiss = 0, kTileCntSentMiss = 1 };
 
 // Per-call accumulator block (uint32 words in HBM, zeroed by the call's descriptor upload, copied back whole):
 //   line s in [0, kStatLines)      : [0] dropped [1] inserted [2] refreshed — insert statistics, block b of the insert
@@ -71,7 +71,6 @@ struct TableCacheDev {
   uint32_t dim;
   float default_value;
   uint32_t flags;  // bit0: static cache (no stamp writes, no inserts)
-  uint32_t* claim; // [num_buckets*14] scratch word per slot for the unique-hit count (nullptr until a session needs it)
 };
 
 // One probe tile: keys [begin, begin + count) of the call's flat key array, all of table `table`.
@@ -91,8 +90,6 @@ struct CallWork {
   int64_t* miss_key;         // tile regions: key of the tile's r-th missed representative
   int32_t* sent_i;           // tile regions: global index of every missed key of the tile, as sent
   int32_t* sent_m;           // tile regions: the same keys' entry m of the tile's miss list (slot[sent_i[r]] == -2 - sent_m[r])
-  int32_t* hit_i;            // tile regions: global index of the tile's hit representatives (unique-hit count only)
-  int32_t* hit_s;            // tile regions: their slots
   int32_t* rep_of;           // tile regions: m -> m of the call-wide representative of the same (table, key)
   int32_t* uidx_of;          // tile regions: valid at representatives: index in the table's unique-miss segment
   unsigned long long* set;   // open addressing, entries (call_tag << 32 | m); other tags = free

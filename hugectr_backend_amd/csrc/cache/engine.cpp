@@ -99,27 +99,6 @@ void EmbeddingCache::AddStatLines(const uint32_t* lines) {
   counters_.refreshed += v[2];
 }
 
-// One scratch word per cache slot, next to the LRU stamps: the probe kernel of a call whose insertion policy needs the
-// hit rate marks the slots it hits, and the miss-unique kernel counts the marks that survived (= distinct slots = unique
-// hit keys).  Probes of one cache run one at a time (BeginRead chains them), so one array per cache is enough.
-Status EmbeddingCache::EnsureClaimWords() {
-  if (has_claim_.load(std::memory_order_acquire)) return Status::Ok();
-  std::lock_guard<std::mutex> lk(order_mu_);
-  if (has_claim_.load(std::memory_order_relaxed)) return Status::Ok();
-  HIP_TRY(hipSetDevice(cfg_.device_id_));
-  HIP_TRY(hipDeviceSynchronize());   // no kernel may be reading the table descriptors while they are replaced
-  for (TableCacheDev& tb : h_tables_) {
-    uint32_t* c = nullptr;
-    HPS_RETURN_IF_ERROR(DevAlloc(&c, (size_t)tb.num_buckets * kBucketSlots));
-    allocations_.push_back(c);
-    tb.claim = c;
-  }
-  HIP_TRY(hipMemcpy(d_tables_, h_tables_.data(), h_tables_.size() * sizeof(TableCacheDev), hipMemcpyHostToDevice));
-  HIP_TRY(hipDeviceSynchronize());
-  has_claim_.store(true, std::memory_order_release);
-  return Status::Ok();
-}
-
 // The call counter of the cache: one tick per lookup call (and per background insert), 32 bits, wraps freely.  What the
 // kernels see of it is Stamp8(): the counter in units of 2^age_shift calls modulo kStampMod (device_types.h).  At the
 // 32-bit wrap the stamps jump once (2^32 is not a multiple of 255 units): a blip in the eviction order, nothing else.
@@ -256,7 +235,6 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
     tb.dim = D;
     tb.default_value = p.default_value_for_each_table[t];
     tb.flags = static_ ? 1u : 0u;
-    tb.claim = nullptr;
     cfg_.embedding_vec_size_.push_back(D);
     cfg_.num_set_in_cache_.push_back(buckets);
     cfg_.capacity_rows_.push_back(cap);
@@ -565,7 +543,7 @@ void LookupSession::Release() {
   auto dfree = [](void* p) { if (p) (void)hipFree(p); };
   hfree(h_keys_pinned_); dfree(d_keys_); hfree(h_block_); dfree(d_block_); hfree(h_acc_); dfree(d_mode_);
   hfree(h_md_); dfree(d_md_);
-  dfree(work_.slot); dfree(work_.tile_cnt); dfree(work_.miss_key); dfree(work_.sent_i); dfree(work_.sent_m); dfree(work_.hit_i); dfree(work_.hit_s);
+  dfree(work_.slot); dfree(work_.tile_cnt); dfree(work_.miss_key); dfree(work_.sent_i); dfree(work_.sent_m);
   dfree(work_.rep_of); dfree(work_.uidx_of); dfree(work_.set); dfree(work_.uniq_keys);
   hfree(h_mode_);
   hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
@@ -664,7 +642,6 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HPS_RETURN_IF_ERROR(DevAlloc(&w.sent_m, regions));
   HPS_RETURN_IF_ERROR(DevAlloc(&w.rep_of, regions));
   HPS_RETURN_IF_ERROR(DevAlloc(&w.uidx_of, regions));
-  w.hit_i = w.hit_s = nullptr;  // allocated with the first call whose policy needs the unique-key count
   uint64_t set_cap = 1024;
   while (set_cap < 2 * (uint64_t)max_keys_) set_cap <<= 1;
   HPS_RETURN_IF_ERROR(DevAlloc(&w.set, set_cap));
@@ -1095,11 +1072,6 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   // docs/architecture.md:66: "the real hit rate of the GPU embedding cache lookup"); a threshold outside (0,1) decides
   // without the rate, and then the unique-hit count is not taken.
   const bool exact = params_.hit_rate_threshold > 0.0f && params_.hit_rate_threshold < 1.0f;
-  if (exact) {
-    HPS_RETURN_IF_ERROR(cache_->EnsureClaimWords());
-    if (!work_.hit_i) HPS_RETURN_IF_ERROR(DevAlloc(&work_.hit_i, max_tiles_ * (size_t)kTileKeys));
-    if (!work_.hit_s) HPS_RETURN_IF_ERROR(DevAlloc(&work_.hit_s, max_tiles_ * (size_t)kTileKeys));
-  }
   uint64_t N = 0;
   HPS_RETURN_IF_ERROR(PrepareCall(d_keys_flat, d_out, n, T, /*probe_only=*/false, &N));
   const CallDesc& c = *h_call_;
@@ -1138,16 +1110,23 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   cache_->BeginRead(stream_);
   if (exclusive_) cache_->LaneEnter(stream_);
   Mark(ev_t0_);
-  const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_, exact);
-  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, exact, tail, stream_, Kt(ev_t0_, tail ? ev_t1_ : nullptr));
-  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), wk, exact, stream_, Kt(nullptr, ev_t1_));
+  const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_);
+  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, tail, stream_, Kt(ev_t0_, tail && !exact ? ev_t1_ : nullptr));
+  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), wk, stream_, Kt(nullptr, exact ? nullptr : ev_t1_));
+  if (e == hipSuccess && exact) {
+    // K_H: unique hit keys per table = distinct slots among the slot words K_P has just written (LDS bitmaps, kernels.hip)
+    uint32_t parts = 0;
+    for (size_t t = 0; t < T; ++t)
+      if (n[t]) parts += UniqueHitsParts((uint64_t)cache_->host_tables()[t].num_buckets * kBucketSlots);
+    e = LaunchUniqueHits(d_call_, cache_->device_tables(), parts, w.slot, d_acc_, stream_, Kt(nullptr, ev_t1_));
+  }
   Mark(ev_t1_);
   // K_G follows K_P at once when the call does not wait for the counts first (no misses lately, or the device-driven tier):
   // the lane is kept across both — handing it to the other session in between costs two more switches of the GPU between
   // streams per pair of calls for nothing (every key resident, two sessions: 20 us of idle GPU per step)
   const bool hold_lane = exclusive_ && !split && e == hipSuccess;
   if (exclusive_ && !hold_lane) cache_->LaneLeave(stream_, ev_lane_[0]);
-  // other sessions' probes chain behind ours: behind K_P, and behind K_M too when it still reads the claim words
+  // other sessions' probes chain behind ours (K_P, and K_M / K_H where they are launches of their own)
   (void)hipEventRecord(ev_probe_, stream_);
   auto gather = [&]() -> hipError_t {
     if (exclusive_ && !hold_lane) cache_->LaneEnter(stream_);
@@ -1328,9 +1307,9 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
 
   cache_->BeginRead(stream_);   // ---- read lock: held (order mutex + reader event) until the interaction is enqueued ----
   Mark(ev_t0_);
-  const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_, false);
-  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), w, probe_variant_, false, tail, stream_, Kt(ev_t0_, tail ? ev_t1_ : nullptr));
-  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), w, false, stream_, Kt(nullptr, ev_t1_));
+  const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_);
+  hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), w, probe_variant_, tail, stream_, Kt(ev_t0_, tail ? ev_t1_ : nullptr));
+  if (e == hipSuccess && !tail) e = LaunchMissUnique(d_call_, cache_->device_tables(), w, stream_, Kt(nullptr, ev_t1_));
   Mark(ev_t1_);
   (void)hipEventRecord(ev_probe_, stream_);
   if (e == hipSuccess) e = LaunchMissDescBuild(cache_->device_tables(), (uint32_t)T, d_acc_, d_md_, /*clear_stats=*/false, nullptr, stream_);

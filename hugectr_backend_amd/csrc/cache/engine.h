@@ -73,9 +73,6 @@ class EmbeddingCache {
   CacheCounters counters() const;
   void AddStatLines(const uint32_t* lines);   // insert statistics of one launch series: kStatLines accumulator lines
 
-  // Allocates the per-slot claim words the probe kernel needs to count a call's unique hit keys (only sessions whose
-  // insertion policy depends on the hit rate ask for them: 0 < hit_rate_threshold < 1).  Idempotent.
-  Status EnsureClaimWords();
   // slot index (>=0) or -1 per key, straight from the device tables; no LRU side effect (tests, refresh)
   Status Query(uint32_t table, const int64_t* h_keys, size_t n, int32_t* h_slots);
   // every resident key of one table (order unspecified)
@@ -155,7 +152,6 @@ class EmbeddingCache {
   hipEvent_t last_fetch_ = nullptr;         // most recent direct PCIe fetch of any session (fetches are chained)
   hipStream_t last_fetch_stream_ = nullptr;
   std::atomic<uint32_t> epoch_{1};
-  std::atomic<bool> has_claim_{false};
 
   mutable std::mutex stat_mu_;
   CacheCounters counters_;

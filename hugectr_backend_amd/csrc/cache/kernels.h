@@ -9,20 +9,24 @@ namespace hps {
 
 uint32_t GatherGridBlocks(uint64_t N, int cu_count);
 
-// K_P: one workgroup per tile of w.tiles.  variant = U + 100 * no_dedup (U in {2,4,8}).  claim: hit representatives
-// mark their slot's claim word (tables[t].claim must be allocated) so that K_M can count the call's unique hit keys.
+// K_P: one workgroup per tile of w.tiles.  variant = U + 100 * no_dedup + 1000 * wide (U in {1,2,4,8}).
 // tail: the tile's first wave also does K_M's work (call-wide unique misses) — then LaunchMissUnique must NOT follow.  Only for
-// variants with tile dedup and without claim (ProbeTailAvailable).
-bool ProbeTailAvailable(int variant, bool claim);
+// variants with tile dedup (ProbeTailAvailable).
+bool ProbeTailAvailable(int variant);
 // KTimer: events that take the KERNEL's own start / stop timestamps (hipExtLaunchKernel): what rocprofv3 reports as the launch's
 // duration.  A pair of hipEventRecord around a launch also measures two packet hand-offs on the queue (6-8 us per kernel on
 // the MI355X box: probe 57 against 51.6 us, gather 249 against 241, scatter 30 against 23 in the same run).
 struct KTimer { hipEvent_t start = nullptr, stop = nullptr; };
-hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
-                            bool tail, hipStream_t stream, KTimer kt = {});
-// K_M: call-wide unique missed keys per table (+ exact: unique hit keys) into w.acc / w.uniq_keys / w.rep_of / w.uidx_of
-hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, bool exact,
+hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool tail,
                             hipStream_t stream, KTimer kt = {});
+// K_M: call-wide unique missed keys per table into w.acc / w.uniq_keys / w.rep_of / w.uidx_of
+hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, hipStream_t stream,
+                            KTimer kt = {});
+// K_H: the call's unique hit keys per table (distinct slots among d_slot's non-negative words) added to
+// d_acc[AccTableWord(t, kAccUniqHit)].  total_parts = sum of UniqueHitsParts(slots of table t) over the tables with keys in the call.
+uint32_t UniqueHitsParts(uint64_t slots);
+hipError_t LaunchUniqueHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t total_parts, const int32_t* d_slot,
+                            uint32_t* d_acc, hipStream_t stream, KTimer kt = {});
 
 // K_G: hit rows cache -> output from the slot indices K_P left (d_call carries the output pointers).
 hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,

@@ -6,8 +6,9 @@
 //
 //   K_P  hps_probe_tile        per tile of 1,024 keys of one table: input dedup in LDS, one bucket probe per
 //                              tile-unique key, slot index for every key, the tile's miss lists      (HBM, latency)
-//   K_M  hps_miss_unique       call-wide unique missed keys per table from the tiles' short miss lists;
-//                              optional exact count of the call's unique hit keys (insertion policy)
+//   K_M  hps_miss_unique       call-wide unique missed keys per table from the tiles' short miss lists
+//   K_H  hps_unique_hits       the call's unique hit keys per table = distinct slots hit, counted in LDS bitmaps
+//                              (only when the insertion policy needs the hit rate)
 //   K_G  hps_gather_hits       hit rows cache -> output from the slot indices   HBM-bound, the roofline kernel
 //   K_C1 hps_miss_scatter      missed rows: staging -> output (walks the tiles' miss lists, not the slot array)
 //   K_C2 hps_cache_insert      unique missed (key,row) -> bucket, LRU victim claimed by CAS
@@ -126,14 +127,11 @@ __device__ __forceinline__ uint64_t set_hash(int64_t key, uint32_t t) {
 //      is bound by the rate of random line requests, not by their bytes: 64-B granules are no faster,
 //      tools/micro/probe_width.hip); a hit whose slot's recency stamp is not the current unit's rewrites that byte
 //   4. every key takes its representative's result: slot[i] >= 0, or -2 - m with m the representative's position in
-//      the tile's miss list; the lists the later kernels walk (missed representatives' keys, missed keys as sent,
-//      kClaim: hit representatives) are compacted in the tile's own region — no global atomic in this kernel.
-// kClaim (insertion policy needs the call's unique-key count): a hit representative writes its global key index
-// into the slot's claim word; after the kernel exactly one representative per distinct slot still finds its own
-// index there (K_M counts those).  Plain stores, no atomics.
+//      the tile's miss list; the lists the later kernels walk (missed representatives' keys, missed keys as sent)
+//      are compacted in the tile's own region — no global atomic in this kernel.
 // Algorithmic bytes per key: 8 (key) + 4 (slot); overhead: one 128-B bucket line per tile-unique key.
 // ------------------------------------------------------------------------------------------------
-template <bool kDedup, bool kClaim, int kU, int kThreads, bool kTail>
+template <bool kDedup, int kU, int kThreads, bool kTail>
 __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc* __restrict__ call,
                                                                             const TableCacheDev* __restrict__ tables,
                                                                             const CallWork w) {
@@ -143,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   __shared__ uint16_t sh_rep[kTileKeys];
   __shared__ int32_t sh_slot[kTileKeys];
   __shared__ uint16_t sh_list[kTileKeys];
-  __shared__ uint32_t sh_cnt[4];  // representatives, missed representatives, missed keys as sent, hit representatives
+  __shared__ uint32_t sh_cnt[4];  // representatives, missed representatives, missed keys as sent
 
   const uint32_t tile = blockIdx.x;
   const TileDesc td = w.tiles[tile];
@@ -235,7 +233,6 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
           // recency: one byte of the line just read, rewritten only when it is not already this unit's stamp
           if (!(tb.flags & 1u) && stamp_of(ln[u].x, ln[u].y, v) != stamp8)
             reinterpret_cast<uint8_t*>(tb.lines + (uint64_t)bb[u] * kLineWords + kBucketSlots)[v] = (uint8_t)stamp8;
-          if (kClaim) tb.claim[(uint32_t)s] = (uint32_t)(td.begin + jj[u]);
         }
         sh_slot[jj[u]] = s;
       }
@@ -243,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   }
   __syncthreads();
 
-  // ---- 4a. missed representatives take their place in the tile's miss list; hit representatives are listed ----
+  // ---- 4a. missed representatives take their place in the tile's miss list ----
   const uint32_t region = tile * (uint32_t)kTileKeys;
 #pragma unroll
   for (int q = 0; q < kPerThread; ++q) {
@@ -260,11 +257,6 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
       }
       sh_slot[j] = -2 - (int32_t)(region + pos);
     }
-    if (kClaim) {
-      const bool hit = is_rep && s >= 0;
-      const uint32_t hp = lds_append(&sh_cnt[3], hit);
-      if (hit) { w.hit_i[region + hp] = (int32_t)(td.begin + j); w.hit_s[region + hp] = s; }
-    }
   }
   __syncthreads();
   // ---- 4b. every key takes its representative's result ----
@@ -280,7 +272,6 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   if (tid == 0) {
     w.tile_cnt[tile * 4 + kTileCntRepMiss] = sh_cnt[1];
     w.tile_cnt[tile * 4 + kTileCntSentMiss] = sh_cnt[2];
-    w.tile_cnt[tile * 4 + kTileCntRepHit] = kClaim ? sh_cnt[3] : 0u;
   }
   // ---- 5. (kTail) call-wide unique misses: what hps_miss_unique_kernel does in a launch of its own, done here by the tile's
   // first wave while the other waves retire.  Round 3: the separate kernel cost 15-17 us per call in the timed region for a few
@@ -289,9 +280,8 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   // publishes a set entry therefore writes its key itself, as a device-scope store (write-through past the XCD's L2), and
   // waits for that store before the compare-and-swap; the loser's read is a device-scope load whose address comes out of the
   // entry.  No fence: a device-scope release / acquire fence on gfx950 writes back / invalidates the whole L2 of the XCD —
-  // tried first: 500 us instead of 45 for this kernel.  Not with kClaim: the unique-hit count needs every tile's claim
-  // stores, i.e. the kernel boundary.
-  if (kTail && !kClaim) {
+  // tried first: 500 us instead of 45 for this kernel.
+  if (kTail) {
     if (tid >= 64) return;
     const uint32_t M = sh_cnt[1], S = sh_cnt[2];
     if ((M | S) == 0) return;
@@ -357,10 +347,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
 // its range of the table's unique segment with ONE atomic on the table's own accumulator line.  A loser learns
 // the winner's m from the CAS and records it (rep_of).  Unique keys go to HBM and, zero-copy, to the pinned host
 // array the parameter-server threads read.
-// kExact: also counts the tile's hit representatives that still own their slot's claim word (one per distinct
-// slot over the whole call): the call's unique hit keys per table.
 // ------------------------------------------------------------------------------------------------
-template <bool kExact>
 __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __restrict__ call,
                                                                const TableCacheDev* __restrict__ tables, const CallWork w) {
   // ONE WAVE per tile (four tiles per workgroup): a tile's miss list is a few dozen entries, and with a wave as the unit
@@ -374,8 +361,7 @@ __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __
   const int64_t first_key = w.miss_key[region + (uint32_t)lane];
   const uint32_t M = uniform_u32(w.tile_cnt[tile * 4 + kTileCntRepMiss]);
   const uint32_t S = uniform_u32(w.tile_cnt[tile * 4 + kTileCntSentMiss]);
-  const uint32_t H = kExact ? uniform_u32(w.tile_cnt[tile * 4 + kTileCntRepHit]) : 0u;
-  if ((M | S | H) == 0) return;
+  if ((M | S) == 0) return;
   const uint32_t t = uniform_u32(w.tiles[tile].table);
   const unsigned long long tag = (unsigned long long)w.call_tag << 32;
   const uint64_t ks = call->key_start[t];
@@ -422,32 +408,89 @@ __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __
       }
     }
   }
-  if (kExact && H) {
-    const uint32_t* __restrict__ claim = tables[t].claim;
-    uint32_t mine = 0;
-    // four independent (list entry -> claim word) chains per lane and step: the claim reads are random 4-B accesses
-    for (uint32_t r0 = 0; r0 < H; r0 += 256) {
-      int32_t idx[4], sl[4];
-      uint32_t cw[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t r = r0 + (uint32_t)u * 64 + (uint32_t)lane;
-        const uint32_t rr = r < H ? r : 0;
-        idx[u] = w.hit_i[region + rr];
-        sl[u] = w.hit_s[region + rr];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) cw[u] = claim[(uint32_t)sl[u]];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t r = r0 + (uint32_t)u * 64 + (uint32_t)lane;
-        mine += (r < H && cw[u] == (uint32_t)idx[u]) ? 1u : 0u;
-      }
-    }
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-    if (lane == 0 && mine) atomicAdd(&w.acc[AccTableWord(t, kAccUniqHit)], mine);
-  }
   if (lane == 0 && S) atomicAdd(&w.acc[AccTableWord(t, kAccSentMiss)], S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_H: the call's unique HIT keys per table, for the insertion policy (hit rate over the call's unique keys,
+// docs/hierarchical_parameter_server.md:69) — taken only for thresholds inside (0,1).  A key that hit owns exactly one
+// cache slot, so unique hit keys = distinct non-negative values among the table's slot words.  One workgroup per
+// (table, range of kHitPartBits = 1 M slots): it walks the table's slot words (coalesced, L2-resident: K_P has just written
+// them), marks the slots of its range in an LDS bitmap (duplicates set the same bit) and counts the bits: no sort, no
+// global set, one global atomic per workgroup.  Rounds 2-3 marked a 4-byte claim word per slot from the probe kernel
+// (random stores into a 277-MB array), listed the hit representatives per tile and re-read the claim words in a K_M
+// launch of its own — which also kept the call-wide unique misses out of the probe kernel's tail: probe pair 87 us
+// instead of 44 on the headline workload.
+// Cost: parts(t) = ceil(slots_t / kHitPartBits) workgroups per table, each reading the table's n_t slot words.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kHitPartBits = 1u << 20;   // 128 KB of LDS per workgroup (one workgroup per CU)
+constexpr int kHitThreads = 1024;
+
+__global__ __launch_bounds__(kHitThreads) void hps_unique_hits_kernel(const CallDesc* __restrict__ call,
+                                                                      const TableCacheDev* __restrict__ tables,
+                                                                      const int32_t* __restrict__ slot, uint32_t* __restrict__ acc) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t hit_bits[];   // [kHitPartBits / 32]
+  __shared__ uint32_t sh_sum[kHitThreads / 64];
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef int32_t i4 __attribute__((ext_vector_type(4)));
+  // which (table, part) is this workgroup?  Every table's part count is fetched by its own thread (a scan that loaded the
+  // descriptors one after the other was 26 dependent round trips = 15 of this kernel's first 20 us), the scan runs over LDS.
+  __shared__ uint32_t sh_parts[kMaxTables];
+  const uint32_t T = call->num_tables;
+  for (uint32_t tt = threadIdx.x; tt < T; tt += kHitThreads) {
+    const uint64_t slots = (uint64_t)tables[tt].num_buckets * kBucketSlots;
+    sh_parts[tt] = call->key_start[tt + 1] > call->key_start[tt] ? (uint32_t)((slots + kHitPartBits - 1) / kHitPartBits) : 0u;
+  }
+  for (uint32_t e = threadIdx.x; e < kHitPartBits / 128; e += kHitThreads) reinterpret_cast<u4*>(hit_bits)[e] = u4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  uint32_t b = blockIdx.x, t = 0;
+  for (; t < T; ++t) {
+    if (b < sh_parts[t]) break;
+    b -= sh_parts[t];
+  }
+  if (t >= T) return;
+  const uint64_t lo = (uint64_t)b * kHitPartBits;
+  const uint64_t i0 = call->key_start[t], i1 = call->key_start[t + 1];
+  auto mark = [&](int32_t sl) {
+    const uint64_t r = (uint64_t)(uint32_t)sl - lo;   // (a negative slot word — miss or padding — is out of every range)
+    // (a hot key's slot comes by thousands of times: once its bit is set the atomic — same-address LDS atomics serialise — is skipped)
+    if (sl >= 0 && r < kHitPartBits && !((hit_bits[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&hit_bits[r >> 5], 1u << (r & 31u));
+  };
+  // the table's slot words: 16 B per lane, sixteen loads in flight per lane; the unaligned head and the tail one word at a time
+  const uint64_t a0 = (i0 + 3) & ~(uint64_t)3, a1 = i1 & ~(uint64_t)3;
+  if (a0 <= a1) {
+    for (uint64_t i = i0 + threadIdx.x; i < a0; i += kHitThreads) mark(slot[i]);
+    for (uint64_t i = a1 + threadIdx.x; i < i1; i += kHitThreads) mark(slot[i]);
+    const i4* __restrict__ s4 = reinterpret_cast<const i4*>(slot + a0);
+    const uint64_t n4 = (a1 - a0) >> 2;
+    constexpr int kLoads = 16;   // (65,536 keys per table = one batch of 16 loads per lane: one L2 round trip, not four)
+    for (uint64_t q = threadIdx.x; q < n4; q += (uint64_t)kLoads * kHitThreads) {
+      i4 v[kLoads];
+#pragma unroll
+      for (int u = 0; u < kLoads; ++u) {
+        const uint64_t qq = q + (uint64_t)u * kHitThreads;
+        v[u] = qq < n4 ? s4[qq] : i4{-1, -1, -1, -1};
+      }
+#pragma unroll
+      for (int u = 0; u < kLoads; ++u) { mark(v[u].x); mark(v[u].y); mark(v[u].z); mark(v[u].w); }
+    }
+  } else {
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += kHitThreads) mark(slot[i]);
+  }
+  __syncthreads();
+  uint32_t mine = 0;
+  for (uint32_t e = threadIdx.x; e < kHitPartBits / 128; e += kHitThreads) {
+    const u4 w4 = reinterpret_cast<const u4*>(hit_bits)[e];
+    mine += (uint32_t)(__popc(w4.x) + __popc(w4.y) + __popc(w4.z) + __popc(w4.w));
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63) == 0) sh_sum[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t v = 0;
+    for (int k = 0; k < kHitThreads / 64; ++k) v += sh_sum[k];
+    if (v) atomicAdd(&acc[AccTableWord(t, kAccUniqHit)], v);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -873,50 +916,64 @@ static inline uint32_t ListSubBlocks(uint32_t tiles) {
   return k < 1 ? 1u : (k > 16 ? 16u : k);
 }
 
-bool ProbeTailAvailable(int variant, bool claim) { return !claim && (variant / 100) % 10 == 0; }
+bool ProbeTailAvailable(int variant) { return (variant / 100) % 10 == 0; }
 
-hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant, bool claim,
+hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, int variant,
                             bool tail, hipStream_t stream, KTimer kt) {
   if (w.num_tiles == 0) return hipSuccess;
-  if (tail && !ProbeTailAvailable(variant, claim)) return hipErrorInvalidValue;
+  if (tail && !ProbeTailAvailable(variant)) return hipErrorInvalidValue;
   // variant = U + 100 * no_dedup + 1000 * wide   (U in {2,4,8}: bucket lines in flight per 16-lane group; wide: 512 threads
   // per tile instead of 256 — twice the groups probing per workgroup, 32 waves per CU at 4 workgroups)
   const int U = variant % 100;
   const bool dedup = (variant / 100) % 10 == 0;
   const bool wide = (variant / 1000) % 10 != 0;
-#define HPS_PT(DD, CC, UU, TT)                                                                                         \
+#define HPS_PT(DD, UU, TT)                                                                                             \
   do {                                                                                                                 \
-    if (tail && DD && !CC)                                                                                             \
-      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, false, UU, TT, DD && !CC>), dim3(w.num_tiles), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w); \
+    if (tail && DD)                                                                                                    \
+      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, UU, TT, DD>), dim3(w.num_tiles), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);    \
     else                                                                                                               \
-      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, CC, UU, TT, false>), dim3(w.num_tiles), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);        \
+      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, UU, TT, false>), dim3(w.num_tiles), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w); \
   } while (0)
-#define HPS_PT_T(DD, CC, UU)                      \
+#define HPS_PT_T(DD, UU)                          \
   do {                                            \
-    if (wide) HPS_PT(DD, CC, UU, 512);            \
-    else HPS_PT(DD, CC, UU, 256);                 \
+    if (wide) HPS_PT(DD, UU, 512);                \
+    else HPS_PT(DD, UU, 256);                     \
   } while (0)
-#define HPS_PT_U(DD, CC)                          \
+#define HPS_PT_U(DD)                              \
   do {                                            \
-    if (U == 1) HPS_PT_T(DD, CC, 1);              \
-    else if (U == 2) HPS_PT_T(DD, CC, 2);         \
-    else if (U == 8) HPS_PT_T(DD, CC, 8);         \
-    else HPS_PT_T(DD, CC, 4);                     \
+    if (U == 1) HPS_PT_T(DD, 1);                  \
+    else if (U == 2) HPS_PT_T(DD, 2);             \
+    else if (U == 8) HPS_PT_T(DD, 8);             \
+    else HPS_PT_T(DD, 4);                         \
   } while (0)
-  if (dedup) { if (claim) HPS_PT_U(true, true); else HPS_PT_U(true, false); }
-  else { if (claim) HPS_PT_U(false, true); else HPS_PT_U(false, false); }
+  if (dedup) HPS_PT_U(true);
+  else HPS_PT_U(false);
 #undef HPS_PT_U
 #undef HPS_PT_T
 #undef HPS_PT
   return hipGetLastError();
 }
 
-hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, bool exact,
-                            hipStream_t stream, KTimer kt) {
+hipError_t LaunchMissUnique(const CallDesc* d_call, const TableCacheDev* d_tables, const CallWork& w, hipStream_t stream,
+                            KTimer kt) {
   if (w.num_tiles == 0) return hipSuccess;
   const uint32_t blocks = (w.num_tiles + 3) / 4;   // one wave per tile
-  if (exact) hipExtLaunchKernelGGL(hps_miss_unique_kernel<true>, dim3(blocks), dim3(256), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);
-  else hipExtLaunchKernelGGL(hps_miss_unique_kernel<false>, dim3(blocks), dim3(256), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);
+  hipExtLaunchKernelGGL(hps_miss_unique_kernel, dim3(blocks), dim3(256), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);
+  return hipGetLastError();
+}
+
+uint32_t UniqueHitsParts(uint64_t slots) { return (uint32_t)((slots + kHitPartBits - 1) / kHitPartBits); }
+
+hipError_t LaunchUniqueHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t total_parts, const int32_t* d_slot,
+                            uint32_t* d_acc, hipStream_t stream, KTimer kt) {
+  if (total_parts == 0) return hipSuccess;
+  constexpr uint32_t lds = kHitPartBits / 8;
+  // (per call, not once: the attribute belongs to the function on the CURRENT device, and a process serves several)
+  const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(hps_unique_hits_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return attr;
+  hipExtLaunchKernelGGL(hps_unique_hits_kernel, dim3(total_parts), dim3(kHitThreads), lds, stream, kt.start, kt.stop, 0, d_call, d_tables, d_slot,
+                        d_acc);
   return hipGetLastError();
 }
 

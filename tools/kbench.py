@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--hit", type=float, default=1.1)
     ap.add_argument("--zipf", type=float, default=1.05)
     ap.add_argument("--xcd", default="1", help="comma list of 0/1: XCD-aware chunk walk of the gather kernel")
-    ap.add_argument("--threshold-permille", type=int, default=1000, help="<1000: the policy needs the unique-key count (claim words)")
+    ap.add_argument("--threshold-permille", type=int, default=1000, help="<1000: the policy needs the unique-key count (K_H: distinct slots in LDS bitmaps)")
     a = ap.parse_args()
     import torch
     from hugectr_backend_amd import build as hb, hps
