@@ -445,6 +445,38 @@ def test_policy_hit_rate_is_over_unique_keys():
     assert st.misses == 300 + 5000
 
 
+def test_unique_hit_count_over_a_cache_of_several_bitmap_parts():
+    """K_H (hps_unique_hits_kernel) counts a table's distinct hit slots in LDS bitmaps of 2^20 slots each: a cache of 3.3 M and
+    one of 1.2 M slots (four and two workgroups), a third table with no key in the call, keys repeated across the whole range,
+    key ranges that do not start on a 16-byte boundary of the slot array.  The count must be the oracle's."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(2026)
+    tables = make_tables([(2_500_000, 1), (900_000, 2), (1000, 4)])
+    ps, cache, s = _mk("khparts", tables, maxcat=[3, 2, 1], gpucacheper=1.0, hit_rate_threshold=0.5, defaults=[1.0, 2.0, 3.0],
+                       max_batch=70_000)
+    resident = [tk[cache.query(t, tk) >= 0] for t, (tk, _) in enumerate(tables)]
+    assert resident[0].size > 2_400_000 and resident[1].size > 850_000
+    for it, nk in enumerate([[200_001, 130_003, 0], [77_777, 5, 0], [3, 139_999, 0]]):
+        parts = []
+        for t, n in enumerate(nk):
+            if n == 0:
+                parts.append(np.zeros(0, np.int64)); continue
+            hot = rng.choice(resident[t], size=max(1, n // 3), replace=False)      # distinct slots all over the table
+            q = rng.choice(hot, size=n, replace=True)                               # ... each several times
+            absent = rng.random(n) < 0.1
+            parts.append(np.where(absent, -1 - rng.integers(0, 1 << 40, n), q).astype(np.int64))
+        q = np.concatenate(parts)
+        uc = O.np_unique_counts(q, nk, resident)
+        out = s.lookup(q, nk).cpu().numpy()
+        st = s.last_stats()
+        assert st.unique_keys == sum(u for u, _ in uc), (it, st.unique_keys, uc)
+        assert st.unique_misses == sum(m for _, m in uc), it
+        modes = O.np_insert_modes(q, nk, resident, 0.5)
+        ref = O.np_lookup(tables, q, nk, [1.0, 2.0, 3.0], resident=[resident[t] if modes[t] else None for t in range(3)])
+        assert np.array_equal(_bits(out), _bits(ref)), it
+        cache.wait_async()
+
+
 @pytest.mark.parametrize("variant", [1, 2, 4, 8, 102, 104, 108, 1001, 1002, 1004, 1008, 1102])
 @pytest.mark.parametrize("xcd_walk", [0, 1])
 def test_probe_variants_and_gather_walks_agree(variant, xcd_walk):
