@@ -11,10 +11,11 @@
 // Recency lives INSIDE the line the probe has to read anyway (round 2 kept 32-bit stamps in a second array: every hit
 // cost a 4-B store into a 277-MB array, and the micro-benchmark tools/micro/probe_width.hip says such a store costs more
 // than the probe itself: 1.1 M probes 30 us, with the store 79 us, with a 1-B store into the probed line 63 us).
-// A stamp is the call counter of the cache in units of 2^age_shift calls, modulo kStampMod = 255 ("stamp8"; the value
+// A stamp is the cache's clock — its turnover: the unique rows its lookups missed, in units of total slots / 64
+// (EmbeddingCache::NextEpoch; HPS_LRU_AGE_SHIFT: units of 2^shift calls instead) — modulo kStampMod = 255 ("stamp8"; the value
 // 255 marks a slot that a group of a running insert kernel owns).  A hit rewrites its
 // slot's stamp only when it differs from the current unit — the comparison is free, the byte came with the keys — so a
-// key that is hit call after call costs one store per 2^age_shift calls.  age = (now8 - stamp8) mod 255; the insert
+// key that is hit call after call costs one store per unit.  age = (now8 - stamp8) mod 255; the insert
 // kernel evicts the slot of greatest age and, while it is at it, pulls stamps older than kAgeSaturate units back to
 // exactly that age so that they cannot wrap around and look young.
 #pragma once
@@ -107,8 +108,8 @@ struct CallWork {
 // (model_instance_state.cpp:180-193).
 struct CallDesc {
   uint32_t num_tables;
-  uint32_t epoch;           // call counter of the cache (monotonic)
-  uint32_t stamp8;          // (epoch >> age_shift) & 255: the recency stamp hits of this call leave in their slots
+  uint32_t epoch;           // time token of the call: (recency unit << 8) | (call counter & 0xFF)
+  uint32_t stamp8;          // recency unit of the call modulo 255: the stamp hits of this call leave in their slots
   uint32_t skip_empty_keys; // 1: a key equal to HPS_EMPTY_KEY is padding of the sharded exchange — no probe, no row, no list
                             // entry, slot = -1 (0: it is a key like any other, in no table by construction: default vector)
   uint64_t total_keys;      // N = sum n_t

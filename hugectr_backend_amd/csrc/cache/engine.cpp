@@ -102,7 +102,12 @@ void EmbeddingCache::AddStatLines(const uint32_t* lines) {
 // The call counter of the cache: one tick per lookup call (and per background insert), 32 bits, wraps freely.  What the
 // kernels see of it is Stamp8(): the counter in units of 2^age_shift calls modulo kStampMod (device_types.h).  At the
 // 32-bit wrap the stamps jump once (2^32 is not a multiple of 255 units): a blip in the eviction order, nothing else.
-uint32_t EmbeddingCache::NextEpoch() { return epoch_.fetch_add(1, std::memory_order_relaxed) + 1; }
+uint32_t EmbeddingCache::NextEpoch() {
+  const uint64_t c = calls_.fetch_add(1, std::memory_order_relaxed) + 1;
+  const uint64_t unit = call_clock_ ? (c + call_start_) >> age_shift_
+                                    : 1 + clock_rows_.load(std::memory_order_relaxed) / rows_per_unit_;   // (lookups start in unit 1)
+  return (uint32_t)((unit << 8) | (c & 0xFFu));
+}
 
 void EmbeddingCache::BeginRead(hipStream_t stream) {
   order_mu_.lock();
@@ -194,9 +199,13 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   static_ = p.embedding_cache_type == EmbeddingCacheType::Static;
-  if (const char* e = std::getenv("HPS_LRU_AGE_SHIFT")) {   // A/B switch: recency unit = 2^shift calls (default 8 calls)
+  if (const char* e = std::getenv("HPS_LRU_AGE_SHIFT")) {   // recency unit = 2^shift CALLS instead of a share of the cache's turnover
     const long v = std::strtol(e, nullptr, 10);
-    if (v >= 0 && v <= 8) age_shift_ = (uint32_t)v;
+    if (v >= 0 && v <= 8) { age_shift_ = (uint32_t)v; call_clock_ = true; insert_age_ = 32; }
+  }
+  if (const char* e = std::getenv("HPS_LRU_UNITS_PER_TURNOVER")) {
+    const long v = std::strtol(e, nullptr, 10);
+    if (v >= 1 && v <= 4096) units_per_turnover_ = (uint32_t)v;
   }
   if (const char* e = std::getenv("HPS_LRU_ADMIT")) {
     const long v = std::strtol(e, nullptr, 10);
@@ -251,7 +260,13 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
     HPS_RETURN_IF_ERROR(SyncDirectIndex(tables));
   }
 
-  epoch_.store((1u << age_shift_) - 1u);
+  // the clock: lookups start in unit 1 (the warm-up below runs in unit 0)
+  total_slots_ = 0;
+  for (const TableCacheDev& tb : h_tables_) total_slots_ += (uint64_t)tb.num_buckets * kBucketSlots;
+  if (total_slots_ == 0) total_slots_ = 1;
+  rows_per_unit_ = std::max<uint64_t>(1, total_slots_ / units_per_turnover_);
+  call_start_ = (1ull << age_shift_) - 1;
+  if (const char* e = std::getenv("HPS_TEST_EPOCH_START")) call_start_ = std::strtoull(e, nullptr, 0);  // test hook: counter wrap (call clock)
   if (!p.init_ec) return Status::Ok();
 
   // ---- warm-up: the first `capacity` rows of each table in file order ----
@@ -324,8 +339,6 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   AddStatLines(lines.data());
   (void)hipFree(d_keys); (void)hipFree(d_rows); (void)hipFree(d_md); (void)hipFree(d_zero_ks); (void)hipFree(d_stats);
   (void)hipFree(d_warm);
-  epoch_.store((1u << age_shift_) - 1u);
-  if (const char* e = std::getenv("HPS_TEST_EPOCH_START")) epoch_.store((uint32_t)std::strtoul(e, nullptr, 0));  // test hook: counter wrap
   return st;
 }
 
@@ -1044,6 +1057,7 @@ Status LookupSession::ReadBackCounts(size_t T, uint64_t N, bool exact) {
   last_misses_ = misses;
   last_unique_ = uniq;
   last_unique_keys_ = uniq_keys;
+  cache_->AdvanceClock(uniq);
   std::lock_guard<std::mutex> lk(cache_->stat_mu_);
   cache_->counters_.lookups += 1;
   cache_->counters_.keys += N;

@@ -116,9 +116,21 @@ class EmbeddingCache {
   void LaneEnter(hipStream_t stream);
   void LaneLeave(hipStream_t stream, hipEvent_t done);
   void ForgetLane(hipEvent_t done);
+  // The cache's clock.  A call takes a TIME TOKEN at its start: (recency unit << 8) | (call counter & 0xFF).  The recency unit
+  // advances with the cache's TURNOVER — the unique rows its lookups missed, in units of total slots / units_per_turnover_
+  // (AdvanceClock) — not with the number of calls: how long ago "an old key" was last hit only means something relative to
+  // how fast new rows arrive, and a horizon counted in calls that suits 1.7 M-key requests is nothing for 28 K-key ones.
+  // Measured (tools/hit_rate_long.py on the GPU, tools/lru_sim.py as the model; headline workload, thousands of calls): with
+  // the unit at 8 calls and new keys entering 256 calls old (rounds 2-3) the hit rate settles at 0.9491 after ~1,000 calls
+  // — the 260 calls of bench.py's timed region never get there —; with new keys entering 2,560 calls old at 0.9589 (19 %
+  // fewer missed rows); in turnovers (one = ~950 calls of that workload) that is 2.5.
+  // HPS_LRU_AGE_SHIFT=s in the environment: the unit is 2^s calls instead (rounds 2-3; tests that count calls).
   uint32_t NextEpoch();
-  // recency stamp the kernels write for call counter `epoch` (device_types.h)
-  uint32_t Stamp8(uint32_t epoch) const { return (epoch >> age_shift_) % kStampMod; }
+  void AdvanceClock(uint64_t missed_rows) {
+    clock_rows_.fetch_add(missed_rows < total_slots_ ? missed_rows : total_slots_, std::memory_order_relaxed);   // (at most one turnover per call)
+  }
+  // recency stamp the kernels write for a call with time token `epoch` (device_types.h)
+  uint32_t Stamp8(uint32_t epoch) const { return (epoch >> 8) % kStampMod; }
   // what the insert kernel gets: the current unit in byte 0, the stamp of a newly inserted key in byte 1 (insert_age_ units
   // in the past: scan-resistant insertion — a key seen once must be seen again before it outranks keys that were hit)
   // bits 16..23: the call counter's low byte, bits 24..27: admit_log2_ (the insert kernel's admission rule, kernels.hip)
@@ -128,8 +140,13 @@ class EmbeddingCache {
   }
   uint32_t admit_log2_ = 4;   // HPS_LRU_ADMIT: a new key does not take a slot hit more recently than the insert age, except one
                               // new key in 2^this (0 = every new key takes the bucket's oldest slot, rounds 1-3's behaviour)
-  uint32_t insert_age_ = 32;  // recency units = 256 calls (HPS_LRU_INSERT_AGE; 0 = plain LRU insertion), < kAgeSaturate
-  uint32_t age_shift_ = 3;   // recency unit = 2^age_shift calls (HPS_LRU_AGE_SHIFT): 8 calls; 192 units = 1,536 calls of horizon
+  uint32_t insert_age_ = 160; // recency units a newly inserted key is aged by (HPS_LRU_INSERT_AGE; 0 = plain LRU insertion),
+                              // < kAgeSaturate: 2.5 turnovers (call clock: 32 units unless given)
+  uint32_t units_per_turnover_ = 64;   // HPS_LRU_UNITS_PER_TURNOVER: 192 usable units = 3 turnovers of horizon
+  bool call_clock_ = false;   // HPS_LRU_AGE_SHIFT given: recency unit = 2^age_shift_ calls
+  uint32_t age_shift_ = 3;
+  uint64_t total_slots_ = 1, rows_per_unit_ = 1, call_start_ = 0;
+  std::atomic<uint64_t> calls_{0}, clock_rows_{0};
 
   std::string model_;
   EmbeddingCacheConfig cfg_;
@@ -151,7 +168,6 @@ class EmbeddingCache {
   std::mutex fetch_mu_;
   hipEvent_t last_fetch_ = nullptr;         // most recent direct PCIe fetch of any session (fetches are chained)
   hipStream_t last_fetch_stream_ = nullptr;
-  std::atomic<uint32_t> epoch_{1};
 
   mutable std::mutex stat_mu_;
   CacheCounters counters_;

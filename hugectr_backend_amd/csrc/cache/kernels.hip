@@ -676,7 +676,7 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(con
 // K_C2: insert unique missed (key,row) pairs.  One 16-lane group per key.  The group reads the key's bucket line (lanes
 // 0..7 and their mirrors 8..15: 16 B each — 14 keys and the two stamp words).  Key already resident: the row is refreshed
 // in place.  Otherwise the victim is a free slot, else the slot of greatest age; a slot whose stamp is the current
-// unit's (hit or written within the last 2^age_shift calls) is never taken.
+// unit's (hit or written since the clock last advanced) is never taken.
 // Ownership inside one launch: a writer claims slot v by a 64-bit compare-and-swap on the stamp WORD that holds v's
 // byte: old word -> same word with byte v = kStampClaimed.  Only slots whose stamp is neither the current unit's nor
 // kStampClaimed are claimed, so a claim always changes the word; a second group that read the same line loses its CAS,
@@ -793,7 +793,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           return true;
         }
         sw[wi] = got;
-        if (((got ^ old) >> sh) & 0xFFull) return false;   // somebody else took slot v
+        const uint32_t nb = (uint32_t)(got >> sh) & 0xFFu, ob = (uint32_t)(old >> sh) & 0xFFu;
+        if (nb != ob) {
+          // Slot v's own byte changed.  Either somebody took the slot (the byte reads kStampClaimed, or the stamp its new owner
+          // left: the current unit's or the insert stamp) — or a neighbour's claim on this word merely pulled v's old stamp back to
+          // the saturation age (saturate_stamps): same occupant, go on with the new word.  (Found by the turnover clock on a
+          // 3,500-slot cache, where stamps older than kAgeSaturate are common: a refresh of all resident keys skipped the rows
+          // whose stamp a neighbour had just re-aged — tests/test_gpu_bounded_host_tier.py.)
+          const uint32_t sat = (now8 + kStampMod - kAgeSaturate) % kStampMod;
+          if (!(nb == sat && ob != kStampClaimed && age_of(now8, ob) > kAgeSaturate)) return false;
+        }
       }
     };
     const bool guarded = adm_k != 0 && ins_age != 0 && ((((uint32_t)(hps_mix64((uint64_t)key) >> 8)) ^ call8) & ((1u << adm_k) - 1u)) != 0;
