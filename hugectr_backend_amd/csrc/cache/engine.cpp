@@ -207,6 +207,7 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 1 && v <= 4096) units_per_turnover_ = (uint32_t)v;
   }
+  if (!p.cache_admission) admit_log2_ = 0;   // ps.json "gpucache_admission": false
   if (const char* e = std::getenv("HPS_LRU_ADMIT")) {
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 0 && v <= 15) admit_log2_ = (uint32_t)v;

@@ -294,6 +294,7 @@ Status ParseParameterServerJson(const Json& root, ParameterServerConfig* out) {
     HPS_RETURN_IF_ERROR(ParseField(p.fp8_quant, j, "fp8_quant", false));
     HPS_RETURN_IF_ERROR(ParseField(p.enable_pagelock, j, "enable_pagelock", false));
     HPS_RETURN_IF_ERROR(ParseField(p.cache_load_factor, j, "gpucache_load_factor", false));
+    HPS_RETURN_IF_ERROR(ParseField(p.cache_admission, j, "gpucache_admission", false));
     HPS_RETURN_IF_ERROR(ParseField(p.ps_direct_access, j, "ps_direct_access", false));
     p.volatile_db = cfg.volatile_db;
     p.persistent_db = cfg.persistent_db;

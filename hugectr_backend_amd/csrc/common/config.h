@@ -99,6 +99,10 @@ struct InferenceParams {  // backend.cpp:318-516
 
   // --- additions of this build (MI355X engine knobs; all optional in ps.json) ---
   double cache_load_factor = 0.75;  // "gpucache_load_factor": slots = ceil(capacity / load_factor)
+  // "gpucache_admission": true (default) = a key seen once does not take a slot that was hit within the last 2.5 cache
+  // turnovers (its row is served, it just is not cached on that call; one such key in 16 is let in regardless); false = every
+  // missed key is inserted, evicting its bucket's least recently used key — the reference's cache
+  bool cache_admission = true;
   // "ps_direct_access": the GPU resolves missed keys through a device-resident index of the host tier and reads
   // the rows in place from pinned host memory over PCIe (no host threads, no staging copy).  Needs gpucache.
   bool ps_direct_access = false;

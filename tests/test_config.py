@@ -163,3 +163,16 @@ def test_default_table_names_and_json_syntax_errors(tmp_path):
     with pytest.raises(hps.HpsError) as e:
         hps.HierParameterServer.create(str(p))
     assert "/nonexistent/m_0" in e.value.msg
+
+
+def test_engine_knobs_of_this_build_are_optional_and_typed():
+    """ps.json keys the reference does not have: accepted when well-formed, refused when not."""
+    from hugectr_backend_amd import hps
+    cfg = ps_config("knobs", _tables(), gpucache=False)
+    cfg["models"][0].update({"gpucache_admission": False, "gpucache_load_factor": 0.5})
+    _mk(cfg)
+    cfg["models"][0]["gpucache_admission"] = "true"          # the reference's tolerant conversions apply
+    _mk(cfg)
+    cfg["models"][0]["gpucache_admission"] = [1]
+    with pytest.raises(hps.HpsError):
+        _mk(cfg)

@@ -737,3 +737,13 @@ def test_admission_rule_keeps_recently_hit_keys_and_lets_new_keys_in_once_they_a
     out = s0.lookup(q, [q.size]).cpu().numpy()
     assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, [q.size], [0.0])))
     assert (cache0.query(0, q) >= 0).mean() > 0.97 and (cache0.query(0, r0) >= 0).sum() < r0.size - 20
+    # the same through ps.json ("gpucache_admission": false) instead of the environment
+    monkeypatch.delenv("HPS_LRU_ADMIT")
+    ps1, cache1, s1 = _mk("admit_cfg", tables, maxcat=[1], gpucacheper=0.5, defaults=[0.0], max_batch=8192,
+                          extra={"gpucache_admission": False})
+    r1 = keys[cache1.query(0, keys) >= 0]
+    c1k = keys[cache1.query(0, keys) < 0]
+    s1.lookup(r1.astype(np.int64), [r1.size])
+    q = c1k[:400].astype(np.int64)
+    s1.lookup(q, [q.size])
+    assert (cache1.query(0, q) >= 0).mean() > 0.97
