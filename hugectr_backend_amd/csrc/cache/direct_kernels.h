@@ -26,6 +26,6 @@ hipError_t LaunchMissDescBuild(const TableCacheDev* d_tables, uint32_t T, uint32
                                const uint32_t* d_table_mode /*optional: 1 = skip table*/, hipStream_t stream);
 hipError_t LaunchPsFetchDirect(const PsIndexDev* d_index, uint32_t T, const MissDesc* d_md, const uint64_t* d_key_start,
                                const int64_t* d_uniq_keys, float* d_staging, uint8_t* d_found, uint64_t max_unique,
-                               int grid_blocks /*0: default*/, hipStream_t stream);
+                               int grid_blocks /*0: default (big request); > 0: at most this many workgroups; < 0: small request, one key per group, up to 128 workgroups*/, hipStream_t stream);
 
 }  // namespace hps

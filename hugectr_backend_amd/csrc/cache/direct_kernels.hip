@@ -180,19 +180,34 @@ __global__ __launch_bounds__(256) void hps_ps_fetch_direct_kernel(const PsIndexD
         }
       }
     } else {
+      // any width: the first chunk of every row (16 B per lane where the width allows, else 4 B) is in flight together; what a
+      // row has beyond 64 (16) floats follows row by row
+      f4d v4[kRows];
+      float v1[kRows];
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        const PsIndexDev& ix = sh_ix[tt[r]];
+        const uint32_t D = ix.dim;
+        v4[r] = f4d{ix.default_value, ix.default_value, ix.default_value, ix.default_value};
+        v1[r] = ix.default_value;
+        if (row[r] >= 0) {
+          const float* src = ix.host_rows + (uint64_t)row[r] * D;
+          if ((D & 3u) == 0) { if ((uint32_t)lig * 4 < D) v4[r] = *reinterpret_cast<const f4d*>(src + lig * 4); }
+          else if ((uint32_t)lig < D) v1[r] = src[lig];
+        }
+      }
+#pragma unroll
       for (int r = 0; r < kRows; ++r) {
         if (f0 + r >= total) continue;
         const PsIndexDev& ix = sh_ix[tt[r]];
         const uint32_t D = ix.dim;
-        if (row[r] >= 0) {
-          const float* src = ix.host_rows + (uint64_t)row[r] * D;
-          if ((D & 3u) == 0) {
-            for (uint32_t c = (uint32_t)lig * 4; c < D; c += 64) *reinterpret_cast<f4d*>(dst[r] + c) = *reinterpret_cast<const f4d*>(src + c);
-          } else {
-            for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[r][c] = src[c];
-          }
+        if ((D & 3u) == 0) {
+          if ((uint32_t)lig * 4 < D) *reinterpret_cast<f4d*>(dst[r] + lig * 4) = v4[r];
+          for (uint32_t c = (uint32_t)lig * 4 + 64; c < D; c += 64)
+            *reinterpret_cast<f4d*>(dst[r] + c) = row[r] >= 0 ? *reinterpret_cast<const f4d*>(ix.host_rows + (uint64_t)row[r] * D + c) : v4[r];
         } else {
-          for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[r][c] = ix.default_value;
+          if ((uint32_t)lig < D) dst[r][lig] = v1[r];
+          for (uint32_t c = (uint32_t)lig + 16; c < D; c += 16) dst[r][c] = row[r] >= 0 ? ix.host_rows[(uint64_t)row[r] * D + c] : ix.default_value;
         }
       }
     }
@@ -244,20 +259,25 @@ hipError_t LaunchPsFetchDirect(const PsIndexDev* d_index, uint32_t T, const Miss
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 4;
   }();
-  const uint64_t per_block = 16ull * (uint64_t)(rows_in_flight >= 8 ? 8 : rows_in_flight >= 4 ? 4 : rows_in_flight >= 2 ? 2 : 1);
+  // grid_blocks < 0: a small request (its whole miss path is tens of microseconds and nothing runs next to it long enough to
+  // be disturbed): one key per group, up to 128 workgroups — every row of a few thousand misses on the link at once.  With the
+  // big-request shape a 28,672-key W&D request took 0.233 / 0.136 / 0.112 ms at 50 / 90 / 99 % hit instead of 0.166 / 0.120 /
+  // 0.100 (tests/tools/bench_configs.py c4 direct).
+  const int rows = grid_blocks < 0 ? 1 : (rows_in_flight >= 8 ? 8 : rows_in_flight >= 4 ? 4 : rows_in_flight >= 2 ? 2 : 1);
+  const uint64_t per_block = 16ull * (uint64_t)rows;
   uint64_t want = (max_unique + per_block - 1) / per_block;
   // grid_blocks > 0: the caller's own bound (the background inserter runs a small grid: it is in no hurry, and
   // fewer PCIe reads in flight disturb the probe kernels of the foreground lookups less)
-  const uint64_t cap = (uint64_t)(grid_blocks > 0 ? grid_blocks : max_blocks);
+  const uint64_t cap = (uint64_t)(grid_blocks > 0 ? grid_blocks : grid_blocks < 0 ? 128 : max_blocks);
   if (want > cap) want = cap;
   const size_t lds = (size_t)(T + 1) * 8 + (size_t)T * (8 + 8 + sizeof(PsIndexDev)) + 16;
-  if (rows_in_flight >= 8)
+  if (rows >= 8)
     hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<8>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
                        d_uniq_keys, d_staging, d_found);
-  else if (rows_in_flight >= 4)
+  else if (rows >= 4)
     hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<4>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
                        d_uniq_keys, d_staging, d_found);
-  else if (rows_in_flight >= 2)
+  else if (rows >= 2)
     hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<2>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
                        d_uniq_keys, d_staging, d_found);
   else

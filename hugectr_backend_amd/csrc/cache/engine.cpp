@@ -1375,7 +1375,7 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   // direct_split_: staging layout + PCIe fetch on the session's second stream, released by the probe alone — they run next
   // to this call's own hit gather; the scatter waits for both
   hipStream_t fs = stream_;
-  if (direct_split_ && !counts_known) {
+  if (direct_split_ && !counts_known && N > kSmallRequestKeys) {   // (a small request's gather is a few microseconds: the hop to the second stream costs more)
     fs = copy_stream_;
     HIP_TRY(hipStreamWaitEvent(fs, ev_probe_, 0));
   }
@@ -1384,7 +1384,7 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
     cache_->BeginFetch(fs);
     if (timing_) (void)hipEventRecord(ev_f0_, fs);
     e = LaunchPsFetchDirect(cache_->device_index(), (uint32_t)T, d_md_, d_call_->key_start, work_.uniq_keys, d_staging_,
-                            d_found_, max_unique, 0, fs);
+                            d_found_, max_unique, N <= kSmallRequestKeys ? -1 : 0, fs);
     if (timing_) (void)hipEventRecord(ev_f1_, fs);
     cache_->EndFetch(fs, ev_fetch_);
     if (fs != stream_) (void)hipStreamWaitEvent(stream_, ev_fetch_, 0);

@@ -279,10 +279,12 @@ def test_refresh_drops_keys_that_left_the_parameter_server():
 
 
 def test_call_counter_wrap(monkeypatch):
-    """The cache's 32-bit call counter wraps freely (the recency stamps in the bucket lines are the counter in units of a
-    few calls modulo 255, and jump once at the wrap); results stay exact and insertion keeps working across it."""
+    """The recency unit travels in 24 bits of a call's time token and wraps freely (the stamps in the bucket lines are the
+    unit modulo 255 and repeat one value at the wrap); results stay exact and insertion keeps working across it.  Call clock,
+    one call per unit, started four calls before the wrap."""
     from oracle import hps_oracle as O
-    monkeypatch.setenv("HPS_TEST_EPOCH_START", str(2**32 - 4))
+    monkeypatch.setenv("HPS_LRU_AGE_SHIFT", "0")
+    monkeypatch.setenv("HPS_TEST_EPOCH_START", str(2**24 - 4))
     rng = np.random.default_rng(8)
     tables = make_tables([(20000, 32)])
     ps, cache, s = _mk("renorm", tables, maxcat=[1], gpucacheper=0.02, max_batch=4096)
