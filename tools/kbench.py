@@ -34,7 +34,10 @@ def main():
     ap.add_argument("--zipf", type=float, default=1.05)
     ap.add_argument("--xcd", default="1", help="comma list of 0/1: XCD-aware chunk walk of the gather kernel")
     ap.add_argument("--threshold-permille", type=int, default=1000, help="<1000: the policy needs the unique-key count (K_H: distinct slots in LDS bitmaps)")
+    ap.add_argument("--env", default="", help="NAME=v1,v2: an environment switch the engine reads per launch, varied like the variants")
     a = ap.parse_args()
+    import os
+    env_name, env_vals = (a.env.split("=")[0], a.env.split("=")[1].split(",")) if a.env else ("", [""])
     import torch
     from hugectr_backend_amd import build as hb, hps
     hb.build()
@@ -62,7 +65,7 @@ def main():
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1)
     cdf = torch.from_numpy(B.zipf_cdf(C, a.zipf)).cuda()
-    variants = [(int(v), int(b)) for v in a.variants.split(",") for b in a.xcd.split(",")]
+    variants = [(int(v), int(b), ev) for v in a.variants.split(",") for b in a.xcd.split(",") for ev in env_vals]
     # with misses in the batches every batch is used ONCE (a replayed batch finds its cold keys inserted): one batch per
     # variant and step, the variants taking turns
     fresh = a.hit < 1.0
@@ -71,25 +74,27 @@ def main():
     nk = [Bn] * T
     print(f"setup {time.time() - t0:.1f}s", flush=True)
     res = {v: [] for v in variants}
-    for i, (v, x) in enumerate(variants):  # warm
+    for i, (v, x, ev) in enumerate(variants):  # warm
+        if env_name: os.environ[env_name] = ev
         s.set_option("probe_variant", v)
         s.set_option("xcd_walk", x)
         s.lookup_device(batches[i % a.iters], nk, out=out)
     nxt = a.iters   # (fresh: the first a.iters batches warmed the variants up)
     for r in range(a.rounds):
-        for v, x in variants:
+        for v, x, ev in variants:
+            if env_name: os.environ[env_name] = ev
             s.set_option("probe_variant", v)
             s.set_option("xcd_walk", x)
             for b in (batches[nxt:nxt + a.iters] if fresh else batches):
                 s.lookup_device(b, nk, out=out)
                 st = s.last_stats()
-                res[(v, x)].append((st.probe_gather_ms, st.hit_gather_ms, st.scatter_ms, st.insert_ms))
+                res[(v, x, ev)].append((st.probe_gather_ms, st.hit_gather_ms, st.scatter_ms, st.insert_ms))
             nxt += a.iters if fresh else 0
     alg = N * (8 + 8 * D)
-    for v, x in variants:
-        arr = np.array(res[(v, x)])
+    for v, x, ev in variants:
+        arr = np.array(res[(v, x, ev)])
         p, g = float(np.median(arr[:, 0])), float(np.median(arr[:, 1]))
-        print(f"variant {v:4d} xcd_walk={x}: probe median {p * 1e3:7.1f} us (min {arr[:, 0].min() * 1e3:7.1f})  gather median {g * 1e3:7.1f} us "
+        print(f"variant {v:4d} xcd_walk={x} {env_name}={ev}: probe median {p * 1e3:7.1f} us (min {arr[:, 0].min() * 1e3:7.1f})  gather median {g * 1e3:7.1f} us "
               f"(min {arr[:, 1].min() * 1e3:7.1f})  scatter median {np.median(arr[:, 2]) * 1e3:6.1f}  insert median {np.median(arr[:, 3]) * 1e3:6.1f} us  "
               f"frac(probe+gather) {alg / ((p + g) * 1e-3) / 8e12:.3f}  n={arr.shape[0]}")
 
