@@ -1098,7 +1098,7 @@ def c4_leg(a, hb):
             "results": res}
 
 
-def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0, check_rows=False, more=None):
+def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0, check_rows=False, more=None, narrow_keys=None):
     """The headline workload on a deployment of its own (own server, the headline's has been released): two sessions, fresh
     batches of host keys every step, exact rows.  direct: the parameter-server tier; key0: the tables' keys are
     key0 .. key0+R-1 (key0 = 2^40: keys that need all 8 bytes over PCIe — the reference takes int64 keys, hps.cc:573)."""
@@ -1119,7 +1119,7 @@ def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0,
         s.set_option("timing", 1)
         s.set_option("probe_variant", a.probe_variant)
         s.set_option("xcd_walk", a.xcd_walk)
-        s.set_option("narrow_keys", a.narrow_keys)
+        s.set_option("narrow_keys", a.narrow_keys if narrow_keys is None else narrow_keys)
         s.set_option("split_probe", 1 if (a.split_probe != 0 and not direct) else 0)
     C = int(np.ceil(a.cache_frac * R))
     resident = []
@@ -1159,7 +1159,8 @@ def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0,
         out["parity_full_batch_vs_direct_row_index"] = ok
     if more is not None:
         try:   # further legs on this deployment while it is up
-            more(out, dict(ps=ps, cache=cache, sessions=sessions, run=run, resident=resident, cdf_d=cdf_d, gen=gen, C=C, model=model))
+            more(out, dict(ps=ps, cache=cache, sessions=sessions, run=run, resident=resident, cdf_d=cdf_d, gen=gen, C=C, model=model,
+                           key0=key0))
         except Exception as e:  # noqa: BLE001
             out["more_error"] = repr(e)[:300]
             sys.stderr.write(f"[bench] leg on the fresh deployment stopped: {e!r}\n")
@@ -1250,9 +1251,43 @@ def other_tier_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
 
 def wide_keys_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
     """The headline workload with keys that need all 64 bits on the wire: tables keyed 2^40 .. 2^40+R-1, same recipe, same
-    tier and session options as the headline, 95 % hit, every step a fresh batch."""
+    tier and session options as the headline, 95 % hit, every step a fresh batch.  Two measurements on the one deployment:
+    the keys sent as they are (narrowing off: what ids without structure — hashed 64-bit ids — cost), then with the engine's
+    default, which narrows them as offsets from each table's smallest key (frame of reference, csrc/cache/key_pack.h)."""
     key0 = 1 << 40
-    out, rec = fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct=bool(a.direct), key0=key0, check_rows=True)
+
+    def with_default_narrowing(out, ctx):
+        run, sessions = ctx["run"], ctx["sessions"]
+        for s in sessions:
+            s.set_option("narrow_keys", a.narrow_keys)
+        steps = 40
+        hb_ = [((x + key0).cpu().numpy(),) for x in make_batches_gpu(torch, ctx["gen"], ctx["resident"], ctx["cdf_d"], R, ctx["C"], B, a.hit, steps + 8)]
+        hb_ = [(x[0], run.pack_host(x[0])) for x in hb_]
+        rec = []
+        run.run(hb_, 8, 0, "host")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run.run(hb_, steps, 8, "host", record=rec)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        o = summarize(rec, N, D, dt, steps)
+        o["key_bytes_over_pcie_mean"] = float(np.mean([r[11] for r in rec]))
+        q = hb_[-1][0]
+        sessions[0].lookup_packed(hb_[-1][1], run.vptrs[0], run.counts)
+        torch.cuda.synchronize()
+        got = run.outs[0].cpu().numpy().reshape(N, D)
+        ok = True
+        for t in range(T):
+            tk, tr = ctx["ps"].table_data(ctx["model"], t)
+            qt = q[t * B:(t + 1) * B]
+            ok &= bool(np.array_equal(tr[qt - key0].view(np.uint32), got[t * B:(t + 1) * B].view(np.uint32)))
+        o["parity_full_batch_vs_direct_row_index"] = ok
+        o["note"] = ("the engine's default on the same deployment: the keys narrowed as offsets from each table's smallest key "
+                     "(3 bytes each here: the tables' ids are dense above 2^40)")
+        out["frame_of_reference_default"] = o
+
+    out, rec = fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct=bool(a.direct), key0=key0, check_rows=True,
+                                    more=with_default_narrowing, narrow_keys=0)
     uniq = float(np.mean([r[6] for r in rec]))
     bytes_step = uniq * 4 * D + N * out["key_bytes_over_pcie_mean"]
     out.update({
@@ -1260,9 +1295,10 @@ def wide_keys_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
         "pcie_bytes_per_step": bytes_step,
         "pcie_GBps": bytes_step / (out["ms_per_step"] * 1e-3) / 1e9,
         "pcie_frac_of_63": bytes_step / (out["ms_per_step"] * 1e-3) / 1e9 / PCIE_PEAK_GBS,
-        "note": "keys 2^40 + (the headline's key distribution): nothing can be narrowed, KEYS cross PCIe at 8 bytes each "
-                "(13.6 MB per step next to ~42 MB of missed rows); the step is PCIe-bound, so the floor is the headline's time x "
-                "(rows + 8-byte keys) / (rows + 3-byte keys)",
+        "note": "keys 2^40 + (the headline's key distribution) sent as they are (session option narrow_keys 0): KEYS cross PCIe at "
+                "8 bytes each (13.6 MB per step next to ~37 MB of missed rows) — what ids without structure cost; the step is "
+                "PCIe-bound, so the floor is the headline's time x (rows + 8-byte keys) / (rows + 3-byte keys).  "
+                "frame_of_reference_default: the same traffic with the engine's default narrowing",
     })
     return out
 

@@ -117,6 +117,7 @@ struct CallDesc {
   const uint32_t* keys32;   // not null: the same keys narrowed to 32 bits (every key of the call is in [0, 2^32); then
                             // `keys` is not read) — halves the host->device bytes of a request's KEYS
   const uint8_t* keys24;    // not null: the keys packed at 3 bytes each, little-endian (every key of the call is in [0, 2^24))
+  int64_t key_base[kMaxTables];        // keys32 / keys24 hold key - key_base[table] (frame of reference per table; 0 otherwise)
   uint64_t key_start[kMaxTables + 1];  // prefix sums of n_t
   float* out[kMaxTables];              // device pointer of table t's output slice
   uint8_t vec_ok[kMaxTables];          // 1: D%4==0 and out[t] 16-B aligned -> float4 path

@@ -599,6 +599,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   for (hipEvent_t& e : ev_lane_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char* e = std::getenv("HPS_EXCLUSIVE_KERNELS")) exclusive_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_DIRECT_SPLIT")) direct_split_ = std::strtol(e, nullptr, 10) != 0;
+  if (const char* e = std::getenv("HPS_KEY_FRAME_OF_REFERENCE")) frame_of_reference_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_FUSED_UNIQUE")) fused_unique_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_KERNEL_TIMESTAMPS")) kernel_stamps_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switches
@@ -802,13 +803,16 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
   }
   {
     constexpr size_t kTaskKeys = 32768, kGroupKeys = (4u << 20) / sizeof(int64_t);
-    struct Task { const int64_t* src; size_t off, n; };
+    struct Task { const int64_t* src; size_t off, n; uint64_t base; };
     std::vector<Task> tasks;
     size_t off = 0;
+    // frame of reference of a narrowed request: every table's keys as offsets from the table's smallest key (key_pack.h)
+    key_base_.assign(num_tables, 0);
     for (size_t t = 0; t < num_tables; ++t) {
       const size_t n = num_keys_per_table[t];
       const int64_t* p = (const int64_t*)h_keys_per_table[t];
-      for (size_t b = 0; b < n; b += kTaskKeys) tasks.push_back({p + b, off + b, std::min(kTaskKeys, n - b)});
+      if (frame_of_reference_) key_base_[t] = tables_[t]->min_key();
+      for (size_t b = 0; b < n; b += kTaskKeys) tasks.push_back({p + b, off + b, std::min(kTaskKeys, n - b), (uint64_t)key_base_[t]});
       off += n;
     }
     // (page-locked keys are DMA'd in place, never narrowed: host threads read that memory an order of magnitude slower
@@ -823,7 +827,8 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
       // failed 4-MB group, a stream synchronisation and a restage (the optimistic check while copying still catches the
       // request with one wide key among narrow ones).
       uint64_t sample = 0;
-      for (const Task& tk : tasks) sample |= (uint64_t)tk.src[0] | (uint64_t)tk.src[tk.n / 2] | (uint64_t)tk.src[tk.n - 1];
+      for (const Task& tk : tasks)
+        sample |= ((uint64_t)tk.src[0] - tk.base) | ((uint64_t)tk.src[tk.n / 2] - tk.base) | ((uint64_t)tk.src[tk.n - 1] - tk.base);
       if (sample >> 32) { try_narrow = try_pack24 = false; NarrowFailed(false); }
       else if (sample >> 24) { if (try_pack24) NarrowFailed(true); try_pack24 = false; }
     }
@@ -838,8 +843,8 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
       auto body = [&](size_t i) {
         const Task& tk = tasks[i];
         if (width == 8) { memcpy(h_keys_pinned_ + tk.off, tk.src, tk.n * sizeof(int64_t)); return; }
-        const uint64_t high = width == 4 ? PackKeys32(tk.src, tk.n, reinterpret_cast<uint32_t*>(dst8) + tk.off)
-                                         : PackKeys24(tk.src, tk.n, dst8 + 3 * tk.off);
+        const uint64_t high = width == 4 ? PackKeys32(tk.src, tk.n, reinterpret_cast<uint32_t*>(dst8) + tk.off, tk.base)
+                                         : PackKeys24(tk.src, tk.n, dst8 + 3 * tk.off, tk.base);
         if (high >> (8 * width)) high_or.fetch_or(high, std::memory_order_relaxed);
       };
       size_t g0 = 0;
@@ -972,6 +977,7 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   const uint64_t tile_keys = total <= kSmallRequestKeys ? kSmallTileKeys : (uint64_t)kTileKeys;
   for (size_t t = 0; t < T; ++t) {
     c.key_start[t] = N;
+    c.key_base[t] = (staged_narrow && t < key_base_.size()) ? key_base_[t] : 0;
     c.out[t] = probe_only ? nullptr : d_out[t];
     if (!probe_only && n[t] && !d_out[t]) return Error(Code::kInvalidArg, "lookup: null output pointer for table ", t);
     const uint32_t D = tables_[t]->dim();
@@ -1254,7 +1260,8 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
         if (!table_async_[t]) continue;
         if (uniq_narrow_) {
           const uint32_t* k32 = reinterpret_cast<const uint32_t*>(h_uniq_keys_) + c.key_start[t];
-          job[t].assign(k32, k32 + uniq_miss_[t]);
+          job[t].resize(uniq_miss_[t]);
+          for (size_t i = 0; i < job[t].size(); ++i) job[t][i] = c.key_base[t] + (int64_t)(uint64_t)k32[i];
         } else {
           job[t].assign(h_uniq_keys_ + c.key_start[t], h_uniq_keys_ + c.key_start[t] + uniq_miss_[t]);
         }
@@ -1517,7 +1524,8 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
         const size_t off = md.stage_off[t] + (size_t)(r - lo) * D;
         jobs.push_back({tables_[t].get(), uniq_narrow_ ? nullptr : h_uniq_keys_ + c.key_start[t] + r, re - r, h_staging_ + off, D,
                         params_.default_value_for_each_table[t], h_found_ + md.useg_start[t] + (r - lo),
-                        uniq_narrow_ ? reinterpret_cast<const uint32_t*>(h_uniq_keys_) + c.key_start[t] + r : nullptr});
+                        uniq_narrow_ ? reinterpret_cast<const uint32_t*>(h_uniq_keys_) + c.key_start[t] + r : nullptr,
+                        uniq_narrow_ ? c.key_base[t] : 0});
         piece_begin = std::min(piece_begin, off);
         piece_end = std::max(piece_end, off + (size_t)(re - r) * D);
         if (piece_end - piece_begin >= kPieceFloats) HPS_RETURN_IF_ERROR(flush());

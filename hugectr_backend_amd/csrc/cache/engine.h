@@ -369,6 +369,8 @@ class LookupSession {
   bool fused_unique_ = true;     // the call-wide unique misses are found in the probe kernel's tail (option "fused_unique", HPS_FUSED_UNIQUE)
   bool exclusive_ = true;        // the HBM-bound kernels of this session take the cache's lane (option "exclusive_kernels")
   hipEvent_t ev_lane_[4] = {nullptr, nullptr, nullptr, nullptr};   // probe pair, hit gather, miss scatter, insert
+  bool frame_of_reference_ = true;   // narrowed keys are offsets from their table's smallest key (HPS_KEY_FRAME_OF_REFERENCE=0: from 0)
+  std::vector<int64_t> key_base_;    // this call's per-table bases
   bool direct_split_ = true;     // device-driven tier: the fetch kernel runs next to the call's own hit gather (HPS_DIRECT_SPLIT=0: behind it)
   bool narrow_publish_ = true;   // a narrowed request's unique missed keys come back to the host as uint32 (option "narrow_publish")
   bool uniq_narrow_ = false;     // this call: h_uniq_keys_ holds uint32 keys
@@ -451,7 +453,8 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
     size_t stride;
     float default_value;
     uint8_t* found;  // optional
-    const uint32_t* keys32 = nullptr;  // when `keys` is null: the same keys as uint32 (widened task by task)
+    const uint32_t* keys32 = nullptr;  // when `keys` is null: the same keys as uint32 offsets (widened task by task)
+    int64_t key_base = 0;              // ... from this base
   };
   Status FetchMulti(const std::vector<FetchJob>& jobs);
 

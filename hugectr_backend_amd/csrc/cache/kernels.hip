@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   const int64_t* __restrict__ keys = call->keys + td.begin;
   const uint32_t stamp8 = call->stamp8;
   const bool skip_empty = call->skip_empty_keys != 0;
+  const int64_t kbase = call->key_base[td.table];   // narrowed keys are offsets from their table's base (key_pack.h)
   constexpr int kPerThread = kTileKeys / kThreads;
 
   if (tid < 4) sh_cnt[tid] = 0;
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
     const uint32_t j = tid + (uint32_t)q * kThreads;
     if (keys24) {
       const uint8_t* p = keys24 + 3ull * (td.begin + j);   // consecutive lanes read consecutive 3-byte keys
-      k[q] = j < n ? (int64_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) : HPS_EMPTY_KEY;
-    } else if (keys32) k[q] = j < n ? (int64_t)(uint64_t)keys32[td.begin + j] : HPS_EMPTY_KEY;
+      k[q] = j < n ? kbase + (int64_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) : HPS_EMPTY_KEY;
+    } else if (keys32) k[q] = j < n ? kbase + (int64_t)(uint64_t)keys32[td.begin + j] : HPS_EMPTY_KEY;
     else k[q] = j < n ? keys[j] : HPS_EMPTY_KEY;
   }
 #pragma unroll
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
           const uint32_t u = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
           w.uidx_of[m] = (int32_t)u;
           w.uniq_keys[ks + u] = key;
-          if (w.uniq_keys_host32) w.uniq_keys_host32[ks + u] = (uint32_t)key;
+          if (w.uniq_keys_host32) w.uniq_keys_host32[ks + u] = (uint32_t)(key - kbase);
           else if (w.uniq_keys_host) w.uniq_keys_host[ks + u] = key;
         }
       }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void hps_miss_unique_kernel(const CallDesc* __
         w.uidx_of[m] = (int32_t)u;
         w.uniq_keys[ks + u] = key;
         // zero-copy store into pinned host memory (host-gather tier), at 4 bytes when the request's keys were narrowed
-        if (w.uniq_keys_host32) w.uniq_keys_host32[ks + u] = (uint32_t)key;
+        if (w.uniq_keys_host32) w.uniq_keys_host32[ks + u] = (uint32_t)(key - call->key_base[t]);
         else if (w.uniq_keys_host) w.uniq_keys_host[ks + u] = key;
       }
     }

@@ -8,26 +8,29 @@
 
 namespace hps {
 
-// dst[j] = (uint32_t)src[j]
-inline uint64_t PackKeys32(const int64_t* src, size_t n, uint32_t* dst) {
+// Frame of reference: a table's keys are narrowed as offsets from `base` (the table's smallest key, HostTable::min_key — feature
+// ids that carry a per-table offset, or any id space that starts high, narrow like ids that start at 0); a key below the
+// base wraps to a huge offset and fails the width like any wide key.
+// dst[j] = (uint32_t)(src[j] - base)
+inline uint64_t PackKeys32(const int64_t* src, size_t n, uint32_t* dst, uint64_t base = 0) {
   uint64_t high = 0;
-  for (size_t j = 0; j < n; ++j) { const uint64_t k = (uint64_t)src[j]; high |= k; dst[j] = (uint32_t)k; }
+  for (size_t j = 0; j < n; ++j) { const uint64_t k = (uint64_t)src[j] - base; high |= k; dst[j] = (uint32_t)k; }
   return high;
 }
 
 // 3 bytes per key, little-endian, dst[3j .. 3j+2]; writes exactly 3*n bytes.  4-byte stores 3 bytes apart, each overwriting the
 // spare byte of the one before; the last key is written byte by byte (the byte behind it belongs to somebody else).
-inline uint64_t PackKeys24(const int64_t* src, size_t n, uint8_t* dst) {
+inline uint64_t PackKeys24(const int64_t* src, size_t n, uint8_t* dst, uint64_t base = 0) {
   uint64_t high = 0;
   if (n == 0) return 0;
   size_t j = 0;
   for (; j + 1 < n; ++j) {
-    const uint64_t k = (uint64_t)src[j];
+    const uint64_t k = (uint64_t)src[j] - base;
     high |= k;
     const uint32_t v = (uint32_t)k;
     memcpy(dst + 3 * j, &v, 4);
   }
-  const uint64_t k = (uint64_t)src[j];
+  const uint64_t k = (uint64_t)src[j] - base;
   high |= k;
   dst[3 * j] = (uint8_t)k;
   dst[3 * j + 1] = (uint8_t)(k >> 8);

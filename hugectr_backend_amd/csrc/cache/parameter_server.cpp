@@ -586,7 +586,7 @@ Status HierParameterServer::FetchMulti(const std::vector<FetchJob>& jobs) {
     int64_t wide[256];   // tasks are at most 256 keys
     const int64_t* keys = J.keys ? J.keys + k.begin : wide;
     if (!J.keys)
-      for (size_t i = k.begin; i < k.end; ++i) wide[i - k.begin] = (int64_t)(uint64_t)J.keys32[i];
+      for (size_t i = k.begin; i < k.end; ++i) wide[i - k.begin] = J.key_base + (int64_t)(uint64_t)J.keys32[i];
     J.table->Fetch(keys, k.end - k.begin, J.out + k.begin * J.stride, J.stride, J.default_value,
                    J.found ? J.found + k.begin : nullptr);
   };

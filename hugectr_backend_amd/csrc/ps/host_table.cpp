@@ -201,14 +201,19 @@ Status HostTable::BuildIndex(ThreadPool* pool) {
   std::vector<size_t> counts(P, 0);
   {
     std::mutex mu;
+    int64_t lowest = INT64_MAX;
     auto body = [&](size_t ti) {
       std::vector<size_t> local(P, 0);
+      int64_t lo = INT64_MAX;
       const size_t b = ti * chunk, e = std::min(R, b + chunk);
-      for (size_t r = b; r < e; ++r) if (keys_[r] != HPS_EMPTY_KEY) ++local[PartitionOf(keys_[r])];
+      for (size_t r = b; r < e; ++r)
+        if (keys_[r] != HPS_EMPTY_KEY) { ++local[PartitionOf(keys_[r])]; lo = std::min(lo, keys_[r]); }
       std::lock_guard<std::mutex> lk(mu);
       for (size_t p = 0; p < P; ++p) counts[p] += local[p];
+      lowest = std::min(lowest, lo);
     };
     if (pool) pool->ParallelFor(ntasks, body); else for (size_t i = 0; i < ntasks; ++i) body(i);
+    min_key_.store(lowest == INT64_MAX ? 0 : lowest, std::memory_order_relaxed);
   }
   HPS_RETURN_IF_ERROR(AllocPartitions(counts));
   // 2) clear
@@ -633,6 +638,11 @@ Status HostTable::Upsert(const int64_t* keys, const float* rows, size_t n) {
 // Appends the rows keys[i], i in fresh, to the row store and re-indexes (updates are rare relative to lookups).
 Status HostTable::AppendRows(const int64_t* keys, const float* rows, const std::vector<size_t>& fresh) {
   const uint32_t D = dim_;
+  {
+    int64_t lo = num_rows_ ? min_key_.load(std::memory_order_relaxed) : INT64_MAX;
+    for (size_t i : fresh) if (keys[i] != HPS_EMPTY_KEY) lo = std::min(lo, keys[i]);
+    if (lo != INT64_MAX) min_key_.store(lo, std::memory_order_relaxed);
+  }
   const size_t newR = num_rows_ + fresh.size();
   if (map_bytes_ || !map_dir_.empty()) {
     // mapped row store: append to its two files, map the longer file

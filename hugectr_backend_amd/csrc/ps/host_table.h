@@ -76,6 +76,9 @@ class HostTable {
   size_t num_partitions() const { return parts_.size(); }
   // true when the loaded data held the same key more than once (only the last row is live)
   bool has_duplicate_keys() const { return has_dups_; }
+  // smallest key the table holds (0 for an empty table; the sentinel key HPS_EMPTY_KEY is left out): the frame of reference
+  // a lookup session narrows a request's keys against (cache/engine.cpp) — a hint only, a key below it just does not narrow
+  int64_t min_key() const { return min_key_.load(std::memory_order_relaxed); }
   int64_t key_at(size_t r) const { return keys_[r]; }
   const int64_t* keys() const { return keys_; }
   const float* row_at(size_t r) const { return rows_ + r * dim_; }
@@ -106,6 +109,7 @@ class HostTable {
   void DataFree(void* p);
   bool pinned_ = false;
   std::atomic<uint64_t> generation_{0};
+  std::atomic<int64_t> min_key_{0};
   Status BuildIndex(ThreadPool* pool);
   Status AllocPartitions(const std::vector<size_t>& counts);
   static uint64_t SlotOf(int64_t key, uint64_t mask);

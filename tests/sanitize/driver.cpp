@@ -263,6 +263,19 @@ static int run_keypack() {
       keys[n / 2] = -5;
       CHECK((hps::PackKeys24(keys.data(), n, packed.get()) >> 24) != 0 && (hps::PackKeys32(keys.data(), n, p32.get()) >> 32) != 0);
     }
+    // frame of reference: ids that start high (and a negative base) narrow as offsets from the table's smallest key; a key
+    // below the base wraps to a huge offset and fails every width
+    for (int64_t base : {(int64_t)1 << 40, (int64_t)-1000000, INT64_MAX - (int64_t)0xFFFFFF}) {
+      for (auto& k : keys) k = base + (int64_t)(rng() & 0xFFFFFFu);
+      CHECK((hps::PackKeys24(keys.data(), n, packed.get(), (uint64_t)base) >> 24) == 0);
+      for (size_t j = 0; j < n; ++j) CHECK(base + (int64_t)hps::UnpackKey24(packed.get() + 3 * j) == keys[j]);
+      CHECK((hps::PackKeys32(keys.data(), n, p32.get(), (uint64_t)base) >> 32) == 0);
+      for (size_t j = 0; j < n; ++j) CHECK(base + (int64_t)(uint64_t)p32[j] == keys[j]);
+      if (n >= 1 && base > INT64_MIN + 8) {
+        keys[n / 2] = base - 7;
+        CHECK((hps::PackKeys32(keys.data(), n, p32.get(), (uint64_t)base) >> 32) != 0);
+      }
+    }
   }
   return 0;
 }

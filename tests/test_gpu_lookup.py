@@ -749,3 +749,36 @@ def test_admission_rule_keeps_recently_hit_keys_and_lets_new_keys_in_once_they_a
     q = c1k[:400].astype(np.int64)
     s1.lookup(q, [q.size])
     assert (cache1.query(0, q) >= 0).mean() > 0.97
+
+
+def test_keys_narrow_as_offsets_from_each_tables_smallest_key():
+    """Frame of reference (csrc/cache/key_pack.h): a request whose keys start high — ids with a per-table offset, here 2^40 + ...,
+    2^33 + ... and a table of negative ids — crosses PCIe at 3 or 4 bytes per key like ids that start at 0, misses are fetched
+    by their full keys, a key below a table's smallest key sends the call down the 8-byte path, and every row is exact."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(4040)
+    R = 60000
+    bases = [1 << 40, (1 << 33) + 12345, -(1 << 35)]
+    tables = []
+    for t, (b, D) in enumerate(zip(bases, [32, 128, 8])):
+        k = (b + rng.permutation(3 * R)[:R]).astype(np.int64)
+        tables.append((k, O.np_synth_rows(7, t, k, D)))
+    ps, cache, s = _mk("forkeys", tables, maxcat=[1, 1, 1], gpucacheper=0.3, defaults=[0.5, 1.5, 2.5], max_batch=65536)
+    co = O.COracle()
+    for k, r in tables:
+        co.add_table_arrays(k, r)
+    nk = [60000, 50000, 40000]                      # > 128 K keys in all: the staged (narrowing) path
+    for it in range(3):
+        q = np.concatenate([rng.choice(k, n) for (k, _), n in zip(tables, nk)]).astype(np.int64)
+        out = s.lookup(q, nk).cpu().numpy()
+        st = s.last_stats()
+        assert np.array_equal(_bits(out), _bits(co.lookup(q, nk, [0.5, 1.5, 2.5]))), it
+        assert st.keys_narrowed == 1 and st.key_bytes == 3 and st.misses > 0, (it, st.key_bytes)
+    # absent keys inside the frame (default rows) keep the width; one key below table 1's base widens the call
+    q = np.concatenate([rng.choice(k, n) for (k, _), n in zip(tables, nk)]).astype(np.int64)
+    q[5] = tables[0][0].min() + 3 * R + 17           # in nobody's table, inside table 0's frame
+    out = s.lookup(q, nk).cpu().numpy()
+    assert np.array_equal(_bits(out), _bits(co.lookup(q, nk, [0.5, 1.5, 2.5]))) and s.last_stats().key_bytes == 3
+    q[nk[0] + 7] = tables[1][0].min() - 1
+    out = s.lookup(q, nk).cpu().numpy()
+    assert np.array_equal(_bits(out), _bits(co.lookup(q, nk, [0.5, 1.5, 2.5]))) and s.last_stats().key_bytes == 8
