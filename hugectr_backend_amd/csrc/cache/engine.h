@@ -54,7 +54,7 @@ struct CacheCounters {
   uint64_t unique_misses = 0;
   uint64_t inserted = 0;
   uint64_t refreshed = 0;         // key already resident at insert time: row refreshed in place
-  uint64_t dropped = 0;           // insert skipped: bucket full of current-epoch keys
+  uint64_t dropped = 0;           // insert skipped: every slot of the bucket was hit in the current recency unit, or (admission) more recently than a new key's nominal age
   uint64_t async_calls = 0;       // lookups answered in async-insert mode
 };
 

@@ -67,6 +67,8 @@ typedef struct hps_cache_table_info {
   uint64_t capacity_rows;   /* ceil(gpucacheper * rows) */
 } hps_cache_table_info_t;
 
+/* dropped: unique missed keys that were served but not cached — their bucket's 14 slots were all hit within the current
+ * recency unit, or (admission, ps.json "gpucache_admission", default on) more recently than a new key's nominal age */
 typedef struct hps_cache_counters {
   uint64_t lookups, keys, misses, unique_misses, inserted, refreshed, dropped, async_calls;
 } hps_cache_counters_t;
