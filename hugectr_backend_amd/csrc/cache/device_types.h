@@ -86,6 +86,7 @@ struct CallWork {
   const TileDesc* tiles;     // [num_tiles]
   uint32_t num_tiles;
   uint32_t call_tag;         // tags this call's entries of `set` (never 0)
+  uint32_t xcd_tiles;        // 1: the probe kernel gives XCD x the x-th eighth of the tiles (kernels.hip; needs >= 8 tiles)
   int32_t* slot;             // [N]
   uint32_t* tile_cnt;        // [num_tiles*4]
   int64_t* miss_key;         // tile regions: key of the tile's r-th missed representative

@@ -997,6 +997,7 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
     call_tag_ = 1;
   }
   work_.num_tiles = tiles;
+  { const char* e = std::getenv("HPS_PROBE_XCD_TILES"); work_.xcd_tiles = (tiles >= 64 && (e ? std::strtol(e, nullptr, 10) != 0 : probe_xcd_tiles_)) ? 1u : 0u; }
   work_.call_tag = call_tag_;
   const size_t block_bytes = block_tiles_off_ + (size_t)tiles * sizeof(TileDesc);
   if (zc_control_) {

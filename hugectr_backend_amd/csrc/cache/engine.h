@@ -369,6 +369,7 @@ class LookupSession {
   bool fused_unique_ = true;     // the call-wide unique misses are found in the probe kernel's tail (option "fused_unique", HPS_FUSED_UNIQUE)
   bool exclusive_ = true;        // the HBM-bound kernels of this session take the cache's lane (option "exclusive_kernels")
   hipEvent_t ev_lane_[4] = {nullptr, nullptr, nullptr, nullptr};   // probe pair, hit gather, miss scatter, insert
+  bool probe_xcd_tiles_ = true;      // probe kernel: XCD x takes the x-th eighth of the tiles (HPS_PROBE_XCD_TILES, read per call)
   bool frame_of_reference_ = true;   // narrowed keys are offsets from their table's smallest key (HPS_KEY_FRAME_OF_REFERENCE=0: from 0)
   std::vector<int64_t> key_base_;    // this call's per-table bases
   bool direct_split_ = true;     // device-driven tier: the fetch kernel runs next to the call's own hit gather (HPS_DIRECT_SPLIT=0: behind it)

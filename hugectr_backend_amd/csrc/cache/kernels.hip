@@ -143,7 +143,17 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   __shared__ uint16_t sh_list[kTileKeys];
   __shared__ uint32_t sh_cnt[4];  // representatives, missed representatives, missed keys as sent
 
-  const uint32_t tile = blockIdx.x;
+  // XCD-aware tile order (w.xcd_tiles, speed only): workgroup b runs on XCD b % 8, and the tiles are table-major — with tile = b
+  // every XCD sees every table's tiles, and the bucket lines of the keys a batch repeats (the hot head of a Zipf-like
+  // distribution turns up in most of a table's 64 tiles) are fetched from HBM by all eight L2s.  Giving XCD x the x-th eighth of
+  // the tiles keeps a table's tiles, and with them its hot bucket lines, in ONE 4-MB L2 (the gather kernel walks its chunks
+  // the same way).  The grid is rounded up to a multiple of eight; workgroups past the last tile leave at once.
+  uint32_t tile = blockIdx.x;
+  if (w.xcd_tiles) {
+    const uint32_t per = (w.num_tiles + 7u) / 8u;
+    tile = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
+    if (tile >= w.num_tiles) return;
+  }
   const TileDesc td = w.tiles[tile];
   const TableCacheDev tb = tables[td.table];
   const uint32_t n = td.count;
@@ -937,12 +947,13 @@ hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_table
   const int U = variant % 100;
   const bool dedup = (variant / 100) % 10 == 0;
   const bool wide = (variant / 1000) % 10 != 0;
+  const uint32_t probe_grid = w.xcd_tiles ? (w.num_tiles + 7u) / 8u * 8u : w.num_tiles;
 #define HPS_PT(DD, UU, TT)                                                                                             \
   do {                                                                                                                 \
     if (tail && DD)                                                                                                    \
-      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, UU, TT, DD>), dim3(w.num_tiles), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);    \
+      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, UU, TT, DD>), dim3(probe_grid), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);      \
     else                                                                                                               \
-      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, UU, TT, false>), dim3(w.num_tiles), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w); \
+      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, UU, TT, false>), dim3(probe_grid), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);   \
   } while (0)
 #define HPS_PT_T(DD, UU)                          \
   do {                                            \
