@@ -86,7 +86,6 @@ struct CallWork {
   const TileDesc* tiles;     // [num_tiles]
   uint32_t num_tiles;
   uint32_t call_tag;         // tags this call's entries of `set` (never 0)
-  uint32_t xcd_tiles;        // 1: the probe kernel gives XCD x the x-th eighth of the tiles (kernels.hip; needs >= 8 tiles)
   int32_t* slot;             // [N]
   uint32_t* tile_cnt;        // [num_tiles*4]
   int64_t* miss_key;         // tile regions: key of the tile's r-th missed representative
@@ -101,6 +100,11 @@ struct CallWork {
   int64_t* uniq_keys_host;   // the same array in host-mapped pinned memory (the host parameter server reads it)
   uint32_t* uniq_keys_host32; // not null: the call's keys all fit 32 bits (the request was narrowed) and the host wants
                               // the unique missed keys as uint32 — half the bytes of the zero-copy stores over PCIe
+  uint32_t xcd_tiles;        // 1: the probe kernel gives XCD x the x-th eighth of the tiles (kernels.hip; needs >= 8 tiles).
+                             // LAST ON PURPOSE: placed between call_tag and slot (every later field 8 bytes further into
+                             // the kernel-argument block, the tail's wide scalar loads no longer aligned) the probe kernel
+                             // took 50-51 us instead of 43, with the order on or off — same ISA but for the offsets
+                             // (profiles/round3/ab_probe_xcd_tiles.txt)
 };
 
 

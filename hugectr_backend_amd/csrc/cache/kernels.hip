@@ -147,13 +147,9 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   // every XCD sees every table's tiles, and the bucket lines of the keys a batch repeats (the hot head of a Zipf-like
   // distribution turns up in most of a table's 64 tiles) are fetched from HBM by all eight L2s.  Giving XCD x the x-th eighth of
   // the tiles keeps a table's tiles, and with them its hot bucket lines, in ONE 4-MB L2 (the gather kernel walks its chunks
-  // the same way).  The grid is rounded up to a multiple of eight; workgroups past the last tile leave at once.
-  uint32_t tile = blockIdx.x;
-  if (w.xcd_tiles) {
-    const uint32_t per = (w.num_tiles + 7u) / 8u;
-    tile = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
-    if (tile >= w.num_tiles) return;
-  }
+  // the same way).  One-to-one without holes: XCD x owns q + (x < r) tiles from x*q + min(x, r), q = tiles / 8, r = tiles % 8.
+  const uint32_t tq = w.num_tiles >> 3, tr = w.num_tiles & 7u, bx = blockIdx.x & 7u;
+  const uint32_t tile = w.xcd_tiles ? bx * tq + (bx < tr ? bx : tr) + (blockIdx.x >> 3) : blockIdx.x;
   const TileDesc td = w.tiles[tile];
   const TableCacheDev tb = tables[td.table];
   const uint32_t n = td.count;
@@ -947,7 +943,7 @@ hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_table
   const int U = variant % 100;
   const bool dedup = (variant / 100) % 10 == 0;
   const bool wide = (variant / 1000) % 10 != 0;
-  const uint32_t probe_grid = w.xcd_tiles ? (w.num_tiles + 7u) / 8u * 8u : w.num_tiles;
+  const uint32_t probe_grid = w.num_tiles;
 #define HPS_PT(DD, UU, TT)                                                                                             \
   do {                                                                                                                 \
     if (tail && DD)                                                                                                    \
