@@ -47,3 +47,73 @@ def test_replica_plan_one_model_on_n_devices_and_duplicates_on_a_small_box():
     assert rep_model == ["criteo_dlrm", "criteo_dlrm", "criteo_dlrm_dup1", "criteo_dlrm_dup1"]
     assert deployed == {"criteo_dlrm": [0, 1], "criteo_dlrm_dup1": [0, 1]}
     assert bench.plan_replicas(1, 1) == (["criteo_dlrm"], ["criteo_dlrm"], {"criteo_dlrm": [0]})
+
+
+def _fat_result():
+    """A result object shaped like round 3's 21-KB line (profiles/round3/r3m/bench_default.json), legs included."""
+    import json
+    from pathlib import Path
+    p = Path(__file__).resolve().parent.parent / "profiles" / "round3" / "r3m" / "bench_default.json"
+    res = json.loads(p.read_text())
+    # what round 4 adds: the insert kernel priced next to the headline fraction, the near-all-hit legs, the logical C3 leg
+    res["roofline"]["frac_with_insert"] = 0.67
+    res["roofline"]["insert_ms"] = 0.035
+    res["roofline"]["insert_on_call_path"] = True
+    leg = dict(res["extra_legs"]["all_hit_two_sessions_host_keys"])
+    res["extra_legs"]["hit_999_two_sessions_host_keys"] = leg
+    res["extra_legs"]["hit_99_two_sessions_host_keys"] = leg
+    res["extra_legs"]["sharded_c3_logical"] = {"shards": 4, "lookups_per_s": 1.2e9, "parity": True, "note": "x" * 900}
+    return res
+
+
+def test_final_line_is_compact_and_round_trips():
+    import json
+    res = _fat_result()
+    assert len(json.dumps(res)) > 16000          # the thing that defeated the driver's parser in round 3
+    line = json.dumps(bench.compact_line(res))
+    assert len(line) < 4096
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["value"] == res["value"] and back["ms_per_step"] == res["ms_per_step"]
+    assert back["config"]["workload"] and len(back["config"]["workload"]) <= 300 and "model" not in back["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "frac_with_insert", "traffic"):
+        assert back["roofline"][k] is not None, k
+    assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert back["cpu_baseline"][k] is not None, k
+    legs = back["legs"]
+    for k in ("all_hit_2s_host_keys_Glps", "hit_999_2s_host_keys_Glps", "hit_99_2s_host_keys_Glps", "c1_triton_Mlps",
+              "c4@0.5_p50_ms", "c4@0.9_p50_ms", "c4@0.99_p50_ms", "triton_abi_Glps", "triton_abi_p99_ms",
+              "triton_abi_slow_requests_ms", "wide_keys_95_8B_Glps", "device_driven_tier_Glps", "c5_dense_frac_of_hbm_peak",
+              "c5_hit_95_fused_ms", "c3_logical_Glps"):
+        assert k in legs, k
+
+
+def test_final_line_stays_under_the_limit_whatever_the_legs_hold():
+    import json
+    res = _fat_result()
+    res["config"]["workload"] = "w" * 5000
+    res["config"]["parallelism"] = "p" * 5000
+    res["cpu_baseline"]["sample"] = "s" * 5000
+    res["roofline"]["kernel"] = "k" * 5000
+    res["extra_legs"]["triton_abi"]["slow_requests_ms"] = [[10.0 + i, 0.0] for i in range(500)]
+    res["extra_legs"]["c4_two_models_triton"]["results"] = {f"target_hit_0.{i}": {"p50_request_ms": 0.1, "lookups_per_s": 1e8}
+                                                             for i in range(400)}
+    res["per_gpu"] = [{"measured_hit_rate": 0.95, "frac_of_hbm_peak_1032B_per_lookup": 0.7}] * 64
+    line = json.dumps(bench.compact_line(res))
+    assert len(line) <= bench.COMPACT_LIMIT < 4096
+    back = json.loads(line)
+    assert back["roofline"]["frac"] and back["cpu_baseline"]["value"] and back["value"] == res["value"]
+
+
+def test_emit_prints_the_compact_line_last_and_writes_the_rest_to_a_file(tmp_path, monkeypatch, capsys):
+    import json
+    res = _fat_result()
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    bench.emit(res)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out[-1]) < 4096 and json.loads(out[-1])["value"] == res["value"]
+    assert json.loads((tmp_path / "bench_extra.json").read_text())["extra_legs"]["triton_abi"]["lookups_per_s"] > 0
