@@ -491,6 +491,11 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       s->s->set_force_host_gather(value != 0);
     } else if (n == "split_probe") {
       s->s->set_split_probe(value != 0);
+    } else if (n == "defer_insert") {
+      s->s->set_defer_insert(value != 0);
+    } else if (n == "in_place_kb") {
+      if (value < 0) return Error(Code::kInvalidArg, "in_place_kb must be >= 0");
+      s->s->set_in_place_bytes((size_t)value << 10);
     } else if (n == "hit_rate_threshold_permille") {
       if (value < 0) return Error(Code::kInvalidArg, "hit_rate_threshold_permille must be >= 0");
       s->s->set_hit_rate_threshold((float)value / 1000.0f);

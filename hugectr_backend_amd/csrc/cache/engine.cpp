@@ -25,7 +25,6 @@ namespace hps {
 
 namespace {
 
-constexpr size_t kInPlaceStagingBytes = 256u << 10;   // missed rows of a chunk up to this size are read by the kernels where the host gathered them
 constexpr size_t kStagingCapBytes = 256ull << 20;  // per-session staging chunk for missed rows
 constexpr uint64_t kSmallRequestKeys = 1u << 17;   // requests up to this many keys are probed in tiles of ...
 constexpr uint64_t kSmallTileKeys = 256;           // ... this many keys
@@ -84,8 +83,22 @@ void EmbeddingCache::Release() {
 }
 
 CacheCounters EmbeddingCache::counters() const {
+  {
+    // inserts that sessions left running behind their last call: their statistics are part of the picture
+    std::lock_guard<std::mutex> lk(sess_mu_);
+    for (LookupSession* s : sessions_) (void)s->CollectDeferred();
+  }
   std::lock_guard<std::mutex> lk(stat_mu_);
   return counters_;
+}
+
+void EmbeddingCache::RegisterSession(LookupSession* s) {
+  std::lock_guard<std::mutex> lk(sess_mu_);
+  sessions_.push_back(s);
+}
+void EmbeddingCache::UnregisterSession(LookupSession* s) {
+  std::lock_guard<std::mutex> lk(sess_mu_);
+  sessions_.erase(std::remove(sessions_.begin(), sessions_.end(), s), sessions_.end());
 }
 
 // Insert statistics come back as kStatLines lines of the accumulator block (device_types.h): sum and add.
@@ -547,6 +560,8 @@ LookupSession::~LookupSession() { Release(); }
 void LookupSession::Release() {
   if (!cache_) return;
   (void)hipSetDevice(device_);
+  cache_->UnregisterSession(this);
+  (void)CollectDeferred();
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
   cache_->ForgetReader(ev_read_);  // our reader event may still be registered with the cache
@@ -561,7 +576,7 @@ void LookupSession::Release() {
   dfree(work_.rep_of); dfree(work_.uidx_of); dfree(work_.set); dfree(work_.uniq_keys);
   hfree(h_mode_);
   hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
-  for (hipEvent_t e : {ev_done_, ev_read_, ev_fetch_, ev_t0_, ev_t1_, ev_f0_, ev_f1_, ev_c1_, ev_probe_, ev_copy_,
+  for (hipEvent_t e : {ev_done_, ev_done2_, ev_read_, ev_fetch_, ev_t0_, ev_t1_, ev_f0_, ev_f1_, ev_c1_, ev_probe_, ev_copy_,
                        ev_g0_, ev_g1_, ev_s0_, ev_s1_, ev_i0_, ev_i1_})
     if (e) (void)hipEventDestroy(e);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
@@ -593,7 +608,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HIP_TRY(hipSetDevice(device_));
   HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&ev_copy_, &ev_done_, &ev_read_, &ev_fetch_, &ev_probe_})
+  for (hipEvent_t* e : {&ev_copy_, &ev_done_, &ev_done2_, &ev_read_, &ev_fetch_, &ev_probe_})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   for (hipEvent_t* e : {&ev_t0_, &ev_t1_, &ev_f0_, &ev_f1_, &ev_c1_, &ev_g0_, &ev_g1_, &ev_s0_, &ev_s1_, &ev_i0_, &ev_i1_}) HIP_TRY(hipEventCreate(e));
   for (hipEvent_t& e : ev_lane_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -605,6 +620,8 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switches
   if (const char* e = std::getenv("HPS_XCD_WALK")) xcd_walk_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_PROBE_VARIANT")) probe_variant_ = (int)std::strtol(e, nullptr, 10);
+  if (const char* e = std::getenv("HPS_DEFER_INSERT")) defer_insert_ = std::strtol(e, nullptr, 10) != 0;
+  if (const char* e = std::getenv("HPS_IN_PLACE_KB")) in_place_bytes_ = (size_t)std::max(0l, std::strtol(e, nullptr, 10)) << 10;
 
   HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_, hipHostMallocMapped));
   {
@@ -689,6 +706,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
     HPS_RETURN_IF_ERROR(EnsureStaging(floats, max_keys_ / 8 + 1));
   }
   HIP_TRY(hipDeviceSynchronize());
+  cache_->RegisterSession(this);
   return Status::Ok();
 }
 
@@ -962,6 +980,10 @@ Status LookupSession::LookupHostTier(const void* const* h_keys_per_table, float*
 // zeroed accumulator block, uploaded with one copy.
 Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T, bool probe_only,
                                   uint64_t* N_out) {
+  // the previous call's insert (left running behind it) has landed by now in all but pathological cases: its statistics
+  // are read before this call's first push overwrites the words, and the page-locked staging it may have read in place
+  // is free for this call's host gather
+  HPS_RETURN_IF_ERROR(CollectDeferred());
   CallDesc& c = *h_call_;
   c.num_tables = (uint32_t)T;
   c.keys = d_keys_flat;
@@ -1010,15 +1032,16 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   return Status::Ok();
 }
 
-Status LookupSession::PushWords(uint32_t words) {
+Status LookupSession::PushWords(uint32_t words, hipEvent_t ev, uint32_t* seq_out) {
   if (zc_control_) {
     if (++push_seq_ == 0) push_seq_ = 1;
     const hipError_t e = LaunchPushWords(d_acc_, h_acc_dev_, words, h_seq_dev_, push_seq_, stream_);
     if (e != hipSuccess) return Error(Code::kInternal, "accumulator push launch failed: ", hipGetErrorString(e));
-  } else {
+  } else if (words) {
     HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, (size_t)words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   }
-  HIP_TRY(hipEventRecord(ev_done_, stream_));
+  if (seq_out) *seq_out = push_seq_;
+  HIP_TRY(hipEventRecord(ev ? ev : ev_done_, stream_));
   return Status::Ok();
 }
 
@@ -1028,28 +1051,47 @@ static inline void SpinPause() {
 #endif
 }
 
-Status LookupSession::WaitPushed() {
-  if (!zc_control_) { HIP_TRY(hipEventSynchronize(ev_done_)); return Status::Ok(); }
-  const uint32_t want = push_seq_;
+Status LookupSession::WaitPushed() { return WaitPushedSeq(push_seq_, ev_done_); }
+
+Status LookupSession::WaitPushedSeq(uint32_t want, hipEvent_t ev) {
+  if (!zc_control_) { HIP_TRY(hipEventSynchronize(ev)); return Status::Ok(); }
+  // the word only moves forward (a later push may have overtaken the one waited for): signed distance, wrap-safe
+  auto landed = [&]() { return (int32_t)(__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) - want) >= 0; };
   // poll the sequence word for a while (the usual wait is tens of microseconds), looking at the event now and then so that a
   // failed stream ends the wait; a long wait (a millisecond of uploads ahead of the push) goes to the runtime's own wait
   const auto t0 = std::chrono::steady_clock::now();
   for (uint32_t i = 1;; ++i) {
-    if (__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) == want) return Status::Ok();
+    if (landed()) return Status::Ok();
     SpinPause();
     if ((i & 511u) == 0) {
-      const hipError_t q = hipEventQuery(ev_done_);
+      const hipError_t q = hipEventQuery(ev);
       if (q != hipSuccess && q != hipErrorNotReady) return Error(Code::kInternal, "lookup stream failed: ", hipGetErrorString(q));
       if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
     }
   }
-  HIP_TRY(hipEventSynchronize(ev_done_));
+  HIP_TRY(hipEventSynchronize(ev));
   // the push kernel has retired: its stores are on their way; give the last one the time to land
   for (uint32_t i = 0; i < (1u << 24); ++i) {
-    if (__atomic_load_n(h_seq_, __ATOMIC_ACQUIRE) == want) return Status::Ok();
+    if (landed()) return Status::Ok();
     SpinPause();
   }
   return Error(Code::kInternal, "accumulator push did not arrive");
+}
+
+// Statistics (and duration) of the insert kernel a call left running behind it.
+Status LookupSession::CollectDeferred() {
+  std::lock_guard<std::mutex> lk(deferred_mu_);
+  if (!deferred_pending_) return Status::Ok();
+  deferred_pending_ = false;
+  (void)hipSetDevice(device_);
+  HPS_RETURN_IF_ERROR(WaitPushedSeq(deferred_seq_, ev_done2_));
+  AddInsertStats();
+  if (deferred_timed_) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev_i0_, ev_i1_) == hipSuccess) last_insert_ms_ = ms;
+    else (void)hipGetLastError();
+  }
+  return Status::Ok();
 }
 
 // After the accumulator block has come back: per-table unique miss counts, the call's statistics.
@@ -1088,7 +1130,8 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
   };
   phase_ms_[0] = phase_ms_[1] = phase_ms_[2] = phase_ms_[3] = 0.f;
-  last_gather_ms_ = last_scatter_ms_ = last_insert_ms_ = 0.f;
+  last_gather_ms_ = last_scatter_ms_ = 0.f;
+  if (!defer_insert_) last_insert_ms_ = 0.f;   // (deferred: the duration of the most recent insert that has finished)
   // The insertion policy compares the table's hit rate over UNIQUE keys with the threshold
   // (docs/hierarchical_parameter_server.md:69: "first determines the associated unique embedding keys";
   // docs/architecture.md:66: "the real hit rate of the GPU embedding cache lookup"); a threshold outside (0,1) decides
@@ -1414,6 +1457,13 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   Mark(ev_s1_);
   if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[2]);
   if (e != hipSuccess) return Error(Code::kInternal, "direct miss path launch failed: ", hipGetErrorString(e));
+  const bool defer = defer_insert_ && zc_control_;
+  uint32_t rows_seq = 0;
+  if (defer) {
+    // rows complete (and, when the call ran ahead of its counts, the counts with them): what the caller waits for
+    if (timing_) (void)hipEventRecord(ev_c1_, stream_);
+    HPS_RETURN_IF_ERROR(PushWords((uint32_t)acc_words_, ev_done_, &rows_seq));
+  }
   cache_->BeginWrite(stream_);
   if (exclusive_) cache_->LaneEnter(stream_);
   Mark(ev_i0_);
@@ -1423,6 +1473,21 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
   if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[3]);
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
+  if (defer) {
+    {
+      std::lock_guard<std::mutex> lk(deferred_mu_);
+      const Status ps2 = PushWords((uint32_t)kStatLines * kAccStride, ev_done2_, &deferred_seq_);
+      if (!ps2.ok()) return ps2;
+      deferred_pending_ = true;
+      deferred_timed_ = timing_;
+    }
+    HPS_RETURN_IF_ERROR(WaitPushedSeq(rows_seq, ev_done_));
+    if (timing_) {
+      (void)hipEventElapsedTime(&phase_ms_[1], ev_f0_, ev_f1_);  // direct path: [1] = the fetch kernel (GPU time)
+      (void)hipEventElapsedTime(&last_scatter_ms_, ev_s0_, ev_s1_);
+    }
+    return Status::Ok();
+  }
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
   HPS_RETURN_IF_ERROR(PushWords((uint32_t)acc_words_));
   HPS_RETURN_IF_ERROR(WaitPushed());
@@ -1438,7 +1503,6 @@ Status LookupSession::HandleMissesDirect(uint64_t N, uint32_t epoch, bool counts
 // Synchronous miss path: parameter-server gather of the unique missed keys into pinned staging,
 // one H2D copy per chunk, missed rows scattered to the output, then inserted into the cache.
 Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
-  (void)N;
   const size_t T = tables_.size();
   const CallDesc& c = *h_call_;
   const int cu = cache_->cu_count();
@@ -1474,6 +1538,11 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     }
     md.useg_start[T] = uq;
     if (!any) break;
+    bool last = true;
+    for (size_t t = 0; t < T; ++t) last &= md.chunk_hi[t] == ucnt[t];
+    // The insert kernel of the call's last chunk is left running BEHIND the call (defer_insert_): the rows are exact without
+    // it, later readers of the cache are ordered behind it by the writer event, its statistics are read at the next call.
+    const bool defer = defer_insert_ && last && zc_control_;
 
     // ---- host parameter-server gather (multi-threaded) into pinned staging ----
     // Gather and upload in pieces of a few MB (runs of consecutive tables): the H2D copy of piece p runs
@@ -1482,9 +1551,18 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     // A small chunk (a small request, or a big one that missed little) is not uploaded at all: the scatter and insert kernels
     // read the gathered rows out of the page-locked staging buffer themselves, and the descriptor is pulled by a kernel — three
     // SDMA copies and their queue hand-offs less on the path of a request that takes 0.15 ms in all.
-    const bool in_place = zc_control_ && fl * sizeof(float) <= kInPlaceStagingBytes && h_staging_dev_ && h_found_dev_ && h_md_dev_;
+    const bool in_place = zc_control_ && fl * sizeof(float) <= in_place_bytes_ && h_staging_dev_ && h_found_dev_ && h_md_dev_;
+    // A chunk read in place needs nothing of this call's hit gather and nothing the gather writes (missed and hit rows are
+    // disjoint): descriptor pull and scatter go down the session's SECOND stream, released by the probe alone, and run next
+    // to K_G instead of behind it — and outside the kernel lane (a few hundred rows do not disturb an HBM-bound kernel,
+    // while waiting for the lane puts the other session's 230-us gather on this call's return path).  Round 3 had
+    // near-all-hit calls (hit 0.9996) at 1.5 x their kernel time because of exactly that wait plus the writer lock.
+    // (a small request's gather is a few microseconds: the hop to the second stream costs more)
+    const bool side = in_place && defer && N > kSmallRequestKeys;
+    hipStream_t ss = side ? copy_stream_ : stream_;
+    if (side) HIP_TRY(hipStreamWaitEvent(ss, ev_probe_, 0));
     if (in_place) {
-      const hipError_t pe = LaunchPull16(h_md_dev_, d_md_, sizeof(MissDesc), stream_);
+      const hipError_t pe = LaunchPull16(h_md_dev_, d_md_, sizeof(MissDesc), ss);
       if (pe != hipSuccess) return Error(Code::kInternal, "miss descriptor pull launch failed: ", hipGetErrorString(pe));
     } else {
       HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, stream_));
@@ -1545,19 +1623,37 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     const auto tt0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tt0).count(); };
     float tr[6] = {0, 0, 0, 0, 0, 0};
-    // Other sessions' kernels wait for our scatter (the lane) and their probes for our writer event.  Let the PCIe copies
-    // (and this call's own hit gather) drain first, so that those waits cover the scatter and the insert kernel alone
-    // (tens of microseconds) and not the millisecond of H2D queued ahead of them on this stream.
-    // (a chunk read in place has nothing queued ahead of its scatter: no drain, one host wait for the whole call)
-    if (!in_place) HIP_TRY(hipStreamSynchronize(stream_));
-    tr[0] = since();
-    if (exclusive_) cache_->LaneEnter(stream_);
-    Mark(ev_s0_);
-    hipError_t e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, rows_src, stream_, Kt(ev_s0_, ev_s1_));
-    Mark(ev_s1_);
-    if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[2]);
-    tr[1] = since();
-    if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
+    hipError_t e = hipSuccess;
+    if (side) {
+      // scatter next to K_G, outside the lane; the session's stream then waits for it
+      Mark(ev_s0_, ss);
+      e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, rows_src, ss, Kt(ev_s0_, ev_s1_));
+      Mark(ev_s1_, ss);
+      if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
+      HIP_TRY(hipEventRecord(ev_copy_, ss));
+      HIP_TRY(hipStreamWaitEvent(stream_, ev_copy_, 0));
+      tr[1] = since();
+    } else {
+      // Other sessions' kernels wait for our scatter (the lane) and their probes for our writer event.  Let the PCIe copies
+      // (and this call's own hit gather) drain first, so that those waits cover the scatter and the insert kernel alone
+      // (tens of microseconds) and not the millisecond of H2D queued ahead of them on this stream.
+      // (a chunk read in place has nothing queued ahead of its scatter: no drain, one host wait for the whole call)
+      if (!in_place) HIP_TRY(hipStreamSynchronize(stream_));
+      tr[0] = since();
+      if (exclusive_) cache_->LaneEnter(stream_);
+      Mark(ev_s0_);
+      e = LaunchMissScatter(d_call_, cache_->device_tables(), d_md_, work_, rows_src, stream_, Kt(ev_s0_, ev_s1_));
+      Mark(ev_s1_);
+      if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[2]);
+      tr[1] = since();
+      if (e != hipSuccess) return Error(Code::kInternal, "miss scatter launch failed: ", hipGetErrorString(e));
+    }
+    uint32_t rows_seq = 0;
+    if (defer) {
+      // the call's rows are complete behind this point of the stream: that is what the caller waits for
+      if (timing_) (void)hipEventRecord(ev_c1_, stream_);
+      HPS_RETURN_IF_ERROR(PushWords(0, ev_done_, &rows_seq));
+    }
     cache_->BeginWrite(stream_);
     tr[2] = since();
     if (exclusive_) cache_->LaneEnter(stream_);
@@ -1569,10 +1665,24 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     cache_->EndWrite(stream_);
     tr[3] = since();
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
+    if (defer) {
+      {
+        std::lock_guard<std::mutex> lk(deferred_mu_);
+        const Status ps2 = PushWords((uint32_t)kStatLines * kAccStride, ev_done2_, &deferred_seq_);
+        if (!ps2.ok()) return ps2;
+        deferred_pending_ = true;
+        deferred_timed_ = timing_;
+      }
+      HPS_RETURN_IF_ERROR(WaitPushedSeq(rows_seq, ev_done_));
+      tr[4] = since();
+      if (kTrace && tr[4] > 3.0f)
+        fprintf(stderr, "[hps tail] drained %.2f  scatter-enqueued %.2f  write-lock %.2f  insert-enqueued %.2f  rows done %.2f ms (fetch %.2f ms before; insert left behind)\n",
+                tr[0], tr[1], tr[2], tr[3], tr[4], phase_ms_[1]);
+      if (timing_) (void)hipEventElapsedTime(&last_scatter_ms_, ev_s0_, ev_s1_);
+      return Status::Ok();
+    }
     // staging is reused by the next chunk
     if (timing_) (void)hipEventRecord(ev_c1_, stream_);
-    bool last = true;
-    for (size_t t = 0; t < T; ++t) last &= md.chunk_hi[t] == ucnt[t];
     if (last) {   // the insert statistics ride the call's final synchronisation
       HPS_RETURN_IF_ERROR(PushWords((uint32_t)kStatLines * kAccStride));
       HPS_RETURN_IF_ERROR(WaitPushed());

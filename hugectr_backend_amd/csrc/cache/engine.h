@@ -36,6 +36,7 @@
 namespace hps {
 
 class HierParameterServer;
+class LookupSession;
 
 struct EmbeddingCacheConfig {  // get_cache_config() of the reference (only num_emb_table_ is read there)
   size_t num_emb_table_ = 0;
@@ -70,6 +71,7 @@ class EmbeddingCache {
   const TableCacheDev* device_tables() const { return d_tables_; }
   const std::vector<TableCacheDev>& host_tables() const { return h_tables_; }
   int cu_count() const { return cu_count_; }
+  // (collects the statistics of inserts that lookup sessions left running behind their last call first)
   CacheCounters counters() const;
   void AddStatLines(const uint32_t* lines);   // insert statistics of one launch series: kStatLines accumulator lines
 
@@ -171,6 +173,12 @@ class EmbeddingCache {
 
   mutable std::mutex stat_mu_;
   CacheCounters counters_;
+  // lookup sessions of this cache (registered in LookupSession::Init, removed in Release): counters() asks each for the
+  // statistics of an insert kernel it left behind its last call (LookupSession::CollectDeferred)
+  mutable std::mutex sess_mu_;
+  std::vector<LookupSession*> sessions_;
+  void RegisterSession(LookupSession* s);
+  void UnregisterSession(LookupSession* s);
 
   // ---- device-driven parameter-server tier ("ps_direct_access", direct_kernels.hip) ----
  public:
@@ -278,6 +286,13 @@ class LookupSession {
   void set_probe_variant(int v) { probe_variant_ = v; }
   void set_force_host_gather(bool b) { force_host_gather_ = b; }
   void set_timing(bool on) { timing_ = on; }
+  void set_defer_insert(bool b) { defer_insert_ = b; }
+  void set_in_place_bytes(size_t b) { in_place_bytes_ = b; }
+  // The insert kernel of a synchronous call is enqueued behind the call and NOT waited for (defer_insert_): the rows the
+  // call returns are exact without it, and every later reader of the cache is ordered behind it by the cache's writer
+  // event.  Its statistics (and, with option "timing", its duration) are collected here — at the start of the session's
+  // next call, by EmbeddingCache::counters(), and when the session goes away.  Thread-safe.
+  Status CollectDeferred();
   // per-session override of the model's hit_rate_threshold (sync vs async insertion, docs/architecture.md:65-67)
   void set_hit_rate_threshold(float v) { params_.hit_rate_threshold = v; }
 
@@ -348,8 +363,18 @@ class LookupSession {
   uint32_t* h_seq_ = nullptr;      // = h_acc_ + acc_words_ (own 128-B line)
   uint32_t* h_seq_dev_ = nullptr;
   uint32_t push_seq_ = 0;
-  Status PushWords(uint32_t words);   // enqueue: d_acc_[0..words) -> h_acc_, then the sequence word; records ev_done_
+  // enqueue: d_acc_[0..words) -> h_acc_, then the sequence word; records `ev` (default ev_done_); *seq_out = the word's value
+  Status PushWords(uint32_t words, hipEvent_t ev = nullptr, uint32_t* seq_out = nullptr);
   Status WaitPushed();                // host: until the last PushWords has landed (or the stream reports an error)
+  Status WaitPushedSeq(uint32_t seq, hipEvent_t ev);   // ... until the push that carried `seq` (or a later one) has landed
+  bool defer_insert_ = true;          // option "defer_insert" / HPS_DEFER_INSERT: the insert kernel is not on the call's return path
+  size_t in_place_bytes_ = 1u << 20;  // option "in_place_bytes" / HPS_IN_PLACE_KB: missed rows of a chunk up to this size are read by
+                                      // the kernels where the host gathered them (page-locked staging), no upload
+  std::mutex deferred_mu_;
+  bool deferred_pending_ = false;     // an insert + statistics push is in flight behind the last call
+  uint32_t deferred_seq_ = 0;
+  bool deferred_timed_ = false;
+  hipEvent_t ev_done2_ = nullptr;     // behind the deferred statistics push
   CallWork work_{};               // device pointers of the per-call work arrays
   uint32_t* d_mode_ = nullptr;    // per-table insertion mode of a mixed call (1 = async)
   uint32_t call_tag_ = 0;
@@ -365,7 +390,7 @@ class LookupSession {
   // hand-offs per kernel)
   bool kernel_stamps_ = true;
   KTimer Kt(hipEvent_t a, hipEvent_t b) const { return (timing_ && kernel_stamps_) ? KTimer{a, b} : KTimer{}; }
-  void Mark(hipEvent_t e) { if (timing_ && !kernel_stamps_) (void)hipEventRecord(e, stream_); }
+  void Mark(hipEvent_t e, hipStream_t s = nullptr) { if (timing_ && !kernel_stamps_) (void)hipEventRecord(e, s ? s : stream_); }
   bool fused_unique_ = true;     // the call-wide unique misses are found in the probe kernel's tail (option "fused_unique", HPS_FUSED_UNIQUE)
   bool exclusive_ = true;        // the HBM-bound kernels of this session take the cache's lane (option "exclusive_kernels")
   hipEvent_t ev_lane_[4] = {nullptr, nullptr, nullptr, nullptr};   // probe pair, hit gather, miss scatter, insert

@@ -237,7 +237,11 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
  * page-locked key arrays in place instead of staging them), "narrow_keys" (pageable keys cross PCIe at the width the
  * request needs — 0: always 8 bytes; 1 (default): 3 bytes each when every key is in [0, 2^24), uint32 when in [0, 2^32);
  * 2: uint32 only.  A width that fails is not tried again for 256 calls, doubling with every failure in a row up to
- * 65,536) */
+ * 65,536), "defer_insert" (0/1, default 1: a synchronous call returns when its rows are complete; the cache-insert kernel
+ * of its missed rows stays enqueued behind it, ordered before every later reader of the cache by the cache's writer
+ * event — hps_cache_counters and hps_cache_query see it done; 0: the call also waits for the insert kernel),
+ * "in_place_kb" (default 1024: missed rows of a call up to this many KB are read by the scatter and insert kernels out of
+ * the page-locked buffer the host gathered them into, next to the hit gather, instead of being uploaded first) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 /* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------

@@ -782,3 +782,110 @@ def test_keys_narrow_as_offsets_from_each_tables_smallest_key():
     q[nk[0] + 7] = tables[1][0].min() - 1
     out = s.lookup(q, nk).cpu().numpy()
     assert np.array_equal(_bits(out), _bits(co.lookup(q, nk, [0.5, 1.5, 2.5]))) and s.last_stats().key_bytes == 8
+
+
+@pytest.mark.usefixtures("plain_lru")
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("defer", [1, 0])
+def test_insert_left_behind_the_call_is_visible_to_every_later_observer(direct, defer):
+    """Option defer_insert (default 1): a synchronous call returns when its rows are complete and leaves its cache-insert
+    kernel enqueued behind it.  Everything that can observe the cache afterwards — the next lookup (this session's or another
+    one's), hps_cache_query, the counters — sees the insert done; rows and counts equal those of defer_insert=0.
+    Big requests (> 128 K keys) with few misses take the side-stream scatter next to the hit gather (host-gather tier)."""
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(40 + defer + 2 * int(direct))
+    T, R, D = 3, 60000, 128
+    tables = make_tables([(R, D)] * T)
+    # (buckets filled to a quarter: no bucket is full, so that "every missed key is resident afterwards" holds to the key)
+    ps, cache, s0 = _mk(f"defer{defer}{int(direct)}", tables, maxcat=[1] * T, gpucacheper=0.5, max_batch=60000,
+                        extra={"ps_direct_access": direct, "gpucache_load_factor": 0.25})
+    s1 = hps.LookupSession.create(ps, f"defer{defer}{int(direct)}", cache)
+    for s in (s0, s1):
+        s.set_option("defer_insert", defer)
+        s.set_option("timing", 1)
+    co = O.COracle()
+    for k, r in tables:
+        co.add_table_arrays(k, r)
+    inserted0 = cache.counters()["inserted"]
+    total_new = 0
+    for it in range(6):
+        sess = (s0, s1)[it % 2]
+        nk = [50000, 47000, 50001]                       # 147,001 keys: a "big" request (1,024-key tiles, side-stream scatter)
+        parts, missing = [], []
+        for t, ((tk, _), n) in enumerate(zip(tables, nk)):
+            res = tk[cache.query(t, tk) >= 0]
+            cold = tk[cache.query(t, tk) < 0]
+            q = rng.choice(res, n)
+            m = rng.choice(cold, 40 + 10 * it, replace=False)   # a few hundred missed rows per call, each sent three times
+            pos = rng.choice(n, 3 * m.size, replace=False)
+            q[pos] = np.tile(m, 3)
+            parts.append(q)
+            missing.append(m)
+        q = np.concatenate(parts).astype(np.int64)
+        out = sess.lookup(q, nk).cpu().numpy()
+        assert np.array_equal(_bits(out), _bits(co.lookup(q, nk, [0.0] * T))), it
+        st = sess.last_stats()
+        new = sum(m.size for m in missing)
+        assert (st.misses, st.unique_misses) == (3 * new, new), it
+        total_new += new
+        # observers: the query (device-synchronous), the counters, and the OTHER session's next lookup
+        for t, m in enumerate(missing):
+            assert (cache.query(t, m) >= 0).all(), (it, t)
+        assert cache.counters()["inserted"] - inserted0 == total_new, it
+        other = (s0, s1)[(it + 1) % 2]
+        q2 = np.concatenate(missing).astype(np.int64)
+        out2 = other.lookup(q2, [m.size for m in missing]).cpu().numpy()
+        assert other.last_stats().misses == 0, it
+        assert np.array_equal(_bits(out2), _bits(co.lookup(q2, [m.size for m in missing], [0.0] * T))), it
+    assert s0.last_stats().insert_ms >= 0.0
+
+
+def test_two_sessions_near_all_hit_stress_rows_stay_exact():
+    """Two sessions on one cache, big requests that miss a few hundred rows each (the regime of a production cache at
+    99.9 % hit): side-stream scatter next to the hit gather, inserts left behind the calls, the other session's probes
+    ordered behind them by the writer event — every row of every call exact, nothing lost from the counters."""
+    import threading
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    T, R, D = 2, 200000, 128
+    tables = make_tables([(R, D)] * T)
+    ps, cache, s0 = _mk("nearhit", tables, maxcat=[1] * T, gpucacheper=0.25, max_batch=100000)
+    s1 = hps.LookupSession.create(ps, "nearhit", cache)
+    co = O.COracle()
+    for k, r in tables:
+        co.add_table_arrays(k, r)
+    res = [tk[cache.query(t, tk) >= 0] for t, (tk, _) in enumerate(tables)]
+    cold = [tk[cache.query(t, tk) < 0] for t, (tk, _) in enumerate(tables)]
+    errs = []
+    sent_new = [0, 0]
+
+    def worker(si, sess):
+        rng = np.random.default_rng(900 + si)
+        try:
+            for it in range(12):
+                nk = [100000, 90000]
+                parts = []
+                for t in range(T):
+                    q = rng.choice(res[t], nk[t])
+                    m = rng.choice(cold[t], 150)
+                    q[rng.choice(nk[t], m.size, replace=False)] = m
+                    parts.append(q)
+                q = np.concatenate(parts).astype(np.int64)
+                out = sess.lookup(q, nk).cpu().numpy()
+                if not np.array_equal(_bits(out), _bits(co.lookup(q, nk, [0.0] * T))):
+                    errs.append(f"session {si} call {it}: rows differ")
+                sent_new[si] += sess.last_stats().unique_misses
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    c0 = cache.counters()
+    th = [threading.Thread(target=worker, args=(i, s)) for i, s in enumerate((s0, s1))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    c1 = cache.counters()
+    # every unique miss of every call went through an insert launch and was counted (inserted, refreshed — the other
+    # session got there first — or dropped by the admission rule)
+    done = sum(c1[k] - c0[k] for k in ("inserted", "refreshed", "dropped"))
+    assert done == sum(sent_new), (done, sent_new)
