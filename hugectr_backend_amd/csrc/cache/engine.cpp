@@ -576,7 +576,7 @@ void LookupSession::Release() {
   dfree(work_.rep_of); dfree(work_.uidx_of); dfree(work_.set); dfree(work_.uniq_keys);
   hfree(h_mode_);
   hfree(h_uniq_keys_); hfree(h_staging_); dfree(d_staging_); hfree(h_found_); dfree(d_found_);
-  for (hipEvent_t e : {ev_done_, ev_done2_, ev_read_, ev_fetch_, ev_t0_, ev_t1_, ev_f0_, ev_f1_, ev_c1_, ev_probe_, ev_copy_,
+  for (hipEvent_t e : {ev_keys_, ev_done_, ev_done2_, ev_read_, ev_fetch_, ev_t0_, ev_t1_, ev_f0_, ev_f1_, ev_c1_, ev_probe_, ev_copy_,
                        ev_g0_, ev_g1_, ev_s0_, ev_s1_, ev_i0_, ev_i1_})
     if (e) (void)hipEventDestroy(e);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
@@ -608,7 +608,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   HIP_TRY(hipSetDevice(device_));
   HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&ev_copy_, &ev_done_, &ev_done2_, &ev_read_, &ev_fetch_, &ev_probe_})
+  for (hipEvent_t* e : {&ev_copy_, &ev_keys_, &ev_done_, &ev_done2_, &ev_read_, &ev_fetch_, &ev_probe_})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   for (hipEvent_t* e : {&ev_t0_, &ev_t1_, &ev_f0_, &ev_f1_, &ev_c1_, &ev_g0_, &ev_g1_, &ev_s0_, &ev_s1_, &ev_i0_, &ev_i1_}) HIP_TRY(hipEventCreate(e));
   for (hipEvent_t& e : ev_lane_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -853,6 +853,10 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     // stage(width): the keys leave at `width` bytes each — 8 as they are, 4 as uint32, 3 packed little-endian.  A narrower
     // width is optimistic: every task ORs its keys together while it copies, and the first group that saw a key too wide
     // ends the attempt (the caller restages at the next width; `seen` tells it which one can work).
+    // The keys go up on the session's SECOND stream: the first one may still hold the previous call's insert kernel (left
+    // running behind that call, waiting for the other session's hit gather to release the cache), and nothing of this
+    // upload depends on it.  The probe waits for the event behind the last piece.
+    hipStream_t ks = copy_stream_;
     uint64_t seen = 0;
     auto stage = [&](int width) -> Status {
       std::atomic<uint64_t> high_or{0};
@@ -875,7 +879,7 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
         const auto tp1 = std::chrono::steady_clock::now();
         if (width < 8 && (seen = high_or.load(std::memory_order_relaxed)) != 0) return Status::Ok();   // caller restages wider
         const size_t first = tasks[g0].off, count = tasks[g1 - 1].off + tasks[g1 - 1].n - first;
-        HIP_TRY(hipMemcpyAsync(dev8 + first * (size_t)width, dst8 + first * (size_t)width, count * (size_t)width, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(dev8 + first * (size_t)width, dst8 + first * (size_t)width, count * (size_t)width, hipMemcpyHostToDevice, ks));
         const auto tp2 = std::chrono::steady_clock::now();
         stage_pool_ms_ += std::chrono::duration<float, std::milli>(tp1 - tp0).count();
         stage_enqueue_ms_ += std::chrono::duration<float, std::milli>(tp2 - tp1).count();
@@ -892,30 +896,35 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
       staged = keys_narrow_;
       if (!staged) {
         NarrowFailed(true);   // keys of more than 24 bits in this traffic
-        HIP_TRY(hipStreamSynchronize(stream_));   // groups already in flight read the staging buffer we are about to rewrite
+        HIP_TRY(hipStreamSynchronize(ks));   // groups already in flight read the staging buffer we are about to rewrite
       } else narrow24_streak_ = 0;
     }
     if (!staged && try_narrow && (seen >> 32) == 0) {
       seen = 0;
       HPS_RETURN_IF_ERROR(stage(4));
       staged = keys_narrow_;
-      if (!staged) HIP_TRY(hipStreamSynchronize(stream_));
+      if (!staged) HIP_TRY(hipStreamSynchronize(ks));
       else narrow_streak_ = 0;
     }
     if (!staged) {
       if (try_narrow) NarrowFailed(false);   // wide (or negative) keys in this traffic: plain copies for the next calls
-      if (direct_dma) HIP_TRY(hipMemcpyAsync(d_keys_, base, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+      if (direct_dma) HIP_TRY(hipMemcpyAsync(d_keys_, base, N * sizeof(int64_t), hipMemcpyHostToDevice, ks));
       else HPS_RETURN_IF_ERROR(stage(8));
     }
+    const auto te0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipEventRecord(ev_keys_, ks));
+    HIP_TRY(hipStreamWaitEvent(stream_, ev_keys_, 0));
+    stage_event_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - te0).count();
   }
   key_stage_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
   const Status st_ = TimedLookupDevice(d_keys_, vectors_per_table, num_keys_per_table, num_tables);
-  static const bool kTraceCalls = std::getenv("HPS_TRACE_TAIL") != nullptr;   // diagnostic: where did a slow call spend its time
-  if (kTraceCalls) {
+  // diagnostic: where did a slow call spend its time (HPS_TRACE_TAIL=<ms>: calls longer than that; no number: 5 ms)
+  static const float kTraceCallsMs = [] { const char* e = std::getenv("HPS_TRACE_TAIL"); if (!e) return -1.f; const float v = std::strtof(e, nullptr); return v > 0.f ? v : 5.f; }();
+  if (kTraceCallsMs > 0.f) {
     const float all = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
-    if (all > 5.0f)
-      fprintf(stderr, "[hps call] %.2f ms: key staging %.2f (pool %.2f, H2D enqueue %.2f), counts on host %.2f, ps fetch %.2f, tail %.2f, engine call %.2f (direct_dma %d narrow %d)\n",
-              all, key_stage_ms_, stage_pool_ms_, stage_enqueue_ms_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3], (int)direct_dma, (int)keys_narrow_);
+    if (all > kTraceCallsMs)
+      fprintf(stderr, "[hps call] %.2f ms: key staging %.2f (pool %.2f, H2D enqueue %.2f, event %.2f), counts on host %.2f, ps fetch %.2f, tail %.2f, engine call %.2f (direct_dma %d narrow %d)\n",
+              all, key_stage_ms_, stage_pool_ms_, stage_enqueue_ms_, stage_event_ms_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3], (int)direct_dma, (int)keys_narrow_);
   }
   return st_;
 }
@@ -1032,16 +1041,17 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   return Status::Ok();
 }
 
-Status LookupSession::PushWords(uint32_t words, hipEvent_t ev, uint32_t* seq_out) {
+Status LookupSession::PushWords(uint32_t words, hipEvent_t ev, uint32_t* seq_out, hipStream_t on) {
+  hipStream_t st = on ? on : stream_;
   if (zc_control_) {
     if (++push_seq_ == 0) push_seq_ = 1;
-    const hipError_t e = LaunchPushWords(d_acc_, h_acc_dev_, words, h_seq_dev_, push_seq_, stream_);
+    const hipError_t e = LaunchPushWords(d_acc_, h_acc_dev_, words, h_seq_dev_, push_seq_, st);
     if (e != hipSuccess) return Error(Code::kInternal, "accumulator push launch failed: ", hipGetErrorString(e));
   } else if (words) {
-    HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, (size_t)words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(h_acc_, d_acc_, (size_t)words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   }
   if (seq_out) *seq_out = push_seq_;
-  HIP_TRY(hipEventRecord(ev ? ev : ev_done_, stream_));
+  HIP_TRY(hipEventRecord(ev ? ev : ev_done_, st));
   return Status::Ok();
 }
 
@@ -1189,7 +1199,10 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   // K_G follows K_P at once when the call does not wait for the counts first (no misses lately, or the device-driven tier):
   // the lane is kept across both — handing it to the other session in between costs two more switches of the GPU between
   // streams per pair of calls for nothing (every key resident, two sessions: 20 us of idle GPU per step)
-  const bool hold_lane = exclusive_ && !split && e == hipSuccess;
+  // (split: the counts leave on the session's SECOND stream, released by the probe's event, so K_G follows K_P on this stream
+  //  just the same — round 3 pushed them between the two kernels: two more dependent packets and ~35 us of idle GPU per call)
+  const bool side_push = split && zc_control_;
+  const bool hold_lane = exclusive_ && (!split || side_push) && e == hipSuccess;
   if (exclusive_ && !hold_lane) cache_->LaneLeave(stream_, ev_lane_[0]);
   // other sessions' probes chain behind ours (K_P, and K_M / K_H where they are launches of their own)
   (void)hipEventRecord(ev_probe_, stream_);
@@ -1212,7 +1225,12 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     read_open = false;
   };
   if (e != hipSuccess) { end_read(); return Error(Code::kInternal, "probe launch failed: ", hipGetErrorString(e)); }
-  if (!split) {
+  if (side_push) {
+    HIP_TRY(hipStreamWaitEvent(copy_stream_, ev_probe_, 0));
+    const Status ps = PushWords((uint32_t)acc_words_, ev_done_, nullptr, copy_stream_);
+    if (!ps.ok()) { end_read(); return ps; }
+  }
+  if (!split || side_push) {
     e = gather();
     end_read();
     if (e != hipSuccess) return Error(Code::kInternal, "hit gather launch failed: ", hipGetErrorString(e));
@@ -1232,11 +1250,11 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     return st;
   }
   if (timing_) (void)hipEventRecord(ev_c1_, stream_);
-  {
+  if (!side_push) {
     const Status ps = PushWords((uint32_t)acc_words_);
     if (!ps.ok()) { end_read(); return ps; }
   }
-  if (split) {
+  if (split && !side_push) {
     // K_G behind the counts: it runs while the host reads them and works on the misses
     e = gather();
     end_read();

@@ -319,9 +319,11 @@ class LookupSession {
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;  // second H2D queue for the missed-row pieces
   hipEvent_t ev_copy_ = nullptr;
+  hipEvent_t ev_keys_ = nullptr;       // behind the key upload (second stream)
   hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr,
              ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr, ev_probe_ = nullptr;
   float last_gpu_call_ms_ = 0.f;
+  float stage_event_ms_ = 0.f;
   float stage_pool_ms_ = 0.f, stage_enqueue_ms_ = 0.f;   // key staging: time in the pool loops / in the H2D enqueues
   float key_stage_ms_ = 0.f;      // host side of lookup(): staging the keys and enqueueing their H2D copies
   bool narrow_keys_ = true;       // option "narrow_keys": stage pageable keys as uint32 when they all fit
@@ -364,7 +366,7 @@ class LookupSession {
   uint32_t* h_seq_dev_ = nullptr;
   uint32_t push_seq_ = 0;
   // enqueue: d_acc_[0..words) -> h_acc_, then the sequence word; records `ev` (default ev_done_); *seq_out = the word's value
-  Status PushWords(uint32_t words, hipEvent_t ev = nullptr, uint32_t* seq_out = nullptr);
+  Status PushWords(uint32_t words, hipEvent_t ev = nullptr, uint32_t* seq_out = nullptr, hipStream_t on = nullptr);
   Status WaitPushed();                // host: until the last PushWords has landed (or the stream reports an error)
   Status WaitPushedSeq(uint32_t seq, hipEvent_t ev);   // ... until the push that carried `seq` (or a later one) has landed
   bool defer_insert_ = true;          // option "defer_insert" / HPS_DEFER_INSERT: the insert kernel is not on the call's return path

@@ -15,17 +15,26 @@ SMALL = ["--rows", "300000", "--batch", "4096", "--steps", "3", "--warmup", "1",
          "--no-cpu-baseline", "--no-extra-legs", "--sharded-steps", "4", "--shard-rows", "400000"]
 
 
-def _line(out):
+def _line(out, cwd):
+    """The compact line the driver parses (the LAST line of stdout, < 4 KB) merged over the full result bench.py leaves in
+    bench_extra.json of its working directory."""
     lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out[-2000:]
-    return json.loads(lines[0])
+    assert len(lines) == 1 and out.strip().splitlines()[-1] == lines[0], out[-2000:]
+    assert len(lines[0]) < 4096
+    compact = json.loads(lines[0])
+    full = json.loads((Path(cwd) / "bench_extra.json").read_text())
+    for k in ("value", "ms_per_step", "n_gpus", "scaling"):
+        assert compact[k] == full[k], k
+    assert compact["roofline"]["frac"] is not None
+    return full
 
 
 @pytest.mark.gpu
-def test_two_replicas_in_one_process_share_one_parameter_server():
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", *SMALL], capture_output=True, text=True, timeout=600)
+def test_two_replicas_in_one_process_share_one_parameter_server(tmp_path):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", *SMALL], capture_output=True, text=True, timeout=600,
+                       cwd=tmp_path)
     assert r.returncode == 0, r.stderr[-3000:]
-    d = _line(r.stdout)
+    d = _line(r.stdout, tmp_path)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert "reduced" not in d["config"]["workload"] and "300000 rows/table" in d["config"]["workload"]
     assert "ONE process, ONE parameter server" in d["config"]["parallelism"]
@@ -37,15 +46,15 @@ def test_two_replicas_in_one_process_share_one_parameter_server():
 
 
 @pytest.mark.gpu
-def test_driver_launch_with_two_ranks_rank0_serves_every_gpu():
+def test_driver_launch_with_two_ranks_rank0_serves_every_gpu(tmp_path):
     """The driver's N > 1 command line: rank 0 runs the replicas measurement for both GPUs, rank 1 waits and joins the
     sharded-table leg (config 3), here over gloo because the two ranks share the one GPU."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29613", str(ROOT / "bench.py"), "--gpus", "2", *SMALL],
-                       capture_output=True, text=True, timeout=900, env=env)
+                       capture_output=True, text=True, timeout=900, env=env, cwd=tmp_path)
     assert r.returncode == 0, r.stderr[-3000:]
-    d = _line(r.stdout)
+    d = _line(r.stdout, tmp_path)
     assert d["n_gpus"] == 2 and len(d["per_gpu"]) == 2
     assert d["parity_full_batch_vs_direct_row_index"] is True
     leg = d["extra_legs"]["sharded_c3"]
