@@ -249,6 +249,13 @@ int hps_server_update_source_drain(hps_server_t* sv, uint32_t timeout_ms) {
   });
 }
 
+int hps_server_update_source_stop(hps_server_t* sv) {
+  return Guard([&]() -> Status {
+    if (!sv) return Error(Code::kInvalidArg, "null argument");
+    return sv->ps->stop_update_source();
+  });
+}
+
 int hps_update_message_encode(const char* model, uint32_t table, uint32_t dim, const int64_t* keys, const float* rows, uint64_t n,
                               void* out, uint64_t out_capacity, uint64_t* out_bytes) {
   return Guard([&]() -> Status {

@@ -502,6 +502,7 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   void OnUpdatesCommitted(const std::set<std::string>& models);
   bool update_source_stats(UpdateSourceStats* out) const;
   Status drain_update_source(size_t timeout_ms);
+  Status stop_update_source();   // joins the consumer thread; pending messages stay uncommitted
 
  private:
   HierParameterServer() = default;

@@ -257,6 +257,12 @@ Status HierParameterServer::drain_update_source(size_t timeout_ms) {
   return updates_->Drain(timeout_ms);
 }
 
+Status HierParameterServer::stop_update_source() {
+  if (!updates_) return Error(Code::kUnavailable, "no update source is configured (ps.json update_source.type)");
+  updates_.reset();
+  return Status::Ok();
+}
+
 // Copies a table's two files into the persistent store directory (created if needed).
 static Status MaterializeStore(const std::string& src, const std::string& dst) {
   std::error_code ec;

@@ -105,6 +105,8 @@ class HostTable {
   size_t FetchTiered(const int64_t* keys, size_t n, float* out, size_t stride, float default_value, uint8_t* found) const;
   Status UpsertTiered(const int64_t* keys, const float* rows, size_t n);
   Status AppendRows(const int64_t* keys, const float* rows, const std::vector<size_t>& fresh);
+  Status IndexAppended(size_t first_new);
+  double index_headroom_ = 1.0;   // AllocPartitions sizes the index for this many times the keys it is given
   void* DataAlloc(size_t bytes);
   void DataFree(void* p);
   bool pinned_ = false;

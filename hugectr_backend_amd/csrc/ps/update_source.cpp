@@ -1,5 +1,7 @@
 #include "update_source.h"
 
+#include <deque>
+
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -26,8 +28,9 @@ std::string EncodeUpdateMessage(const std::string& model, uint32_t table, uint32
 namespace {
 
 // Follows an append-only file of framed messages.  A frame that is not complete yet (the producer is in the middle of an
-// append) is left for the next poll; a frame that cannot be one (bad magic, larger than the receive buffer) poisons the
-// source: the consumer reports it and stops reading rather than guessing where the next frame starts.
+// append) is left for the next poll; a frame that cannot be one (bad magic, no row width, an absurd length) poisons the
+// source: the consumer reports it once and stops reading rather than guessing where the next frame starts.  A well-formed
+// frame that is merely larger than the receive buffer is stepped over (its length is known).
 class FileTailTransport : public UpdateTransport {
  public:
   FileTailTransport(std::string path, size_t max_message) : path_(std::move(path)), max_message_(std::max<size_t>(max_message, 4096)) {
@@ -52,17 +55,22 @@ class FileTailTransport : public UpdateTransport {
     }
   }
 
-  Status Commit() override {
-    if (committed_ == read_) return Status::Ok();
+  Status Commit(size_t messages) override {
+    // only what the consumer has dealt with: the end of the `messages`-th message handed out since the last commit
+    uint64_t upto = committed_;
+    for (size_t i = 0; i < messages && !ends_.empty(); ++i) { upto = ends_.front(); ends_.pop_front(); }
+    if (upto == committed_) return Status::Ok();
     const std::string tmp = path_ + ".offset.tmp";
     FILE* f = fopen(tmp.c_str(), "w");
     if (!f) return Error(Code::kInternal, "update source: cannot write '", tmp, "'");
-    fprintf(f, "%llu\n", (unsigned long long)read_);
+    fprintf(f, "%llu\n", (unsigned long long)upto);
     fclose(f);
     if (rename(tmp.c_str(), (path_ + ".offset").c_str()) != 0) return Error(Code::kInternal, "update source: cannot replace '", path_, ".offset'");
-    committed_ = read_;
+    committed_ = upto;
     return Status::Ok();
   }
+  uint64_t TakeSkipped() override { const uint64_t n = skipped_; skipped_ = 0; return n; }
+  bool dead() const override { return poisoned_; }
 
  private:
   Status ReadSome(size_t max_messages, std::vector<UpdateMessage>* out) {
@@ -77,12 +85,21 @@ class FileTailTransport : public UpdateTransport {
       UpdateMessageHeader h;
       if (pread(fd_, &h, sizeof h, (off_t)read_) != (ssize_t)sizeof h) break;
       const uint64_t payload = (uint64_t)h.model_len + (uint64_t)h.count * sizeof(int64_t) + (uint64_t)h.count * h.dim * sizeof(float);
-      if (h.magic != kUpdateMagic || h.dim == 0 || payload > max_message_) {
+      if (h.magic != kUpdateMagic || h.dim == 0 || payload > (1ull << 32)) {   // (a length nobody would wait for: not a frame)
         poisoned_ = true;
         return Error(Code::kInternal, "update source '", path_, "': frame at offset ", read_, " is not a message (magic ", h.magic,
-                     ", ", payload, " payload bytes; receive_buffer_size bounds a message at ", max_message_, ")");
+                     ", dim ", h.dim, ")");
       }
       if (read_ + sizeof h + payload > size) break;   // still being appended
+      if (payload > max_message_) {
+        // a well-formed message, only larger than receive_buffer_size allows: its length is known, so it is stepped over
+        // (one rejection, one log line) and the source lives on
+        fprintf(stderr, "[hps update source] '%s': message of %llu payload bytes at offset %llu skipped (receive_buffer_size bounds a message at %zu)\n",
+                path_.c_str(), (unsigned long long)payload, (unsigned long long)read_, max_message_);
+        ++skipped_;
+        read_ += sizeof h + payload;
+        continue;
+      }
       buf_.resize((size_t)payload);
       if (payload && pread(fd_, buf_.data(), (size_t)payload, (off_t)(read_ + sizeof h)) != (ssize_t)payload) break;
       UpdateMessage m;
@@ -95,6 +112,7 @@ class FileTailTransport : public UpdateTransport {
       memcpy(m.rows.data(), buf_.data() + h.model_len + (size_t)h.count * sizeof(int64_t), m.rows.size() * sizeof(float));
       out->push_back(std::move(m));
       read_ += sizeof h + payload;
+      ends_.push_back(read_);
     }
     return Status::Ok();
   }
@@ -103,6 +121,8 @@ class FileTailTransport : public UpdateTransport {
   size_t max_message_;
   int fd_ = -1;
   uint64_t read_ = 0, committed_ = 0;
+  std::deque<uint64_t> ends_;   // end offsets of the messages handed out and not committed yet, in order
+  uint64_t skipped_ = 0;
   bool poisoned_ = false;
   std::vector<char> buf_;
 };
@@ -138,7 +158,11 @@ Status UpdateConsumer::Drain(size_t timeout_ms) {
   { std::lock_guard<std::mutex> lk(mu_); seen = idle_polls_; }
   const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
   for (;;) {
-    { std::lock_guard<std::mutex> lk(mu_); if (idle_polls_ >= seen + 2) return Status::Ok(); }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!dead_.empty()) return Error(Code::kInternal, dead_);
+      if (idle_polls_ >= seen + 2) return Status::Ok();
+    }
     if (std::chrono::steady_clock::now() >= deadline) return Error(Code::kUnavailable, "update source: still busy after ", timeout_ms, " ms");
     usleep(1000);
   }
@@ -146,11 +170,11 @@ Status UpdateConsumer::Drain(size_t timeout_ms) {
 
 void UpdateConsumer::Run() {
   std::set<std::string> touched;
-  size_t since_commit = 0;
+  size_t since_commit = 0;   // messages dealt with (applied, or dropped with a log line) since the last commit
   auto commit = [&] {
     if (since_commit == 0) return;
     if (committed_) committed_(touched);   // the GPU caches take the new rows before the source forgets the messages
-    if (transport_->Commit().ok()) {
+    if (transport_->Commit(since_commit).ok()) {
       std::lock_guard<std::mutex> lk(mu_);
       ++stats_.commits;
     }
@@ -163,7 +187,18 @@ void UpdateConsumer::Run() {
   while (!stop_.load()) {
     const size_t room = std::max<size_t>(1, p_.max_commit_interval) - std::min(since_commit, std::max<size_t>(1, p_.max_commit_interval) - 1);
     const Status ps = transport_->Poll(poll_ms, room, &msgs);
+    if (const uint64_t sk = transport_->TakeSkipped()) { std::lock_guard<std::mutex> lk(mu_); stats_.rejected_messages += sk; }
     if (!ps.ok()) {
+      if (transport_->dead()) {
+        // unreadable for good: counted and logged once; what was applied before is delivered, then the thread only waits for
+        // the server to stop (Drain reports the error instead of calling a dead source drained)
+        bool first;
+        { std::lock_guard<std::mutex> lk(mu_); first = dead_.empty(); if (first) { dead_ = ps.message(); ++stats_.rejected_messages; } }
+        if (first) fprintf(stderr, "[hps update source] %s\n", ps.message().c_str());
+        commit();
+        usleep((useconds_t)std::max<size_t>(1, std::min<size_t>(p_.failure_backoff_ms, 100)) * 1000);
+        continue;
+      }
       { std::lock_guard<std::mutex> lk(mu_); ++stats_.rejected_messages; }
       fprintf(stderr, "[hps update source] %s\n", ps.message().c_str());
       commit();
@@ -184,10 +219,15 @@ void UpdateConsumer::Run() {
     }
     waited_ms = 0;
     for (const UpdateMessage& m : msgs) {
+      // Shutting down: this message and every later one of the poll stay UNCOMMITTED (they are replayed after a restart) —
+      // nothing is counted for them and no commit follows: a commit here would move the offset past messages that never
+      // reached the database layers.
+      if (stop_.load()) return;
       const size_t n = m.keys.size();
       const size_t chunk = std::max<size_t>(1, p_.max_batch_size);
-      bool ok = true;
-      for (size_t b = 0; b < n && ok && !stop_.load(); b += chunk) {
+      bool ok = true, cut_short = false;
+      for (size_t b = 0; b < n && ok; b += chunk) {
+        if (stop_.load()) { cut_short = true; break; }
         const size_t e = std::min(n, b + chunk);
         // a layer that refuses the chunk is asked again after failure_backoff_ms (three times; then the message is dropped
         // with a log line: a message for a model this server does not hold would otherwise block the source for ever)
@@ -205,6 +245,7 @@ void UpdateConsumer::Run() {
           fprintf(stderr, "[hps update source] message for model '%s' table %u dropped: %s\n", m.model.c_str(), m.table, st.message().c_str());
         }
       }
+      if (cut_short) return;   // partly applied (upserts are idempotent): replayed whole after a restart, not committed
       if (ok) {
         touched.insert(m.model);
         std::lock_guard<std::mutex> lk(mu_);

@@ -54,8 +54,13 @@ class UpdateTransport {
   virtual ~UpdateTransport() = default;
   // Up to `max_messages` complete messages that arrived since the last Poll, waiting at most timeout_ms for the first.
   virtual Status Poll(size_t timeout_ms, size_t max_messages, std::vector<UpdateMessage>* out) = 0;
-  // Everything handed out by Poll so far has been applied: a restarted consumer must not see it again.
-  virtual Status Commit() = 0;
+  // The first `messages` of the messages handed out by Poll since the last Commit have been dealt with (applied, or dropped
+  // with a log line): a restarted consumer must not see THEM again — and must see every later one, handed out or not.
+  virtual Status Commit(size_t messages) = 0;
+  // well-formed frames the transport skipped since the last call because they exceed its message bound
+  virtual uint64_t TakeSkipped() { return 0; }
+  // the source can never be read again (a frame that is not a frame): Poll keeps returning the same error
+  virtual bool dead() const { return false; }
   virtual const char* name() const = 0;
 };
 
@@ -89,6 +94,7 @@ class UpdateConsumer {
   mutable std::mutex mu_;
   UpdateSourceStats stats_;
   uint64_t idle_polls_ = 0;   // polls that found nothing with nothing pending (Drain waits for one to pass)
+  std::string dead_;          // not empty: the source is unreadable for good (Drain reports it)
 };
 
 }  // namespace hps

@@ -129,6 +129,7 @@ def _load() -> C.CDLL:
         "hps_update_message_encode": (C.c_int, [cp, u32, u32, P, P, u64, P, u64, C.POINTER(u64)]),
         "hps_server_update_source_stats": (C.c_int, [P, P]),
         "hps_server_update_source_drain": (C.c_int, [P, u32]),
+        "hps_server_update_source_stop": (C.c_int, [P]),
         "hps_shard_owner": (u32, [i64, u32]),
         "hps_shard_bucket_workspace_bytes": (u64, [u64, u32]),
         "hps_shard_bucket_device": (C.c_int, [P, u64, u32, P, P, P, P, P]),
@@ -165,7 +166,7 @@ EXPORTED_SYMBOLS = [
     "hps_server_create_embedding_cache_per_model", "hps_server_destroy_embedding_cache_per_model",
     "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
-    "hps_server_table_data", "hps_update_message_encode", "hps_server_update_source_stats", "hps_server_update_source_drain",
+    "hps_server_table_data", "hps_update_message_encode", "hps_server_update_source_stats", "hps_server_update_source_drain", "hps_server_update_source_stop",
     "hps_cache_on_device", "hps_wake_copy_engines", "hps_session_create_from_cache",
     "hps_shard_unique_id", "hps_shard_session_create", "hps_shard_group_create_local", "hps_shard_group_destroy",
     "hps_shard_session_create_local", "hps_shard_session_lookup", "hps_shard_session_lookup_host", "hps_shard_session_last_timing",
@@ -349,6 +350,9 @@ class HierParameterServer:
 
     def drain_update_source(self, timeout_ms: int = 10000):
         _check(LIB.hps_server_update_source_drain(self._h, int(timeout_ms)))
+
+    def stop_update_source(self):
+        _check(LIB.hps_server_update_source_stop(self._h))
 
     def host_tier_stats(self, model: str, table: int) -> dict:
         st = HostTierStats()

@@ -166,11 +166,16 @@ int hps_server_upsert(hps_server_t* server, const char* model, uint32_t table, c
  * GPU caches.  "kafka_message_queue" is refused at start-up (no Kafka client in this build).
  *   hps_update_message_encode   one message frame for a producer to append (out = NULL: only the size)
  *   hps_server_update_source_stats   out6 = messages, keys, dispatches, commits, dispatch failures, rejected messages
- *   hps_server_update_source_drain   returns once the source has been found empty twice in a row (tests, tools) */
+ *   hps_server_update_source_drain   returns once the source has been found empty twice in a row (tests, tools); an error when
+ *                                    the source is unreadable for good (a frame that is not a frame)
+ *   hps_server_update_source_stop    stops the consumer thread (orderly shutdown: nothing is applied or committed afterwards;
+ *                                    messages not applied yet stay uncommitted and are replayed by the next server); the
+ *                                    statistics calls then report HPS_ERR_UNAVAILABLE */
 int hps_update_message_encode(const char* model, uint32_t table, uint32_t dim, const int64_t* keys, const float* rows, uint64_t n,
                               void* out, uint64_t out_capacity, uint64_t* out_bytes);
 int hps_server_update_source_stats(hps_server_t* server, uint64_t* out6);
 int hps_server_update_source_drain(hps_server_t* server, uint32_t timeout_ms);
+int hps_server_update_source_stop(hps_server_t* server);
 
 /* Host tier smaller than the table (volatile_db.overflow_margin / overflow_policy / overflow_resolution_target /
  * initial_cache_rate / cache_missed_embeddings, persistent_db.*;  docs/hierarchical_parameter_server.md:460-569). */

@@ -103,12 +103,104 @@ def test_a_frame_that_cannot_be_a_message_stops_the_source_without_taking_the_se
     path = tmp_path / "updates.bin"
     path.write_bytes(b"this is not a message frame at all, just text....")
     ps = _server(tmp_path, tables, {"type": "file_tail", "brokers": str(path), "poll_timeout_ms": 20, "failure_backoff_ms": 5})
-    ps.drain_update_source(10000)
-    assert ps.update_source_stats()["rejected_messages"] >= 1 and ps.update_source_stats()["messages"] == 0
+    # a dead source is not "drained": the call says what is wrong with it
+    with pytest.raises(hps.HpsError, match="not a message"):
+        ps.drain_update_source(3000)
+    import time
+    time.sleep(0.3)   # dozens of polls later the frame is still counted ONCE
+    assert ps.update_source_stats()["rejected_messages"] == 1 and ps.update_source_stats()["messages"] == 0
     sess = hps.LookupSession.create(ps, "upd", None)
     q = tables[0][0][:10]
     assert np.array_equal(_bits(sess.lookup(q, [10]).reshape(10, 4)), _bits(tables[0][1][:10]))
     sess.close()
+
+
+def test_a_well_formed_message_over_the_receive_buffer_is_skipped_and_the_source_lives_on(tmp_path):
+    """receive_buffer_size bounds one message; a producer's max_batch_size of 8,192 keys can easily exceed a small buffer.
+    Such a frame has a valid header and a known length: it is stepped over (one rejection), later messages are applied."""
+    from hugectr_backend_amd import hps
+    tables = make_tables([(300, 8)])
+    path = tmp_path / "updates.bin"
+    src = {"type": "file_tail", "brokers": str(path), "poll_timeout_ms": 20, "failure_backoff_ms": 5, "receive_buffer_size": 2048}
+    ps = _server(tmp_path, tables, src)
+    k = tables[0][0]
+    with open(path, "ab") as f:
+        f.write(hps.encode_update_message("upd", 0, k[:10], np.full((10, 8), 1.5, np.float32)))          # 10 * (8 + 32) = 400 B: fits
+        f.write(hps.encode_update_message("upd", 0, k[10:260], np.full((250, 8), 2.5, np.float32)))      # 10,000 B: too large (the bound is never below 4 KB)
+        f.write(hps.encode_update_message("upd", 0, k[260:270], np.full((10, 8), 3.5, np.float32)))      # fits again
+    ps.drain_update_source(10000)
+    st = ps.update_source_stats()
+    assert st["messages"] == 2 and st["rejected_messages"] == 1 and st["keys"] == 20
+    sess = hps.LookupSession.create(ps, "upd", None)
+    out = sess.lookup(k[:270], [270]).reshape(270, 8)
+    assert np.all(out[:10] == 1.5) and np.all(out[260:] == 3.5)
+    assert np.array_equal(_bits(out[10:260]), _bits(tables[0][1][10:260]))     # the skipped message changed nothing
+    assert int(open(str(path) + ".offset").read()) == os.path.getsize(path)
+    # ... and it is still alive
+    with open(path, "ab") as f:
+        f.write(hps.encode_update_message("upd", 0, k[:1], np.full((1, 8), 4.5, np.float32)))
+    ps.drain_update_source(10000)
+    assert np.all(sess.lookup(k[:1], [1]) == 4.5)
+    sess.close()
+
+
+def test_a_consumer_stopped_in_the_middle_of_a_backlog_commits_only_what_it_applied(tmp_path):
+    """Advisor finding of round 3: with the stop flag set, the messages of a poll that had not been applied yet were counted
+    and the offset moved past them — after a restart those updates were gone.  Now: stop = no further count, no commit.
+    Every message in front of the committed offset IS in the host tier of the server that committed it, and a restarted
+    server applies every message behind it."""
+    import threading
+    import time
+    from hugectr_backend_amd import hps
+    tables = make_tables([(2000, 8)])
+    path = tmp_path / "updates.bin"
+    src = {"type": "file_tail", "brokers": str(path), "poll_timeout_ms": 20, "max_batch_size": 8, "max_commit_interval": 32,
+           "failure_backoff_ms": 5}
+    ends, blob = [], bytearray()
+    NMSG, PER = 3000, 64
+    for i in range(NMSG):      # every message brings keys of its own: a message that is lost leaves a hole nothing fills
+        k = 10_000_000 + i * PER + np.arange(PER, dtype=np.int64)
+        blob += hps.encode_update_message("upd", 0, k, np.full((PER, 8), float(i + 1), np.float32))
+        ends.append(len(blob))
+    q = 10_000_000 + np.arange(NMSG * PER, dtype=np.int64)
+
+    def applied(ps_):
+        s_ = hps.LookupSession.create(ps_, "upd", None)
+        out = s_.lookup(q, [q.size]).reshape(NMSG, PER, 8)
+        s_.close()
+        return np.array([bool(np.all(out[i] == float(i + 1))) for i in range(NMSG)])
+
+    ps = _server(tmp_path, tables, src)      # (tables loaded: from here on messages for "upd" are applied)
+
+    def produce():
+        with open(path, "ab") as f:
+            f.write(blob)
+
+    w = threading.Thread(target=produce)
+    w.start()
+    deadline = time.time() + 30
+    while ps.update_source_stats()["messages"] < 200 and time.time() < deadline:   # somewhere inside the backlog
+        time.sleep(0.0002)
+    ps.stop_update_source()
+    w.join()
+    off_file = str(path) + ".offset"
+    committed = int(open(off_file).read()) if os.path.exists(off_file) else 0
+    assert committed == 0 or committed in ends
+    n_committed = ends.index(committed) + 1 if committed else 0
+    assert n_committed < NMSG, "the backlog was meant to outlast the first consumer (make it longer)"
+    got = applied(ps)
+    assert got[:n_committed].all(), f"committed past messages that never reached the host tier: {np.flatnonzero(~got[:n_committed])[:10]}"
+    with pytest.raises(hps.HpsError):
+        ps.update_source_stats()          # no consumer any more
+    ps.close()
+    # the next server starts behind the commit and applies every message behind it (its host tier starts from the model files:
+    # what the first server held in RAM is gone with it, which is why the offset must never run ahead)
+    ps2 = _server(tmp_path, tables, src)
+    ps2.drain_update_source(60000)
+    assert int(open(off_file).read()) == ends[-1]
+    assert ps2.update_source_stats()["messages"] == NMSG - n_committed
+    assert applied(ps2)[n_committed:].all()
+    ps2.close()
 
 
 @pytest.mark.gpu
