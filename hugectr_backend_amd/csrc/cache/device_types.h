@@ -12,10 +12,10 @@
 // cost a 4-B store into a 277-MB array, and the micro-benchmark tools/micro/probe_width.hip says such a store costs more
 // than the probe itself: 1.1 M probes 30 us, with the store 79 us, with a 1-B store into the probed line 63 us).
 // A stamp is the cache's clock — its turnover: the unique rows its lookups missed, in units of total slots / 64
-// (EmbeddingCache::NextEpoch; HPS_LRU_AGE_SHIFT: units of 2^shift calls instead) — modulo kStampMod = 255 ("stamp8"; the value
-// 255 marks a slot that a group of a running insert kernel owns).  A hit rewrites its
+// (EmbeddingCache::NextEpoch; HPS_LRU_AGE_SHIFT: units of 2^shift calls instead) — modulo kStampMod = 254 ("stamp8"; the value
+// 255 marks a slot that a group of a running insert kernel owns, 254 a slot that never held a key).  A hit rewrites its
 // slot's stamp only when it differs from the current unit — the comparison is free, the byte came with the keys — so a
-// key that is hit call after call costs one store per unit.  age = (now8 - stamp8) mod 255; the insert
+// key that is hit call after call costs one store per unit.  age = (now8 - stamp8) mod 254; the insert
 // kernel evicts the slot of greatest age and, while it is at it, pulls stamps older than kAgeSaturate units back to
 // exactly that age so that they cannot wrap around and look young.
 #pragma once
@@ -28,9 +28,12 @@ namespace hps {
 constexpr int kBucketSlots = HPS_BUCKET_SLOTS;  // 14 keys per bucket line
 constexpr int kLineWords = 16;                   // 8-byte words per bucket line (14 keys + 2 words of stamps)
 constexpr int kProbeLanes = 8;                   // lanes that share one probe: 16 B each
-constexpr uint32_t kStampMod = 255;              // stamps live in [0, 255)
+constexpr uint32_t kStampMod = 254;              // stamps of slots that hold (or held) a key live in [0, 254)
 constexpr uint32_t kStampClaimed = 255;          // stamp byte of a slot owned by a group of the running insert kernel
-constexpr uint32_t kStampFree = 128;             // stamp of the never-used slots of a fresh cache (the warm-up runs in unit 0)
+constexpr uint32_t kStampFree = 254;             // stamp of the never-used slots of a fresh cache: no clock value.  (Rounds 1-3 used
+                                                 // 128, a legal clock value: while the clock — or the insert stamp — read 128, every
+                                                 // never-used slot looked "written in the current unit" and could not be claimed; a
+                                                 // cold cache (init_ec=false) dropped its misses for one whole unit each time.)
 constexpr uint32_t kAgeSaturate = 192;           // stamps older than this many units are pulled back to it by the insert kernel
 constexpr int kMaxTables = 256;                  // per model
 constexpr int kProbeBlockThreads = 256;

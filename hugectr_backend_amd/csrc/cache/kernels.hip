@@ -288,6 +288,14 @@ __global__ __launch_bounds__(kThreads) void hps_probe_tile_kernel(const CallDesc
   // waits for that store before the compare-and-swap; the loser's read is a device-scope load whose address comes out of the
   // entry.  No fence: a device-scope release / acquire fence on gfx950 writes back / invalidates the whole L2 of the XCD —
   // tried first: 500 us instead of 45 for this kernel.
+  // What this rests on, at the ISA level (gfx950 = gfx9 family, LLVM AMDGPU memory model for gfx942/gfx950): an atomic store
+  // of agent scope is a global_store with sc1 — it writes through the XCD's L2 and is counted by vmcnt until the write is
+  // acknowledged at the device's point of coherence; an atomic load of agent scope is a global_load with sc1, which an L2
+  // does not serve from a line it cannot vouch for.  The compiler's own release sequence is `buffer_wbl2 sc1; s_waitcnt
+  // vmcnt(0)`: the write-back is there for EARLIER PLAIN stores; the only store a loser depends on is the sc1 store itself,
+  // so the wait alone orders it before the compare-and-swap, and the loser's load carries an address dependency on the entry
+  // it read.  tests/test_gpu_lookup.py::test_fused_unique_tail_against_the_separate_kernel_on_full_size_duplicate_heavy_batches
+  // hammers exactly this hand-off (1,664 tiles on all XCDs, every tile of a table missing the same keys).
   if (kTail) {
     if (tid >= 64) return;
     const uint32_t M = sh_cnt[1], S = sh_cnt[2];
@@ -706,7 +714,7 @@ __device__ __forceinline__ uint64_t saturate_stamps(uint64_t word, uint32_t now8
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     uint32_t st = (uint32_t)(word >> (8 * k)) & 0xFFu;
-    if (st != kStampClaimed && age_of(now8, st) > kAgeSaturate) st = (now8 + kStampMod - kAgeSaturate) % kStampMod;
+    if (st < kStampMod && age_of(now8, st) > kAgeSaturate) st = (now8 + kStampMod - kAgeSaturate) % kStampMod;   // (claimed / never-used: left alone)
     r |= (uint64_t)st << (8 * k);
   }
   return r;
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           // 3,500-slot cache, where stamps older than kAgeSaturate are common: a refresh of all resident keys skipped the rows
           // whose stamp a neighbour had just re-aged — tests/test_gpu_bounded_host_tier.py.)
           const uint32_t sat = (now8 + kStampMod - kAgeSaturate) % kStampMod;
-          if (!(nb == sat && ob != kStampClaimed && age_of(now8, ob) > kAgeSaturate)) return false;
+          if (!(nb == sat && ob < kStampMod && age_of(now8, ob) > kAgeSaturate)) return false;
         }
       }
     };
@@ -834,7 +842,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           //  its first owner's row stores may still be in flight when the second owner's arrive — so the stamp of new keys
           //  is off limits like the current unit's; a key that was last hit exactly insert-age units ago shares the privilege)
           if (st != now8 && st != ins8 && st != kStampClaimed) {
-            const uint32_t a = ((empty >> lig) & 1u) ? 256u : age_of(now8, st);
+            // (a never-used slot carries kStampFree, which is no clock value: it passes the test above whatever the clock reads)
+            const uint32_t a = (((empty >> lig) & 1u) || st == kStampFree) ? 256u : age_of(now8, st);
             if (!(guarded && a < ins_age)) cand = (a << 4) | (15u - (uint32_t)lig);
           }
         }
@@ -884,7 +893,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   }
 }
 
-// Utility: every key slot EMPTY, every stamp `stamp8` (the warm-up runs in unit 0: 0x80 leaves the free slots claimable).
+// Utility: every key slot EMPTY, every stamp `stamp8` (kStampFree: no clock value, always claimable).
 __global__ void hps_cache_clear_kernel(int64_t* lines, uint64_t num_buckets, uint32_t stamp8) {
   const uint64_t words = num_buckets * kLineWords;
   const uint64_t sw = 0x0101010101010101ull * (uint64_t)(stamp8 & 0xFFu);

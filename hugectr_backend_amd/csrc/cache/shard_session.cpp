@@ -359,7 +359,11 @@ Status ShardedSession::Run(const void* d_keys, uint32_t key_bytes, size_t n, flo
     // some rank's block was too small.  Every rank has seen the same maximum (each rank's largest need travels in every
     // block header it sends), so every rank picks the same new capacity and the second attempt fits.
     if (need > cap_max_) {
-      transport_->Abort();
+      // No abort here: `need` is the maximum every rank computed from the same block headers of an exchange that has
+      // COMPLETED, so every rank arrives at this line together and returns the same error; nobody is left inside a
+      // collective.  (Round 3 aborted the transport — ncclCommAbort / the group's aborted flag — and one oversized or
+      // skewed request killed the sharded session on all ranks for good.)  The session stays usable: the next request
+      // that fits is served.
       return Error(Code::kInvalidArg, "sharded lookup: one rank has ", need, " keys for one shard, more than the block limit of ", cap_max_,
                    " keys; raise the model's max_batch_size (request capacity / shards bounds the block size)");
     }

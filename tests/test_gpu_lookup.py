@@ -701,6 +701,51 @@ def test_call_wide_unique_misses_with_the_same_missed_keys_in_every_tile(fused):
     s.close()
 
 
+def test_fused_unique_tail_against_the_separate_kernel_on_full_size_duplicate_heavy_batches():
+    """Advisor finding of round 3 (kernels.hip, the probe kernel's tail): a loser of the call-wide set reads the WINNER's key,
+    written moments earlier by another workgroup of the same launch — possibly on another XCD, whose L2 is not coherent with
+    the reader's.  The code relies on what device-scope atomics are on gfx950 (sc1 stores write through the XCD's L2 and are
+    counted by vmcnt until acknowledged at the device's coherence point; sc1 loads are not served from a stale L2 line): a
+    stale read would either miss a duplicate (a key fetched and inserted twice in one launch: unique count too high) or match
+    a wrong representative (a wrong row).  Stress: the headline's shape — 26 tables x 65,536 keys = 1,664 tiles, every XCD
+    busy — with ALL 64 tiles of a table drawing their misses from the same 400 keys, many calls on one session (stale set
+    entries of earlier calls), the tail against the separate hps_miss_unique launch: same unique counts, to the key, and
+    exact rows."""
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(4242)
+    T, R, D, B = 26, 40000, 8, 65536
+    tables = make_tables([(R, D)] * T)
+    ps, cache, s1 = _mk("fuqbig", tables, maxcat=[1] * T, gpucacheper=0.05, hit_rate_threshold=1.0, defaults=[0.5] * T, max_batch=B,
+                        extra={"gpucache_admission": False})
+    s0 = hps.LookupSession.create(ps, "fuqbig", cache)
+    s1.set_option("fused_unique", 1)
+    s0.set_option("fused_unique", 0)
+    nk = [B] * T
+    for it in range(24):
+        resident = [tk[cache.query(t, tk) >= 0] for t, (tk, _) in enumerate(tables)]
+        parts = []
+        for t, (keys, _) in enumerate(tables):
+            cold = np.setdiff1d(keys, resident[t])
+            pool = np.concatenate([rng.choice(cold, 300, replace=False), -7 - rng.integers(0, 1 << 45, size=100)])
+            q = rng.choice(resident[t], B)
+            miss = rng.random(B) < 0.3
+            q[miss] = rng.choice(pool, int(miss.sum()))
+            parts.append(q.astype(np.int64))
+        q = np.concatenate(parts)
+        uc = O.np_unique_counts(q, nk, resident)
+        want_unique = sum(m for _, m in uc)
+        ref = O.np_lookup(tables, q, nk, [0.5] * T)
+        # the tail first (it meets the keys as misses); the separate kernel afterwards sees what the first call could not
+        # insert (absent keys, dropped keys) — so it is checked on a fresh draw of its own every other round
+        sess = s1 if it % 2 == 0 else s0
+        out = sess.lookup(q, nk).cpu().numpy()
+        assert np.array_equal(_bits(out), _bits(ref)), it
+        assert sess.last_stats().unique_misses == want_unique, (it, sess.last_stats().unique_misses, want_unique)
+    s0.close()
+    s1.close()
+
+
 def test_admission_rule_keeps_recently_hit_keys_and_lets_new_keys_in_once_they_aged(monkeypatch):
     """Default insertion policy (kernels.hip, hps_cache_insert_kernel): a new key's nominal age is the insert age, so it never
     takes a slot that was hit more recently than that — its row is served exactly, it just stays out of the cache; once
@@ -889,3 +934,26 @@ def test_two_sessions_near_all_hit_stress_rows_stay_exact():
     # session got there first — or dropped by the admission rule)
     done = sum(c1[k] - c0[k] for k in ("inserted", "refreshed", "dropped"))
     assert done == sum(sent_new), (done, sent_new)
+
+
+def test_never_used_slots_of_a_cold_cache_stay_claimable_whatever_the_clock_reads(monkeypatch):
+    """Advisor finding of round 3: never-used slots carried the stamp 128, a legal clock value — while the clock (or the
+    stamp of newly inserted keys) read 128, they looked "written in the current unit" and no miss could take one: a cold
+    cache (init_ec=false) dropped every miss that landed in a fresh bucket for a whole unit.  Free slots now carry a value
+    the clock never takes.  Call clock with one call per unit: the clock reads 128 at call 128, the insert stamp at call 160."""
+    monkeypatch.setenv("HPS_LRU_AGE_SHIFT", "0")
+    monkeypatch.setenv("HPS_LRU_ADMIT", "0")
+    from oracle import hps_oracle as O
+    tables = make_tables([(60000, 16)])
+    ps, cache, s = _mk("coldfree", tables, maxcat=[1], gpucacheper=1.0, max_batch=4096, extra={"init_ec": False})
+    keys = tables[0][0]
+    assert (cache.query(0, keys[:1000]) < 0).all()            # cold
+    for call in range(200):
+        q = keys[call * 50:(call + 1) * 50]                   # 50 keys nobody has asked for yet
+        out = s.lookup(q, [50]).cpu().numpy()
+        assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, [50], [0.0]))), call
+        assert s.last_stats().misses == 50, call
+        slots = cache.query(0, q)
+        assert (slots >= 0).all(), f"call {call}: {int((slots < 0).sum())} of 50 missed keys found no slot in a cache that is {call * 50 / 80000:.0%} full"
+    c = cache.counters()
+    assert c["inserted"] == 200 * 50 and c["dropped"] == 0

@@ -374,3 +374,58 @@ def test_native_sharded_session_a_failing_rank_releases_the_others():
     hps.LIB.hps_shard_group_destroy(grp)
     for _, sess in made:
         sess.close()
+
+
+@pytest.mark.gpu
+def test_native_sharded_session_an_oversized_block_is_refused_on_every_rank_and_the_session_lives_on():
+    """A request that puts more keys on one shard than a block may hold (block limit = lookup-session capacity / shards) is
+    found out AFTER the key exchange, from the block headers every rank received: all ranks return the same error together
+    and nobody is left waiting — so the transport is NOT aborted (round 3 did: one skewed request killed the sharded session
+    on all ranks until every session was recreated).  The next request that fits is served exactly."""
+    import ctypes as C
+    import threading
+    import torch
+    from hugectr_backend_amd import hps, sharded
+    from oracle import hps_oracle as O
+    P = 2
+    tables, made = _native_shards(P, max_local=1000)        # lookup sessions hold 2,000 keys: block limit 1,000
+    keys = tables[0][0]
+    owner = sharded.owner_of(keys, P)
+    grp = C.c_void_p()
+    hps._check(hps.LIB.hps_shard_group_create_local(P, C.byref(grp)))
+    shards = []
+    for r, (_, sess) in enumerate(made):
+        h = C.c_void_p()
+        hps._check(hps.LIB.hps_shard_session_create_local(sess._h, grp, r, 1500, C.byref(h)))
+        shards.append(h)
+    rng = np.random.default_rng(5)
+    skewed = [rng.choice(keys[owner == 0], 1500).astype(np.int64) for _ in range(P)]     # 1,500 keys for shard 0 from each rank
+    fair = [rng.choice(keys, 1500).astype(np.int64) for _ in range(P)]
+    rc = [[None, None, None] for _ in range(P)]
+    errs = []
+
+    def work(r):
+        torch.cuda.set_device(0)
+        for it, q in enumerate((skewed[r], fair[r], skewed[r])):
+            dq = torch.from_numpy(q).cuda()
+            out = torch.empty(q.size * 128, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            rc[r][it] = hps.LIB.hps_shard_session_lookup(shards[r], dq.data_ptr(), q.size, out.data_ptr())
+            if it == 1 and rc[r][it] == 0:
+                ref = O.np_lookup(tables, q, [q.size], [2.0])
+                if not np.array_equal(_bits(out.cpu().numpy()), _bits(ref)):
+                    errs.append((r, "rows differ"))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th)
+    assert not errs, errs
+    for r in range(P):
+        assert rc[r][0] == hps.ERR_INVALID_ARG and rc[r][2] == hps.ERR_INVALID_ARG, rc
+        assert rc[r][1] == 0, rc                 # the session survived the refusal
+    for h in shards:
+        hps.LIB.hps_shard_session_destroy(h)
+    hps.LIB.hps_shard_group_destroy(grp)
+    for _, sess in made:
+        sess.close()
