@@ -3,6 +3,7 @@
 #include "key_pack.h"
 
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1073,6 +1074,7 @@ Status LookupSession::WaitPushedSeq(uint32_t want, hipEvent_t ev) {
   for (uint32_t i = 1;; ++i) {
     if (landed()) return Status::Ok();
     SpinPause();
+    if ((i & 127u) == 0) sched_yield();   // a waiter must not keep a CPU from a pool worker that has work (thread_pool.cpp)
     if ((i & 511u) == 0) {
       const hipError_t q = hipEventQuery(ev);
       if (q != hipSuccess && q != hipErrorNotReady) return Error(Code::kInternal, "lookup stream failed: ", hipGetErrorString(q));

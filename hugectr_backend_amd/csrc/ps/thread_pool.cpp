@@ -184,6 +184,9 @@ void ThreadPool::WorkerMain() {
       for (unsigned it = 0;; ++it) {
         if (seq_.load(std::memory_order_acquire) != seen) { woke = true; break; }
         CpuRelax();
+        // an idle spinner must not keep a CPU from a thread that has work (see ParallelFor): offer it now and then —
+        // a yield with nobody waiting returns at once
+        if ((it & 255) == 255) sched_yield();
         if ((it & 63) == 63 &&
             std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) break;
       }
@@ -231,7 +234,15 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
         cv_.notify_all();
       }
       RunFast(*L, gen);
-      while (L->done.load(std::memory_order_acquire) != (uint32_t)num_tasks) CpuRelax();
+      // Stragglers.  Usually microseconds.  But a worker that claimed a grain and then lost its CPU (more runnable threads
+      // than CPUs in the container: 13 spinning workers, the session threads, the HIP runtime's own) comes back a
+      // scheduler slice later — 4 to 6 ms, the 5-to-12-ms requests of rounds 2-3 (HPS_TRACE_TAIL: "pool 4.12 ms" of a
+      // 0.15-ms staging loop, "ps fetch 5.56 ms").  The grain cannot be taken over (fn dies with this call), but the CPU
+      // can be handed over: after a short spin the waiter yields, and the runnable worker gets it at once.
+      for (uint32_t it = 0; L->done.load(std::memory_order_acquire) != (uint32_t)num_tasks; ++it) {
+        if (it < 2048) CpuRelax();
+        else sched_yield();
+      }
       L->state.store(0, std::memory_order_release);
       return;
     }
