@@ -82,6 +82,8 @@ def parse_args():
     ap.add_argument("--no-triton-leg", action="store_true",
                     help="one GPU: skip the leg through TRITONBACKEND_ModelInstanceExecute (tools/triton_abi_bench.cpp)")
     ap.add_argument("--triton-timeout", type=float, default=240.0)
+    ap.add_argument("--no-c3-leg", action="store_true",
+                    help="one GPU: skip the BASELINE config 3 leg with P = 4 LOGICAL shards in this process (in-process transport)")
     ap.add_argument("--no-sharded-leg", action="store_true",
                     help="N>1: skip the BASELINE config 3 leg (one table sharded over the ranks, RCCL all-to-all)")
     ap.add_argument("--shard-rows", type=int, default=1 << 28,
@@ -388,7 +390,10 @@ def compact_line(res, limit=COMPACT_LIMIT):
     c3 = ex.get("sharded_c3_logical") or {}
     put("c3_logical_P", c3.get("shards"))
     put("c3_logical_Glps", _scale(c3.get("lookups_per_s"), 1e-9))
+    put("c3_logical_zipf_Glps", _scale(_dig(c3, ("zipf", "lookups_per_s")), 1e-9))
+    put("c3_logical_row_MB_per_peer", [_scale(_dig(c3, (k_, "row_bytes_per_peer_and_step")), 1e-6) for k_ in ("uniform", "zipf")] if c3 else None)
     put("c3_logical_parity", c3.get("parity"))
+    put("c3_error", (str(c3["error"])[:120] if c3.get("error") else None))
     c3r = ex.get("sharded_c3") or {}
     put("c3_rccl_Glps", _scale(c3r.get("lookups_per_s"), 1e-9))
     put("c3_rccl_ranks", c3r.get("ranks"))
@@ -1161,6 +1166,15 @@ def main():
                 dleg = {"error": repr(e)[:300]}
                 sys.stderr.write(f"[bench] device-driven tier leg stopped: {e!r}\n")
             res["extra_legs"] = dict(res["extra_legs"] or {}, device_driven_tier=dleg)
+        if not a.no_c3_leg:
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                c3 = c3_logical_leg(a, torch, hps, dev)
+            except Exception as e:  # noqa: BLE001
+                c3 = {"error": repr(e)[:300]}
+                sys.stderr.write(f"[bench] logical config-3 leg stopped: {e!r}\n")
+            res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3_logical=c3)
 
     # ---- BASELINE config 3 leg (only under torch.distributed.run with N > 1 ranks): ONE table sharded over the ranks, one
     # rank per GPU, RCCL send/recv inside the engine.  Runs after the headline measurement is complete and its resources are
@@ -1472,6 +1486,121 @@ def wide_keys_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
                 "frame_of_reference_default: the same traffic with the engine's default narrowing",
     })
     return out
+
+
+def c3_logical_leg(a, torch, hps, dev, P=4, rows_total=1 << 24, steps=30):
+    """BASELINE configs[2] on the ONE GPU of this box: one table sharded over P LOGICAL shards (owner = mix64(key) mod P), P
+    servers + caches + lookup sessions + native sharded sessions in this process, P host threads — the production path of
+    csrc/cache/shard_session.cpp (input dedup, bucket into fixed-capacity blocks, exchange, padded local lookup, exchange,
+    gather back) with device-to-device copies standing in for RCCL's send/recv groups.  What it times: the bucket / prepare /
+    padded-lookup / gather-back kernels and the session's control flow.  What it does NOT time: RCCL and xGMI — no multi-GPU node
+    was in reach of this project (SCALE_r01..r03: skipped)."""
+    import ctypes as C
+    from oracle import hps_oracle as O
+    D = a.dim
+    N = a.tables * a.batch
+    n_local = N // P
+    recv_cap = int(n_local * 1.25) + 4096
+    t0 = time.time()
+    servers, sessions, shards = [], [], []
+    grp = C.c_void_p()
+    hps._check(hps.LIB.hps_shard_group_create_local(P, C.byref(grp)))
+    for r in range(P):
+        model = f"c3_logical_{r}"
+        cfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8},
+               "models": [{"model": model, "sparse_files": ["synthetic://shard"], "num_of_worker_buffer_in_pool": 2,
+                           "embedding_vecsize_per_table": [D], "maxnum_catfeature_query_per_table_per_sample": [1],
+                           "default_value_for_each_table": [0.0], "deployed_device_list": [dev], "max_batch_size": recv_cap,
+                           "gpucache": True, "gpucacheper": 1.0, "hit_rate_threshold": 1.0}]}
+        ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+        ps.load_table_synthetic(model, 0, SEED, 0, rows_total, shard=r, num_shards=P)
+        ps.create_embedding_cache_per_model(model)
+        sess = hps.LookupSession.create(ps, model, ps.get_embedding_cache(model, dev))
+        h = C.c_void_p()
+        hps._check(hps.LIB.hps_shard_session_create_local(sess._h, grp, r, n_local, C.byref(h)))
+        servers.append(ps), sessions.append(sess), shards.append(h)
+    t_setup = time.time() - t0
+    rng = np.random.default_rng(SEED + 303)
+    zw = 1.0 / np.power(np.arange(1, 1_000_001, dtype=np.float64), a.zipf)
+    zw /= zw.sum()
+    zipf_ids = rng.permutation(rows_total)[:1_000_000].astype(np.int64)
+
+    def batches(kind):
+        if kind == "uniform":
+            return [[rng.integers(0, rows_total, n_local, dtype=np.int64) for _ in range(4)] for _ in range(P)]
+        return [[zipf_ids[rng.choice(zipf_ids.size, n_local, p=zw)] for _ in range(4)] for _ in range(P)]
+
+    outs = [torch.empty(n_local * D, dtype=torch.float32, device=torch.device("cuda", dev)) for _ in range(P)]
+    res = {"shards": P, "rows_total": rows_total, "keys_per_step": N, "keys_per_rank_and_step": n_local, "setup_seconds": t_setup,
+           "transport": "in-process (device-to-device copies on one GPU) — RCCL / xGMI NOT measured: no multi-GPU node in reach",
+           "note": c3_logical_leg.__doc__.split("\n")[0]}
+    for kind, warm in (("uniform", 4), ("zipf", 40)):     # (zipf: 32 calls let the block capacity follow the deduplicated traffic down)
+        bt = batches(kind)
+        bar = threading.Barrier(P + 1)
+        errs, tim, stat = [], [[] for _ in range(P)], [None] * P
+
+        def work(r):
+            try:
+                torch.cuda.set_device(dev)
+                for i in range(warm):
+                    hps._check(hps.LIB.hps_shard_session_lookup_host(shards[r], bt[r][i % 4].ctypes.data, n_local, outs[r].data_ptr()))
+                bar.wait()
+                bar.wait()
+                for i in range(steps):
+                    hps._check(hps.LIB.hps_shard_session_lookup_host(shards[r], bt[r][i % 4].ctypes.data, n_local, outs[r].data_ptr()))
+                    t = [C.c_float(0) for _ in range(3)]
+                    recv, kb = C.c_uint64(0), C.c_int32(0)
+                    hps._check(hps.LIB.hps_shard_session_last_timing(shards[r], C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(recv), C.byref(kb)))
+                    tim[r].append([x.value for x in t] + [recv.value, kb.value])
+                att, cap = C.c_uint32(0), C.c_uint64(0)
+                sent = (C.c_uint64 * P)()
+                hps._check(hps.LIB.hps_shard_session_last_stats(shards[r], C.byref(cap), C.byref(att), sent, P))
+                stat[r] = (att.value, cap.value, int(sum(sent)))
+                bar.wait()
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e)[:200])
+                bar.abort()
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+        [x.start() for x in th]
+        try:
+            bar.wait()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            bar.wait()
+            bar.wait()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+        except threading.BrokenBarrierError:
+            dt = float("nan")
+        [x.join() for x in th]
+        if errs:
+            res[kind] = {"error": errs[0]}
+            continue
+        # parity: every rank's last answer against the row recipe, 256 sampled positions each
+        ok = True
+        for r in range(P):
+            kh = bt[r][(steps - 1) % 4]
+            idx = np.linspace(0, n_local - 1, 256).astype(np.int64)
+            exp = np.concatenate([O.c_synth_rows(SEED, 0, int(kh[i]), 1, D) for i in idx]).reshape(256, D)
+            got = outs[r].view(-1, D)[torch.from_numpy(idx).to(outs[r].device)].cpu().numpy()
+            ok &= bool(np.array_equal(got.view(np.uint32), exp.view(np.uint32)))
+        tm = np.mean(np.array([x for r in range(P) for x in tim[r]], dtype=np.float64), axis=0)
+        cap = stat[0][1]
+        res[kind] = {"lookups_per_s": N * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "parity": ok,
+                     "keys_exchange_ms": float(tm[0]), "local_lookup_ms": float(tm[1]), "rows_exchange_ms": float(tm[2]),
+                     "key_bytes_over_pcie": float(tm[4]), "block_capacity_keys": cap, "attempts_last_step": max(s_[0] for s_ in stat),
+                     "distinct_keys_sent_per_rank": float(np.mean([s_[2] for s_ in stat])),
+                     "row_bytes_per_peer_and_step": cap * 4 * D,
+                     "padding_fraction_of_row_blocks": 1.0 - float(np.mean([s_[2] for s_ in stat])) / P / cap}
+    res["lookups_per_s"] = (res.get("uniform") or {}).get("lookups_per_s")
+    res["parity"] = bool((res.get("uniform") or {}).get("parity") and (res.get("zipf") or {}).get("parity"))
+    for h in shards:
+        hps.LIB.hps_shard_session_destroy(h)
+    hps.LIB.hps_shard_group_destroy(grp)
+    for s_ in sessions:
+        s_.close()
+    return res
 
 
 def sharded_leg(a, torch, dist, hps, rank, world, local_rank, shared_gpu):

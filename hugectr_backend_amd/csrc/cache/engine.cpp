@@ -924,8 +924,8 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
   if (kTraceCallsMs > 0.f) {
     const float all = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
     if (all > kTraceCallsMs)
-      fprintf(stderr, "[hps call] %.2f ms: key staging %.2f (pool %.2f, H2D enqueue %.2f, event %.2f), counts on host %.2f, ps fetch %.2f, tail %.2f, engine call %.2f (direct_dma %d narrow %d)\n",
-              all, key_stage_ms_, stage_pool_ms_, stage_enqueue_ms_, stage_event_ms_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3], (int)direct_dma, (int)keys_narrow_);
+      fprintf(stderr, "[hps call] %.2f ms: key staging %.2f (pool %.2f, H2D enqueue %.2f, event %.2f), counts on host %.2f, ps fetch %.2f, tail %.2f, engine call %.2f, GPU span %.2f (direct_dma %d narrow %d)\n",
+              all, key_stage_ms_, stage_pool_ms_, stage_enqueue_ms_, stage_event_ms_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3], last_gpu_call_ms_, (int)direct_dma, (int)keys_narrow_);
   }
   return st_;
 }
@@ -1078,7 +1078,10 @@ Status LookupSession::WaitPushedSeq(uint32_t want, hipEvent_t ev) {
     if ((i & 511u) == 0) {
       const hipError_t q = hipEventQuery(ev);
       if (q != hipSuccess && q != hipErrorNotReady) return Error(Code::kInternal, "lookup stream failed: ", hipGetErrorString(q));
-      if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+      // (the runtime's own wait sleeps on an interrupt after a short spin; on the microVM boxes its wake-up was seen to take
+      //  4-5 ms now and then — "rows done 4.4 ms" behind a scatter enqueued at 0.2 ms — so the word is polled for as long as a
+      //  call can reasonably take, yielding the CPU between looks)
+      if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(6000)) break;
     }
   }
   HIP_TRY(hipEventSynchronize(ev));

@@ -28,15 +28,48 @@ __device__ __forceinline__ int64_t load_key(const void* keys, uint32_t key_bytes
 constexpr uint32_t kNoOwner = 0xFFFFFFFFu;
 constexpr uint32_t kPosDefault = 0xFFFFFFFFu;   // pos[] of a key that is never sent (the cache's reserved key): default vector
 
+// K1 in front of the exchange: the request's keys are deduplicated call-wide BEFORE they are bucketed, so that a key a rank
+// asks for a thousand times (Zipf traffic) crosses the links once and its row comes back once.  rep[i] = index of the key's
+// representative (itself for the first claimant of its set entry; a duplicate learns it from the entry and compares against
+// the INPUT array, which no kernel of the call writes — no intra-launch hand-off of data).  Open addressing, entries
+// (tag << 32 | index), entries of earlier calls (other tags) are free: the set is never cleared.
+__global__ __launch_bounds__(256) void hps_shard_dedup_kernel(const void* __restrict__ keys, uint32_t key_bytes, uint64_t n,
+                                                              unsigned long long* __restrict__ set, uint64_t mask, uint32_t tag,
+                                                              uint32_t* __restrict__ rep) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const int64_t key = load_key(keys, key_bytes, i);
+    uint32_t r = (uint32_t)i;
+    if (key != HPS_EMPTY_KEY) {
+      uint64_t h = (hps_mix64((uint64_t)key) >> 13) & mask;   // (the owner is the same hash modulo P: other bits here)
+      const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)i;
+      unsigned long long cur = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        if ((uint32_t)(cur >> 32) != tag) {
+          const unsigned long long prev = atomicCAS(&set[h], cur, mine);
+          if (prev == cur) break;
+          cur = prev;
+          continue;
+        }
+        const uint32_t j = (uint32_t)cur;
+        if (load_key(keys, key_bytes, j) == key) { r = j; break; }
+        h = (h + 1) & mask;
+        cur = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    rep[i] = r;
+  }
+}
+
 __global__ __launch_bounds__(kShardBlock) void hps_shard_hist_padded_kernel(const void* __restrict__ keys, uint32_t key_bytes, uint64_t n,
-                                                                           uint32_t P, uint32_t* __restrict__ hist /*[blocks][P]*/) {
+                                                                           uint32_t P, const uint32_t* __restrict__ rep /*optional*/,
+                                                                           uint32_t* __restrict__ hist /*[blocks][P]*/) {
   __shared__ uint32_t sh[kMaxShards];
   if (threadIdx.x < P) sh[threadIdx.x] = 0;
   __syncthreads();
   const uint64_t i = (uint64_t)blockIdx.x * kShardBlock + threadIdx.x;
   if (i < n) {
     const int64_t key = load_key(keys, key_bytes, i);
-    if (key != HPS_EMPTY_KEY) atomicAdd(&sh[owner_of(key, P)], 1u);
+    if (key != HPS_EMPTY_KEY && (!rep || rep[i] == (uint32_t)i)) atomicAdd(&sh[owner_of(key, P)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < P) hist[(uint64_t)blockIdx.x * P + threadIdx.x] = sh[threadIdx.x];
@@ -149,13 +182,15 @@ __global__ __launch_bounds__(64) void hps_shard_scan_padded_kernel(const uint32_
 __global__ __launch_bounds__(kShardBlock) void hps_shard_scatter_padded_kernel(const void* __restrict__ keys, uint32_t key_bytes, uint64_t n, uint32_t P,
                                                                               const uint64_t* __restrict__ offsets,
                                                                               int64_t* __restrict__ send, uint64_t stride, uint64_t cap,
+                                                                              const uint32_t* __restrict__ rep /*optional*/,
                                                                               uint32_t* __restrict__ pos) {
   __shared__ uint32_t wave_cnt[kShardBlock / 64][kMaxShards];
   const uint64_t i = (uint64_t)blockIdx.x * kShardBlock + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool inb = i < n;
   const int64_t key = inb ? load_key(keys, key_bytes, i) : 0;
-  const bool valid = inb && key != HPS_EMPTY_KEY;   // the cache's reserved key never travels: its answer is the default vector
+  const bool dup = inb && rep && rep[i] != (uint32_t)i;   // travels as its representative; the gather reads pos[rep[i]]
+  const bool valid = inb && !dup && key != HPS_EMPTY_KEY;   // the cache's reserved key never travels: its answer is the default vector
   const uint32_t own = valid ? owner_of(key, P) : kNoOwner;
   for (uint32_t s = lane; s < P; s += 64) wave_cnt[wave][s] = 0;
   __syncthreads();
@@ -172,7 +207,7 @@ __global__ __launch_bounds__(kShardBlock) void hps_shard_scatter_padded_kernel(c
     const uint64_t r = offsets[(uint64_t)blockIdx.x * P + own] + before + rank_in_wave;   // rank inside the shard's block
     if (r < cap) send[(uint64_t)own * stride + 2 + r] = key;
     pos[i] = (uint32_t)((uint64_t)own * cap + (r < cap ? r : cap - 1));   // overflowed keys: a valid slot; the call is retried
-  } else if (inb) {
+  } else if (inb && !dup) {
     pos[i] = kPosDefault;
   }
 }
@@ -197,16 +232,18 @@ __global__ __launch_bounds__(256) void hps_shard_prepare_kernel(const int64_t* _
 
 // out[i] = rows[pos[i]]   (16-lane group per row, 16 B per lane; input order restored by construction)
 __global__ __launch_bounds__(256) void hps_shard_gather_back_kernel(const float* __restrict__ rows, const uint32_t* __restrict__ pos,
+                                                                    const uint32_t* __restrict__ rep /*optional*/,
                                                                     uint64_t n, uint32_t D, float* __restrict__ out, int vec, float default_value) {
   const int lig = threadIdx.x & 15;
   const uint64_t groups_total = (uint64_t)gridDim.x * 16;
   for (uint64_t i = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4); i < n; i += groups_total) {
     float* dst = out + i * D;
-    if (pos[i] == kPosDefault) {   // the reserved key: in no table by construction (docs/hierarchical_parameter_server.md:244-246)
+    const uint32_t p = pos[rep ? rep[i] : i];   // a duplicate's row sits where its representative's does
+    if (p == kPosDefault) {   // the reserved key: in no table by construction (docs/hierarchical_parameter_server.md:244-246)
       for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = default_value;
       continue;
     }
-    const float* src = rows + (uint64_t)pos[i] * D;
+    const float* src = rows + (uint64_t)p * D;
     if (vec) {
       for (uint32_t c = (uint32_t)lig * 4; c < D; c += 64)
         __builtin_nontemporal_store(*reinterpret_cast<const f4s*>(src + c), reinterpret_cast<f4s*>(dst + c));
@@ -237,19 +274,29 @@ hipError_t LaunchShardBucket(const int64_t* d_keys, uint64_t n, uint32_t P, int6
   return hipGetLastError();
 }
 
+hipError_t LaunchShardDedup(const void* d_keys, uint32_t key_bytes, uint64_t n, unsigned long long* d_set, uint64_t set_mask, uint32_t tag,
+                            uint32_t* d_rep, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  if ((key_bytes != 8 && key_bytes != 4) || tag == 0 || (set_mask & (set_mask + 1)) != 0 || set_mask + 1 < 2 * n) return hipErrorInvalidValue;
+  uint64_t want = (n + 255) / 256;
+  if (want > 4096) want = 4096;
+  hipLaunchKernelGGL(hps_shard_dedup_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_keys, key_bytes, n, d_set, set_mask, tag, d_rep);
+  return hipGetLastError();
+}
+
 hipError_t LaunchShardBucketPadded(const void* d_keys, uint32_t key_bytes, uint64_t n, uint32_t P, uint64_t cap, int64_t* d_send, uint32_t* d_pos,
-                                   uint64_t* d_totals, void* d_workspace, hipStream_t stream) {
+                                   uint64_t* d_totals, void* d_workspace, hipStream_t stream, const uint32_t* d_rep) {
   if (key_bytes != 8 && key_bytes != 4) return hipErrorInvalidValue;
   if (P == 0 || P > (uint32_t)kMaxShards || cap == 0) return hipErrorInvalidValue;
   const uint64_t stride = cap + 2;
   uint32_t blocks = (uint32_t)((n + kShardBlock - 1) / kShardBlock);
   uint32_t* hist = reinterpret_cast<uint32_t*>(d_workspace);
   uint64_t* offsets = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d_workspace) + (((size_t)(blocks ? blocks : 1) * P * sizeof(uint32_t) + 15) & ~(size_t)15));
-  if (blocks) hipLaunchKernelGGL(hps_shard_hist_padded_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, key_bytes, n, P, hist);
+  if (blocks) hipLaunchKernelGGL(hps_shard_hist_padded_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, key_bytes, n, P, d_rep, hist);
   hipLaunchKernelGGL(hps_shard_scan_padded_kernel, dim3(1), dim3(64), 0, stream, hist, blocks, P, offsets, d_send, stride, cap, d_totals);
   if (blocks)
     hipLaunchKernelGGL(hps_shard_scatter_padded_kernel, dim3(blocks), dim3(kShardBlock), 0, stream, d_keys, key_bytes, n, P, offsets, d_send,
-                       stride, cap, d_pos);
+                       stride, cap, d_rep, d_pos);
   return hipGetLastError();
 }
 
@@ -263,12 +310,12 @@ hipError_t LaunchShardPrepare(const int64_t* d_recv, uint32_t P, uint64_t cap, i
 }
 
 hipError_t LaunchShardGatherBack(const float* d_rows, const uint32_t* d_pos, uint64_t n, uint32_t D, float* d_out, float default_value,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, const uint32_t* d_rep) {
   if (n == 0) return hipSuccess;
   uint64_t want = (n + 15) / 16;
   if (want > 2048) want = 2048;
   const int vec = ((D & 3u) == 0 && ((uintptr_t)d_rows & 15u) == 0 && ((uintptr_t)d_out & 15u) == 0) ? 1 : 0;
-  hipLaunchKernelGGL(hps_shard_gather_back_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_rows, d_pos, n, D, d_out, vec, default_value);
+  hipLaunchKernelGGL(hps_shard_gather_back_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_rows, d_pos, d_rep, n, D, d_out, vec, default_value);
   return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "../ps/thread_pool.h"
@@ -258,6 +259,15 @@ Status ShardedSession::Create(std::shared_ptr<LookupSession> session, std::uniqu
   HPS_RETURN_IF_ERROR(dev(&s->d_flags_, 4));
   HPS_RETURN_IF_ERROR(dev(&s->d_totals_, P));
   HPS_RETURN_IF_ERROR(dev(&s->d_keys_in_, max_local_keys));
+  if (const char* e = std::getenv("HPS_SHARD_DEDUP")) s->dedup_ = std::strtol(e, nullptr, 10) != 0;
+  if (s->dedup_) {
+    uint64_t set_cap = 1024;
+    while (set_cap < 2 * (uint64_t)max_local_keys) set_cap <<= 1;
+    HPS_RETURN_IF_ERROR(dev(&s->d_rep_, max_local_keys));
+    HPS_RETURN_IF_ERROR(dev(&s->d_set_, set_cap));
+    HIP_TRY(hipMemset(s->d_set_, 0, set_cap * sizeof(unsigned long long)));   // tag 0 is never used by a call
+    s->set_mask_ = set_cap - 1;
+  }
   {
     void* v = nullptr;
     HIP_TRY(hipMalloc(&v, ShardBucketWorkspaceBytes(max_local_keys, s->P_) + 64));
@@ -280,7 +290,7 @@ ShardedSession::~ShardedSession() {
   (void)hipSetDevice(device_);
   if (stream_ && session_) (void)hipStreamSynchronize(stream_);   // (the stream belongs to the session, alive through session_)
   for (void* p : {(void*)d_send_, (void*)d_recv_, (void*)d_keys_pad_, (void*)d_rows_pad_, (void*)d_rows_back_, (void*)d_pos_, (void*)d_flags_,
-                  (void*)d_totals_, (void*)d_keys_in_, d_ws_})
+                  (void*)d_totals_, (void*)d_keys_in_, (void*)d_rep_, (void*)d_set_, d_ws_})
     if (p) (void)hipFree(p);
   if (h_flags_) (void)hipHostFree(h_flags_);
   if (h_totals_) (void)hipHostFree(h_totals_);
@@ -292,7 +302,16 @@ Status ShardedSession::Attempt(const void* d_keys, uint32_t key_bytes, size_t n,
   const uint64_t stride = cap + 2;
   const size_t D = dim_;
   HIP_TRY(hipMemsetAsync(d_flags_, 0, 4 * sizeof(uint32_t), stream_));
-  HIP_TRY(LaunchShardBucketPadded(d_keys, key_bytes, n, P_, cap, d_send_, d_pos_, d_totals_, d_ws_, stream_));
+  const uint32_t* rep = nullptr;
+  if (dedup_ && n) {
+    if (++set_tag_ == 0) {   // 2^32 attempts later: entries of the first ones would look like this one's
+      HIP_TRY(hipMemsetAsync(d_set_, 0, (set_mask_ + 1) * sizeof(unsigned long long), stream_));
+      set_tag_ = 1;
+    }
+    HIP_TRY(LaunchShardDedup(d_keys, key_bytes, n, d_set_, set_mask_, set_tag_, d_rep_, stream_));
+    rep = d_rep_;
+  }
+  HIP_TRY(LaunchShardBucketPadded(d_keys, key_bytes, n, P_, cap, d_send_, d_pos_, d_totals_, d_ws_, stream_, rep));
   HIP_TRY(hipEventRecord(ev_[0], stream_));
   HPS_RETURN_IF_ERROR(transport_->AllToAll(d_send_, d_recv_, stride * sizeof(int64_t), stream_));
   HIP_TRY(hipEventRecord(ev_[1], stream_));
@@ -305,7 +324,7 @@ Status ShardedSession::Attempt(const void* d_keys, uint32_t key_bytes, size_t n,
   HIP_TRY(hipEventRecord(ev_[2], stream_));
   HPS_RETURN_IF_ERROR(transport_->AllToAll(d_rows_pad_, d_rows_back_, cap * D * sizeof(float), stream_));
   HIP_TRY(hipEventRecord(ev_[3], stream_));
-  HIP_TRY(LaunchShardGatherBack(d_rows_back_, d_pos_, n, dim_, d_out, default_value_, stream_));
+  HIP_TRY(LaunchShardGatherBack(d_rows_back_, d_pos_, n, dim_, d_out, default_value_, stream_, rep));
   HIP_TRY(hipMemcpyAsync(h_flags_, d_flags_, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipMemcpyAsync(h_totals_, d_totals_, P_ * sizeof(uint64_t), hipMemcpyDeviceToHost, stream_));
   HIP_TRY(hipStreamSynchronize(stream_));
@@ -355,7 +374,23 @@ Status ShardedSession::Run(const void* d_keys, uint32_t key_bytes, size_t n, flo
     }
     stats_.capacity = cap_;
     stats_.sent.assign(h_totals_, h_totals_ + P_);
-    if (need <= cap_) return Status::Ok();
+    stats_.unique_keys = 0;
+    for (uint64_t v : stats_.sent) stats_.unique_keys += v;
+    if (need <= cap_) {
+      // The capacity follows the traffic DOWN too (blocks travel whole: capacity is what the links carry).  Deduplicated Zipf
+      // traffic needs half the blocks uniform traffic of the same size does; after 32 calls that all fitted a capacity a tenth
+      // smaller, the capacity becomes the largest need of those calls (+ 1/16 + 64).  `need` is the same number on every
+      // rank, so is the call count: every rank resizes in the same call.  A burst that no longer fits costs one repeated
+      // call (the growth below), never a wrong row.
+      recent_need_ = std::max(recent_need_, need);
+      if (++calls_since_resize_ >= 32) {
+        const uint64_t target = std::min<uint64_t>(cap_max_, recent_need_ + recent_need_ / 16 + 64);
+        if (target * 10 < cap_ * 9) cap_ = std::max<uint64_t>(target, 1);
+        recent_need_ = 0;
+        calls_since_resize_ = 0;
+      }
+      return Status::Ok();
+    }
     // some rank's block was too small.  Every rank has seen the same maximum (each rank's largest need travels in every
     // block header it sends), so every rank picks the same new capacity and the second attempt fits.
     if (need > cap_max_) {
@@ -368,6 +403,8 @@ Status ShardedSession::Run(const void* d_keys, uint32_t key_bytes, size_t n, flo
                    " keys; raise the model's max_batch_size (request capacity / shards bounds the block size)");
     }
     cap_ = std::min<uint64_t>(cap_max_, need + need / 16 + 64);   // a little headroom: the next call's hot key may be hotter
+    recent_need_ = 0;
+    calls_since_resize_ = 0;
   }
 }
 

@@ -60,7 +60,8 @@ struct ShardCallStats {
   uint64_t received = 0;        // keys this rank's shard was asked for in the last call (without padding)
   float keys_exchange_ms = 0, lookup_ms = 0, rows_exchange_ms = 0;   // last attempt, HIP events on the session's stream
   int key_bytes = 8;            // width at which a host request's keys crossed PCIe (Lookup: 8, device keys)
-  std::vector<uint64_t> sent;   // keys this rank sent to every rank in the last call
+  std::vector<uint64_t> sent;   // keys this rank sent to every rank in the last call (distinct keys when the input dedup is on)
+  uint64_t unique_keys = 0;     // distinct keys of this rank's request in the last call (= sum of sent; without dedup: keys as sent)
 };
 
 class ShardedSession {
@@ -100,6 +101,16 @@ class ShardedSession {
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};   // around the two exchanges
   float *d_rows_pad_ = nullptr, *d_rows_back_ = nullptr;
   uint32_t *d_pos_ = nullptr, *d_flags_ = nullptr;
+  // input dedup in front of the exchange (HPS_SHARD_DEDUP, default on): a key the request repeats travels once
+  bool dedup_ = true;
+  uint32_t* d_rep_ = nullptr;
+  unsigned long long* d_set_ = nullptr;
+  uint64_t set_mask_ = 0;
+  uint32_t set_tag_ = 0;
+  // the block capacity follows the traffic down as well as up: every rank sees the same largest need per call (it travels in
+  // the block headers), so every rank takes the same decision after the same number of calls
+  uint64_t recent_need_ = 0;
+  uint32_t calls_since_resize_ = 0;
   uint64_t* d_totals_ = nullptr;
   void* d_ws_ = nullptr;
   uint32_t* h_flags_ = nullptr;     // pinned: [0] largest block any rank needed, [1] keys received

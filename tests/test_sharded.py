@@ -158,8 +158,9 @@ def _native_shards(P, R=20000, D=128, cache_frac=0.5, max_local=30000, seed=3):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dedup", [1, 0])
 @pytest.mark.parametrize("P", [2, 4])
-def test_native_sharded_session_logical_shards_in_one_process(P):
+def test_native_sharded_session_logical_shards_in_one_process(P, dedup, monkeypatch):
     """The engine's sharded session (fixed-capacity blocks, positions recorded by the bucket kernel, padded local lookup)
     with P endpoints in one process: device-to-device copies stand in for RCCL, everything else is the production path.
     Uniform keys, absent keys, ragged sizes, an empty request on one rank, and a skewed request that overflows the block
@@ -169,6 +170,7 @@ def test_native_sharded_session_logical_shards_in_one_process(P):
     import torch
     from hugectr_backend_amd import hps
     from oracle import hps_oracle as O
+    monkeypatch.setenv("HPS_SHARD_DEDUP", str(dedup))   # read when the sharded session is created
     tables, made = _native_shards(P)
     keys = tables[0][0]
     max_local = 30000
@@ -207,8 +209,9 @@ def test_native_sharded_session_logical_shards_in_one_process(P):
                 sent = (C.c_uint64 * P)()
                 hps._check(hps.LIB.hps_shard_session_last_stats(shards[r], C.byref(cap), C.byref(att), sent, P))
                 attempts[r][it] = att.value
-                if sum(sent) != q.size:
-                    errs.append((r, it, "sent counts do not add up"))
+                # with the input dedup only one key of every distinct value travels
+                if sum(sent) != (np.unique(q).size if dedup else q.size):
+                    errs.append((r, it, f"sent counts do not add up: {sum(sent)} of {q.size} keys, {np.unique(q).size} distinct"))
                 ref = O.np_lookup(tables, q, [q.size], [2.0])
                 if not np.array_equal(_bits(out[: q.size * 128].cpu().numpy()), _bits(ref)):
                     errs.append((r, it, "mismatch"))
@@ -220,7 +223,10 @@ def test_native_sharded_session_logical_shards_in_one_process(P):
     [t.join(timeout=300) for t in th]
     assert not errs, errs
     assert all(a[0] == 1 for a in attempts)                 # uniform keys fit the first capacity
-    assert all(a[3] == 2 for a in attempts)                 # the skewed round was repeated ONCE, on every rank alike
+    if dedup:
+        assert all(a[3] == 1 for a in attempts)             # one hot key is ONE key after the dedup: nothing overflows
+    else:
+        assert all(a[3] == 2 for a in attempts)             # the skewed round was repeated ONCE, on every rank alike
     assert all(a[4] == 1 for a in attempts)                 # ... and the capacity it found is kept
     for h in shards:
         hps.LIB.hps_shard_session_destroy(h)
@@ -256,7 +262,7 @@ def test_native_sharded_session_over_rccl_single_rank():
 
 
 @pytest.mark.gpu
-def test_native_sharded_session_zipf_skew_host_keys_and_reserved_key():
+def test_native_sharded_session_zipf_skew_host_keys_and_reserved_key(monkeypatch):
     """P = 4 logical shards, keys in HOST memory (hps_shard_session_lookup_host: staged + narrowed to uint32 when they fit),
     drawn Zipf-like so that a handful of keys make up most of a request: the first call overflows its blocks and is repeated
     ONCE with the capacity the headers reported (never a third attempt); later calls fit.  The cache's reserved key
@@ -266,6 +272,7 @@ def test_native_sharded_session_zipf_skew_host_keys_and_reserved_key():
     import torch
     from hugectr_backend_amd import hps
     from oracle import hps_oracle as O
+    monkeypatch.setenv("HPS_SHARD_DEDUP", "0")   # every key as sent: the overflow / exact-retry mechanics (the dedup has its own test below)
     P = 4
     max_local = 40000
     tables, made = _native_shards(P, max_local=max_local)
@@ -429,3 +436,90 @@ def test_native_sharded_session_an_oversized_block_is_refused_on_every_rank_and_
     hps.LIB.hps_shard_group_destroy(grp)
     for _, sess in made:
         sess.close()
+
+
+
+@pytest.mark.gpu
+def test_native_sharded_session_zipf_request_ships_each_row_once_and_the_blocks_shrink():
+    """Input dedup in front of the exchange (K1 before the bucket step): a Zipf request — a handful of keys make up most of it —
+    sends every distinct key ONCE, so the hot key that overflowed a block in round 3 no longer does (one attempt), and because
+    blocks travel whole, the block capacity follows the traffic down: after 32 calls that all fitted a smaller capacity the
+    session ships blocks of the size the traffic needs.  Asserted: keys sent = distinct keys of the request, the row bytes per
+    peer (capacity x D x 4) drop well below what the same request cost as sent, every rank resizes in the same call, rows exact
+    throughout — and a later request of distinct keys that needs the old capacity again is served (one repeated call)."""
+    import ctypes as C
+    import threading
+    import torch
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    P = 4
+    max_local = 40000
+    tables, made = _native_shards(P, R=60000, max_local=max_local)
+    keys = tables[0][0]
+    grp = C.c_void_p()
+    hps._check(hps.LIB.hps_shard_group_create_local(P, C.byref(grp)))
+    shards = []
+    for r, (_, sess) in enumerate(made):
+        h = C.c_void_p()
+        hps._check(hps.LIB.hps_shard_session_create_local(sess._h, grp, r, max_local, C.byref(h)))
+        shards.append(h)
+    for _, sess in made:
+        sess.close()
+    rng = np.random.default_rng(91)
+    ranks = np.argsort(rng.random(keys.size))
+    w = 1.0 / np.arange(1, keys.size + 1) ** 1.3
+    w /= w.sum()
+    CALLS = 36
+    rounds = [[keys[ranks[rng.choice(keys.size, size=max_local, p=w)]].astype(np.int64) for _ in range(P)] for _ in range(CALLS)]
+    # last round: all-distinct keys again (what the first capacity was made for)
+    rounds.append([rng.choice(keys, size=max_local, replace=False).astype(np.int64) for _ in range(P)])
+    errs = []
+    info = [[None] * len(rounds) for _ in range(P)]
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            for it, per_rank in enumerate(rounds):
+                q = per_rank[r]
+                out = torch.empty(q.size * 128, dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                hps._check(hps.LIB.hps_shard_session_lookup_host(shards[r], q.ctypes.data, q.size, out.data_ptr()))
+                att, cap = C.c_uint32(0), C.c_uint64(0)
+                sent = (C.c_uint64 * P)()
+                hps._check(hps.LIB.hps_shard_session_last_stats(shards[r], C.byref(cap), C.byref(att), sent, P))
+                info[r][it] = (att.value, cap.value, sum(sent))
+                if it % 6 == 0 or it >= CALLS - 1:
+                    ref = O.np_lookup(tables, q, [q.size], [2.0])
+                    if not np.array_equal(_bits(out.cpu().numpy()), _bits(ref)):
+                        errs.append((r, it, "mismatch"))
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, "exception", repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=600) for t in th]
+    assert not errs, errs
+    cap0 = info[0][0][1]
+    for r in range(P):
+        for it in range(CALLS):
+            assert info[r][it][0] == 1, (r, it, info[r][it])                                  # nothing overflows
+            assert info[r][it][2] == np.unique(rounds[it][r]).size, (r, it)                  # each distinct key travels once
+            assert info[r][it][1] == info[0][it][1], (r, it)                                  # same capacity on every rank, call by call
+        assert info[r][31][1] == cap0 and info[r][32][1] < 0.7 * cap0, (info[r][31], info[r][32], cap0)   # resized after 32 calls
+        largest = max(max(np.bincount(hps_owner(rounds[it][q_], P), minlength=P)) for it in range(32) for q_ in range(P))
+        assert info[r][32][1] >= largest                                                       # ... to what the traffic needed
+        # the all-distinct request no longer fits: ONE repeated call with the capacity it needs, rows exact (checked above)
+        assert info[r][CALLS][0] == 2 and info[r][CALLS][1] > info[r][32][1]
+    # bytes: what one rank ships to one peer per call (blocks travel whole)
+    as_sent = cap0 * 128 * 4
+    deduped = info[0][32][1] * 128 * 4
+    assert deduped < 0.7 * as_sent
+    for h in shards:
+        hps.LIB.hps_shard_session_destroy(h)
+    hps.LIB.hps_shard_group_destroy(grp)
+
+
+def hps_owner(q, P):
+    """owners of the DISTINCT keys of a request (what travels with the dedup on)"""
+    from hugectr_backend_amd import sharded
+    return sharded.owner_of(np.unique(q), P)
