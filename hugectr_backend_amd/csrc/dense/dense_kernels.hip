@@ -250,10 +250,24 @@ __global__ __launch_bounds__(kMlp2Threads) void hps_dense_mlp128_kernel(DenseMlp
 constexpr uint32_t kTriElems = 32 * 31 / 2 + 16;  // 496 pair slots + 16 spare slots for lanes without an element
 constexpr int kZPad = 8;  // f16 of padding per LDS row: 16-byte fragment reads of 16 consecutive rows hit distinct banks
 
+// NT: the embedding rows are read exactly once, by exactly one wave: non-temporal loads (round 4: 190 -> 178-186 us under
+// rocprofv3; the read pattern alone streams at 6.0 TB/s with plain loads and 6.75 TB/s with non-temporal ones,
+// tools/micro/read_stream.hip).  Where the rest of the time goes (tools/micro/interact_stages.hip, same box): the loads alone
+// 132 us; + conversion and LDS tile, + the 8 MFMAs, + the triangle through LDS: still 132-134 us — all of it hides under the
+// read stream; + the 63 MB of output rows: 172-177 us.  The 7 % of the bytes that are WRITES cost 42 us, whatever their shape:
+// 4-B or 16-B stores per lane, one store instruction per row or four, rows 960 B or 1,024 B apart (whole 128-B lines),
+// non-temporal or not (170-178 us in every combination).  A second register set that issues sample i+1's loads before sample
+// i is touched changes nothing either (189.5 us, at 2 waves per SIMD instead of 3) and was withdrawn.
+template <bool NT>
+__device__ __forceinline__ f4v ld_row(const float* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+  return *reinterpret_cast<const f4v*>(p);
+}
+
 // NCH = float4 chunks per lane held in registers (NCH*64 >= T*D/4): the loads of the wave's NEXT sample are issued
 // before the LDS/MFMA/store phase of the current one, so a wave always has a full sample (13 KB at T=26, D=128) in
 // flight.  NCH = 0: any size, two-phase (8 loads in flight, none during the compute phase).
-template <int NCH>
+template <int NCH, bool NT>
 __global__ __launch_bounds__(256) void hps_dense_interact_kernel(const float* __restrict__ emb, const _Float16* __restrict__ bottom,
                                                                  uint64_t batch, uint32_t T, uint32_t D, uint32_t out_stride,
                                                                  _Float16* __restrict__ out) {
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(256) void hps_dense_interact_kernel(const float* __
     }
     if (i < batch) {
 #pragma unroll
-      for (int u = 0; u < NR; ++u) pre[u] = *reinterpret_cast<const f4v*>(emb + goff[u] + i * D);
+      for (int u = 0; u < NR; ++u) pre[u] = ld_row<NT>(emb + goff[u] + i * D);
     }
   }
   for (; i < batch; i += waves_total) {
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(256) void hps_dense_interact_kernel(const float* __
       }
       const uint64_t nxt = i + waves_total < batch ? i + waves_total : i;   // the last round re-reads itself
 #pragma unroll
-      for (int u = 0; u < NR; ++u) pre[u] = *reinterpret_cast<const f4v*>(emb + goff[u] + nxt * D);
+      for (int u = 0; u < NR; ++u) pre[u] = ld_row<NT>(emb + goff[u] + nxt * D);
     } else {
       // (straight-line on purpose: with the loads under per-chunk branches the compiler drains vmcnt before each
       //  one and a wave keeps a single load in flight)
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(256) void hps_dense_interact_kernel(const float* __
           const uint32_t c = c0 + u * 64 + lane;
           const uint32_t ce = c < nchunks ? c : nchunks - 1;
           const uint32_t t = ce / d4, q = ce - t * d4;
-          v[u] = *reinterpret_cast<const f4v*>(emb + ((uint64_t)t * batch + i) * D + q * 4);
+          v[u] = ld_row<NT>(emb + ((uint64_t)t * batch + i) * D + q * 4);
           zo[u] = c < nchunks ? (1 + t) * zstride + q * 4 : 0xFFFFFFFFu;
         }
 #pragma unroll
@@ -403,6 +417,7 @@ hipError_t LaunchDenseInteract(const float* d_emb, const void* d_bottom_f16, uin
   const uint64_t cap = (uint64_t)cu_count * per_cu;
   if (want > cap) want = cap;
   const uint32_t per_lane = (T * (D / 4) + 63) / 64;
+  static const bool nt = [] { const char* e = getenv("HPS_DENSE_NT"); return e ? atoi(e) != 0 : true; }();   // A/B switch
   auto go = [&](auto kernel) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -410,11 +425,18 @@ hipError_t LaunchDenseInteract(const float* d_emb, const void* d_bottom_f16, uin
                        batch, T, D, out_stride, reinterpret_cast<_Float16*>(d_out_f16));
     return hipGetLastError();
   };
-  if (per_lane <= 4) return go(hps_dense_interact_kernel<4>);
-  if (per_lane <= 8) return go(hps_dense_interact_kernel<8>);
-  if (per_lane <= 13) return go(hps_dense_interact_kernel<13>);   // T = 26, D = 128: 13 chunks exactly (fewer registers than <16>)
-  if (per_lane <= 16) return go(hps_dense_interact_kernel<16>);
-  return go(hps_dense_interact_kernel<0>);
+  if (nt) {
+    if (per_lane <= 4) return go(hps_dense_interact_kernel<4, true>);
+    if (per_lane <= 8) return go(hps_dense_interact_kernel<8, true>);
+    if (per_lane <= 13) return go(hps_dense_interact_kernel<13, true>);   // T = 26, D = 128: 13 chunks exactly (fewer registers than <16>)
+    if (per_lane <= 16) return go(hps_dense_interact_kernel<16, true>);
+    return go(hps_dense_interact_kernel<0, true>);
+  }
+  if (per_lane <= 4) return go(hps_dense_interact_kernel<4, false>);
+  if (per_lane <= 8) return go(hps_dense_interact_kernel<8, false>);
+  if (per_lane <= 13) return go(hps_dense_interact_kernel<13, false>);
+  if (per_lane <= 16) return go(hps_dense_interact_kernel<16, false>);
+  return go(hps_dense_interact_kernel<0, false>);
 }
 
 }  // namespace hps
