@@ -17,6 +17,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <regex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -517,6 +518,7 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   std::map<std::pair<std::string, int>, std::shared_ptr<EmbeddingCache>> caches_;
   std::mutex upd_mu_;
   std::map<std::string, std::vector<std::vector<int64_t>>> updated_keys_;   // model -> per table: keys applied since the last commit
+  std::vector<std::regex> update_filters_;    // volatile_db.update_filters, compiled (set before the consumer starts, then read-only)
   std::unique_ptr<UpdateConsumer> updates_;   // last member: its thread stops before anything it uses goes away
 };
 

@@ -1007,18 +1007,11 @@ hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_table
                             const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream, KTimer kt) {
   if (N == 0) return hipSuccess;
   const size_t lds = sizeof(TableLds) * num_tables + sizeof(uint64_t) * (num_tables + 1);
-  // rows in flight per 16-lane group (two 16-B loads per lane and row): 8 by default (106 VGPRs, 4 waves per SIMD).  Against 4
-  // (64 VGPRs, 8 waves per SIMD): the same 210 us on the boxes whose copies run at 5.5+ TB/s, 228-234 against 235-246 us on the
-  // slow-gather boxes (profiles/round3/ab_gather_rows_in_flight.txt); 16 (214 VGPRs) no better than 8.  HPS_GATHER_U=4/2 for A/B.
-  static const int gather_u = [] { const char* e = getenv("HPS_GATHER_U"); return e ? atoi(e) : 8; }();
-  if (all_128_aligned && gather_u == 8)
+  // rows in flight per 16-lane group (two 16-B loads per lane and row): 8 (106 VGPRs, 4 waves per SIMD).  Against 4 (64 VGPRs,
+  // 8 waves per SIMD): the same 210 us on the boxes whose copies run at 5.5+ TB/s, 228-234 against 235-246 us on the slow-gather
+  // boxes (profiles/round3/ab_gather_rows_in_flight.txt); 16 (214 VGPRs) no better than 8.  (The A/B switch went with round 4.)
+  if (all_128_aligned)
     hipExtLaunchKernelGGL((hps_gather_hits_kernel<8, true>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
-                          d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
-  else if (all_128_aligned && gather_u == 2)
-    hipExtLaunchKernelGGL((hps_gather_hits_kernel<2, true>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
-                          d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
-  else if (all_128_aligned)
-    hipExtLaunchKernelGGL((hps_gather_hits_kernel<4, true>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
                           d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
   else
     hipExtLaunchKernelGGL((hps_gather_hits_kernel<4, false>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,

@@ -7,6 +7,8 @@
 #include <cstring>
 
 #include "engine.h"
+
+#include <regex>
 #include "kernels.h"
 
 namespace hps {
@@ -186,6 +188,19 @@ Status HierParameterServer::create_from_config(const ParameterServerConfig& cfg,
   if (cfg.volatile_db.overflow_margin == 0) return Error(Code::kInvalidArg, "volatile_db.overflow_margin must be > 0");
   HPS_RETURN_IF_ERROR(ps->Build(load_tables));
   if (cfg.update_source.type == UpdateSourceType::FileTail) {
+    // update_filters (docs/hierarchical_parameter_server.md:509-512, 570-573; parsed at backend.cpp:207-216, 250-259): regular
+    // expressions over the update's tag "hps_<model>.<table name>" that decide which updates a database layer takes.  This
+    // build writes an update through both layers in one step (HostTable::Upsert), so the two lists must say the same.
+    if (cfg.persistent_db.type != DatabaseType::Disabled && cfg.persistent_db.update_filters != cfg.volatile_db.update_filters)
+      return Error(Code::kUnsupported, "volatile_db.update_filters and persistent_db.update_filters differ: this build applies an "
+                                       "online update to both database layers together; give both the same list");
+    for (const std::string& f : cfg.volatile_db.update_filters) {
+      try {
+        ps->update_filters_.emplace_back(f, std::regex::ECMAScript | std::regex::optimize);
+      } catch (const std::regex_error& e) {
+        return Error(Code::kInvalidArg, "volatile_db.update_filters: '", f, "' is not a regular expression (", e.what(), ")");
+      }
+    }
     std::unique_ptr<UpdateTransport> tr;
     HPS_RETURN_IF_ERROR(MakeFileTailTransport(cfg.update_source.brokers, cfg.update_source.receive_buffer_size, &tr));
     HierParameterServer* raw = ps.get();   // the consumer is a member: it never outlives the server
@@ -203,6 +218,16 @@ Status HierParameterServer::ApplyUpdate(const std::string& model, uint32_t table
   if (table >= tabs.size()) return Error(Code::kNotFound, "update for model '", model, "' table ", table, ": no such table in this server");
   if (tabs[table]->dim() != dim)
     return Error(Code::kInvalidArg, "update for model '", model, "' table ", table, ": rows are ", dim, " wide, the table is ", tabs[table]->dim());
+  {
+    // the layers take an update only if its tag matches one of their update_filters (default "^hps_.+$": every model)
+    std::string tag = "hps_" + model + ".";
+    InferenceParams ip;
+    if (model_params(model, &ip) && table < ip.embedding_table_names.size()) tag += ip.embedding_table_names[table];
+    else tag += "sparse_embedding" + std::to_string(table + 1);
+    bool take = false;
+    for (const std::regex& f : update_filters_) take = take || std::regex_search(tag, f);
+    if (!take) return Error(Code::kNotFound, "update '", tag, "' matches none of the update_filters: not applied");
+  }
   HPS_RETURN_IF_ERROR(upsert_table(model, table, keys, rows, n));
   std::lock_guard<std::mutex> lk(upd_mu_);
   auto& per_table = updated_keys_[model];

@@ -13,14 +13,14 @@ TRITONSERVER_Error* HPSBackend::Create(TRITONBACKEND_Backend* triton_backend, HP
 }
 
 TRITONSERVER_Error* HPSBackend::HPS_backend() {
-  HPS_TRITON_LOG(INFO, "*****The Hierarchical Parameter Server is creating... *****");
+  HPS_TRITON_LOG(INFO, "hps backend: building the parameter server from ", ps_json_config_file_);
   RETURN_IF_STATUS_ERROR(HierParameterServer::create(ps_json_config_file_, &ps_));
-  HPS_TRITON_LOG(INFO, "*****The Hierarchical Parameter Server has been created successfully! *****");
+  HPS_TRITON_LOG(INFO, "hps backend: parameter server ready (host tier loaded, GPU caches warm)");
   return nullptr;
 }
 
 TRITONSERVER_Error* HPSBackend::ParseParameterServer(const std::string& path) {
-  HPS_TRITON_LOG(INFO, "*****Parsing Parameter Server Configuration from ", path);
+  HPS_TRITON_LOG(INFO, "hps backend: reading parameter-server configuration ", path);
   RETURN_IF_STATUS_ERROR(ps_->parse_config(path));
   return nullptr;
 }

@@ -229,3 +229,38 @@ def test_resident_rows_are_replaced_in_the_gpu_cache_and_absent_keys_stay_out(tm
     out = sess.lookup(cold[:64], [64]).cpu().numpy()     # ... and the host tier has the new rows for the others
     assert np.all(out == 9.0)
     sess.close()
+
+
+def test_update_filters_decide_which_updates_the_database_layers_take(tmp_path):
+    """volatile_db.update_filters / persistent_db.update_filters (docs/hierarchical_parameter_server.md:509-512): regular
+    expressions over the update's tag hps_<model>.<table name>.  Round 3 parsed and ignored them."""
+    from hugectr_backend_amd import hps
+    tables = make_tables([(100, 4), (100, 4)])
+    path = tmp_path / "updates.bin"
+    src = {"type": "file_tail", "brokers": str(path), "poll_timeout_ms": 20, "failure_backoff_ms": 5}
+    cfg = ps_config("upd", tables, gpucache=False)
+    cfg["update_source"] = src
+    cfg["models"][0]["embedding_table_names"] = ["user", "item"]
+    cfg["volatile_db"]["update_filters"] = ["^hps_upd\\.item$", "^hps_somebody_else\\..+$"]
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    for t, (k, r) in enumerate(tables):
+        ps.load_table_arrays("upd", t, k, r)
+    with open(path, "ab") as f:
+        f.write(hps.encode_update_message("upd", 0, tables[0][0][:5], np.full((5, 4), 3.0, np.float32)))   # hps_upd.user: filtered out
+        f.write(hps.encode_update_message("upd", 1, tables[1][0][:5], np.full((5, 4), 4.0, np.float32)))   # hps_upd.item: taken
+    ps.drain_update_source(10000)
+    st = ps.update_source_stats()
+    assert st["messages"] == 1 and st["rejected_messages"] == 1
+    sess = hps.LookupSession.create(ps, "upd", None)
+    out = sess.lookup(np.concatenate([tables[0][0][:5], tables[1][0][:5]]), [5, 5]).reshape(10, 4)
+    assert np.array_equal(_bits(out[:5]), _bits(tables[0][1][:5])) and np.all(out[5:] == 4.0)
+    sess.close()
+    ps.close()
+    # not a regular expression / lists that differ between the layers: refused at start-up, not ignored
+    cfg["volatile_db"]["update_filters"] = ["("]
+    with pytest.raises(hps.HpsError, match="regular expression"):
+        hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    cfg["volatile_db"]["update_filters"] = [".+"]
+    cfg["persistent_db"] = {"type": "rocks_db", "path": str(tmp_path / "store"), "update_filters": ["^hps_a.+$"]}
+    with pytest.raises(hps.HpsError, match="differ"):
+        hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
