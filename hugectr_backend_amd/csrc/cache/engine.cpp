@@ -623,6 +623,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   if (const char* e = std::getenv("HPS_PROBE_VARIANT")) probe_variant_ = (int)std::strtol(e, nullptr, 10);
   if (const char* e = std::getenv("HPS_DEFER_INSERT")) defer_insert_ = std::strtol(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("HPS_IN_PLACE_KB")) in_place_bytes_ = (size_t)std::max(0l, std::strtol(e, nullptr, 10)) << 10;
+  if (const char* e = std::getenv("HPS_SIDE_SCATTER_MB")) side_bytes_ = (size_t)std::max(0l, std::strtol(e, nullptr, 10)) << 20;
 
   HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_, hipHostMallocMapped));
   {
@@ -1078,10 +1079,10 @@ Status LookupSession::WaitPushedSeq(uint32_t want, hipEvent_t ev) {
     if ((i & 511u) == 0) {
       const hipError_t q = hipEventQuery(ev);
       if (q != hipSuccess && q != hipErrorNotReady) return Error(Code::kInternal, "lookup stream failed: ", hipGetErrorString(q));
-      // (the runtime's own wait sleeps on an interrupt after a short spin; on the microVM boxes its wake-up was seen to take
-      //  4-5 ms now and then — "rows done 4.4 ms" behind a scatter enqueued at 0.2 ms — so the word is polled for as long as a
-      //  call can reasonably take, yielding the CPU between looks)
-      if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(6000)) break;
+      // (Not longer: polling for 6 ms instead — tried in round 4 against the runtime's occasional 4-ms wake-ups — made things
+      //  worse: 9-ms waits for the miss counts.  Work queued behind a cross-stream event wait is released by a thread of the
+      //  HIP runtime; a caller that spins keeps that thread off the CPU, a caller that blocks in hipEventSynchronize lets it run.)
+      if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
     }
   }
   HIP_TRY(hipEventSynchronize(ev));
@@ -1581,14 +1582,18 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     // while waiting for the lane puts the other session's 230-us gather on this call's return path).  Round 3 had
     // near-all-hit calls (hit 0.9996) at 1.5 x their kernel time because of exactly that wait plus the writer lock.
     // (a small request's gather is a few microseconds: the hop to the second stream costs more)
-    const bool side = in_place && defer && N > kSmallRequestKeys;
+    // The same arrangement for a chunk that IS uploaded, up to side_bytes_ of rows (a call at 99 % hit: 17 K rows, 9 MB): the
+    // uploads already go down the second stream; descriptor, found flags and the scatter follow them there, so nothing waits
+    // for a host-side drain of K_G and nothing waits for the lane.  Beyond that size (the headline's 37 MB at 95 % hit) the
+    // scatter is an HBM-bound kernel of its own and keeps its turn in the lane behind a drained stream.
+    const bool side = defer && N > kSmallRequestKeys && (in_place || fl * sizeof(float) <= side_bytes_);
     hipStream_t ss = side ? copy_stream_ : stream_;
     if (side) HIP_TRY(hipStreamWaitEvent(ss, ev_probe_, 0));
-    if (in_place) {
+    if (in_place || (side && h_md_dev_ && zc_control_)) {
       const hipError_t pe = LaunchPull16(h_md_dev_, d_md_, sizeof(MissDesc), ss);
       if (pe != hipSuccess) return Error(Code::kInternal, "miss descriptor pull launch failed: ", hipGetErrorString(pe));
     } else {
-      HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, stream_));
+      HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, ss));
     }
     static const size_t kPieceFloats = [] {   // upload piece: HPS_PIECE_MB (A/B switch), default 4 MB
       const char* e = std::getenv("HPS_PIECE_MB");
@@ -1606,7 +1611,7 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       // split call: the session's stream is busy with K_G, the pieces go down the copy stream
       // (A/B on the MI355X box: alternating the pieces between two copy streams was slower — 1.24 vs 1.06 ms/step)
       if (!in_place) {
-        hipStream_t cs = split_call_ ? copy_stream_ : stream_;
+        hipStream_t cs = (split_call_ || side) ? copy_stream_ : stream_;
         HIP_TRY(hipMemcpyAsync(d_staging_ + piece_begin, h_staging_ + piece_begin, (piece_end - piece_begin) * sizeof(float),
                                hipMemcpyHostToDevice, cs));
         used_copy_stream |= (cs == copy_stream_);
@@ -1634,10 +1639,10 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       }
     }
     HPS_RETURN_IF_ERROR(flush());
-    if (!in_place) HIP_TRY(hipMemcpyAsync(d_found_, h_found_, uq, hipMemcpyHostToDevice, stream_));
+    if (!in_place) HIP_TRY(hipMemcpyAsync(d_found_, h_found_, uq, hipMemcpyHostToDevice, ss));
     const float* rows_src = in_place ? h_staging_dev_ : d_staging_;
     const uint8_t* found_src = in_place ? h_found_dev_ : d_found_;
-    if (used_copy_stream) {
+    if (used_copy_stream && !side) {
       HIP_TRY(hipEventRecord(ev_copy_, copy_stream_));
       HIP_TRY(hipStreamWaitEvent(stream_, ev_copy_, 0));
     }

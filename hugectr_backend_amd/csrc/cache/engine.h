@@ -373,6 +373,8 @@ class LookupSession {
   bool defer_insert_ = true;          // option "defer_insert" / HPS_DEFER_INSERT: the insert kernel is not on the call's return path
   size_t in_place_bytes_ = 1u << 20;  // option "in_place_bytes" / HPS_IN_PLACE_KB: missed rows of a chunk up to this size are read by
                                       // the kernels where the host gathered them (page-locked staging), no upload
+  size_t side_bytes_ = 16u << 20;     // HPS_SIDE_SCATTER_MB: missed rows of a call up to this size are uploaded AND scattered on the
+                                      // second stream, next to the hit gather and outside the kernel lane
   std::mutex deferred_mu_;
   bool deferred_pending_ = false;     // an insert + statistics push is in flight behind the last call
   uint32_t deferred_seq_ = 0;

@@ -832,20 +832,21 @@ def test_keys_narrow_as_offsets_from_each_tables_smallest_key():
 @pytest.mark.usefixtures("plain_lru")
 @pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("defer", [1, 0])
-def test_insert_left_behind_the_call_is_visible_to_every_later_observer(direct, defer):
+@pytest.mark.parametrize("base_misses", [40, 2500])   # 0.1-0.2 MB of missed rows: read in place; 4-5 MB: uploaded, scattered on the second stream
+def test_insert_left_behind_the_call_is_visible_to_every_later_observer(direct, defer, base_misses):
     """Option defer_insert (default 1): a synchronous call returns when its rows are complete and leaves its cache-insert
     kernel enqueued behind it.  Everything that can observe the cache afterwards — the next lookup (this session's or another
     one's), hps_cache_query, the counters — sees the insert done; rows and counts equal those of defer_insert=0.
     Big requests (> 128 K keys) with few misses take the side-stream scatter next to the hit gather (host-gather tier)."""
     from hugectr_backend_amd import hps
     from oracle import hps_oracle as O
-    rng = np.random.default_rng(40 + defer + 2 * int(direct))
+    rng = np.random.default_rng(40 + defer + 2 * int(direct) + base_misses)
     T, R, D = 3, 60000, 128
     tables = make_tables([(R, D)] * T)
     # (buckets filled to a quarter: no bucket is full, so that "every missed key is resident afterwards" holds to the key)
-    ps, cache, s0 = _mk(f"defer{defer}{int(direct)}", tables, maxcat=[1] * T, gpucacheper=0.5, max_batch=60000,
+    ps, cache, s0 = _mk(f"defer{defer}{int(direct)}_{base_misses}", tables, maxcat=[1] * T, gpucacheper=0.5, max_batch=60000,
                         extra={"ps_direct_access": direct, "gpucache_load_factor": 0.25})
-    s1 = hps.LookupSession.create(ps, f"defer{defer}{int(direct)}", cache)
+    s1 = hps.LookupSession.create(ps, f"defer{defer}{int(direct)}_{base_misses}", cache)
     for s in (s0, s1):
         s.set_option("defer_insert", defer)
         s.set_option("timing", 1)
@@ -862,7 +863,7 @@ def test_insert_left_behind_the_call_is_visible_to_every_later_observer(direct, 
             res = tk[cache.query(t, tk) >= 0]
             cold = tk[cache.query(t, tk) < 0]
             q = rng.choice(res, n)
-            m = rng.choice(cold, 40 + 10 * it, replace=False)   # a few hundred missed rows per call, each sent three times
+            m = rng.choice(cold, base_misses + 10 * it, replace=False)   # missed rows, each sent three times
             pos = rng.choice(n, 3 * m.size, replace=False)
             q[pos] = np.tile(m, 3)
             parts.append(q)
