@@ -915,7 +915,8 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     }
     const auto te0 = std::chrono::steady_clock::now();
     HIP_TRY(hipEventRecord(ev_keys_, ks));
-    HIP_TRY(hipStreamWaitEvent(stream_, ev_keys_, 0));
+    keys_wait_pending_ = true;   // the first stream waits for the keys AFTER the call block's pull has been enqueued (PrepareCall):
+                                 // the pull needs nothing of the keys and runs under the tail of their upload
     stage_event_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - te0).count();
   }
   key_stage_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
@@ -1039,6 +1040,10 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   } else {
     HIP_TRY(hipMemcpyAsync(d_block_, h_block_, block_bytes, hipMemcpyHostToDevice, stream_));
   }
+  if (keys_wait_pending_) {
+    keys_wait_pending_ = false;
+    HIP_TRY(hipStreamWaitEvent(stream_, ev_keys_, 0));
+  }
   *N_out = N;
   return Status::Ok();
 }
@@ -1075,7 +1080,8 @@ Status LookupSession::WaitPushedSeq(uint32_t want, hipEvent_t ev) {
   for (uint32_t i = 1;; ++i) {
     if (landed()) return Status::Ok();
     SpinPause();
-    if ((i & 127u) == 0) sched_yield();   // a waiter must not keep a CPU from a pool worker that has work (thread_pool.cpp)
+    static const bool kYield = [] { const char* e = std::getenv("HPS_POOL_YIELD"); return !(e && e[0] == '0'); }();
+    if ((i & 127u) == 0 && kYield) sched_yield();   // a waiter must not keep a CPU from a pool worker that has work (thread_pool.cpp)
     if ((i & 511u) == 0) {
       const hipError_t q = hipEventQuery(ev);
       if (q != hipSuccess && q != hipErrorNotReady) return Error(Code::kInternal, "lookup stream failed: ", hipGetErrorString(q));
@@ -1609,7 +1615,11 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       HPS_RETURN_IF_ERROR(ps_->FetchMulti(jobs));
       phase_ms_[1] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tf0).count();
       // split call: the session's stream is busy with K_G, the pieces go down the copy stream
-      // (A/B on the MI355X box: alternating the pieces between two copy streams was slower — 1.24 vs 1.06 ms/step)
+      // (A/B on the MI355X box: alternating the pieces between two copy streams was slower — 1.24 vs 1.06 ms/step.
+      //  Round 4: "upload turns" — one call's missed rows on the link at a time, the session that finds the turn taken gathers
+      //  everything and sends ONE copy when its turn comes — 1.70-1.72 G lookups/s and p50 1.93-1.99 ms against 2.00 G and
+      //  1.60 ms: a single stream of copies leaves the link idle between a call's pieces, two streams fill each other's gaps.
+      //  Withdrawn; profiles/round4/ab_upload_turns_withdrawn.txt.)
       if (!in_place) {
         hipStream_t cs = (split_call_ || side) ? copy_stream_ : stream_;
         HIP_TRY(hipMemcpyAsync(d_staging_ + piece_begin, h_staging_ + piece_begin, (piece_end - piece_begin) * sizeof(float),

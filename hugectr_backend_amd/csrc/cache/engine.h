@@ -321,6 +321,7 @@ class LookupSession {
   hipStream_t copy_stream_ = nullptr;  // second H2D queue for the missed-row pieces
   hipEvent_t ev_copy_ = nullptr;
   hipEvent_t ev_keys_ = nullptr;       // behind the key upload (second stream)
+  bool keys_wait_pending_ = false;     // lookup() recorded ev_keys_; PrepareCall makes the first stream wait for it behind the block pull
   hipEvent_t ev_done_ = nullptr, ev_read_ = nullptr, ev_fetch_ = nullptr, ev_t0_ = nullptr, ev_t1_ = nullptr,
              ev_f0_ = nullptr, ev_f1_ = nullptr, ev_c1_ = nullptr, ev_probe_ = nullptr;
   float last_gpu_call_ms_ = 0.f;

@@ -114,6 +114,9 @@ void ThreadPool::RunLoop(Loop* l) {
   }
 }
 
+// HPS_POOL_YIELD=0: waiters and idle spinners never yield (A/B of the round-4 change)
+static const bool kPoolYield = [] { const char* e = std::getenv("HPS_POOL_YIELD"); return !(e && e[0] == '0'); }();
+
 static inline void CpuRelax() {
 #if defined(__x86_64__) || defined(__i386__)
   __builtin_ia32_pause();
@@ -186,7 +189,7 @@ void ThreadPool::WorkerMain() {
         CpuRelax();
         // an idle spinner must not keep a CPU from a thread that has work (see ParallelFor): offer it now and then —
         // a yield with nobody waiting returns at once
-        if ((it & 255) == 255) sched_yield();
+        if ((it & 255) == 255 && kPoolYield) sched_yield();
         if ((it & 63) == 63 &&
             std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) break;
       }
@@ -240,7 +243,7 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
       // 0.15-ms staging loop, "ps fetch 5.56 ms").  The grain cannot be taken over (fn dies with this call), but the CPU
       // can be handed over: after a short spin the waiter yields, and the runnable worker gets it at once.
       for (uint32_t it = 0; L->done.load(std::memory_order_acquire) != (uint32_t)num_tasks; ++it) {
-        if (it < 2048) CpuRelax();
+        if (it < 2048 || !kPoolYield) CpuRelax();
         else sched_yield();
       }
       L->state.store(0, std::memory_order_release);
