@@ -115,10 +115,24 @@ int main(int argc, char** argv) {
       ++i;
     }
   });
+  // a monitoring thread reads the cache's counters while the sessions run: since round 4 that call collects the statistics of
+  // insert kernels the sessions left running behind their last calls (LookupSession::CollectDeferred, from a foreign thread)
+  std::thread monitor([&] {
+    uint64_t last = 0;
+    while (!stop.load()) {
+      std::this_thread::sleep_for(std::chrono::milliseconds(3));
+      if (!cache) continue;
+      hps_cache_counters_t c;
+      if (hps_cache_counters(cache, &c) != 0) { fprintf(stderr, "counters: %s\n", hps_last_error()); bad.fetch_add(1); break; }
+      if (c.inserted + c.refreshed + c.dropped < last) { fprintf(stderr, "counters went backwards\n"); bad.fetch_add(1); break; }
+      last = c.inserted + c.refreshed + c.dropped;
+    }
+  });
   std::this_thread::sleep_for(std::chrono::milliseconds((long)(seconds * 1000)));
   stop.store(true);
   for (auto& t : th) t.join();
   churn.join();
+  monitor.join();
   if (cache) { hps_cache_wait_async(cache); hps_cache_release(cache); }
   hps_server_destroy(sv);
   printf("abi_driver %s: %ld lookups, %ld bad -> %s\n", mode.c_str(), calls.load(), bad.load(), bad.load() ? "FAILED" : "ok");
