@@ -86,8 +86,12 @@ void EmbeddingCache::Release() {
 CacheCounters EmbeddingCache::counters() const {
   {
     // inserts that sessions left running behind their last call: their statistics are part of the picture
+    // (CollectDeferred selects the cache's device when there is something to wait for: the caller's current device is put back)
+    int dev = -1;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(sess_mu_);
     for (LookupSession* s : sessions_) (void)s->CollectDeferred();
+    if (dev >= 0) (void)hipSetDevice(dev);
   }
   std::lock_guard<std::mutex> lk(stat_mu_);
   return counters_;
