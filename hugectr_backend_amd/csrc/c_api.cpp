@@ -500,6 +500,9 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       s->s->set_split_probe(value != 0);
     } else if (n == "defer_insert") {
       s->s->set_defer_insert(value != 0);
+    } else if (n == "side_scatter_mb") {
+      if (value < 0) return Error(Code::kInvalidArg, "side_scatter_mb must be >= 0");
+      s->s->set_side_bytes((size_t)value << 20);
     } else if (n == "in_place_kb") {
       if (value < 0) return Error(Code::kInvalidArg, "in_place_kb must be >= 0");
       s->s->set_in_place_bytes((size_t)value << 10);

@@ -289,6 +289,7 @@ class LookupSession {
   void set_timing(bool on) { timing_ = on; }
   void set_defer_insert(bool b) { defer_insert_ = b; }
   void set_in_place_bytes(size_t b) { in_place_bytes_ = b; }
+  void set_side_bytes(size_t b) { side_bytes_ = b; }
   // The insert kernel of a synchronous call is enqueued behind the call and NOT waited for (defer_insert_): the rows the
   // call returns are exact without it, and every later reader of the cache is ordered behind it by the cache's writer
   // event.  Its statistics (and, with option "timing", its duration) are collected here — at the start of the session's

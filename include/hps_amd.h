@@ -246,7 +246,9 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
  * of its missed rows stays enqueued behind it, ordered before every later reader of the cache by the cache's writer
  * event — hps_cache_counters and hps_cache_query see it done; 0: the call also waits for the insert kernel),
  * "in_place_kb" (default 1024: missed rows of a call up to this many KB are read by the scatter and insert kernels out of
- * the page-locked buffer the host gathered them into, next to the hit gather, instead of being uploaded first) */
+ * the page-locked buffer the host gathered them into, next to the hit gather, instead of being uploaded first),
+ * "side_scatter_mb" (default 16: missed rows up to this many MB are uploaded and scattered on the session's second stream,
+ * without a turn in the kernel lane; beyond it the scatter takes its turn behind a drained stream) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 /* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------

@@ -88,3 +88,65 @@ def test_random_models_mixed_policy(seed, direct):
         ref = O.np_lookup(tables, q, nk, defaults, resident=[resident[t] if modes[t] else None for t in range(T)])
         assert np.array_equal(_bits(out), _bits(ref)), (seed, direct, it, thr, modes, nk)
         assert s.last_stats().async_insert == int(any(modes))
+
+
+@pytest.mark.parametrize("seed", list(range(4)))
+@pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
+def test_big_requests_under_random_return_path_options(seed, direct):
+    """Round 4 gave a synchronous call several return paths (missed rows read in place / uploaded and scattered on the second
+    stream / scattered in the kernel lane behind a drained stream; insert left behind the call or waited for; miss counts read
+    before or after the hit gather).  Two sessions on one cache, requests above 128 K keys (the big-request tiles), the options
+    redrawn before every call, the miss volume swept from nothing to half the request: every row exact, every unique miss
+    accounted for by the insert statistics."""
+    import threading
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    rng0 = np.random.default_rng(7000 + seed)
+    T = int(rng0.integers(2, 5))
+    D = [int(rng0.choice([16, 64, 128, 128])) for _ in range(T)]
+    R = 120000
+    tables = make_tables([(R, d) for d in D], seed=50 + seed)
+    per_table = 150000 // T + 2000
+    name = f"opt{seed}{'d' if direct else 'h'}"
+    ps, cache, s0 = _mk(name, tables, maxcat=[1] * T, gpucacheper=0.3, max_batch=per_table, extra={"ps_direct_access": direct})
+    s1 = hps.LookupSession.create(ps, name, cache)
+    co = O.COracle()
+    for k, r in tables:
+        co.add_table_arrays(k, r)
+    errs, uniq_seen = [], [0, 0]
+
+    def worker(si, sess):
+        rng = np.random.default_rng(8000 + 10 * seed + si)
+        try:
+            for it in range(10):
+                sess.set_option("defer_insert", int(rng.integers(0, 2)))
+                sess.set_option("in_place_kb", int(rng.choice([0, 64, 1024, 8192])))
+                sess.set_option("side_scatter_mb", int(rng.choice([0, 1, 16, 256])))
+                sess.set_option("split_probe", int(rng.integers(0, 2)))
+                nk = [int(rng.integers(per_table - 4000, per_table)) for _ in range(T)]
+                miss_frac = float(rng.choice([0.0, 0.0005, 0.01, 0.1, 0.5]))
+                parts = []
+                for t, ((keys, _), n) in enumerate(zip(tables, nk)):
+                    hot = keys[: int(0.25 * R)]                    # mostly resident (the warm set), the rest anywhere in the table
+                    q = rng.choice(hot, n)
+                    m = rng.random(n) < miss_frac
+                    q[m] = rng.choice(keys, int(m.sum()))          # (keys that exist: a key in no tier is served the default and never counted)
+                    parts.append(q.astype(np.int64))
+                q = np.concatenate(parts)
+                out = sess.lookup(q, nk).cpu().numpy()
+                ref = co.lookup(q, nk, [0.0] * T, threads=2)
+                if not np.array_equal(_bits(out), _bits(ref)):
+                    errs.append(f"session {si} call {it}: rows differ (miss_frac {miss_frac})")
+                uniq_seen[si] += sess.last_stats().unique_misses
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    c0 = cache.counters()
+    th = [threading.Thread(target=worker, args=(i, s)) for i, s in enumerate((s0, s1))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    c1 = cache.counters()
+    assert sum(c1[k] - c0[k] for k in ("inserted", "refreshed", "dropped")) == sum(uniq_seen)
+    s0.close()
+    s1.close()

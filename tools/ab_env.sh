@@ -16,5 +16,5 @@ for f in fs:
     except Exception as e:
         print(f, "FAILED", e); continue
     r=d["roofline"]
-    print(f.split("bench_")[1][:-5], "%.3f G lookups/s"%(d["value"]/1e9), "frac", round(r["frac"],3), "probe %.1f gather %.1f scatter %.1f insert %.1f us"%(r["probe_ms"]*1e3, r["gather_ms"]*1e3, r["scatter_ms"]*1e3, r["insert_ms_not_counted"]*1e3), "fetch %.3f ms"%((d.get("mean_phase_ms") or {}).get("ps_fetch", 0.0)), "ms/step %.3f"%d["ms_per_step"], "hit %.4f"%d.get("measured_hit_rate"), "p50 %.2f p99 %.2f ms"%(d["p50_batch_latency_ms"], d["p99_batch_latency_ms"]), "parity", d["parity_vs_oracle_bit_exact"], d["parity_full_batch_vs_direct_row_index"])
+    print(f.split("bench_")[1][:-5], "%.3f G lookups/s"%(d["value"]/1e9), "frac", round(r["frac"],3), "probe %.1f gather %.1f scatter %.1f insert %.1f us"%(r["probe_ms"]*1e3, r["gather_ms"]*1e3, r["scatter_ms"]*1e3, r["insert_ms"]*1e3), "ms/step %.3f"%d["ms_per_step"], "hit %.4f"%d.get("measured_hit_rate"), "p50 %.2f p99 %.2f ms"%(d["p50_batch_latency_ms"], d["p99_batch_latency_ms"]), "parity", d["parity_vs_oracle_bit_exact"], d.get("parity_full_batch"))
 P
