@@ -612,7 +612,20 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   device_ = cache_->device();
   HIP_TRY(hipSetDevice(device_));
   HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+  {
+    // The second stream carries the small things a call's host side waits for while the first stream's 230-us hit gather
+    // owns every CU: the miss counts' push, the descriptor pull, the side scatter.  It is a HIGH-PRIORITY queue: its workgroups
+    // are placed before the gather's remaining ones — the counts reach the host 50 us earlier (0.23-0.25 against 0.28-0.31 ms),
+    // headline 2.03 / 2.05 / 2.08 against 2.01 / 1.69 / 1.92 G lookups/s in three interleaved pairs (the two low ones look like
+    // the box's host noise: 2.01 is the fair comparison), p50 1.55-1.58 against 1.61 ms
+    // (profiles/round4/ab_side_stream_priority.txt).  HPS_SIDE_PRIORITY=0: a queue of normal priority.
+    static const bool hi = [] { const char* e = std::getenv("HPS_SIDE_PRIORITY"); return !(e && e[0] == '0'); }();
+    int least = 0, greatest = 0;
+    if (hi && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+      HIP_TRY(hipStreamCreateWithPriority(&copy_stream_, hipStreamNonBlocking, greatest));
+    else
+      HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+  }
   for (hipEvent_t* e : {&ev_copy_, &ev_keys_, &ev_done_, &ev_done2_, &ev_read_, &ev_fetch_, &ev_probe_})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   for (hipEvent_t* e : {&ev_t0_, &ev_t1_, &ev_f0_, &ev_f1_, &ev_c1_, &ev_g0_, &ev_g1_, &ev_s0_, &ev_s1_, &ev_i0_, &ev_i1_}) HIP_TRY(hipEventCreate(e));
