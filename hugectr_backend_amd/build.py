@@ -41,6 +41,8 @@ ENGINE_SRCS = [
     "cache/kernels.hip",
     "cache/shard_kernels.hip",
     "cache/shard_session.cpp",
+    "cache/entry_kernels.hip",
+    "cache/shard_entry.cpp",
     "cache/direct_kernels.hip",
     "cache/copy_engines.cpp",
     "cache/engine.cpp",

@@ -15,6 +15,7 @@
 #include "cache/copy_engines.h"
 #include "cache/engine.h"
 #include "cache/shard_kernels.h"
+#include "cache/shard_entry.h"
 #include "cache/shard_session.h"
 #include "dense/dense.h"
 
@@ -28,6 +29,7 @@ struct hps_cache { std::shared_ptr<HierParameterServer> ps; std::string model; i
 struct hps_session { std::shared_ptr<HierParameterServer> ps; std::shared_ptr<LookupSession> s; };   // shared: a sharded session built on it keeps it alive
 struct hps_dense { std::unique_ptr<DenseInteraction> d; };
 struct hps_shard_group { std::shared_ptr<LocalShardGroup> g; };
+struct hps_shard_entry { std::shared_ptr<HierParameterServer> ps; std::unique_ptr<ShardedEntrySession> s; };   // (s goes first)
 struct hps_shard_session { std::shared_ptr<HierParameterServer> ps; std::unique_ptr<ShardedSession> s; };   // (s goes first)
 
 namespace {
@@ -622,6 +624,88 @@ int hps_shard_session_last_stats(hps_shard_session_t* shard, uint64_t* capacity,
 }
 
 void hps_shard_session_destroy(hps_shard_session_t* shard) { delete shard; }
+
+int hps_server_get_shard_cache(hps_server_t* sv, const char* model, uint32_t shard, hps_cache_t** out) {
+  return Guard([&]() -> Status {
+    if (!sv || !model || !out) return Error(Code::kInvalidArg, "null argument");
+    *out = nullptr;
+    auto c = sv->ps->get_shard_cache(model, shard);
+    if (c) *out = new hps_cache{sv->ps, model, c->device(), c};
+    return Status::Ok();
+  });
+}
+
+int hps_shard_entry_create(hps_server_t* sv, const char* model, int32_t entry_device, hps_shard_entry_t** out) {
+  return Guard([&]() -> Status {
+    if (!sv || !model || !out) return Error(Code::kInvalidArg, "null argument");
+    std::unique_ptr<ShardedEntrySession> s;
+    HPS_RETURN_IF_ERROR(ShardedEntrySession::Create(sv->ps, model, entry_device, &s));
+    *out = new hps_shard_entry{sv->ps, std::move(s)};
+    return Status::Ok();
+  });
+}
+
+void hps_shard_entry_destroy(hps_shard_entry_t* e) { delete e; }
+
+int hps_shard_entry_lookup(hps_shard_entry_t* e, const void* const* h_keys_per_table, float* const* d_vectors_per_table,
+                           const size_t* num_keys_per_table, size_t num_tables) {
+  return Guard([&]() -> Status {
+    if (!e || !h_keys_per_table || !d_vectors_per_table || !num_keys_per_table) return Error(Code::kInvalidArg, "null argument");
+    return e->s->lookup(h_keys_per_table, d_vectors_per_table, num_keys_per_table, num_tables);
+  });
+}
+
+int hps_shard_entry_lookup_device(hps_shard_entry_t* e, const int64_t* d_keys_flat, float* const* d_vectors_per_table,
+                                  const size_t* num_keys_per_table, size_t num_tables) {
+  return Guard([&]() -> Status {
+    if (!e || !d_vectors_per_table || !num_keys_per_table) return Error(Code::kInvalidArg, "null argument");
+    return e->s->lookup_from_device(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
+  });
+}
+
+int hps_shard_entry_last_stats(hps_shard_entry_t* e, hps_shard_entry_stats_t* out) {
+  return Guard([&]() -> Status {
+    if (!e || !out) return Error(Code::kInvalidArg, "null argument");
+    const ShardEntryStats& st = e->s->last_stats();
+    memset(out, 0, sizeof *out);
+    out->keys = st.keys; out->unique_keys = st.unique_keys;
+    out->misses = st.misses; out->unique_misses = st.unique_misses;
+    out->bucket_ms = st.bucket_ms; out->lookup_ms = st.lookup_ms; out->expand_ms = st.expand_ms; out->key_stage_ms = st.key_stage_ms;
+    out->num_shards = e->s->num_shards();
+    for (uint32_t s = 0; s < e->s->num_shards() && s < 64; ++s) {
+      out->sent[s] = st.sent[s]; out->passes[s] = st.passes[s]; out->shard_ms[s] = st.shard_ms[s];
+    }
+    return Status::Ok();
+  });
+}
+
+int hps_shard_entry_set_option(hps_shard_entry_t* e, const char* name, int value) {
+  return Guard([&]() -> Status {
+    if (!e || !name) return Error(Code::kInvalidArg, "null argument");
+    const std::string n(name);
+    if (n == "dedup") e->s->set_dedup(value != 0);
+    else if (n == "timing") e->s->set_timing(value != 0);
+    else return Error(Code::kInvalidArg, "unknown option '", n, "'");
+    return Status::Ok();
+  });
+}
+
+uint64_t hps_shard_entry_shard_capacity(hps_shard_entry_t* e) { return e ? e->s->shard_capacity() : 0; }
+
+uint64_t hps_shard_plan_passes(const uint32_t* counts, uint32_t num_tables, uint64_t capacity, uint64_t* out, uint64_t max_passes) {
+  if (!counts || num_tables == 0) return 0;
+  try {
+    const std::vector<ShardPass> plan = PlanShardPasses(counts, num_tables, (size_t)capacity);
+    for (size_t i = 0; i < plan.size() && i < max_passes && out; ++i) {
+      uint64_t* row = out + i * (1 + (size_t)num_tables);
+      row[0] = plan[i].offset;
+      for (uint32_t t = 0; t < num_tables; ++t) row[1 + t] = plan[i].n[t];
+    }
+    return plan.size();
+  } catch (...) {
+    return 0;
+  }
+}
 
 int hps_dense_create(int device, uint32_t num_dense, uint32_t num_layers, const uint32_t* layer_dims, const float* const* weights,
                      const float* const* biases, uint32_t num_tables, uint32_t emb_dim, hps_dense_t** out) {

@@ -129,6 +129,10 @@ struct CallDesc {
   uint64_t key_start[kMaxTables + 1];  // prefix sums of n_t
   float* out[kMaxTables];              // device pointer of table t's output slice
   uint8_t vec_ok[kMaxTables];          // 1: D%4==0 and out[t] 16-B aligned -> float4 path
+  const uint32_t* dst_index;           // not null (table-sharded lookup, shard_entry.h): the row of key i goes to
+                                       // out[t] + dst_index[i] * D_t instead of out[t] + (i - key_start[t]) * D_t — the keys of
+                                       // this call are one owner's bucket of a larger request and every row is written
+                                       // straight to its place in the request's output (possibly on another GPU, over xGMI)
 };
 
 // Second descriptor, valid after the host has sized the miss staging (per call, per chunk).

@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "kernels.h"
+#include "shard_kernels.h"
 
 namespace hps {
 
@@ -198,8 +199,13 @@ void EmbeddingCache::EndWrite(hipStream_t stream) {
 }
 
 Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
-                            const std::vector<std::shared_ptr<HostTable>>& tables, int device) {
+                            const std::vector<std::shared_ptr<HostTable>>& tables, int device, int shard, uint32_t num_shards) {
   HPS_RETURN_IF_ERROR(RequireDevice(device));
+  if (shard >= 0 && (num_shards == 0 || (uint32_t)shard >= num_shards)) return Error(Code::kInvalidArg, "shard ", shard, " of ", num_shards);
+  shard_ = shard;
+  num_shards_ = shard >= 0 ? num_shards : 1;
+  const bool sharded = shard >= 0 && num_shards > 1;
+  auto owned = [&](int64_t key) { return !sharded || ShardOwnerHost(key, num_shards) == (uint32_t)shard; };
   HIP_TRY(hipSetDevice(device));
   {
     // every SDMA engine takes one tiny copy now, while the model loads (copy_engines.h); HPS_WAKE_COPY_ENGINES=0: A/B
@@ -243,7 +249,19 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
 
   for (size_t t = 0; t < T; ++t) {
     const uint32_t D = tables[t]->dim();
-    const size_t R = tables[t]->size();
+    size_t R = tables[t]->size();
+    if (sharded) {
+      // a shard is sized by the rows it owns (counted: hashed owners split a table evenly, a small table they may not)
+      const int64_t* kk = tables[t]->keys();
+      const size_t chunk = 1u << 18, tasks = (R + chunk - 1) / chunk;
+      std::atomic<size_t> mine{0};
+      ThreadPool::Global().ParallelFor(tasks, [&](size_t i) {
+        size_t c = 0;
+        for (size_t r = i * chunk, e = std::min(R, r + chunk); r < e; ++r) c += owned(kk[r]) ? 1 : 0;
+        mine.fetch_add(c, std::memory_order_relaxed);
+      });
+      R = mine.load();
+    }
     // capacity = ceil(gpucacheper * rows) (docs/architecture.md:50), at least one bucket
     size_t cap = (size_t)std::ceil((double)p.cache_size_percentage * (double)R);
     if (cap < 1) cap = 1;
@@ -316,23 +334,39 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   for (size_t t = 0; t < T && st.ok(); ++t) {
     const HostTable& ht = *tables[t];
     const uint32_t D = ht.dim();
-    const size_t want = std::min(cfg_.capacity_rows_[t], ht.size());
-    for (size_t r0 = 0; r0 < want && st.ok(); r0 += chunk_rows) {
-      const size_t n = std::min(chunk_rows, want - r0);
+    // a replica takes the first `capacity` rows of the file; a shard the first `capacity` rows it OWNS, wherever they are
+    const size_t want = sharded ? cfg_.capacity_rows_[t] : std::min(cfg_.capacity_rows_[t], ht.size());
+    const size_t scan_end = sharded ? ht.size() : want;
+    size_t taken = 0;
+    std::vector<size_t> pick;
+    for (size_t r0 = 0; r0 < scan_end && taken < want && st.ok(); r0 += chunk_rows) {
+      const size_t n = std::min(chunk_rows, scan_end - r0);
       // canonical rows only: a key repeated in the file is represented by its last row
       hk.clear(); hr.clear();
       const int64_t* src_keys = ht.keys() + r0;
       const float* src_rows = ht.row_at(r0);
-      const bool contiguous = !ht.has_duplicate_keys();
+      const bool contiguous = !ht.has_duplicate_keys() && !sharded;
       size_t m = n;
       if (!contiguous) {
-        for (size_t i = 0; i < n; ++i) {
-          if (ht.Find(src_keys[i]) != (int64_t)(r0 + i)) continue;
-          hk.push_back(src_keys[i]);
-          hr.insert(hr.end(), ht.row_at(r0 + i), ht.row_at(r0 + i) + D);
+        const bool dups = ht.has_duplicate_keys();
+        pick.clear();
+        for (size_t i = 0; i < n && taken + pick.size() < want; ++i) {
+          if (!owned(src_keys[i])) continue;
+          if (dups && ht.Find(src_keys[i]) != (int64_t)(r0 + i)) continue;
+          pick.push_back(i);
         }
-        m = hk.size(); src_keys = hk.data(); src_rows = hr.data();
+        m = pick.size();
+        hk.resize(m); hr.resize(m * (size_t)D);
+        const size_t grain = 4096, tasks = (m + grain - 1) / grain;
+        ThreadPool::Global().ParallelFor(tasks, [&](size_t ti) {
+          for (size_t j = ti * grain, e = std::min(m, j + grain); j < e; ++j) {
+            hk[j] = src_keys[pick[j]];
+            memcpy(hr.data() + j * (size_t)D, ht.row_at(r0 + pick[j]), (size_t)D * sizeof(float));
+          }
+        });
+        src_keys = hk.data(); src_rows = hr.data();
       }
+      taken += m;
       if (m == 0) continue;
       if (hipMemcpy(d_keys, src_keys, m * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess ||
           hipMemcpy(d_rows, src_rows, m * (size_t)D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
@@ -590,7 +624,7 @@ void LookupSession::Release() {
   cache_.reset();
 }
 
-Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, std::shared_ptr<EmbeddingCache> cache) {
+Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, std::shared_ptr<EmbeddingCache> cache, size_t max_keys_override) {
   ps_ = ps;
   params_ = p;
   tables_ = ps->tables_of(p.model_name);
@@ -601,6 +635,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
   size_t per_sample = 0;
   for (size_t c : p.maxnum_catfeature_query_per_table_per_sample) per_sample += c;
   max_keys_ = p.max_batchsize * per_sample;  // model_instance_state.cpp:98-99
+  if (max_keys_override) max_keys_ = max_keys_override;   // a shard session of a table-sharded model's entry instance (shard_entry.h)
   if (max_keys_ == 0) return Error(Code::kInvalidArg, "model '", p.model_name, "': max_batch_size * sum(maxnum_catfeature...) is 0");
   max_tiles_ = std::max(max_keys_ / kTileKeys, std::min<size_t>(max_keys_, kSmallRequestKeys) / kSmallTileKeys) + T;
   if (max_tiles_ * (size_t)kTileKeys >= (1ull << 31) - 2)
@@ -711,6 +746,11 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
     size_t worst = 4 * T;
     for (size_t t = 0; t < T; ++t)
       worst += p.max_batchsize * p.maxnum_catfeature_query_per_table_per_sample[t] * (size_t)tables_[t]->dim();
+    if (max_keys_override) {   // any mix of tables up to max_keys_ keys
+      size_t maxD = 1;
+      for (size_t t = 0; t < T; ++t) maxD = std::max<size_t>(maxD, tables_[t]->dim());
+      worst = 4 * T + max_keys_ * maxD;
+    }
     HPS_RETURN_IF_ERROR(DevAlloc(&d_staging_, worst));
     HPS_RETURN_IF_ERROR(DevAlloc(&d_found_, max_keys_));
     staging_floats_ = worst;
@@ -721,6 +761,11 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
     size_t floats = 0;
     for (size_t t = 0; t < T; ++t)
       floats += p.max_batchsize * p.maxnum_catfeature_query_per_table_per_sample[t] * (size_t)tables_[t]->dim();
+    if (max_keys_override) {
+      size_t maxD = 1;
+      for (size_t t = 0; t < T; ++t) maxD = std::max<size_t>(maxD, tables_[t]->dim());
+      floats = max_keys_ * maxD;
+    }
     floats = std::min(floats / 8 + 4 * T, kStagingCapBytes / sizeof(float));
     HPS_RETURN_IF_ERROR(EnsureStaging(floats, max_keys_ / 8 + 1));
   }
@@ -984,6 +1029,15 @@ Status LookupSession::lookup_from_device_padded(const int64_t* d_keys_flat, floa
   return st;
 }
 
+Status LookupSession::lookup_from_device_indexed(const int64_t* d_keys_flat, const uint32_t* d_dst_index, float* const* d_vectors_per_table,
+                                                 const size_t* num_keys_per_table, size_t num_tables) {
+  if (!d_dst_index) return Error(Code::kInvalidArg, "lookup_from_device_indexed: null destination index");
+  dst_index_next_ = d_dst_index;
+  const Status st = lookup_from_device(d_keys_flat, d_vectors_per_table, num_keys_per_table, num_tables);
+  dst_index_next_ = nullptr;
+  return st;
+}
+
 void LookupSession::discount_padding(uint64_t padding_keys) {
   if (!cache_ || padding_keys == 0) return;
   std::lock_guard<std::mutex> lk(cache_->stat_mu_);
@@ -1042,6 +1096,7 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
   c.epoch = cache_->NextEpoch();
   c.stamp8 = cache_->Stamp8(c.epoch);
   c.skip_empty_keys = skip_empty_next_ ? 1u : 0u;
+  c.dst_index = probe_only ? nullptr : dst_index_next_;
   if (++call_tag_ == 0) {  // 2^32 calls later: entries of the first calls would look like this call's
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemsetAsync(work_.set, 0, (work_.set_mask + 1) * sizeof(unsigned long long), stream_));
@@ -1239,7 +1294,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
     if (exclusive_ && !hold_lane) cache_->LaneEnter(stream_);
     Mark(ev_g0_);
     const hipError_t ge = LaunchGatherHits(d_call_, cache_->device_tables(), (uint32_t)T, N, w.slot, gather_blocks, all128, xcd_walk_, stream_,
-                                           Kt(ev_g0_, ev_g1_));
+                                           Kt(ev_g0_, ev_g1_), c.dst_index != nullptr);
     Mark(ev_g1_);
     if (exclusive_) cache_->LaneLeave(stream_, ev_lane_[1]);
     return ge;

@@ -20,6 +20,7 @@
 #include <regex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../common/config.h"
@@ -67,6 +68,8 @@ class EmbeddingCache {
   ~EmbeddingCache();
   const EmbeddingCacheConfig& get_cache_config() const { return cfg_; }
   int device() const { return cfg_.device_id_; }
+  int shard() const { return shard_; }                 // -1: a replica (holds any key)
+  uint32_t num_shards() const { return num_shards_; }
   const std::string& model_name() const { return model_; }
   uint32_t num_tables() const { return (uint32_t)cfg_.num_emb_table_; }
   const TableCacheDev* device_tables() const { return d_tables_; }
@@ -91,8 +94,10 @@ class EmbeddingCache {
   friend class HierParameterServer;
   friend class LookupSession;
   EmbeddingCache() = default;
+  // shard >= 0: this cache is shard `shard` of `num_shards` of a table-sharded model (ps.json "table_sharding": "hash"): it
+  // is sized for, warmed with and only ever asked for the keys with mix64(key) mod num_shards == shard
   Status Init(const std::string& model, const InferenceParams& p, const std::vector<std::shared_ptr<HostTable>>& tables,
-              int device);
+              int device, int shard = -1, uint32_t num_shards = 1);
   void Release();
   void FreeInserter();
 
@@ -152,6 +157,8 @@ class EmbeddingCache {
   std::atomic<uint64_t> calls_{0}, clock_rows_{0};
 
   std::string model_;
+  int shard_ = -1;
+  uint32_t num_shards_ = 1;
   EmbeddingCacheConfig cfg_;
   std::vector<TableCacheDev> h_tables_;
   TableCacheDev* d_tables_ = nullptr;
@@ -260,6 +267,11 @@ class LookupSession {
   Status lookup_from_device_padded(const int64_t* d_keys_flat, float* const* d_vectors_per_table, const size_t* num_keys_per_table,
                                    size_t num_tables);
   void discount_padding(uint64_t padding_keys);
+  // lookup_from_device for ONE OWNER'S BUCKET of a table-sharded request (shard_entry.h): the row of key i is written to
+  // d_vectors_per_table[t] + d_dst_index[i] * D_t — its place in the entry instance's output, which may sit on another GPU
+  // (peer-mapped: the gather / scatter / default-fill kernels store over xGMI).  d_keys_flat / d_dst_index may be peer memory too.
+  Status lookup_from_device_indexed(const int64_t* d_keys_flat, const uint32_t* d_dst_index, float* const* d_vectors_per_table,
+                                    const size_t* num_keys_per_table, size_t num_tables);
   // last call's numbers
   uint64_t last_miss_count() const { return last_misses_; }
   uint64_t last_unique_miss_count() const { return last_unique_; }
@@ -301,7 +313,7 @@ class LookupSession {
  private:
   friend class HierParameterServer;
   LookupSession() = default;
-  Status Init(HierParameterServer* ps, const InferenceParams& p, std::shared_ptr<EmbeddingCache> cache);
+  Status Init(HierParameterServer* ps, const InferenceParams& p, std::shared_ptr<EmbeddingCache> cache, size_t max_keys_override = 0);
   Status LookupHostTier(const void* const* h_keys_per_table, float* const* h_vectors_per_table,
                         const size_t* num_keys_per_table, size_t num_tables);
   Status LookupDevice(const int64_t* d_keys_flat, float* const* d_vectors_per_table, const size_t* n, size_t T);
@@ -333,6 +345,7 @@ class LookupSession {
   bool pack24_keys_ = true;       // ... and at 3 bytes each when they all fit 24 bits (option value 2 turns only this off)
   bool keys_narrow_ = false;      // this call's staged keys are uint32
   bool skip_empty_next_ = false;  // the call being prepared treats HPS_EMPTY_KEY as padding (lookup_from_device_padded)
+  const uint32_t* dst_index_next_ = nullptr;   // the call being prepared writes its rows through this index (lookup_from_device_indexed)
   int narrow_backoff_ = 0;        // calls left before narrowing is tried again after a wide key was seen
   int narrow24_backoff_ = 0;      // the same for the 3-byte packing after a key of 25..32 bits
   int narrow_streak_ = 0, narrow24_streak_ = 0;   // failed attempts in a row: the pause doubles with each, 256 .. 65,536 calls
@@ -453,6 +466,11 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   bool model_params(const std::string& model, InferenceParams* out);
 
   std::shared_ptr<EmbeddingCache> get_embedding_cache(const std::string& model, int device);
+  // table-sharded model (ps.json "table_sharding": "hash"): the cache of shard s (on deployed_device_list[s])
+  std::shared_ptr<EmbeddingCache> get_shard_cache(const std::string& model, uint32_t shard);
+  // a lookup session sized for `max_keys` keys per call instead of the model's request capacity (shard sessions of an entry instance)
+  Status create_lookup_session_sized(const std::string& model, std::shared_ptr<EmbeddingCache> cache, size_t max_keys,
+                                     std::unique_ptr<LookupSession>* out);
   Status update_database_per_model(const InferenceParams& p);          // (re)load sparse files into the host tier
   Status create_embedding_cache_per_model(const InferenceParams& p);   // build caches on deployed_devices
   Status destory_embedding_cache_per_model(const std::string& model);  // [sic] reference spelling
@@ -514,12 +532,14 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   Status Build(bool load_tables);
   Status EnsureTables(const InferenceParams& p, bool load);
   Status MutateTables(const std::string& model, const std::function<Status()>& fn);
+  Status RefreshOne(const std::string& model, const std::shared_ptr<EmbeddingCache>& cache);
 
   ParameterServerConfig cfg_;
   ThreadPool* pool_ = nullptr;
   std::mutex mu_;
   std::map<std::string, std::vector<std::shared_ptr<HostTable>>> tables_;
-  std::map<std::pair<std::string, int>, std::shared_ptr<EmbeddingCache>> caches_;
+  // (model, device, shard): shard = -1 for the replicas of an ordinary model, 0..P-1 for the shards of a table-sharded one
+  std::map<std::tuple<std::string, int, int>, std::shared_ptr<EmbeddingCache>> caches_;
   std::mutex upd_mu_;
   std::map<std::string, std::vector<std::vector<int64_t>>> updated_keys_;   // model -> per table: keys applied since the last commit
   std::vector<std::regex> update_filters_;    // volatile_db.update_filters, compiled (set before the consumer starts, then read-only)

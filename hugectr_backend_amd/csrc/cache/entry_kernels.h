@@ -1,0 +1,39 @@
+// Launchers of entry_kernels.hip: the entry side of a table-sharded lookup (shard_entry.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+namespace hps {
+
+// One request as the entry instance sees it.  Filled on the host (pinned), copied to the entry GPU, read by the kernels.
+struct EntryDesc {
+  uint32_t num_tables;
+  uint32_t num_shards;
+  uint32_t num_tiles;
+  uint32_t pad_;
+  uint64_t total_keys;
+  uint64_t key_start[kMaxTables + 1];    // prefix sums of the request's keys per table
+  uint32_t first_tile[kMaxTables + 1];   // first tile of table t (tiles never straddle tables); first_tile[T] = num_tiles
+  float* out[kMaxTables];                // the request's output slice of table t (entry GPU)
+  uint32_t dim[kMaxTables];
+};
+
+// d_rep[i] = index of the representative of (table of i, key i): i itself for one key of every distinct pair.
+// d_set: set_mask + 1 (a power of two >= 2 n) words, zeroed once; tag != 0, different from the tags still in the set.
+hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const int64_t* d_keys, uint64_t n, unsigned long long* d_set, uint64_t set_mask,
+                            uint32_t tag, uint32_t* d_rep, hipStream_t stream);
+// Stable bucket of the request's representatives (all keys when d_rep is null) by owner = mix64(key) mod num_shards:
+//   d_bkeys / d_bidx   owner-major, table-major inside an owner, input order inside a table; d_bidx = row position of the key
+//                      in its table's output slice
+//   d_base[P + 1]      first bucket position per owner; d_base[P] = keys bucketed
+//   d_counts[P][T]     keys per (owner, table)
+//   d_hist, d_within   workspace, num_tiles * num_shards words each
+hipError_t LaunchEntryBucket(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, uint32_t num_shards,
+                             const int64_t* d_keys, const uint32_t* d_rep, uint32_t* d_hist, uint32_t* d_within, uint32_t* d_base,
+                             uint32_t* d_counts, int64_t* d_bkeys, uint32_t* d_bidx, hipStream_t stream);
+// out[i] = out[d_rep[i]] where d_rep[i] != i
+hipError_t LaunchEntryExpand(const EntryDesc* d_desc, const uint32_t* d_rep, uint64_t n, hipStream_t stream);
+
+}  // namespace hps

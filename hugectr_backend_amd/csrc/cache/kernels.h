@@ -30,7 +30,8 @@ hipError_t LaunchUniqueHits(const CallDesc* d_call, const TableCacheDev* d_table
 
 // K_G: hit rows cache -> output from the slot indices K_P left (d_call carries the output pointers).
 hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream, KTimer kt = {});
+                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream, KTimer kt = {},
+                            bool indexed = false /* rows go to out[t] + d_call->dst_index[i] * D */);
 
 hipError_t LaunchMissScatter(const CallDesc* d_call, const TableCacheDev* d_tables, const MissDesc* d_md, const CallWork& w,
                              const float* d_staging, hipStream_t stream, KTimer kt = {});

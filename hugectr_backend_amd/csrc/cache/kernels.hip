@@ -534,6 +534,7 @@ __global__ __launch_bounds__(256) void hps_miss_scatter_kernel(const CallDesc* _
   const bool fast = vec && D == 128;
   float* __restrict__ out = call->out[t];
   const uint64_t ks = call->key_start[t];
+  const uint32_t* __restrict__ dst_index = call->dst_index;   // table-sharded lookup: where each key's row goes (device_types.h)
   const uint32_t region = tile * (uint32_t)kTileKeys;
   const int lig = (int)(threadIdx.x & 15), g = (int)(threadIdx.x >> 4);
   constexpr int kRows = 4;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256) void hps_miss_scatter_kernel(const CallDesc* _
       const int32_t i = w.sent_i[region + base + threadIdx.x];
       const uint32_t m = (uint32_t)w.sent_m[region + base + threadIdx.x];
       const uint32_t u = (uint32_t)w.uidx_of[(uint32_t)w.rep_of[m]];
-      sh_i[threadIdx.x] = i;
+      sh_i[threadIdx.x] = dst_index ? (int32_t)dst_index[i] : (int32_t)((uint64_t)i - ks);   // row position in the table's output slice
       sh_u[threadIdx.x] = (u >= lo && u < hi) ? u - lo : 0xFFFFFFFFu;   // other chunk of this call
     }
     __syncthreads();
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256) void hps_miss_scatter_kernel(const CallDesc* _
           dst[r] = nullptr;
           if (q < cnt && sh_u[q] != 0xFFFFFFFFu) {
             const float* src = staging + stage_off + (uint64_t)sh_u[q] * 128u;
-            dst[r] = out + ((uint64_t)sh_i[q] - ks) * 128u;
+            dst[r] = out + (uint64_t)(uint32_t)sh_i[q] * 128u;
             v[r][0] = *reinterpret_cast<const f4*>(src + lig * 4);
             v[r][1] = *reinterpret_cast<const f4*>(src + 64 + lig * 4);
           }
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256) void hps_miss_scatter_kernel(const CallDesc* _
         for (int r = 0; r < kRows; ++r) {
           const uint32_t q = q0 + r;
           if (q >= cnt || sh_u[q] == 0xFFFFFFFFu) continue;
-          copy_row<true>(staging + stage_off + (uint64_t)sh_u[q] * D, out + ((uint64_t)sh_i[q] - ks) * D, D, lig, vec);
+          copy_row<true>(staging + stage_off + (uint64_t)sh_u[q] * D, out + (uint64_t)(uint32_t)sh_i[q] * D, D, lig, vec);
         }
       }
     }
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(256) void hps_miss_fill_default_kernel(const CallDe
   const int lig = (int)(threadIdx.x & 15);
   for (uint32_t r = blockIdx.y * 16 + (threadIdx.x >> 4); r < S; r += 16 * gridDim.y) {
     const int32_t i = w.sent_i[region + r];
-    float* dst = out + ((uint64_t)i - ks) * D;
+    float* dst = out + (call->dst_index ? (uint64_t)call->dst_index[i] : (uint64_t)i - ks) * D;
     for (uint32_t c = (uint32_t)lig; c < D; c += 16) dst[c] = dv;
   }
 }
@@ -617,7 +618,9 @@ __global__ __launch_bounds__(256) void hps_miss_fill_default_kernel(const CallDe
 // ------------------------------------------------------------------------------------------------
 // kFast: every table is 128 wide with 16-B aligned output (checked on the host): rows are staged in registers, 2*kU
 // independent 16-B loads per lane in flight.  Otherwise: one row at a time with copy_row.
-template <int kU, bool kFast>
+// kIndexed: the row of key i goes to out[t] + dst_index[i] * D (CallDesc::dst_index, table-sharded lookup) — one more
+// coalesced 4-B load per key next to the slot word.
+template <int kU, bool kFast, bool kIndexed>
 __global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(const CallDesc* __restrict__ call,
                                                                              const TableCacheDev* __restrict__ tables,
                                                                              const int32_t* __restrict__ slot_in, uint32_t xcd_walk) {
@@ -628,6 +631,7 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(con
   load_tables_to_lds(sh_tab, sh_ks, call, tables, T);
   __syncthreads();
   const uint64_t N = call->total_keys;
+  const uint32_t* __restrict__ dst_index = kIndexed ? call->dst_index : nullptr;
   const int lane = lane_id();
   const int g = lane >> 4, lig = lane & 15;
   const uint64_t chunks = (N + 63) / 64;
@@ -646,6 +650,9 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(con
     const int32_t s = i < N ? slot_in[i] : -1;
     int t = (int)uniform_u32((uint32_t)find_table(sh_ks, T, chunk * 64));
     if (i < N) { while (i >= sh_ks[t + 1]) ++t; }
+    // kIndexed: the key's row position inside its table's output slice comes from the caller
+    uint32_t di = 0;
+    if (kIndexed) di = i < N ? dst_index[i] : 0u;
 #pragma unroll 1
     for (int j0 = 0; j0 < 16; j0 += kU) {
       if (kFast) {
@@ -656,10 +663,13 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(con
           const int src = g * 16 + j0 + u;
           const int32_t ss = __shfl(s, src, 64);
           const int tt = __shfl(t, src, 64);
+          uint64_t pos;
+          if (kIndexed) pos = (uint64_t)(uint32_t)__shfl((int)di, src, 64);
+          else pos = chunk * 64 + (uint64_t)src - sh_tab[tt].key_start;
           dst[u] = nullptr;
           if (ss >= 0) {
             const float* row = sh_tab[tt].rows + (uint64_t)(uint32_t)ss * 128u;
-            dst[u] = sh_tab[tt].out + (chunk * 64 + (uint64_t)src - sh_tab[tt].key_start) * 128u;
+            dst[u] = sh_tab[tt].out + pos * 128u;
             v[u][0] = *reinterpret_cast<const f4*>(row + lig * 4);
             v[u][1] = *reinterpret_cast<const f4*>(row + 64 + lig * 4);
           }
@@ -677,10 +687,11 @@ __global__ __launch_bounds__(kProbeBlockThreads) void hps_gather_hits_kernel(con
           const int src = g * 16 + j0 + u;
           const int32_t ss = __shfl(s, src, 64);
           const int tt = __shfl(t, src, 64);
+          const uint32_t dd = kIndexed ? (uint32_t)__shfl((int)di, src, 64) : 0u;
           if (ss < 0) continue;
           const TableLds& tb = sh_tab[tt];
-          copy_row<true>(tb.rows + (uint64_t)(uint32_t)ss * tb.dim, tb.out + (chunk * 64 + (uint64_t)src - tb.key_start) * tb.dim,
-                         tb.dim, lig, (tb.flags & 2u) != 0);
+          const uint64_t pos = kIndexed ? (uint64_t)dd : chunk * 64 + (uint64_t)src - tb.key_start;
+          copy_row<true>(tb.rows + (uint64_t)(uint32_t)ss * tb.dim, tb.out + pos * tb.dim, tb.dim, lig, (tb.flags & 2u) != 0);
         }
       }
     }
@@ -1004,18 +1015,19 @@ hipError_t LaunchUniqueHits(const CallDesc* d_call, const TableCacheDev* d_table
 }
 
 hipError_t LaunchGatherHits(const CallDesc* d_call, const TableCacheDev* d_tables, uint32_t num_tables, uint64_t N,
-                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream, KTimer kt) {
+                            const int32_t* d_slot, uint32_t grid, bool all_128_aligned, bool xcd_walk, hipStream_t stream, KTimer kt,
+                            bool indexed) {
   if (N == 0) return hipSuccess;
   const size_t lds = sizeof(TableLds) * num_tables + sizeof(uint64_t) * (num_tables + 1);
   // rows in flight per 16-lane group (two 16-B loads per lane and row): 8 (106 VGPRs, 4 waves per SIMD).  Against 4 (64 VGPRs,
   // 8 waves per SIMD): the same 210 us on the boxes whose copies run at 5.5+ TB/s, 228-234 against 235-246 us on the slow-gather
   // boxes (profiles/round3/ab_gather_rows_in_flight.txt); 16 (214 VGPRs) no better than 8.  (The A/B switch went with round 4.)
-  if (all_128_aligned)
-    hipExtLaunchKernelGGL((hps_gather_hits_kernel<8, true>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
-                          d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
-  else
-    hipExtLaunchKernelGGL((hps_gather_hits_kernel<4, false>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0,
-                          d_call, d_tables, d_slot, xcd_walk ? 1u : 0u);
+#define HPS_KG(UU, FF, II)                                                                                                          \
+  hipExtLaunchKernelGGL((hps_gather_hits_kernel<UU, FF, II>), dim3(grid), dim3(kProbeBlockThreads), (uint32_t)lds, stream, kt.start, kt.stop, 0, \
+                        d_call, d_tables, d_slot, xcd_walk ? 1u : 0u)
+  if (all_128_aligned) { if (indexed) HPS_KG(8, true, true); else HPS_KG(8, true, false); }
+  else { if (indexed) HPS_KG(4, false, true); else HPS_KG(4, false, false); }
+#undef HPS_KG
   return hipGetLastError();
 }
 

@@ -249,7 +249,7 @@ void HierParameterServer::OnUpdatesCommitted(const std::set<std::string>& models
     std::vector<std::shared_ptr<EmbeddingCache>> caches;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      for (auto& kv : caches_) if (kv.first.first == model) caches.push_back(kv.second);
+      for (auto& kv : caches_) if (std::get<0>(kv.first) == model) caches.push_back(kv.second);
     }
     for (auto& c : caches) {
       if (keys.size() != c->num_tables()) continue;
@@ -397,7 +397,7 @@ Status HierParameterServer::MutateTables(const std::string& model, const std::fu
   {
     std::lock_guard<std::mutex> lk(mu_);
     for (auto& kv : caches_)
-      if (kv.first.first == model && kv.second->direct()) direct.push_back(kv.second);
+      if (std::get<0>(kv.first) == model && kv.second->direct()) direct.push_back(kv.second);
   }
   std::vector<std::unique_lock<std::shared_mutex>> locks;
   for (auto& c : direct) {
@@ -462,8 +462,19 @@ std::vector<std::shared_ptr<HostTable>> HierParameterServer::tables_of(const std
 
 std::shared_ptr<EmbeddingCache> HierParameterServer::get_embedding_cache(const std::string& model, int device) {
   std::lock_guard<std::mutex> lk(mu_);
-  auto it = caches_.find({model, device});
-  return it == caches_.end() ? nullptr : it->second;
+  auto it = caches_.find({model, device, -1});
+  if (it != caches_.end()) return it->second;
+  // table-sharded model: the (first) shard that lives on that device
+  for (auto& kv : caches_)
+    if (std::get<0>(kv.first) == model && std::get<1>(kv.first) == device) return kv.second;
+  return nullptr;
+}
+
+std::shared_ptr<EmbeddingCache> HierParameterServer::get_shard_cache(const std::string& model, uint32_t shard) {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (auto& kv : caches_)
+    if (std::get<0>(kv.first) == model && std::get<2>(kv.first) == (int)shard) return kv.second;
+  return nullptr;
 }
 
 Status HierParameterServer::update_database_per_model(const InferenceParams& p) {
@@ -476,15 +487,31 @@ Status HierParameterServer::create_embedding_cache_per_model(const InferencePara
   auto tabs = tables_of(p.model_name);
   if (tabs.size() != p.num_tables())
     return Error(Code::kNotFound, "model '", p.model_name, "': tables are not loaded; call update_database_per_model first");
+  if (p.table_sharding) {
+    // entry s of deployed_device_list is shard s (a device may hold several: logical shards)
+    const uint32_t P = (uint32_t)p.deployed_devices.size();
+    for (uint32_t s = 0; s < P; ++s) {
+      const int dev = p.deployed_devices[s];
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (caches_.count({p.model_name, dev, (int)s})) continue;
+      }
+      std::shared_ptr<EmbeddingCache> c(new EmbeddingCache());
+      HPS_RETURN_IF_ERROR(c->Init(p.model_name, p, tabs, dev, (int)s, P));
+      std::lock_guard<std::mutex> lk(mu_);
+      caches_[{p.model_name, dev, (int)s}] = std::move(c);
+    }
+    return Status::Ok();
+  }
   for (int dev : p.deployed_devices) {
     {
       std::lock_guard<std::mutex> lk(mu_);
-      if (caches_.count({p.model_name, dev})) continue;
+      if (caches_.count({p.model_name, dev, -1})) continue;
     }
     std::shared_ptr<EmbeddingCache> c(new EmbeddingCache());
     HPS_RETURN_IF_ERROR(c->Init(p.model_name, p, tabs, dev));
     std::lock_guard<std::mutex> lk(mu_);
-    caches_[{p.model_name, dev}] = std::move(c);
+    caches_[{p.model_name, dev, -1}] = std::move(c);
   }
   return Status::Ok();
 }
@@ -494,7 +521,7 @@ Status HierParameterServer::destory_embedding_cache_per_model(const std::string&
   {
     std::lock_guard<std::mutex> lk(mu_);
     for (auto it = caches_.begin(); it != caches_.end();) {
-      if (it->first.first == model) { victims.push_back(it->second); it = caches_.erase(it); }
+      if (std::get<0>(it->first) == model) { victims.push_back(it->second); it = caches_.erase(it); }
       else ++it;
     }
   }
@@ -503,8 +530,18 @@ Status HierParameterServer::destory_embedding_cache_per_model(const std::string&
 }
 
 Status HierParameterServer::refresh_embedding_cache(const std::string& model, int device) {
-  auto cache = get_embedding_cache(model, device);
-  if (!cache) return Error(Code::kNotFound, "no embedding cache for model '", model, "' on device ", device);
+  std::vector<std::shared_ptr<EmbeddingCache>> on_device;   // one replica, or every shard of a table-sharded model on that device
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto& kv : caches_)
+      if (std::get<0>(kv.first) == model && std::get<1>(kv.first) == device) on_device.push_back(kv.second);
+  }
+  if (on_device.empty()) return Error(Code::kNotFound, "no embedding cache for model '", model, "' on device ", device);
+  for (auto& c : on_device) HPS_RETURN_IF_ERROR(RefreshOne(model, c));
+  return Status::Ok();
+}
+
+Status HierParameterServer::RefreshOne(const std::string& model, const std::shared_ptr<EmbeddingCache>& cache) {
   InferenceParams p;
   {
     std::lock_guard<std::mutex> lk(mu_);
@@ -547,6 +584,17 @@ Status HierParameterServer::create_lookup_session(const std::string& model, std:
   }
   std::unique_ptr<LookupSession> s(new LookupSession());
   HPS_RETURN_IF_ERROR(s->Init(this, p, std::move(cache)));
+  *out = std::move(s);
+  return Status::Ok();
+}
+
+Status HierParameterServer::create_lookup_session_sized(const std::string& model, std::shared_ptr<EmbeddingCache> cache, size_t max_keys,
+                                                        std::unique_ptr<LookupSession>* out) {
+  InferenceParams p;
+  if (!model_params(model, &p)) return Error(Code::kNotFound, "model '", model, "' is not in the parameter server configuration");
+  if (max_keys == 0) return Error(Code::kInvalidArg, "create_lookup_session_sized: max_keys is 0");
+  std::unique_ptr<LookupSession> s(new LookupSession());
+  HPS_RETURN_IF_ERROR(s->Init(this, p, std::move(cache), max_keys));
   *out = std::move(s);
   return Status::Ok();
 }

@@ -1,0 +1,392 @@
+#include "shard_entry.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "../ps/thread_pool.h"
+#include "shard_kernels.h"
+
+namespace hps {
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return ::hps::Error(::hps::Code::kInternal, #expr, " failed: ", hipGetErrorString(_e), " (", \
+                          __FILE__, ":", __LINE__, ")");                                           \
+  } while (0)
+
+namespace {
+float MsSince(std::chrono::steady_clock::time_point t) {
+  return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
+}
+}  // namespace
+
+std::vector<ShardPass> PlanShardPasses(const uint32_t* counts, size_t T, size_t capacity) {
+  std::vector<ShardPass> plan;
+  if (capacity == 0) return plan;
+  uint64_t offset = 0;
+  ShardPass cur;
+  cur.n.assign(T, 0);
+  size_t in_pass = 0;
+  for (size_t t = 0; t < T; ++t) {
+    size_t left = counts[t];
+    while (left) {
+      const size_t take = std::min(left, capacity - in_pass);
+      cur.n[t] += take;
+      in_pass += take;
+      left -= take;
+      if (in_pass == capacity) {
+        cur.offset = offset;
+        plan.push_back(cur);
+        offset += in_pass;
+        cur.n.assign(T, 0);
+        in_pass = 0;
+      }
+    }
+  }
+  if (in_pass) {
+    cur.offset = offset;
+    plan.push_back(cur);
+  }
+  return plan;
+}
+
+Status ShardedEntrySession::Create(std::shared_ptr<HierParameterServer> ps, const std::string& model, int entry_device,
+                                   std::unique_ptr<ShardedEntrySession>* out) {
+  if (!ps || !out) return Error(Code::kInvalidArg, "null argument");
+  InferenceParams p;
+  if (!ps->model_params(model, &p)) return Error(Code::kNotFound, "model '", model, "' is not in the parameter server configuration");
+  if (!p.table_sharding)
+    return Error(Code::kInvalidArg, "model '", model, "' is not table-sharded (ps.json \"table_sharding\": \"hash\")");
+  if (std::find(p.deployed_devices.begin(), p.deployed_devices.end(), entry_device) == p.deployed_devices.end())
+    return Error(Code::kInvalidArg, "model '", model, "': device ", entry_device, " is not in deployed_device_list");
+  const size_t T = p.num_tables();
+  if (T == 0 || T > (size_t)kMaxTables) return Error(Code::kInvalidArg, "model '", model, "': ", T, " tables (supported: 1..", kMaxTables, ")");
+  std::unique_ptr<ShardedEntrySession> s(new ShardedEntrySession());
+  s->ps_ = ps;
+  s->params_ = p;
+  s->P_ = (uint32_t)p.deployed_devices.size();
+  s->device_ = entry_device;
+  s->dedup_ = p.shard_dedup;
+  size_t per_sample = 0;
+  for (size_t c : p.maxnum_catfeature_query_per_table_per_sample) per_sample += c;
+  s->max_keys_ = p.max_batchsize * per_sample;
+  if (s->max_keys_ == 0) return Error(Code::kInvalidArg, "model '", model, "': max_batch_size * sum(maxnum_catfeature...) is 0");
+  if (s->max_keys_ >= (1ull << 31) - 2) return Error(Code::kUnsupported, "more than 2^31 keys per request are not supported");
+  s->max_tiles_ = s->max_keys_ / kTileKeys + T;
+  // one owner's session: its fair share of a full request times the configured slack; more than that goes in passes
+  const double share = std::ceil((double)s->max_keys_ / s->P_ * p.shard_capacity_factor);
+  s->shard_cap_ = (size_t)std::min<double>((double)s->max_keys_, share + 1024.0);
+  auto tabs = ps->tables_of(model);
+  if (tabs.size() != T) return Error(Code::kNotFound, "model '", model, "': tables are not loaded");
+  for (size_t t = 0; t < T; ++t) s->dims_.push_back(tabs[t]->dim());
+
+  // ---- the P shard sessions, each on its shard's device; their kernels read the bucket keys out of, and store the rows
+  //      into, the entry device's memory: peer access from every other shard device to the entry device ----
+  for (uint32_t sh = 0; sh < s->P_; ++sh) {
+    auto cache = ps->get_shard_cache(model, sh);
+    if (!cache)
+      return Error(Code::kNotFound, "model '", model, "': shard ", sh, " has no embedding cache (create_embedding_cache_per_model first)");
+    const int dev = cache->device();
+    s->shard_device_.push_back(dev);
+    if (dev != entry_device) {
+      HIP_TRY(hipSetDevice(dev));
+      int can = 0;
+      HIP_TRY(hipDeviceCanAccessPeer(&can, dev, entry_device));
+      if (!can)
+        return Error(Code::kUnavailable, "model '", model, "': device ", dev, " (shard ", sh, ") cannot access device ", entry_device,
+                     " as a peer; the table-sharded lookup needs peer access between the deployed devices");
+      const hipError_t pe = hipDeviceEnablePeerAccess(entry_device, 0);
+      if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+        return Error(Code::kInternal, "hipDeviceEnablePeerAccess(", entry_device, ") from device ", dev, " failed: ", hipGetErrorString(pe));
+      (void)hipGetLastError();
+    }
+    std::unique_ptr<LookupSession> ls;
+    HPS_RETURN_IF_ERROR(ps->create_lookup_session_sized(model, cache, s->shard_cap_, &ls));
+    s->sessions_.push_back(std::move(ls));
+  }
+
+  // ---- the entry device's side ----
+  HIP_TRY(hipSetDevice(entry_device));
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream_, hipStreamNonBlocking));
+  for (hipEvent_t& e : s->ev_) HIP_TRY(hipEventCreate(&e));
+  auto dev_alloc = [](auto** ptr, size_t count) -> Status {
+    void* v = nullptr;
+    if (hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(**ptr)) != hipSuccess)
+      return Error(Code::kInternal, "sharded entry session: out of device memory");
+    *ptr = (std::remove_reference_t<decltype(**ptr)>*)v;
+    return Status::Ok();
+  };
+  auto pin_alloc = [](auto** ptr, size_t count) -> Status {
+    void* v = nullptr;
+    if (hipHostMalloc(&v, std::max<size_t>(count, 1) * sizeof(**ptr), hipHostMallocDefault) != hipSuccess)
+      return Error(Code::kInternal, "sharded entry session: out of page-locked memory");
+    *ptr = (std::remove_reference_t<decltype(**ptr)>*)v;
+    return Status::Ok();
+  };
+  const size_t N = s->max_keys_, P = s->P_;
+  s->tiles_off_ = (sizeof(EntryDesc) + 127) & ~(size_t)127;
+  const size_t block_bytes = s->tiles_off_ + s->max_tiles_ * sizeof(TileDesc);
+  HPS_RETURN_IF_ERROR(pin_alloc(&s->h_block_, block_bytes));
+  memset(s->h_block_, 0, block_bytes);
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_block_, block_bytes));
+  HPS_RETURN_IF_ERROR(pin_alloc(&s->h_keys_, N));
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_keys_, N));
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_rep_, N));
+  uint64_t set_cap = 1024;
+  while (set_cap < 2 * (uint64_t)N) set_cap <<= 1;
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_set_, set_cap));
+  HIP_TRY(hipMemset(s->d_set_, 0, set_cap * sizeof(unsigned long long)));   // tag 0 is never used by a call
+  s->set_mask_ = set_cap - 1;
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_hist_, s->max_tiles_ * P));
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_within_, s->max_tiles_ * P));
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_counts_, (P + 1) + P * T));
+  HPS_RETURN_IF_ERROR(pin_alloc(&s->h_counts_, (P + 1) + P * T));
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_bkeys_, N));
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_bidx_, N));
+  HIP_TRY(hipDeviceSynchronize());
+
+  for (uint32_t sh = 0; sh < s->P_; ++sh) s->workers_.emplace_back(new Worker());
+  ShardedEntrySession* raw = s.get();
+  for (uint32_t sh = 0; sh < s->P_; ++sh) s->workers_[sh]->th = std::thread([raw, sh] { raw->WorkerMain(sh); });
+  s->stats_.sent.assign(P, 0);
+  s->stats_.passes.assign(P, 0);
+  s->stats_.shard_ms.assign(P, 0.f);
+  *out = std::move(s);
+  return Status::Ok();
+}
+
+ShardedEntrySession::~ShardedEntrySession() {
+  for (auto& w : workers_) {
+    if (!w) continue;
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->stop = true;
+    }
+    w->cv.notify_all();
+  }
+  for (auto& w : workers_) if (w && w->th.joinable()) w->th.join();
+  sessions_.clear();
+  (void)hipSetDevice(device_);
+  if (stream_) { (void)hipStreamSynchronize(stream_); (void)hipStreamDestroy(stream_); }
+  for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
+  for (void* p : {(void*)d_block_, (void*)d_keys_, (void*)d_rep_, (void*)d_set_, (void*)d_hist_, (void*)d_within_, (void*)d_counts_,
+                  (void*)d_bkeys_, (void*)d_bidx_})
+    if (p) (void)hipFree(p);
+  for (void* p : {(void*)h_block_, (void*)h_keys_, (void*)h_counts_}) if (p) (void)hipHostFree(p);
+}
+
+void ShardedEntrySession::set_timing(bool b) {
+  for (auto& s : sessions_) s->set_timing(b);
+}
+
+// One worker per shard: drives that shard's lookups on the shard's device while the others drive theirs.
+void ShardedEntrySession::WorkerMain(uint32_t s) {
+  (void)hipSetDevice(shard_device_[s]);
+  Worker& w = *workers_[s];
+  const size_t T = dims_.size();
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(w.mu);
+      w.cv.wait(lk, [&] { return w.has_job || w.stop; });
+      if (w.stop) return;
+      w.has_job = false;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    Status st = Status::Ok();
+    uint64_t misses = 0, unique = 0;
+    for (const ShardPass& pass : w.plan) {
+      st = sessions_[s]->lookup_from_device_indexed(w.keys + pass.offset, w.idx + pass.offset, w.out, pass.n.data(), T);
+      if (!st.ok()) break;
+      misses += sessions_[s]->last_miss_count();
+      unique += sessions_[s]->last_unique_miss_count();
+    }
+    {
+      std::lock_guard<std::mutex> lk(w.mu);
+      w.st = st;
+      w.ms = MsSince(t0);
+      w.misses = misses;
+      w.unique = unique;
+      w.done = true;
+    }
+    w.cv.notify_all();
+  }
+}
+
+Status ShardedEntrySession::lookup_from_device(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
+  if (T != dims_.size()) return Error(Code::kInvalidArg, "lookup: got ", T, " tables, model '", params_.model_name, "' has ", dims_.size());
+  if (!n || !d_out) return Error(Code::kInvalidArg, "null argument");
+  HIP_TRY(hipSetDevice(device_));
+  stats_.key_stage_ms = 0.f;
+  return Run(d_keys_flat, d_out, n, T);
+}
+
+Status ShardedEntrySession::lookup(const void* const* h_keys_per_table, float* const* d_out, const size_t* n, size_t T) {
+  if (T != dims_.size()) return Error(Code::kInvalidArg, "lookup: got ", T, " tables, model '", params_.model_name, "' has ", dims_.size());
+  if (!h_keys_per_table || !n || !d_out) return Error(Code::kInvalidArg, "null argument");
+  size_t N = 0;
+  for (size_t t = 0; t < T; ++t) N += n[t];
+  if (N > max_keys_)
+    return Error(Code::kInvalidArg, "lookup: ", N, " keys exceed the request capacity of ", max_keys_,
+                 " (max_batch_size x sum(maxnum_catfeature_query_per_table_per_sample))");
+  HIP_TRY(hipSetDevice(device_));
+  stats_.key_stage_ms = 0.f;
+  if (N == 0) return Run(nullptr, d_out, n, T);
+  const auto t0 = std::chrono::steady_clock::now();
+  // one flat array in page-locked memory (Triton's pinned input pool): DMA in place; else staged through page-locked memory
+  // in 32 K-key tasks on the serving pool, 4-MB groups, each group's upload enqueued while the next is staged
+  bool flat = true;
+  const int64_t* base = nullptr;
+  {
+    const int64_t* expect = nullptr;
+    for (size_t t = 0; t < T; ++t) {
+      if (n[t] == 0) continue;
+      const int64_t* p = (const int64_t*)h_keys_per_table[t];
+      if (!p) return Error(Code::kInvalidArg, "lookup: null key pointer for table ", t);
+      if (!base) base = p;
+      else if (p != expect) flat = false;
+      expect = p + n[t];
+    }
+  }
+  bool in_place = false;
+  if (flat) {
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof attr);
+    if (hipPointerGetAttributes(&attr, base) == hipSuccess && attr.type == hipMemoryTypeHost) in_place = true;
+    else (void)hipGetLastError();
+  }
+  if (in_place) {
+    HIP_TRY(hipMemcpyAsync(d_keys_, base, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+  } else {
+    constexpr size_t kTaskKeys = 32768, kGroupKeys = (4u << 20) / sizeof(int64_t);
+    struct Task { const int64_t* src; size_t off, n; };
+    std::vector<Task> tasks;
+    size_t off = 0;
+    for (size_t t = 0; t < T; ++t) {
+      const int64_t* p = (const int64_t*)h_keys_per_table[t];
+      for (size_t b = 0; b < n[t]; b += kTaskKeys) tasks.push_back({p + b, off + b, std::min(kTaskKeys, n[t] - b)});
+      off += n[t];
+    }
+    size_t g0 = 0;
+    while (g0 < tasks.size()) {
+      size_t g1 = g0, keys_in_group = 0;
+      while (g1 < tasks.size() && (keys_in_group == 0 || keys_in_group + tasks[g1].n <= kGroupKeys)) keys_in_group += tasks[g1++].n;
+      auto body = [&](size_t i) { const Task& tk = tasks[g0 + i]; memcpy(h_keys_ + tk.off, tk.src, tk.n * sizeof(int64_t)); };
+      if (g1 - g0 <= 2) for (size_t i = 0; i < g1 - g0; ++i) body(i);
+      else ThreadPool::Serving().ParallelFor(g1 - g0, body);
+      const size_t first = tasks[g0].off, count = tasks[g1 - 1].off + tasks[g1 - 1].n - first;
+      HIP_TRY(hipMemcpyAsync(d_keys_ + first, h_keys_ + first, count * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+      g0 = g1;
+    }
+  }
+  stats_.key_stage_ms = MsSince(t0);
+  return Run(d_keys_, d_out, n, T);
+}
+
+Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
+  const auto t0 = std::chrono::steady_clock::now();
+  EntryDesc& d = *reinterpret_cast<EntryDesc*>(h_block_);
+  TileDesc* tiles = reinterpret_cast<TileDesc*>(h_block_ + tiles_off_);
+  uint64_t N = 0;
+  uint32_t nt = 0;
+  for (size_t t = 0; t < T; ++t) {
+    if (n[t] && !d_out[t]) return Error(Code::kInvalidArg, "lookup: null output pointer for table ", t);
+    d.key_start[t] = N;
+    d.first_tile[t] = nt;
+    d.out[t] = d_out[t];
+    d.dim[t] = dims_[t];
+    for (uint64_t b = 0; b < n[t]; b += kTileKeys) tiles[nt++] = TileDesc{N + b, (uint32_t)std::min<uint64_t>(kTileKeys, n[t] - b), (uint32_t)t};
+    N += n[t];
+  }
+  if (N > max_keys_)
+    return Error(Code::kInvalidArg, "lookup: ", N, " keys exceed the request capacity of ", max_keys_,
+                 " (max_batch_size x sum(maxnum_catfeature_query_per_table_per_sample))");
+  d.key_start[T] = N;
+  d.first_tile[T] = nt;
+  d.num_tables = (uint32_t)T;
+  d.num_shards = P_;
+  d.num_tiles = nt;
+  d.total_keys = N;
+  stats_.keys = N;
+  stats_.unique_keys = 0;
+  stats_.misses = stats_.unique_misses = 0;
+  stats_.bucket_ms = stats_.lookup_ms = stats_.expand_ms = 0.f;
+  std::fill(stats_.sent.begin(), stats_.sent.end(), 0);
+  std::fill(stats_.passes.begin(), stats_.passes.end(), 0);
+  std::fill(stats_.shard_ms.begin(), stats_.shard_ms.end(), 0.f);
+  if (N == 0) return Status::Ok();
+  if (!d_keys_flat) return Error(Code::kInvalidArg, "lookup: null key pointer");
+
+  // ---- bucket the request by owner on the entry device ----
+  const EntryDesc* dd = reinterpret_cast<const EntryDesc*>(d_block_);
+  const TileDesc* dt = reinterpret_cast<const TileDesc*>(d_block_ + tiles_off_);
+  HIP_TRY(hipMemcpyAsync(d_block_, h_block_, tiles_off_ + (size_t)nt * sizeof(TileDesc), hipMemcpyHostToDevice, stream_));
+  const bool dedup = dedup_;
+  if (dedup) {
+    if (++set_tag_ == 0) {   // 2^32 requests later: entries of the first ones would look like this one's
+      HIP_TRY(hipMemsetAsync(d_set_, 0, (set_mask_ + 1) * sizeof(unsigned long long), stream_));
+      set_tag_ = 1;
+    }
+    HIP_TRY(LaunchEntryDedup(dd, d_keys_flat, N, d_set_, set_mask_, set_tag_, d_rep_, stream_));
+  }
+  uint32_t* d_base = d_counts_;
+  uint32_t* d_cnt = d_counts_ + (P_ + 1);
+  HIP_TRY(LaunchEntryBucket(dd, dt, nt, P_, d_keys_flat, dedup ? d_rep_ : nullptr, d_hist_, d_within_, d_base, d_cnt, d_bkeys_, d_bidx_, stream_));
+  HIP_TRY(hipMemcpyAsync(h_counts_, d_counts_, ((size_t)(P_ + 1) + (size_t)P_ * T) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  // the bucket arrays are complete (and visible to the peers' kernels) once this returns
+  HIP_TRY(hipStreamSynchronize(stream_));
+  stats_.bucket_ms = MsSince(t0);
+  const uint32_t* base = h_counts_;
+  const uint32_t* counts = h_counts_ + (P_ + 1);
+  stats_.unique_keys = base[P_];
+
+  // ---- every owner looks its bucket up, all of them side by side; rows land in d_out over the peer mappings ----
+  const auto t1 = std::chrono::steady_clock::now();
+  for (uint32_t s = 0; s < P_; ++s) {
+    const uint32_t total = base[s + 1] - base[s];
+    stats_.sent[s] = total;
+    if (total == 0) continue;
+    Worker& w = *workers_[s];
+    {
+      std::lock_guard<std::mutex> lk(w.mu);
+      w.plan = PlanShardPasses(counts + (size_t)s * T, T, sessions_[s]->max_keys());
+      w.keys = d_bkeys_ + base[s];
+      w.idx = d_bidx_ + base[s];
+      w.out = d_out;
+      w.done = false;
+      w.has_job = true;
+      stats_.passes[s] = (uint32_t)w.plan.size();
+    }
+    w.cv.notify_all();
+  }
+  Status first = Status::Ok();
+  for (uint32_t s = 0; s < P_; ++s) {
+    if (stats_.sent[s] == 0) continue;
+    Worker& w = *workers_[s];
+    std::unique_lock<std::mutex> lk(w.mu);
+    w.cv.wait(lk, [&] { return w.done; });
+    if (!w.st.ok() && first.ok()) first = Error(w.st.code(), "shard ", s, " (device ", shard_device_[s], "): ", w.st.message());
+    stats_.shard_ms[s] = w.ms;
+    stats_.misses += w.misses;
+    stats_.unique_misses += w.unique;
+  }
+  stats_.lookup_ms = MsSince(t1);
+  HPS_RETURN_IF_ERROR(first);
+
+  // ---- the request's repeated keys take their representative's row (local copy on the entry device) ----
+  if (dedup && stats_.unique_keys < N) {
+    const auto t2 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(LaunchEntryExpand(dd, d_rep_, N, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    stats_.expand_ms = MsSince(t2);
+  }
+  return Status::Ok();
+}
+
+}  // namespace hps

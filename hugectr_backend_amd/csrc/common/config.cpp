@@ -296,6 +296,27 @@ Status ParseParameterServerJson(const Json& root, ParameterServerConfig* out) {
     HPS_RETURN_IF_ERROR(ParseField(p.cache_load_factor, j, "gpucache_load_factor", false));
     HPS_RETURN_IF_ERROR(ParseField(p.cache_admission, j, "gpucache_admission", false));
     HPS_RETURN_IF_ERROR(ParseField(p.ps_direct_access, j, "ps_direct_access", false));
+    {
+      // "table_sharding": "hash" — the model's GPU caches are SHARDS, not replicas: entry s of deployed_device_list holds the
+      // keys with mix64(key) mod P == s (P = the length of the list; a device may appear more than once: logical shards)
+      std::string sharding;
+      HPS_RETURN_IF_ERROR(ParseField(sharding, j, "table_sharding", false));
+      sharding = Normalised(sharding, false);
+      if (sharding == "hash") p.table_sharding = true;
+      else if (!(sharding.empty() || sharding == "none" || sharding == "replicas"))
+        return Error(Code::kInvalidArg, "Model '", p.model_name, "': table_sharding must be \"hash\" or \"none\", got '", sharding, "'");
+      HPS_RETURN_IF_ERROR(ParseField(p.shard_capacity_factor, j, "shard_capacity_factor", false));
+      HPS_RETURN_IF_ERROR(ParseField(p.shard_dedup, j, "shard_dedup", false));
+      if (p.table_sharding) {
+        if (!p.use_gpu_embedding_cache)
+          return Error(Code::kInvalidArg, "Model '", p.model_name, "': table_sharding shards the GPU caches and needs gpucache = true");
+        if (p.deployed_devices.empty() || p.deployed_devices.size() > 64)
+          return Error(Code::kInvalidArg, "Model '", p.model_name, "': table_sharding needs 1..64 entries in deployed_device_list, got ",
+                       p.deployed_devices.size());
+        if (!(p.shard_capacity_factor >= 1.0))
+          return Error(Code::kInvalidArg, "Model '", p.model_name, "': shard_capacity_factor must be >= 1");
+      }
+    }
     p.volatile_db = cfg.volatile_db;
     p.persistent_db = cfg.persistent_db;
     p.update_source = cfg.update_source;

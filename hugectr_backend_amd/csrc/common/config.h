@@ -106,6 +106,15 @@ struct InferenceParams {  // backend.cpp:318-516
   // "ps_direct_access": the GPU resolves missed keys through a device-resident index of the host tier and reads
   // the rows in place from pinned host memory over PCIe (no host threads, no staging copy).  Needs gpucache.
   bool ps_direct_access = false;
+  // "table_sharding": "hash" — BASELINE config 3 behind the plugin boundary (csrc/cache/shard_entry.h; not in the reference,
+  // which is replicas only: docs/architecture.md:11,29).  Entry s of deployed_device_list is SHARD s: its cache holds the keys
+  // with mix64(key) mod P == s, gpucacheper of them.  An instance on any listed device serves whole requests: it buckets the
+  // keys by owner and the owners write their rows straight into its output buffer (peer-mapped, over xGMI).
+  bool table_sharding = false;
+  double shard_capacity_factor = 2.0;   // one owner's lookup session holds factor x (request capacity / P) keys; a request that
+                                        // sends an owner more is served in several passes
+  bool shard_dedup = true;              // "shard_dedup": a key the request repeats travels to its owner once
+  size_t num_shards() const { return table_sharding ? deployed_devices.size() : 1; }
   size_t num_tables() const { return sparse_model_files.size(); }
 };
 

@@ -23,6 +23,7 @@ TRITONSERVER_Error* ModelInstanceState::Create(ModelState* model_state,
 }
 
 ModelInstanceState::~ModelInstanceState() {
+  sharded_entry_.reset();
   lookupsession_.reset();
   embedding_cache_.reset();
   if (d_result_) {
@@ -32,6 +33,15 @@ ModelInstanceState::~ModelInstanceState() {
 }
 
 TRITONSERVER_Error* ModelInstanceState::LoadHPSInstance() {
+  if (model_state_->UsesGpuCache() && model_state_->Params().table_sharding) {
+    // A table-sharded model (BASELINE config 3): Triton still hands this instance whole requests and blocks on them
+    // (hps.cc:353-369, 406), so the instance is an ENTRY session: it buckets a request by owner and the shards' lookup
+    // sessions write their rows into this instance's output buffer over the peer mappings.
+    RETURN_IF_STATUS_ERROR(ShardedEntrySession::Create(model_state_->Server(), model_state_->Name(), device_id_, &sharded_entry_));
+    HPS_TRITON_LOG(INFO, "instance ", name_, ": entry session of the table-sharded model on device ", device_id_, ", ",
+                   sharded_entry_->num_shards(), " shards, ", sharded_entry_->shard_capacity(), " keys per shard and pass");
+    return nullptr;
+  }
   if (model_state_->UsesGpuCache()) {
     embedding_cache_ = model_state_->CacheOn(device_id_);
     if (!embedding_cache_)
@@ -86,7 +96,10 @@ TRITONSERVER_Error* ModelInstanceState::ProcessRequest(const int64_t* keys, bool
     koff += num_keys_per_table[t];
     ooff += num_keys_per_table[t] * p.embedding_vecsize_per_table[t];
   }
-  if (keys_on_device) {
+  if (sharded_entry_) {
+    if (keys_on_device) RETURN_IF_STATUS_ERROR(sharded_entry_->lookup_from_device(keys, out_per_table.data(), num_keys_per_table.data(), T));
+    else RETURN_IF_STATUS_ERROR(sharded_entry_->lookup(keys_per_table.data(), out_per_table.data(), num_keys_per_table.data(), T));
+  } else if (keys_on_device) {
     if (!gpu) return HPS_TRITON_ERROR(INTERNAL, "device-resident KEYS reached a host-only lookup session");
     RETURN_IF_STATUS_ERROR(lookupsession_->lookup_from_device(keys, out_per_table.data(), num_keys_per_table.data(), T));
   } else {

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "../cache/shard_entry.h"
 #include "model_state.h"
 
 namespace hps { namespace triton {
@@ -50,6 +51,8 @@ class ModelInstanceState {
   int32_t device_id_;
   std::shared_ptr<EmbeddingCache> embedding_cache_;
   std::unique_ptr<LookupSession> lookupsession_;
+  // ps.json "table_sharding": "hash": the instance serves whole requests over the model's shards (cache/shard_entry.h)
+  std::unique_ptr<ShardedEntrySession> sharded_entry_;
   std::vector<int64_t> key_staging_;
   std::vector<int32_t> count_staging_;
   float* d_result_ = nullptr;  // device result buffer, only when Triton hands out a host output buffer

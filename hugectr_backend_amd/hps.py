@@ -78,6 +78,13 @@ class LookupStats(C.Structure):
                 ("scatter_ms", C.c_float), ("insert_ms", C.c_float), ("keys_narrowed", C.c_int32), ("key_bytes", C.c_int32)]
 
 
+class ShardEntryStats(C.Structure):
+    _fields_ = [("keys", C.c_uint64), ("unique_keys", C.c_uint64), ("misses", C.c_uint64), ("unique_misses", C.c_uint64),
+                ("bucket_ms", C.c_float), ("lookup_ms", C.c_float), ("expand_ms", C.c_float), ("key_stage_ms", C.c_float),
+                ("num_shards", C.c_uint32), ("reserved_", C.c_uint32), ("sent", C.c_uint64 * 64), ("passes", C.c_uint32 * 64),
+                ("shard_ms", C.c_float * 64)]
+
+
 def _load() -> C.CDLL:
     if not _LIBPATH.exists():
         raise ImportError(
@@ -145,6 +152,15 @@ def _load() -> C.CDLL:
         "hps_shard_session_lookup": (C.c_int, [P, P, u64, P]),
         "hps_shard_session_last_stats": (C.c_int, [P, C.POINTER(u64), C.POINTER(u32), P, u32]),
         "hps_shard_session_destroy": (None, [P]),
+        "hps_server_get_shard_cache": (C.c_int, [P, cp, u32, C.POINTER(P)]),
+        "hps_shard_entry_create": (C.c_int, [P, cp, i32, C.POINTER(P)]),
+        "hps_shard_entry_destroy": (None, [P]),
+        "hps_shard_entry_lookup": (C.c_int, [P, P, P, P, C.c_size_t]),
+        "hps_shard_entry_lookup_device": (C.c_int, [P, P, P, P, C.c_size_t]),
+        "hps_shard_entry_last_stats": (C.c_int, [P, C.POINTER(ShardEntryStats)]),
+        "hps_shard_entry_set_option": (C.c_int, [P, cp, C.c_int]),
+        "hps_shard_entry_shard_capacity": (u64, [P]),
+        "hps_shard_plan_passes": (u64, [P, u32, u64, P, u64]),
         "hps_dense_create": (C.c_int, [C.c_int, u32, u32, P, P, P, u32, u32, C.POINTER(P)]),
         "hps_dense_destroy": (None, [P]),
         "hps_dense_out_dim": (u32, [P]),
@@ -177,6 +193,9 @@ EXPORTED_SYMBOLS = [
     "hps_session_set_option", "hps_shard_owner", "hps_shard_bucket_workspace_bytes", "hps_shard_bucket_device",
     "hps_shard_unpermute_device", "hps_dense_create", "hps_dense_destroy", "hps_dense_out_dim", "hps_dense_out_stride",
     "hps_dense_forward", "hps_session_lookup_interact_device",
+    "hps_server_get_shard_cache", "hps_shard_entry_create", "hps_shard_entry_destroy", "hps_shard_entry_lookup",
+    "hps_shard_entry_lookup_device", "hps_shard_entry_last_stats", "hps_shard_entry_set_option", "hps_shard_entry_shard_capacity",
+    "hps_shard_plan_passes",
 ]
 
 
@@ -299,6 +318,12 @@ class HierParameterServer:
         if not LIB.hps_cache_on_device(h):   # gpucache=false model: the handle carries server + model only
             c.on_device = False
         return c
+
+    def get_shard_cache(self, model: str, shard: int):
+        """The cache of shard `shard` of a table-sharded model (ps.json "table_sharding": "hash"), or None."""
+        h = C.c_void_p()
+        _check(LIB.hps_server_get_shard_cache(self._h, model.encode(), shard, C.byref(h)))
+        return EmbeddingCache(h, -1) if h else None
 
     def load_table_arrays(self, model: str, table: int, keys, rows):
         keys = np.ascontiguousarray(keys, dtype=np.int64)
@@ -503,6 +528,95 @@ class LookupSession:
     def close(self):
         if self._h:
             LIB.hps_session_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_shard_passes(counts, capacity: int):
+    """[(offset, [n_0 .. n_{T-1}]), ...]: the lookup calls that serve one owner's bucket (hps_shard_plan_passes; host logic)."""
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    T = counts.size
+    need = int(LIB.hps_shard_plan_passes(counts.ctypes.data, T, int(capacity), None, 0))
+    out = np.zeros((max(need, 1), 1 + T), dtype=np.uint64)
+    got = int(LIB.hps_shard_plan_passes(counts.ctypes.data, T, int(capacity), out.ctypes.data, need))
+    assert got == need
+    return [(int(r[0]), [int(v) for v in r[1:]]) for r in out[:need]]
+
+
+class ShardedEntrySession:
+    """Entry session of a table-sharded model (include/hps_amd.h: hps_shard_entry_*): what one Triton instance of such a
+    model is — whole requests in, rows from every shard written into the entry device's output."""
+
+    def __init__(self, handle, server: HierParameterServer, model: str, device: int):
+        self._h = handle
+        self._server = server
+        self.model = model
+        self.device = int(device)
+        mi = server.model_info(model)
+        self.num_tables = int(mi.num_tables)
+        self.dims = [int(server.table_info(model, t).embedding_vecsize) for t in range(self.num_tables)]
+
+    @classmethod
+    def create(cls, server: HierParameterServer, model: str, entry_device: int = 0) -> "ShardedEntrySession":
+        h = C.c_void_p()
+        _check(LIB.hps_shard_entry_create(server._h, model.encode(), int(entry_device), C.byref(h)))
+        return cls(h, server, model, entry_device)
+
+    _slices = LookupSession._slices
+
+    def lookup(self, keys, num_keys, out=None):
+        """KEYS flat table-major int64 in host memory -> OUTPUT0 (torch CUDA tensor on the entry device)."""
+        import torch
+        keys = np.ascontiguousarray(keys, dtype=np.int64).ravel()
+        num_keys = [int(n) for n in num_keys]
+        koff, ooff, nk, no = self._slices(num_keys)
+        if nk != keys.size:
+            raise HpsError(ERR_INVALID_ARG, f"sum(NUMKEYS)={nk} != len(KEYS)={keys.size}")
+        if out is None:
+            out = torch.empty(no, dtype=torch.float32, device=torch.device("cuda", self.device))
+        assert out.is_cuda and out.dtype == torch.float32 and out.numel() >= no and out.is_contiguous()
+        torch.cuda.current_stream(out.device).synchronize()
+        T = len(num_keys)
+        kp = (C.c_void_p * T)(*[C.c_void_p(keys.ctypes.data + 8 * o) for o in koff])
+        vp = (C.c_void_p * T)(*[C.c_void_p(out.data_ptr() + 4 * o) for o in ooff])
+        nkc = (C.c_size_t * T)(*num_keys)
+        _check(LIB.hps_shard_entry_lookup(self._h, kp, vp, nkc, T))
+        return out
+
+    def lookup_device(self, d_keys, num_keys, out=None):
+        import torch
+        num_keys = [int(n) for n in num_keys]
+        _, ooff, nk, no = self._slices(num_keys)
+        assert d_keys.is_cuda and d_keys.dtype == torch.int64 and d_keys.numel() == nk and d_keys.is_contiguous()
+        if out is None:
+            out = torch.empty(no, dtype=torch.float32, device=d_keys.device)
+        torch.cuda.current_stream(d_keys.device).synchronize()
+        T = len(num_keys)
+        vp = (C.c_void_p * T)(*[C.c_void_p(out.data_ptr() + 4 * o) for o in ooff])
+        nkc = (C.c_size_t * T)(*num_keys)
+        _check(LIB.hps_shard_entry_lookup_device(self._h, C.c_void_p(d_keys.data_ptr()), vp, nkc, T))
+        return out
+
+    def last_stats(self) -> ShardEntryStats:
+        s = ShardEntryStats()
+        _check(LIB.hps_shard_entry_last_stats(self._h, C.byref(s)))
+        return s
+
+    def set_option(self, name: str, value: int):
+        _check(LIB.hps_shard_entry_set_option(self._h, name.encode(), int(value)))
+
+    @property
+    def shard_capacity(self) -> int:
+        return int(LIB.hps_shard_entry_shard_capacity(self._h))
+
+    def close(self):
+        if self._h:
+            LIB.hps_shard_entry_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -305,6 +305,47 @@ int hps_shard_bucket_device(const int64_t* d_keys, uint64_t n, uint32_t num_shar
 int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint64_t n, uint32_t dim, float* d_out,
                                void* stream);
 
+/* ---- table sharding behind ONE instance (BASELINE config 3 through the reference's own boundary) -------------------------
+ * ps.json model key "table_sharding": "hash": entry s of deployed_device_list is SHARD s — its GPU cache holds gpucacheper
+ * of the keys with mix64(key) mod P == s (P = the length of the list; a device may be listed more than once: logical
+ * shards); the host tier stays whole.  An ENTRY session on any listed device serves whole requests the way
+ * TRITONBACKEND_ModelInstanceExecute gets them (one request, one instance, blocking: src/hps.cc:353-369, 406): it buckets
+ * the keys by owner on its device, drives one lookup session per shard on the shard's device from its own threads, and the
+ * shards' gather / scatter kernels store the rows straight into the entry device's output over peer mappings (xGMI).  No
+ * collective, no lock-step between instances (csrc/cache/shard_entry.h).  libtriton_hps.so creates one entry session per
+ * model instance of such a model.  Optional keys: "shard_capacity_factor" (default 2.0: a shard session holds that many
+ * times its fair share of a full request; more is served in several passes), "shard_dedup" (default true: a key the request
+ * repeats travels to its owner once). */
+typedef struct hps_shard_entry hps_shard_entry_t;
+typedef struct hps_shard_entry_stats {
+  uint64_t keys, unique_keys;          /* last request: keys as sent / distinct (table, key) pairs that travelled */
+  uint64_t misses, unique_misses;      /* summed over the shards' lookups */
+  float bucket_ms, lookup_ms, expand_ms, key_stage_ms;   /* wall clock of the phases of the last request */
+  uint32_t num_shards;
+  uint32_t reserved_;
+  uint64_t sent[64];                   /* keys each shard was asked for */
+  uint32_t passes[64];                 /* lookup calls per shard */
+  float shard_ms[64];                  /* wall time of each shard's lookups */
+} hps_shard_entry_stats_t;
+/* the cache of shard s of a table-sharded model (for residency queries, counters); *out = NULL when there is none */
+int hps_server_get_shard_cache(hps_server_t* server, const char* model, uint32_t shard, hps_cache_t** out);
+int hps_shard_entry_create(hps_server_t* server, const char* model, int32_t entry_device, hps_shard_entry_t** out);
+void hps_shard_entry_destroy(hps_shard_entry_t* entry);
+/* same contracts as hps_session_lookup / hps_session_lookup_device; the vectors are on the entry device */
+int hps_shard_entry_lookup(hps_shard_entry_t* entry, const void* const* h_keys_per_table, float* const* d_vectors_per_table,
+                           const size_t* num_keys_per_table, size_t num_tables);
+int hps_shard_entry_lookup_device(hps_shard_entry_t* entry, const int64_t* d_keys_flat, float* const* d_vectors_per_table,
+                                  const size_t* num_keys_per_table, size_t num_tables);
+int hps_shard_entry_last_stats(hps_shard_entry_t* entry, hps_shard_entry_stats_t* out);
+/* options: "dedup" (0/1), "timing" (0/1: forwarded to the shard sessions) */
+int hps_shard_entry_set_option(hps_shard_entry_t* entry, const char* name, int value);
+/* keys a shard session of this entry holds per call */
+uint64_t hps_shard_entry_shard_capacity(hps_shard_entry_t* entry);
+/* Pure host logic, no GPU: the passes that serve one owner's bucket of counts[t] keys per table with a session of `capacity`
+ * keys.  Writes up to max_passes rows of (1 + num_tables) uint64 — [offset, n_0 .. n_{T-1}] — and returns the number of
+ * passes needed (which may exceed max_passes). */
+uint64_t hps_shard_plan_passes(const uint32_t* counts, uint32_t num_tables, uint64_t capacity, uint64_t* out, uint64_t max_passes);
+
 /* ---- dense step of BASELINE config 5: DLRM bottom MLP + pairwise dot interaction, consuming OUTPUT0 in place ------
  * Not in the reference backend: there the dense model is another Triton backend reached through an ensemble
  * hand-off (samples/hps-triton-ensemble); here it runs on the GPU that holds the lookup's output.

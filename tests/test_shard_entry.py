@@ -1,0 +1,342 @@
+"""Table-sharded model served through ONE instance (BASELINE config 3 behind the plugin boundary; csrc/cache/shard_entry.h).
+
+ps.json "table_sharding": "hash": entry s of deployed_device_list is shard s; an entry session (= what a Triton instance of
+such a model is) buckets a request by owner, the shards' lookup sessions write their rows into the entry device's output.
+CPU: configuration, the pass plan, the ownership function, loud failure without a GPU.
+GPU: P = 2 / 4 logical shards on the one device, bit-exact against the oracle over the WHOLE table — several tables of
+different widths, uniform and Zipf requests, host and device keys, misses served by both parameter-server tiers, owners
+served in several passes, and the same through TRITONBACKEND_ModelInstanceExecute with a request on every instance at once.
+"""
+import json
+import threading
+
+import numpy as np
+import pytest
+
+from tests.conftest import make_tables, ps_config
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _sharded_cfg(model, tables, P, dirs=None, device_list=None, **kw):
+    extra = dict(kw.pop("extra", {}) or {})
+    extra.setdefault("table_sharding", "hash")
+    cfg = ps_config(model, tables, dirs=dirs, gpucache=True, extra=extra, **kw)
+    cfg["models"][0]["deployed_device_list"] = device_list if device_list is not None else [0] * P
+    return cfg
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU
+# ------------------------------------------------------------------------------------------------------------------
+def test_table_sharding_configuration_is_parsed_and_checked():
+    from hugectr_backend_amd import hps
+    tables = make_tables([(100, 4)])
+    ok = _sharded_cfg("m", tables, 4)
+    ps = hps.HierParameterServer.create_from_dict(ok, load_tables=False)
+    assert ps.model_info("m").num_deployed_devices == 4
+    ps.close()
+    for bad, what in [({"table_sharding": "ring"}, "table_sharding"), ({"shard_capacity_factor": 0.5}, "shard_capacity_factor")]:
+        cfg = _sharded_cfg("m", tables, 2, extra=bad)
+        with pytest.raises(hps.HpsError) as e:
+            hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+        assert e.value.code == hps.ERR_INVALID_ARG and what in e.value.msg
+    # sharding shards the GPU caches: a model without GPU cache cannot be sharded
+    cfg = _sharded_cfg("m", tables, 2)
+    cfg["models"][0]["gpucache"] = False
+    with pytest.raises(hps.HpsError) as e:
+        hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    assert "gpucache" in e.value.msg
+    # "none" / "replicas" / absent: an ordinary model
+    for v in ("none", "replicas"):
+        cfg = _sharded_cfg("m", tables, 1, extra={"table_sharding": v})
+        hps.HierParameterServer.create_from_dict(cfg, load_tables=False).close()
+
+
+def test_pass_plan_covers_a_bucket_in_order_with_bounded_passes():
+    from hugectr_backend_amd import hps
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        T = int(rng.integers(1, 7))
+        counts = rng.integers(0, 50, T) * (rng.random(T) < 0.7)
+        cap = int(rng.integers(1, 60))
+        plan = hps.plan_shard_passes(counts, cap)
+        total = int(counts.sum())
+        assert len(plan) == (total + cap - 1) // cap
+        off = 0
+        taken = np.zeros(T, np.int64)
+        for k, (o, n) in enumerate(plan):
+            assert o == off and 0 < sum(n) <= cap
+            if k + 1 < len(plan):
+                assert sum(n) == cap          # only the last pass may be short
+            # a pass is a consecutive range of the table-major bucket: the tables it touches are consecutive non-empty ones
+            nz = [t for t in range(T) if n[t]]
+            assert all(taken[t] == counts[t] for t in range(nz[0])), "earlier tables must be finished"
+            assert all(taken[t] == 0 for t in range(nz[-1] + 1, T)), "later tables must be untouched"
+            taken += np.asarray(n)
+            off += sum(n)
+        assert np.array_equal(taken, counts)
+    assert hps.plan_shard_passes([0, 0, 0], 8) == []
+
+
+def test_entry_session_needs_the_shard_caches_and_says_so():
+    """No GPU (or caches not built yet): creating an entry session fails loudly — there is no CPU fallback."""
+    from hugectr_backend_amd import hps
+    tables = make_tables([(100, 4)])
+    ps = hps.HierParameterServer.create_from_dict(_sharded_cfg("m", tables, 2), load_tables=False)
+    ps.load_table_arrays("m", 0, *tables[0])
+    with pytest.raises(hps.HpsError) as e:
+        hps.ShardedEntrySession.create(ps, "m", 0)
+    assert e.value.code in (hps.ERR_NOT_FOUND, hps.ERR_UNAVAILABLE)
+    # an ordinary model has no entry sessions
+    ps2 = hps.HierParameterServer.create_from_dict(ps_config("r", tables, gpucache=True), load_tables=False)
+    with pytest.raises(hps.HpsError) as e:
+        hps.ShardedEntrySession.create(ps2, "r", 0)
+    assert e.value.code == hps.ERR_INVALID_ARG and "table-sharded" in e.value.msg
+    # the entry device must be one the model is deployed on
+    with pytest.raises(hps.HpsError) as e:
+        hps.ShardedEntrySession.create(ps, "m", 3)
+    assert "deployed_device_list" in e.value.msg
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------------------------
+def _server(model, tables, P, **kw):
+    from hugectr_backend_amd import hps
+    ps = hps.HierParameterServer.create_from_dict(_sharded_cfg(model, tables, P, **kw), load_tables=False)
+    for t, (k, r) in enumerate(tables):
+        ps.load_table_arrays(model, t, k, r)
+    ps.create_embedding_cache_per_model(model)
+    return ps
+
+
+def _draw(rng, tables, nk, zipf=False, absent=0.05):
+    parts = []
+    for (keys, _), n in zip(tables, nk):
+        if zipf:
+            idx = np.minimum(rng.zipf(1.2, n) - 1, keys.size - 1)
+        else:
+            idx = rng.integers(0, keys.size, n)
+        q = keys[idx].astype(np.int64)
+        miss = rng.random(n) < absent
+        q[miss] = -5 - rng.integers(0, 1 << 40, int(miss.sum()))
+        parts.append(q)
+    return np.concatenate(parts) if parts else np.zeros(0, np.int64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
+@pytest.mark.parametrize("P", [2, 4])
+def test_entry_session_over_logical_shards_is_bit_exact(P, direct, plain_lru):
+    import torch
+    from hugectr_backend_amd import hps, sharded
+    from oracle import hps_oracle as O
+    tables = make_tables([(30000, 128), (9000, 16), (4000, 5)], seed=21)
+    defaults = [0.0, 1.5, -2.0]
+    ps = _server("c3", tables, P, gpucacheper=0.4, hit_rate_threshold=1.0, defaults=defaults, maxcat=[4, 2, 1], max_batch=8192,
+                 extra={"ps_direct_access": direct})
+    try:
+        # the shards partition the table: what a shard holds after warm-up is owned by it, and it holds its share
+        resident = 0
+        keys = tables[0][0]
+        own = sharded.owner_of(keys, P)
+        for s in range(P):
+            c = ps.get_shard_cache("c3", s)
+            assert c is not None
+            mine, theirs = keys[own == s], keys[own != s][:2000]
+            got = c.query(0, mine)
+            resident += int((got >= 0).sum())
+            assert (c.query(0, theirs) < 0).all()
+            assert c.table_info(0).capacity_rows == int(np.ceil(float(np.float32(0.4)) * mine.size))
+        # (a warm-up row whose bucket is already full stays out, as in any cache: a few per cent at load factor 0.75)
+        assert 0.95 * 0.4 * keys.size <= resident <= 0.4 * keys.size + P
+        e0 = hps.ShardedEntrySession.create(ps, "c3", 0)
+        rng = np.random.default_rng(P * 10 + direct)
+        cases = [([4096 * 4, 4096 * 2, 4096], False), ([8192 * 4, 8192 * 2, 8192], True), ([1, 0, 7], False), ([0, 0, 0], False),
+                 ([0, 3000, 0], True), ([20000, 10, 0], True), ([1025, 1023, 1024], False)]
+        for it, (nk, zipf) in enumerate(cases):
+            q = _draw(rng, tables, nk, zipf)
+            ref = O.np_lookup(tables, q, nk, defaults)
+            for mode in ("host", "device", "pinned"):
+                if mode == "host":
+                    out = e0.lookup(q, nk)
+                elif mode == "device":
+                    out = e0.lookup_device(torch.from_numpy(q).cuda(), nk)
+                else:
+                    qp = torch.from_numpy(q).pin_memory()
+                    out = e0.lookup(qp.numpy(), nk)
+                torch.cuda.synchronize()
+                assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref)), (it, nk, zipf, mode)
+                st = e0.last_stats()
+                assert st.keys == q.size and st.num_shards == P
+                assert sum(st.sent[:P]) == st.unique_keys <= q.size
+                # every distinct (table, key) travels exactly once
+                off, distinct = 0, 0
+                for n in nk:
+                    distinct += np.unique(q[off:off + n]).size
+                    off += n
+                assert st.unique_keys == distinct
+        # without the input dedup every key travels as sent; same rows
+        e0.set_option("dedup", 0)
+        nk = [8192, 4096, 100]
+        q = _draw(rng, tables, nk, True)
+        out = e0.lookup(q, nk)
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(O.np_lookup(tables, q, nk, defaults)))
+        assert e0.last_stats().unique_keys == q.size
+        e0.close()
+    finally:
+        ps.close()
+
+
+@pytest.mark.gpu
+def test_an_owner_that_gets_more_than_its_session_holds_is_served_in_passes(plain_lru):
+    """shard_capacity_factor 1.0: a shard session holds request capacity / P (+ 1,024) keys.  A request whose keys all belong
+    to ONE owner is then several times that: the entry serves that owner in consecutive passes — exact rows, no error."""
+    import torch
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    from hugectr_backend_amd import sharded
+    P = 4
+    tables = make_tables([(40000, 32), (40000, 8)], seed=4)
+    ps = _server("skew", tables, P, gpucacheper=0.5, hit_rate_threshold=1.0, maxcat=[3, 1], max_batch=4096,
+                 extra={"shard_capacity_factor": 1.0})
+    try:
+        e = hps.ShardedEntrySession.create(ps, "skew", 0)
+        cap = e.shard_capacity
+        assert cap == 4096 * 4 // P + 1024
+        own = [sharded.owner_of(t[0], P) for t in tables]
+        rng = np.random.default_rng(1)
+        # all-distinct keys of owner 2 only (dedup cannot shrink them)
+        nk = [min(4096 * 3, int((own[0] == 2).sum())), min(4096, int((own[1] == 2).sum()))]
+        q = np.concatenate([rng.permutation(tables[0][0][own[0] == 2])[:nk[0]], rng.permutation(tables[1][0][own[1] == 2])[:nk[1]]]).astype(np.int64)
+        out = e.lookup(q, nk)
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(O.np_lookup(tables, q, nk, [0.0, 0.0])))
+        st = e.last_stats()
+        assert list(st.sent[:P]) == [0, 0, q.size, 0]
+        assert st.passes[2] == (q.size + cap - 1) // cap and st.passes[2] >= 2
+        assert [st.passes[s] for s in (0, 1, 3)] == [0, 0, 0]
+        # a request beyond the MODEL's capacity is refused like any oversized request
+        too_many = np.zeros(4096 * 4 + 1, np.int64)
+        with pytest.raises(hps.HpsError) as err:
+            e.lookup(too_many, [4096 * 3 + 1, 4096])
+        assert err.value.code == hps.ERR_INVALID_ARG
+        e.close()
+    finally:
+        ps.close()
+
+
+@pytest.mark.gpu
+def test_async_insert_mode_and_refresh_on_a_sharded_model(plain_lru):
+    """Insertion policy and refresh work per shard as for any cache: threshold 0 answers misses with the default vector and
+    inserts them in the background; afterwards the same keys are served exactly; an updated row reaches the shard that owns it."""
+    import torch
+    from hugectr_backend_amd import hps, sharded
+    from oracle import hps_oracle as O
+    P = 2
+    tables = make_tables([(8000, 16)], seed=9)
+    ps = _server("as", tables, P, gpucacheper=0.25, hit_rate_threshold=0.0, defaults=[3.0], maxcat=[8], max_batch=1024)
+    try:
+        e = hps.ShardedEntrySession.create(ps, "as", 0)
+        rng = np.random.default_rng(2)
+        q = rng.permutation(tables[0][0])[:6000].astype(np.int64)
+        first = e.lookup(q, [q.size]).cpu().numpy().reshape(-1, 16)
+        exact = O.np_lookup(tables, q, [q.size], [3.0]).reshape(-1, 16)
+        is_default = (first == np.float32(3.0)).all(axis=1)
+        assert is_default.any() and (~is_default).any()
+        assert np.array_equal(_bits(first[~is_default]), _bits(exact[~is_default]))
+        for s in range(P):
+            ps.get_shard_cache("as", s).wait_async()
+        # an online update of a key that is resident NOW (the background inserts above have turned the small caches over) +
+        # refresh of device 0 (= every shard on it): the owner's shard serves the new row
+        own = sharded.owner_of(q, P)
+        for s in range(P):
+            mine = q[own == s]
+            k = mine[ps.get_shard_cache("as", s).query(0, mine) >= 0][:1]
+            assert k.size == 1
+            new_row = np.full((1, 16), 7.25 + s, np.float32)
+            ps.upsert("as", 0, k, new_row)
+            ps.refresh_embedding_cache("as", 0)
+            got = e.lookup(k, [1]).cpu().numpy()
+            assert np.array_equal(_bits(got), _bits(new_row.ravel())), s
+        e.close()
+    finally:
+        ps.close()
+
+
+def _write_tables(tmp_path, name, tables):
+    from oracle import hps_oracle as O
+    dirs = []
+    for t, (k, r) in enumerate(tables):
+        d = tmp_path / f"{name}_{t}"
+        O.np_write_table(d, k, r)
+        dirs.append(str(d))
+    return dirs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [2, 4])
+def test_sharded_model_through_the_triton_plugin_a_request_on_every_instance_at_once(tmp_path, P):
+    """config.pbtxt + ps.json with "table_sharding": "hash" through TRITONBACKEND_ModelInstanceExecute (mock core): every
+    instance is an entry session; P instances execute requests concurrently; bit-exact; response parameters as always."""
+    import torch
+    from oracle import hps_oracle as O
+    from tests import triton_mock as tm
+    tables = make_tables([(20000, 128), (6000, 16)], seed=31)
+    dirs = _write_tables(tmp_path, "c3t", tables)
+    cfg = _sharded_cfg("c3t", tables, P, dirs=dirs, gpucacheper=0.5, hit_rate_threshold=1.0, defaults=[0.0, 0.5], maxcat=[3, 1],
+                       max_batch=4096)
+    cfg["models"][0]["num_of_worker_buffer_in_pool"] = P
+    ps_path = tmp_path / "ps.json"
+    ps_path.write_text(json.dumps(cfg))
+    srv = tm.Server(ps_path)
+    try:
+        mod = srv.load_model("c3t", tm.model_config("c3t", gpus=[0], count=P, max_batch_size=4096))
+        insts = [mod.create_instance(f"c3t_{i}", tm.KIND_GPU, 0) for i in range(P)]
+        errs = []
+
+        def work(i):
+            rng = np.random.default_rng(100 + i)
+            for it in range(6):
+                batch = int(rng.integers(1, 4096))
+                nk = [batch * 3, batch]
+                q = _draw(rng, tables, nk, zipf=bool(it % 2))
+                n = nk[0] * 128 + nk[1] * 16
+                req = tm.Request(f"{i}-{it}")
+                if it % 3 == 2:
+                    dk = torch.from_numpy(q).cuda()
+                    torch.cuda.synchronize()
+                    req.add_input_raw("KEYS", tm.TYPE_INT64, [1, q.size], dk.data_ptr(), q.nbytes, tm.MEM_GPU, 0)
+                    req._keep.append(dk)
+                else:
+                    req.add_input("KEYS", q.reshape(1, -1))
+                req.add_input("NUMKEYS", np.asarray([nk], np.int32)).request_output("OUTPUT0")
+                out = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                req.set_output_buffer(out.data_ptr(), n * 4, tm.MEM_GPU, 0, keep=out)
+                insts[i].execute([req])
+                torch.cuda.synchronize()
+                ref = O.np_lookup(tables, q, nk, [0.0, 0.5])
+                if req.error_code != -1 or not np.array_equal(_bits(out.cpu().numpy()), _bits(ref)):
+                    errs.append((i, it, req.error_message))
+                if req.int_param("NumSample") != (nk[0] + nk[1]) // 4 or req.int_param("DeviceID") != 0:
+                    errs.append((i, it, "response parameters"))
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(P)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not errs, errs[:3]
+        # host output buffer (Triton gave CPU memory): the instance's device buffer + one D2H copy
+        rng = np.random.default_rng(7)
+        nk = [300, 100]
+        q = _draw(rng, tables, nk)
+        req = tm.Request("host-out")
+        req.add_input("KEYS", q.reshape(1, -1)).add_input("NUMKEYS", np.asarray([nk], np.int32)).request_output("OUTPUT0")
+        insts[0].execute([req])
+        assert req.error_code == -1, req.error_message
+        assert np.array_equal(_bits(req.output_numpy()), _bits(O.np_lookup(tables, q, nk, [0.0, 0.5])))
+    finally:
+        srv.shutdown()
