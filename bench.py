@@ -330,10 +330,11 @@ def compact_line(res, limit=COMPACT_LIMIT):
     out = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                    "scaling", "vs_baseline", "dtype", "data")}
     out["config"] = {"workload": str(cfg.get("workload", ""))[:300], "parallelism": str(cfg.get("parallelism", ""))[:120],
-                     "ps_tier": str(cfg.get("ps_tier", ""))[:80]}
+                     "ps_tier": str(cfg.get("ps_tier", ""))[:80], "blocks": cfg.get("blocks"), "value_is": cfg.get("value_is"),
+                     "resident_draw_probability": cfg.get("resident_draw_probability")}
     for k in ("p50_batch_latency_ms", "p99_batch_latency_ms", "measured_hit_rate"):
         out[k] = res.get(k)
-    out["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_with_insert", "traffic",
+    out["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_return_path_kernels", "traffic",
                                                "algorithmic_bytes_per_call", "probe_ms", "gather_ms", "scatter_ms", "insert_ms",
                                                "insert_on_call_path", "frac_kernels_alone", "box_d2d_copy_GBps")}
     out["roofline"]["kernel"] = str(rf.get("kernel", ""))[:160]
@@ -394,9 +395,21 @@ def compact_line(res, limit=COMPACT_LIMIT):
     put("c3_logical_row_MB_per_peer", [_scale(_dig(c3, (k_, "row_bytes_per_peer_and_step")), 1e-6) for k_ in ("uniform", "zipf")] if c3 else None)
     put("c3_logical_parity", c3.get("parity"))
     put("c3_error", (str(c3["error"])[:120] if c3.get("error") else None))
+    c3e = ex.get("sharded_c3_single_entry") or {}
+    put("c3_single_entry_P", c3e.get("shards"))
+    put("c3_single_entry_devices", sorted(set(c3e["shard_devices"])) if c3e.get("shard_devices") else None)
+    put("c3_single_entry_Glps", _scale(c3e.get("lookups_per_s"), 1e-9))
+    put("c3_single_entry_p50_ms", _dig(c3e, ("uniform", "p50_request_ms")))
+    put("c3_single_entry_zipf_Glps", _scale(_dig(c3e, ("zipf", "lookups_per_s")), 1e-9))
+    put("c3_single_entry_all_instances_Glps", _scale(_dig(c3e, ("uniform", "all_instances_at_once", "lookups_per_s")), 1e-9))
+    put("c3_single_entry_rows_GBps_into_entry", _dig(c3e, ("uniform", "rows_GBps_into_entry_gpu")))
+    put("c3_single_entry_parity", c3e.get("parity"))
+    put("c3_single_entry_error", (str(c3e["error"])[:120] if c3e.get("error") else None))
     c3r = ex.get("sharded_c3") or {}
     put("c3_rccl_Glps", _scale(c3r.get("lookups_per_s"), 1e-9))
     put("c3_rccl_ranks", c3r.get("ranks"))
+    put("c3_rccl_rows_frac_of_link", c3r.get("rows_frac_of_153_GBps_link") or _dig(c3r, ("rccl_groups", "rows_frac_of_153_GBps_link")))
+    put("c3_rccl_parity", c3r.get("parity") if "parity" in c3r else c3r.get("parity_vs_oracle_bit_exact"))
     put("c3_rccl_error", (str(c3r["error"])[:120] if c3r.get("error") else None))
     put("legs_error", (str(ex["legs_error"])[:120] if ex.get("legs_error") else None))
     out["legs"] = legs
@@ -957,7 +970,7 @@ def main():
                     okf &= bool(np.array_equal(tk[qt], qt))
                     okf &= bool(np.array_equal(tr[qt].view(np.uint32), got_all[t * B:(t + 1) * B].view(np.uint32)))
                 parity_full = okf
-            if a.no_cpu_baseline or n_rep > 1:
+            if a.no_cpu_baseline:
                 return
             # ---- cpu_baseline: the oracle (a port of the reference's hash_map parameter-server lookup: a hash-map find per
             # key, row copy or default) on the timed region's own batches, ALL tables, all host cores.  The oracle builds its
@@ -1009,7 +1022,11 @@ def main():
         probe, gather, scatter = m["probe_ms"], m["gather_ms"], m["scatter_ms"]
         hbm_ms = probe + gather + scatter
         alg = N * (8 + 8 * D)                       # 8 B key + 4D row read + 4D row write per lookup
-        achieved = alg / (hbm_ms * 1e-3) / 1e9
+        # the primary figure counts the cache-insert kernel too: since round 4 it is off the call's return path, but it occupies
+        # the GPU on every call that missed (and serialises with the other session's probe through the writer event) — the three
+        # kernels that produce the call's rows alone are `frac_return_path_kernels`
+        achieved_rows = alg / (hbm_ms * 1e-3) / 1e9
+        achieved = alg / ((hbm_ms + m["insert_ms"]) * 1e-3) / 1e9
         # HBM traffic of the kernels comes from the committed rocprofv3 PMC passes (bench.py cannot run the profiler on
         # itself): profiles/pmc_latest.json, written by tools/summarize_profile.py
         traffic = traffic_src = None
@@ -1051,6 +1068,7 @@ def main():
                 "host_cpus_per_gpu": ncpu / n_rep,
                 "ps_tier": "device-driven (ps_direct_access)" if a.direct else
                            ("host gather" + (f" [{direct_note}]" if direct_note else "")),
+                "blocks": blocks, "value_is": "median block", "resident_draw_probability": a.hit,
                 "timed_region": f"{blocks} blocks of exactly {K} steps per GPU (every device synchronised on both sides; a block ends when "
                                 f"the last GPU has finished its {K} steps = max over GPUs), every step a fresh batch; value = the MEDIAN block",
             },
@@ -1080,11 +1098,12 @@ def main():
                 "bound": "hbm",
                 # every lookup priced at 1,032 algorithmic bytes over ALL HBM-side kernels of the lookup
                 "kernel": "hps_probe_tile_kernel (tile dedup + probe + call-wide unique misses in its tail) + hps_gather_hits_kernel + "
-                          "hps_miss_scatter_kernel",
+                          "hps_miss_scatter_kernel + hps_cache_insert_kernel (enqueued behind the call, counted here)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "frac_return_path_kernels": achieved_rows / HBM_PEAK_GBS,   # probe + gather + scatter: what the caller waits for
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_call": alg,
@@ -1103,10 +1122,10 @@ def main():
                 "frac_probe_plus_gather": alg / ((probe + gather) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 # the gather kernel alone on its own bytes (4 B slot per key + 8D per hit) — the dominant kernel
                 "frac_gather_own_bytes": (N * 4 + hits * 8 * D) / (gather * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "frac_of_copy_ceiling_6290": achieved / 6290.0,
+                "frac_of_copy_ceiling_6290": achieved_rows / 6290.0,
                 # a 1-GiB device-to-device copy on THIS box right before the timed region (read + write bytes / time)
                 "box_d2d_copy_GBps": box_copy_gbs,
-                "achieved_over_box_copy": achieved / box_copy_gbs if box_copy_gbs else None,
+                "achieved_over_box_copy": achieved_rows / box_copy_gbs if box_copy_gbs else None,
                 # the whole job against the same roofline: at 95 % hit with synchronous insertion the path is bound by PCIe
                 # (every unique missed row + the keys cross the link once), not by HBM
                 "frac_end_to_end": alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
@@ -1175,18 +1194,63 @@ def main():
                 c3 = {"error": repr(e)[:300]}
                 sys.stderr.write(f"[bench] logical config-3 leg stopped: {e!r}\n")
             res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3_logical=c3)
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                c3e = c3_single_entry_leg(a, torch, hps, [dev] * 4, 1 << 24)
+            except Exception as e:  # noqa: BLE001
+                c3e = {"error": repr(e)[:300]}
+                sys.stderr.write(f"[bench] single-entry config-3 leg stopped: {e!r}\n")
+            res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3_single_entry=c3e)
 
     # ---- BASELINE config 3 leg (only under torch.distributed.run with N > 1 ranks): ONE table sharded over the ranks, one
     # rank per GPU, RCCL send/recv inside the engine.  Runs after the headline measurement is complete and its resources are
     # released (the barrier below is what the idle ranks have been waiting at); a watchdog prints the headline line and ends
     # the rank if the leg does not finish (a collective that hangs cannot be caught any other way).
-    if world > 1:
+    if n_rep > 1:
         import gc
         del sessions, cache, caches, ps, made, run, host_batches, reps
         gc.collect()
         for d in sorted(set(devs)):
             with torch.cuda.device(d):
                 torch.cuda.empty_cache()
+    if n_rep > 1 and not a.no_extra_legs and not a.no_c3_leg:
+        # ---- BASELINE config 3 on the N GPUs of this process, both variants: (a) behind the plugin's contract — a table-sharded
+        # model whose entry instances serve whole requests, the owners writing rows over peer mappings (shard_entry.h); (b) the
+        # SPMD session over RCCL with one rank per device, the ranks being threads of this process.  Fewer devices than
+        # replicas (development box): (a) runs with logical shards on the devices there are, (b) with as many RCCL ranks as
+        # there are devices.
+        entry_rows = min(a.shard_rows, 1 << 26) if not shared_gpu else 1 << 24
+        try:
+            c3e = c3_single_entry_leg(a, torch, hps, devs, entry_rows)
+        except Exception as e:  # noqa: BLE001
+            c3e = {"error": repr(e)[:300]}
+            sys.stderr.write(f"[bench] single-entry config-3 leg stopped: {e!r}\n")
+        res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3_single_entry=c3e)
+        gc.collect()
+        if world == 1:
+            ranks = min(n_rep, ndev)
+            done = threading.Event()
+            box = {}
+
+            def rccl_leg():
+                try:
+                    box["r"] = c3_rccl_threads_leg(a, torch, hps, ranks, entry_rows)
+                except Exception as e:  # noqa: BLE001
+                    box["r"] = {"ranks": ranks, "error": repr(e)[:300]}
+                done.set()
+
+            # a collective that hangs cannot be caught from inside: the leg runs on a thread of its own and the line is
+            # printed without it if it does not come back
+            tl = threading.Thread(target=rccl_leg, daemon=True)
+            tl.start()
+            if done.wait(a.sharded_timeout):
+                res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3=box["r"])
+            else:
+                res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3={"ranks": ranks, "error": f"no result within {a.sharded_timeout} s"})
+                emit(res)
+                os._exit(0)
+    if world > 1:
         dist.barrier()
         if not a.no_sharded_leg:
             def give_up():
@@ -1603,6 +1667,259 @@ def c3_logical_leg(a, torch, hps, dev, P=4, rows_total=1 << 24, steps=30):
     return res
 
 
+def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
+    """BASELINE configs[2] BEHIND THE PLUGIN'S CONTRACT (one blocking call per request on one instance, hps.cc:353-369): one
+    table-sharded model (ps.json "table_sharding": "hash", csrc/cache/shard_entry.h) — ONE server, the host tier whole, shard s
+    = entry s of deployed_device_list with 100 % of the keys it owns resident; an ENTRY session per instance buckets a request of
+    the headline's size by owner on its device, drives P lookup sessions (one per shard, on the shard's device) from its own
+    threads, and the shards' gather kernels store the rows straight into the entry's output over peer mappings.  No collective.
+    Timed: one instance alone (host keys, then device keys; uniform, then Zipf keys), then a request on EVERY instance at once."""
+    import ctypes as C
+    from oracle import hps_oracle as O
+    P, D = len(shard_devs), a.dim
+    N = a.tables * a.batch
+    model = "criteo_c3_entry"
+    t0 = time.time()
+    cfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8},
+           "models": [{"model": model, "sparse_files": ["synthetic://one_table"], "num_of_worker_buffer_in_pool": max(2, P),
+                       "embedding_vecsize_per_table": [D], "maxnum_catfeature_query_per_table_per_sample": [1],
+                       "default_value_for_each_table": [0.0], "deployed_device_list": list(shard_devs), "max_batch_size": N,
+                       "gpucache": True, "gpucacheper": 1.0, "gpucache_load_factor": float(os.environ.get("ENTRY_LOAD_FACTOR", "0.6")),
+                       "hit_rate_threshold": 1.0, "table_sharding": "hash"}]}
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    ps.load_table_synthetic(model, 0, SEED, 0, rows_total)
+    t_table = time.time() - t0
+    ps.create_embedding_cache_per_model(model)
+    t_cache = time.time() - t0 - t_table
+    entry_devs = list(shard_devs)          # one instance per deployed entry (Triton: instance_group count per GPU)
+    entries = [hps.ShardedEntrySession.create(ps, model, d) for d in entry_devs]
+    rng = np.random.default_rng(SEED + 404)
+    zw = 1.0 / np.power(np.arange(1, 1_000_001, dtype=np.float64), a.zipf)
+    zw /= zw.sum()
+    zipf_ids = rng.permutation(rows_total)[:1_000_000].astype(np.int64)
+
+    def batches(kind, count):
+        if kind == "uniform":
+            return [rng.integers(0, rows_total, N, dtype=np.int64) for _ in range(count)]
+        return [zipf_ids[rng.choice(zipf_ids.size, N, p=zw)] for _ in range(count)]
+
+    outs = [torch.empty(N * D, dtype=torch.float32, device=torch.device("cuda", d)) for d in entry_devs]
+    distinct_devs = sorted(set(shard_devs))
+    res = {"shards": P, "shard_devices": list(shard_devs), "rows_total": rows_total, "keys_per_request": N,
+           "setup_seconds": {"host_table": t_table, "shard_caches": t_cache}, "shard_capacity_keys": entries[0].shard_capacity,
+           "transport": ("peer-mapped stores over xGMI (owners write into the entry GPU's output); no collective" if len(distinct_devs) > 1 else
+                         "ALL SHARDS ON ONE GPU (logical shards): the owners' stores stay in local HBM — xGMI NOT measured"),
+           "note": c3_single_entry_leg.__doc__.split("\n")[0]}
+
+    def sync_all():
+        for d in distinct_devs:
+            torch.cuda.synchronize(d)
+
+    def check(e, out, kh):
+        idx = np.linspace(0, N - 1, 256).astype(np.int64)
+        exp = np.concatenate([O.c_synth_rows(SEED, 0, int(kh[i]), 1, D) for i in idx]).reshape(256, D)
+        got = out.view(-1, D)[torch.from_numpy(idx).to(out.device)].cpu().numpy()
+        return bool(np.array_equal(got.view(np.uint32), exp.view(np.uint32)))
+
+    ok_all = True
+    for kind in ("uniform", "zipf"):
+        bt = batches(kind, 4)
+        e, out = entries[0], outs[0]
+        for i in range(4):
+            e.lookup(bt[i % 4], [N], out=out)
+        sync_all()
+        lat, ph = [], []
+        t1 = time.perf_counter()
+        for i in range(steps):
+            ts = time.perf_counter()
+            e.lookup(bt[i % 4], [N], out=out)
+            lat.append((time.perf_counter() - ts) * 1e3)
+            st = e.last_stats()
+            ph.append((st.key_stage_ms, st.bucket_ms, st.lookup_ms, st.expand_ms, st.unique_keys, max(st.shard_ms[:P]), max(st.sent[:P])))
+        sync_all()
+        dt = time.perf_counter() - t1
+        ok = check(e, out, bt[(steps - 1) % 4])
+        ok_all &= ok
+        pm = np.mean(np.array(ph, dtype=np.float64), axis=0)
+        own_dev = entry_devs[0]
+        st = e.last_stats()
+        remote = float(sum(st.sent[s] for s in range(P) if shard_devs[s] != own_dev))
+        one = {"lookups_per_s": N * steps / dt, "ms_per_request": dt / steps * 1e3, "p50_request_ms": float(np.percentile(lat, 50)),
+               "p99_request_ms": float(np.percentile(lat, 99)), "parity": ok,
+               "phase_ms": {"key_stage": float(pm[0]), "bucket": float(pm[1]), "shard_lookups": float(pm[2]), "expand_repeats": float(pm[3])},
+               "distinct_keys_per_request": float(pm[4]), "slowest_shard_ms": float(pm[5]), "largest_bucket_keys": float(pm[6]),
+               "row_bytes_from_other_gpus_per_request": remote * 4 * D,
+               "rows_GBps_into_entry_gpu": remote * 4 * D / (pm[2] * 1e-3) / 1e9 if pm[2] > 0 and remote else None}
+        # device keys (an ensemble step upstream holds them in HBM)
+        dk = [torch.from_numpy(b).to(out.device) for b in bt[:2]]
+        for i in range(2):
+            e.lookup_device(dk[i % 2], [N], out=out)
+        sync_all()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            e.lookup_device(dk[i % 2], [N], out=out)
+        sync_all()
+        one["device_keys_lookups_per_s"] = N * steps / (time.perf_counter() - t1)
+        del dk
+        # a request on EVERY instance at once (P entry sessions, each driving its own P shard sessions)
+        bar = threading.Barrier(P + 1)
+        errs = []
+
+        def work(r):
+            try:
+                torch.cuda.set_device(entry_devs[r])
+                for i in range(2):
+                    entries[r].lookup(bt[(r + i) % 4], [N], out=outs[r])
+                bar.wait()
+                bar.wait()
+                for i in range(steps):
+                    entries[r].lookup(bt[(r + i) % 4], [N], out=outs[r])
+                bar.wait()
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex)[:200])
+                bar.abort()
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+        [x.start() for x in th]
+        thr0 = thr1 = None
+        try:
+            bar.wait()
+            sync_all()
+            thr0 = cpu_throttle_stat()
+            t1 = time.perf_counter()
+            bar.wait()
+            bar.wait()
+            sync_all()
+            dtc = time.perf_counter() - t1
+            thr1 = cpu_throttle_stat()
+        except threading.BrokenBarrierError:
+            dtc = float("nan")
+        [x.join() for x in th]
+        if errs:
+            one["all_instances_error"] = errs[0]
+        else:
+            okc = all(check(entries[r], outs[r], bt[(r + steps - 1) % 4]) for r in range(P))
+            ok_all &= okc
+            one["all_instances_at_once"] = {"instances": P, "lookups_per_s": P * N * steps / dtc, "ms_per_round": dtc / steps * 1e3, "parity": okc,
+                                            "cpu_quota_throttled_ms": (thr1[1] - thr0[1]) / 1e3 if thr0 and thr1 else None}
+        res[kind] = one
+    res["lookups_per_s"] = (res.get("uniform") or {}).get("lookups_per_s")
+    res["parity"] = bool(ok_all)
+    for e in entries:
+        e.close()
+    ps.close()
+    return res
+
+
+def c3_rccl_threads_leg(a, torch, hps, ranks, rows_total, steps=30):
+    """The SPMD variant of config 3 (csrc/cache/shard_session.cpp: RCCL send/recv groups) with `ranks` RCCL ranks inside THIS
+    process — one thread, one device, one communicator per rank — so that a plain `python bench.py --gpus N` drives RCCL with N
+    ranks as torch.distributed.run would with N processes."""
+    import ctypes as C
+    from oracle import hps_oracle as O
+    P, D = ranks, a.dim
+    N = a.tables * a.batch
+    n_local = N // P
+    recv_cap = int(n_local * 1.25) + 4096
+    uid = (C.c_uint8 * 128)()
+    hps._check(hps.LIB.hps_shard_unique_id(uid))
+    servers, sessions, shards = [None] * P, [None] * P, [None] * P
+    errs = []
+    t0 = time.time()
+
+    def make(r):
+        try:
+            torch.cuda.set_device(r)
+            model = f"c3_rccl_{r}"
+            cfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8},
+                   "models": [{"model": model, "sparse_files": ["synthetic://shard"], "num_of_worker_buffer_in_pool": 2,
+                               "embedding_vecsize_per_table": [D], "maxnum_catfeature_query_per_table_per_sample": [1],
+                               "default_value_for_each_table": [0.0], "deployed_device_list": [r], "max_batch_size": recv_cap,
+                               "gpucache": True, "gpucacheper": 1.0, "gpucache_load_factor": 0.6, "hit_rate_threshold": 1.0}]}
+            ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+            ps.load_table_synthetic(model, 0, SEED, 0, rows_total, shard=r, num_shards=P)
+            ps.create_embedding_cache_per_model(model)
+            sess = hps.LookupSession.create(ps, model, ps.get_embedding_cache(model, r))
+            h = C.c_void_p()
+            hps._check(hps.LIB.hps_shard_session_create(sess._h, r, P, uid, n_local, C.byref(h)))   # collective: ncclCommInitRank
+            servers[r], sessions[r], shards[r] = ps, sess, h
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex)[:200])
+
+    th = [threading.Thread(target=make, args=(r,)) for r in range(P)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    if errs:
+        return {"ranks": P, "error": errs[0]}
+    t_setup = time.time() - t0
+    rng = np.random.default_rng(SEED + 505)
+    bt = [[rng.integers(0, rows_total, n_local, dtype=np.int64) for _ in range(4)] for _ in range(P)]
+    outs = [torch.empty(n_local * D, dtype=torch.float32, device=torch.device("cuda", r)) for r in range(P)]
+    bar = threading.Barrier(P + 1)
+    tim = [[] for _ in range(P)]
+    caps = [0] * P
+
+    def work(r):
+        try:
+            torch.cuda.set_device(r)
+            for i in range(4):
+                hps._check(hps.LIB.hps_shard_session_lookup_host(shards[r], bt[r][i % 4].ctypes.data, n_local, outs[r].data_ptr()))
+            bar.wait()
+            bar.wait()
+            for i in range(steps):
+                hps._check(hps.LIB.hps_shard_session_lookup_host(shards[r], bt[r][i % 4].ctypes.data, n_local, outs[r].data_ptr()))
+                t = [C.c_float(0) for _ in range(3)]
+                recv, kb = C.c_uint64(0), C.c_int32(0)
+                hps._check(hps.LIB.hps_shard_session_last_timing(shards[r], C.byref(t[0]), C.byref(t[1]), C.byref(t[2]), C.byref(recv), C.byref(kb)))
+                tim[r].append([x.value for x in t])
+            att, cap = C.c_uint32(0), C.c_uint64(0)
+            sent = (C.c_uint64 * P)()
+            hps._check(hps.LIB.hps_shard_session_last_stats(shards[r], C.byref(cap), C.byref(att), sent, P))
+            caps[r] = cap.value
+            bar.wait()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex)[:200])
+            bar.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [x.start() for x in th]
+    try:
+        bar.wait()
+        t1 = time.perf_counter()
+        bar.wait()
+        bar.wait()
+        for r in range(P):
+            torch.cuda.synchronize(r)
+        dt = time.perf_counter() - t1
+    except threading.BrokenBarrierError:
+        dt = float("nan")
+    [x.join() for x in th]
+    if errs:
+        return {"ranks": P, "error": errs[0]}
+    ok = True
+    for r in range(P):
+        kh = bt[r][(steps - 1) % 4]
+        idx = np.linspace(0, n_local - 1, 128).astype(np.int64)
+        exp = np.concatenate([O.c_synth_rows(SEED, 0, int(kh[i]), 1, D) for i in idx]).reshape(128, D)
+        got = outs[r].view(-1, D)[torch.from_numpy(idx).to(outs[r].device)].cpu().numpy()
+        ok &= bool(np.array_equal(got.view(np.uint32), exp.view(np.uint32)))
+    tm = np.mean(np.array([x for r in range(P) for x in tim[r]], dtype=np.float64), axis=0)
+    cap = caps[0]
+    out = {"ranks": P, "ranks_are": "threads of this process, one device + one RCCL communicator each", "rows_total": rows_total,
+           "lookups_per_s": N * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "parity": ok, "setup_seconds": t_setup,
+           "keys_exchange_ms": float(tm[0]), "local_lookup_ms": float(tm[1]), "rows_exchange_ms": float(tm[2]),
+           "block_capacity_keys": cap, "row_block_bytes_per_peer": cap * 4 * D,
+           "rows_GBps_per_link": cap * 4 * D / (tm[2] * 1e-3) / 1e9 if tm[2] > 0 and P > 1 else None,
+           "rows_frac_of_153_GBps_link": cap * 4 * D / (tm[2] * 1e-3) / 1e9 / 153.0 if tm[2] > 0 and P > 1 else None}
+    for h in shards:
+        hps.LIB.hps_shard_session_destroy(h)
+    for s_ in sessions:
+        s_.close()
+    for p_ in servers:
+        p_.close()
+    return out
+
+
 def sharded_leg(a, torch, dist, hps, rank, world, local_rank, shared_gpu):
     """One table of Rt rows x D sharded over the P ranks (owner = mix64(key) mod P), every rank resident at 100 % in
     its own HBM; per step every rank looks up N/P uniform keys through the engine's sharded session
@@ -1680,6 +1997,7 @@ def sharded_leg(a, torch, dist, hps, rank, world, local_rank, shared_gpu):
     res = {
         "workload": f"one table of {Rt} rows x {D} fp32 sharded over {P} ranks by mix64(key) mod {P}, 100 % resident in HBM "
                     f"({per_rank_rows} rows per rank), {N} uniform keys per step in total ({n_local} issued per rank)",
+        "ranks": P, "ranks_are": "processes (torch.distributed.run), one GPU each",
         "lookups_per_s": N * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
         "p50_step_latency_ms": float(np.percentile(lat, 50)),
         "rows_bytes_sent_per_rank_per_step": sent_remote * 4 * D,

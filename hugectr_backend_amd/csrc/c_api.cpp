@@ -244,6 +244,14 @@ int hps_server_update_source_stats(hps_server_t* sv, uint64_t* out6) {
   });
 }
 
+int hps_server_update_source_filtered(hps_server_t* sv, uint64_t* out) {
+  return Guard([&]() -> Status {
+    if (!sv || !out) return Error(Code::kInvalidArg, "null argument");
+    *out = sv->ps->filtered_update_count();
+    return Status::Ok();
+  });
+}
+
 int hps_server_update_source_drain(hps_server_t* sv, uint32_t timeout_ms) {
   return Guard([&]() -> Status {
     if (!sv) return Error(Code::kInvalidArg, "null argument");

@@ -88,10 +88,23 @@ CacheCounters EmbeddingCache::counters() const {
   {
     // inserts that sessions left running behind their last call: their statistics are part of the picture
     // (CollectDeferred selects the cache's device when there is something to wait for: the caller's current device is put back)
+    // The wait for the GPU happens OUTSIDE sess_mu_ (a monitoring call must not hold up RegisterSession, or a session's next
+    // call behind it): the list is copied under the lock, and a session that goes away meanwhile waits in UnregisterSession
+    // until the collectors that may still hold its pointer are done.
     int dev = -1;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(sess_mu_);
-    for (LookupSession* s : sessions_) (void)s->CollectDeferred();
+    std::vector<LookupSession*> list;
+    {
+      std::lock_guard<std::mutex> lk(sess_mu_);
+      list = sessions_;
+      ++collectors_;
+    }
+    for (LookupSession* s : list) (void)s->CollectDeferred();
+    {
+      std::lock_guard<std::mutex> lk(sess_mu_);
+      --collectors_;
+    }
+    sess_cv_.notify_all();
     if (dev >= 0) (void)hipSetDevice(dev);
   }
   std::lock_guard<std::mutex> lk(stat_mu_);
@@ -103,8 +116,9 @@ void EmbeddingCache::RegisterSession(LookupSession* s) {
   sessions_.push_back(s);
 }
 void EmbeddingCache::UnregisterSession(LookupSession* s) {
-  std::lock_guard<std::mutex> lk(sess_mu_);
+  std::unique_lock<std::mutex> lk(sess_mu_);
   sessions_.erase(std::remove(sessions_.begin(), sessions_.end(), s), sessions_.end());
+  sess_cv_.wait(lk, [&] { return collectors_ == 0; });   // a counters() call may still be collecting from the copy it took
 }
 
 // Insert statistics come back as kStatLines lines of the accumulator block (device_types.h): sum and add.
@@ -594,6 +608,11 @@ Status EmbeddingCache::DumpKeys(uint32_t table, std::vector<int64_t>* keys) {
 // =================================================================================================
 // LookupSession
 // =================================================================================================
+namespace {
+constexpr int kMaxSideDevices = 64;
+std::atomic<int> g_side_hi[kMaxSideDevices];   // sessions with a high-priority side stream, per device (at most two)
+}  // namespace
+
 LookupSession::~LookupSession() { Release(); }
 
 void LookupSession::Release() {
@@ -619,6 +638,8 @@ void LookupSession::Release() {
                        ev_g0_, ev_g1_, ev_s0_, ev_s1_, ev_i0_, ev_i1_})
     if (e) (void)hipEventDestroy(e);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+  if (side_hi_ && device_ >= 0 && device_ < kMaxSideDevices) g_side_hi[device_].fetch_sub(1, std::memory_order_relaxed);
+  side_hi_ = false;
   if (stream_) (void)hipStreamDestroy(stream_);
   stream_ = nullptr;
   cache_.reset();
@@ -654,12 +675,22 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
     // headline 2.03 / 2.05 / 2.08 against 2.01 / 1.69 / 1.92 G lookups/s in three interleaved pairs (the two low ones look like
     // the box's host noise: 2.01 is the fair comparison), p50 1.55-1.58 against 1.61 ms
     // (profiles/round4/ab_side_stream_priority.txt).  HPS_SIDE_PRIORITY=0: a queue of normal priority.
+    // Round 5: NOT for more than two sessions per device, and never for the shard sessions of a table-sharded model's entry
+    // instances.  A high-priority queue that is merely WAITING (its head is a barrier on another queue's event) makes the
+    // hardware scheduler preempt the waves of the normal-priority queue it waits for: with 16 sessions on one GPU (4 entry
+    // instances x 4 shards) kernels that had started stood still for 60-160 ms with the GPU idle until the scheduler's quantum
+    // expired — 35 ms per round of requests against 4 ms with normal-priority side streams
+    // (profiles/round5/ab_side_priority_many_sessions.txt; rocprofv3: hps_pull16_kernel "running" for 283 ms).
     static const bool hi = [] { const char* e = std::getenv("HPS_SIDE_PRIORITY"); return !(e && e[0] == '0'); }();
     int least = 0, greatest = 0;
-    if (hi && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-      HIP_TRY(hipStreamCreateWithPriority(&copy_stream_, hipStreamNonBlocking, greatest));
-    else
-      HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    side_hi_ = false;
+    if (hi && !max_keys_override && device_ >= 0 && device_ < kMaxSideDevices &&
+        hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+      if (g_side_hi[device_].fetch_add(1, std::memory_order_relaxed) < 2) side_hi_ = true;
+      else g_side_hi[device_].fetch_sub(1, std::memory_order_relaxed);
+    }
+    if (side_hi_) HIP_TRY(hipStreamCreateWithPriority(&copy_stream_, hipStreamNonBlocking, greatest));
+    else HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
   }
   for (hipEvent_t* e : {&ev_copy_, &ev_keys_, &ev_done_, &ev_done2_, &ev_read_, &ev_fetch_, &ev_probe_})
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -1149,7 +1180,8 @@ Status LookupSession::WaitPushedSeq(uint32_t want, hipEvent_t ev) {
   // poll the sequence word for a while (the usual wait is tens of microseconds), looking at the event now and then so that a
   // failed stream ends the wait; a long wait (a millisecond of uploads ahead of the push) goes to the runtime's own wait
   const auto t0 = std::chrono::steady_clock::now();
-  for (uint32_t i = 1;; ++i) {
+  static const long kSpinUs = [] { const char* e = std::getenv("HPS_WAIT_SPIN_US"); return e ? std::strtol(e, nullptr, 10) : 300l; }();
+  for (uint32_t i = 1; kSpinUs > 0; ++i) {
     if (landed()) return Status::Ok();
     SpinPause();
     static const bool kYield = [] { const char* e = std::getenv("HPS_POOL_YIELD"); return !(e && e[0] == '0'); }();
@@ -1160,7 +1192,7 @@ Status LookupSession::WaitPushedSeq(uint32_t want, hipEvent_t ev) {
       // (Not longer: polling for 6 ms instead — tried in round 4 against the runtime's occasional 4-ms wake-ups — made things
       //  worse: 9-ms waits for the miss counts.  Work queued behind a cross-stream event wait is released by a thread of the
       //  HIP runtime; a caller that spins keeps that thread off the CPU, a caller that blocks in hipEventSynchronize lets it run.)
-      if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+      if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinUs)) break;
     }
   }
   HIP_TRY(hipEventSynchronize(ev));
@@ -1176,9 +1208,9 @@ Status LookupSession::WaitPushedSeq(uint32_t want, hipEvent_t ev) {
 Status LookupSession::CollectDeferred() {
   std::lock_guard<std::mutex> lk(deferred_mu_);
   if (!deferred_pending_) return Status::Ok();
-  deferred_pending_ = false;
   (void)hipSetDevice(device_);
-  HPS_RETURN_IF_ERROR(WaitPushedSeq(deferred_seq_, ev_done2_));
+  HPS_RETURN_IF_ERROR(WaitPushedSeq(deferred_seq_, ev_done2_));   // (a failed wait leaves the statistics pending: not lost silently)
+  deferred_pending_ = false;
   AddInsertStats();
   if (deferred_timed_) {
     float ms = 0.f;

@@ -184,6 +184,8 @@ class EmbeddingCache {
   // lookup sessions of this cache (registered in LookupSession::Init, removed in Release): counters() asks each for the
   // statistics of an insert kernel it left behind its last call (LookupSession::CollectDeferred)
   mutable std::mutex sess_mu_;
+  mutable std::condition_variable sess_cv_;
+  mutable int collectors_ = 0;   // counters() calls working on a copy of sessions_
   std::vector<LookupSession*> sessions_;
   void RegisterSession(LookupSession* s);
   void UnregisterSession(LookupSession* s);
@@ -332,6 +334,7 @@ class LookupSession {
   int device_ = 0;
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;  // second H2D queue for the missed-row pieces
+  bool side_hi_ = false;               // copy_stream_ is a high-priority queue (the first two sessions of a device only)
   hipEvent_t ev_copy_ = nullptr;
   hipEvent_t ev_keys_ = nullptr;       // behind the key upload (second stream)
   bool keys_wait_pending_ = false;     // lookup() recorded ev_keys_; PrepareCall makes the first stream wait for it behind the block pull
@@ -386,7 +389,7 @@ class LookupSession {
   Status WaitPushed();                // host: until the last PushWords has landed (or the stream reports an error)
   Status WaitPushedSeq(uint32_t seq, hipEvent_t ev);   // ... until the push that carried `seq` (or a later one) has landed
   bool defer_insert_ = true;          // option "defer_insert" / HPS_DEFER_INSERT: the insert kernel is not on the call's return path
-  size_t in_place_bytes_ = 1u << 20;  // option "in_place_bytes" / HPS_IN_PLACE_KB: missed rows of a chunk up to this size are read by
+  size_t in_place_bytes_ = 1u << 20;  // option "in_place_kb" / HPS_IN_PLACE_KB: missed rows of a chunk up to this size are read by
                                       // the kernels where the host gathered them (page-locked staging), no upload
   size_t side_bytes_ = 16u << 20;     // HPS_SIDE_SCATTER_MB: missed rows of a call up to this size are uploaded AND scattered on the
                                       // second stream, next to the hit gather and outside the kernel lane
@@ -524,6 +527,7 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   // (keys that are not resident stay out: an update is not a request).
   void OnUpdatesCommitted(const std::set<std::string>& models);
   bool update_source_stats(UpdateSourceStats* out) const;
+  uint64_t filtered_update_count() const { return filtered_updates_.load(std::memory_order_relaxed); }
   Status drain_update_source(size_t timeout_ms);
   Status stop_update_source();   // joins the consumer thread; pending messages stay uncommitted
 
@@ -543,7 +547,10 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   std::mutex upd_mu_;
   std::map<std::string, std::vector<std::vector<int64_t>>> updated_keys_;   // model -> per table: keys applied since the last commit
   std::vector<std::regex> update_filters_;    // volatile_db.update_filters, compiled (set before the consumer starts, then read-only)
-  std::unique_ptr<UpdateConsumer> updates_;   // last member: its thread stops before anything it uses goes away
+  // filtered: update messages no update_filters entry selected (skipped silently, as a subscription filter does)
+  std::atomic<uint64_t> filtered_updates_{0};
+  mutable std::mutex updates_mu_;             // guards the POINTER: stats / drain take a reference under it, stop moves it out
+  std::shared_ptr<UpdateConsumer> updates_;   // last member: its thread stops before anything it uses goes away
 };
 
 }  // namespace hps

@@ -22,8 +22,8 @@ struct EntryDesc {
 
 // d_rep[i] = index of the representative of (table of i, key i): i itself for one key of every distinct pair.
 // d_set: set_mask + 1 (a power of two >= 2 n) words, zeroed once; tag != 0, different from the tags still in the set.
-hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const int64_t* d_keys, uint64_t n, unsigned long long* d_set, uint64_t set_mask,
-                            uint32_t tag, uint32_t* d_rep, hipStream_t stream);
+hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, const int64_t* d_keys, uint64_t n,
+                            unsigned long long* d_set, uint64_t set_mask, uint32_t tag, uint32_t* d_rep, hipStream_t stream);
 // Stable bucket of the request's representatives (all keys when d_rep is null) by owner = mix64(key) mod num_shards:
 //   d_bkeys / d_bidx   owner-major, table-major inside an owner, input order inside a table; d_bidx = row position of the key
 //                      in its table's output slice

@@ -36,22 +36,43 @@ __device__ __forceinline__ int entry_find_table(const uint64_t* ks, int T, uint6
   return lo;
 }
 
-// rep[i] = index of the first claimant of (table(i), key(i)) in the call-wide set.  Open addressing, entries (tag << 32 | index);
-// entries of earlier calls (other tags) are free, so the set is never cleared.  A duplicate compares against the INPUT array,
-// which no kernel of the call writes: no intra-launch hand-off of data.
-__global__ __launch_bounds__(256) void hps_entry_dedup_kernel(const EntryDesc* __restrict__ d, const int64_t* __restrict__ keys,
-                                                              unsigned long long* __restrict__ set, uint64_t mask, uint32_t tag,
-                                                              uint32_t* __restrict__ rep) {
-  __shared__ uint64_t sh_ks[kMaxTables + 1];
-  const int T = (int)d->num_tables;
-  for (int t = threadIdx.x; t <= T; t += blockDim.x) sh_ks[t] = d->key_start[t];
+// rep[i] = index of the representative of (table(i), key(i)).  Two levels, like the probe kernel's input dedup (kernels.hip):
+//   tile   one workgroup per tile of <= 1,024 keys of one table: a 32-bit LDS CAS set gives every key its tile-local
+//          representative — the hot head of a Zipf request (one key = 7 % of 1.7 M keys) collapses to one key per tile HERE, in
+//          LDS, instead of 120 K same-address atomics on one word of the call-wide set (0.35 ms of a 0.7-ms bucket step)
+//   call   the tile representatives claim entries (tag << 32 | index) of the call-wide open-addressing set; entries of
+//          earlier calls (other tags) are free, so the set is never cleared.  A loser compares against the INPUT array, which no
+//          kernel of the call writes: no intra-launch hand-off of data.
+__global__ __launch_bounds__(kEntryTile) void hps_entry_dedup_kernel(const EntryDesc* __restrict__ d, const TileDesc* __restrict__ tiles,
+                                                                    const int64_t* __restrict__ keys, unsigned long long* __restrict__ set,
+                                                                    uint64_t mask, uint32_t tag, uint32_t* __restrict__ rep) {
+  __shared__ int64_t sh_key[kEntryTile];
+  __shared__ uint32_t sh_set[2 * kEntryTile];
+  __shared__ uint32_t sh_grep[kEntryTile];
+  const TileDesc td = tiles[blockIdx.x];
+  const uint32_t j = threadIdx.x;
+  const bool inb = j < td.count;
+  const uint64_t i = td.begin + j;
+  const int64_t key = inb ? keys[i] : 0;
+  const uint32_t t = td.table;
+  const uint64_t h0 = hps_mix64((uint64_t)key ^ ((uint64_t)(t + 1) * 0x9E3779B97F4A7C15ull));
+  sh_key[j] = key;
+  sh_set[j] = 0xFFFFFFFFu;
+  sh_set[j + kEntryTile] = 0xFFFFFFFFu;
   __syncthreads();
-  const uint64_t n = d->total_keys;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const int64_t key = keys[i];
-    const int t = entry_find_table(sh_ks, T, i);
-    const uint64_t lo = sh_ks[t], hi = sh_ks[t + 1];
-    uint64_t h = (hps_mix64((uint64_t)key ^ ((uint64_t)(t + 1) * 0x9E3779B97F4A7C15ull)) >> 11) & mask;
+  uint32_t lrep = j;
+  if (inb) {
+    uint32_t e = (uint32_t)h0 & (2 * kEntryTile - 1);
+    for (;;) {
+      const uint32_t prev = atomicCAS(&sh_set[e], 0xFFFFFFFFu, j);
+      if (prev == 0xFFFFFFFFu) break;
+      if (sh_key[prev] == key) { lrep = prev; break; }
+      e = (e + 1) & (2 * kEntryTile - 1);
+    }
+  }
+  if (inb && lrep == j) {
+    const uint64_t lo = d->key_start[t], hi = d->key_start[t + 1];
+    uint64_t h = (h0 >> 11) & mask;
     const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)i;
     unsigned long long cur = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t r = (uint32_t)i;
@@ -62,13 +83,15 @@ __global__ __launch_bounds__(256) void hps_entry_dedup_kernel(const EntryDesc* _
         cur = prev;
         continue;
       }
-      const uint32_t j = (uint32_t)cur;
-      if (j >= lo && j < hi && keys[j] == key) { r = j; break; }   // same table, same key
+      const uint32_t g = (uint32_t)cur;
+      if (g >= lo && g < hi && keys[g] == key) { r = g; break; }   // same table, same key
       h = (h + 1) & mask;
       cur = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    rep[i] = r;
+    sh_grep[j] = r;
   }
+  __syncthreads();
+  if (inb) rep[i] = sh_grep[lrep];
 }
 
 __global__ __launch_bounds__(kEntryTile) void hps_entry_hist_kernel(const EntryDesc* __restrict__ d, const TileDesc* __restrict__ tiles,
@@ -210,13 +233,11 @@ __global__ __launch_bounds__(256) void hps_entry_expand_kernel(const EntryDesc* 
   }
 }
 
-hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const int64_t* d_keys, uint64_t n, unsigned long long* d_set, uint64_t set_mask,
-                            uint32_t tag, uint32_t* d_rep, hipStream_t stream) {
-  if (n == 0) return hipSuccess;
+hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, const int64_t* d_keys, uint64_t n,
+                            unsigned long long* d_set, uint64_t set_mask, uint32_t tag, uint32_t* d_rep, hipStream_t stream) {
+  if (n == 0 || num_tiles == 0) return hipSuccess;
   if (tag == 0 || (set_mask & (set_mask + 1)) != 0 || set_mask + 1 < 2 * n) return hipErrorInvalidValue;
-  uint64_t want = (n + 255) / 256;
-  if (want > 4096) want = 4096;
-  hipLaunchKernelGGL(hps_entry_dedup_kernel, dim3((uint32_t)want), dim3(256), 0, stream, d_desc, d_keys, d_set, set_mask, tag, d_rep);
+  hipLaunchKernelGGL(hps_entry_dedup_kernel, dim3(num_tiles), dim3(kEntryTile), 0, stream, d_desc, d_tiles, d_keys, d_set, set_mask, tag, d_rep);
   return hipGetLastError();
 }
 

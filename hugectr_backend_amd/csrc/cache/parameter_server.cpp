@@ -141,7 +141,11 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
 // HierParameterServer
 // =================================================================================================
 HierParameterServer::~HierParameterServer() {
-  updates_.reset();   // the consumer thread calls back into this object
+  {
+    std::shared_ptr<UpdateConsumer> u;
+    { std::lock_guard<std::mutex> lk(updates_mu_); u = std::move(updates_); }
+    u.reset();   // the consumer thread calls back into this object
+  }
   for (auto& kv : caches_) kv.second->WaitAsync();
   caches_.clear();
 }
@@ -190,15 +194,19 @@ Status HierParameterServer::create_from_config(const ParameterServerConfig& cfg,
   if (cfg.update_source.type == UpdateSourceType::FileTail) {
     // update_filters (docs/hierarchical_parameter_server.md:509-512, 570-573; parsed at backend.cpp:207-216, 250-259): regular
     // expressions over the update's tag "hps_<model>.<table name>" that decide which updates a database layer takes.  This
-    // build writes an update through both layers in one step (HostTable::Upsert), so the two lists must say the same.
+    // build writes an update through both layers in one step (HostTable::Upsert): an update is taken when EITHER layer's list
+    // selects it (round 4 refused configurations whose two lists differed textually — e.g. [".+"] against the default
+    // "^hps_.+$", which select the same updates).
+    std::vector<std::pair<const char*, const std::vector<std::string>*>> lists{{"volatile_db", &cfg.volatile_db.update_filters}};
     if (cfg.persistent_db.type != DatabaseType::Disabled && cfg.persistent_db.update_filters != cfg.volatile_db.update_filters)
-      return Error(Code::kUnsupported, "volatile_db.update_filters and persistent_db.update_filters differ: this build applies an "
-                                       "online update to both database layers together; give both the same list");
-    for (const std::string& f : cfg.volatile_db.update_filters) {
-      try {
-        ps->update_filters_.emplace_back(f, std::regex::ECMAScript | std::regex::optimize);
-      } catch (const std::regex_error& e) {
-        return Error(Code::kInvalidArg, "volatile_db.update_filters: '", f, "' is not a regular expression (", e.what(), ")");
+      lists.push_back({"persistent_db", &cfg.persistent_db.update_filters});
+    for (const auto& l : lists) {
+      for (const std::string& f : *l.second) {
+        try {
+          ps->update_filters_.emplace_back(f, std::regex::ECMAScript | std::regex::optimize);
+        } catch (const std::regex_error& e) {
+          return Error(Code::kInvalidArg, l.first, ".update_filters: '", f, "' is not a regular expression (", e.what(), ")");
+        }
       }
     }
     std::unique_ptr<UpdateTransport> tr;
@@ -226,7 +234,9 @@ Status HierParameterServer::ApplyUpdate(const std::string& model, uint32_t table
     else tag += "sparse_embedding" + std::to_string(table + 1);
     bool take = false;
     for (const std::regex& f : update_filters_) take = take || std::regex_search(tag, f);
-    if (!take) return Error(Code::kNotFound, "update '", tag, "' matches none of the update_filters: not applied");
+    // not subscribed to: skipped silently, like a message on a topic nobody listens to (the consumer counts the message as dealt
+    // with; hps_server_update_source_filtered says how many there were)
+    if (!take) { filtered_updates_.fetch_add(1, std::memory_order_relaxed); return Status(Code::kOk, kUpdateFiltered); }
   }
   HPS_RETURN_IF_ERROR(upsert_table(model, table, keys, rows, n));
   std::lock_guard<std::mutex> lk(upd_mu_);
@@ -271,20 +281,28 @@ void HierParameterServer::OnUpdatesCommitted(const std::set<std::string>& models
   }
 }
 
+// (a monitoring thread polling the statistics, or a drain in progress, may run next to a stop: each takes its own reference to
+//  the consumer under the lock; the consumer's thread is joined by whoever drops the last one)
 bool HierParameterServer::update_source_stats(UpdateSourceStats* out) const {
-  if (!updates_) return false;
-  if (out) *out = updates_->stats();
+  std::shared_ptr<UpdateConsumer> u;
+  { std::lock_guard<std::mutex> lk(updates_mu_); u = updates_; }
+  if (!u) return false;
+  if (out) *out = u->stats();
   return true;
 }
 
 Status HierParameterServer::drain_update_source(size_t timeout_ms) {
-  if (!updates_) return Error(Code::kUnavailable, "no update source is configured (ps.json update_source.type)");
-  return updates_->Drain(timeout_ms);
+  std::shared_ptr<UpdateConsumer> u;
+  { std::lock_guard<std::mutex> lk(updates_mu_); u = updates_; }
+  if (!u) return Error(Code::kUnavailable, "no update source is configured (ps.json update_source.type)");
+  return u->Drain(timeout_ms);
 }
 
 Status HierParameterServer::stop_update_source() {
-  if (!updates_) return Error(Code::kUnavailable, "no update source is configured (ps.json update_source.type)");
-  updates_.reset();
+  std::shared_ptr<UpdateConsumer> u;
+  { std::lock_guard<std::mutex> lk(updates_mu_); u = std::move(updates_); updates_.reset(); }
+  if (!u) return Error(Code::kUnavailable, "no update source is configured (ps.json update_source.type)");
+  u->Stop();   // joins the thread: what was applied is delivered to the caches and committed, nothing more is applied
   return Status::Ok();
 }
 

@@ -332,7 +332,7 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
       HIP_TRY(hipMemsetAsync(d_set_, 0, (set_mask_ + 1) * sizeof(unsigned long long), stream_));
       set_tag_ = 1;
     }
-    HIP_TRY(LaunchEntryDedup(dd, d_keys_flat, N, d_set_, set_mask_, set_tag_, d_rep_, stream_));
+    HIP_TRY(LaunchEntryDedup(dd, dt, nt, d_keys_flat, N, d_set_, set_mask_, set_tag_, d_rep_, stream_));
   }
   uint32_t* d_base = d_counts_;
   uint32_t* d_cnt = d_counts_ + (P_ + 1);

@@ -140,8 +140,11 @@ UpdateConsumer::UpdateConsumer(const UpdateSourceParams& p, std::unique_ptr<Upda
   thread_ = std::thread([this] { Run(); });
 }
 
-UpdateConsumer::~UpdateConsumer() {
+UpdateConsumer::~UpdateConsumer() { Stop(); }
+
+void UpdateConsumer::Stop() {
   stop_.store(true);
+  std::lock_guard<std::mutex> lk(join_mu_);
   if (thread_.joinable()) thread_.join();
 }
 
@@ -219,14 +222,15 @@ void UpdateConsumer::Run() {
     }
     waited_ms = 0;
     for (const UpdateMessage& m : msgs) {
-      // Shutting down: this message and every later one of the poll stay UNCOMMITTED (they are replayed after a restart) —
-      // nothing is counted for them and no commit follows: a commit here would move the offset past messages that never
-      // reached the database layers.
-      if (stop_.load()) return;
+      // Shutting down: this message and every later one of the poll stay UNCOMMITTED (they are replayed after a restart) and
+      // nothing is counted for them.  What HAS been applied since the last commit is delivered like any commit: the GPU caches
+      // take the new rows (the server keeps serving after the stop; round 4 left the caches with the old rows of keys the host
+      // tier had already updated) and the offset moves past exactly those messages.
+      if (stop_.load()) { commit(); return; }
       const size_t n = m.keys.size();
       const size_t chunk = std::max<size_t>(1, p_.max_batch_size);
-      bool ok = true, cut_short = false;
-      for (size_t b = 0; b < n && ok; b += chunk) {
+      bool ok = true, cut_short = false, filtered = false;
+      for (size_t b = 0; b < n && ok && !filtered; b += chunk) {
         if (stop_.load()) { cut_short = true; break; }
         const size_t e = std::min(n, b + chunk);
         // a layer that refuses the chunk is asked again after failure_backoff_ms (three times; then the message is dropped
@@ -238,6 +242,7 @@ void UpdateConsumer::Run() {
           if (st.ok() || st.code() == Code::kNotFound || st.code() == Code::kInvalidArg) break;
           usleep((useconds_t)std::max<size_t>(1, p_.failure_backoff_ms) * 1000);
         }
+        if (st.ok() && st.message() == kUpdateFiltered) filtered = true;   // no database layer subscribed to it: nothing to count
         if (!st.ok()) {
           ok = false;
           std::lock_guard<std::mutex> lk(mu_);
@@ -245,8 +250,14 @@ void UpdateConsumer::Run() {
           fprintf(stderr, "[hps update source] message for model '%s' table %u dropped: %s\n", m.model.c_str(), m.table, st.message().c_str());
         }
       }
-      if (cut_short) return;   // partly applied (upserts are idempotent): replayed whole after a restart, not committed
-      if (ok) {
+      if (cut_short) {
+        // partly applied (upserts are idempotent): replayed whole after a restart, NOT committed — but the chunks that did reach
+        // the host tier must reach the GPU caches too
+        commit();
+        if (committed_) committed_({m.model});
+        return;
+      }
+      if (ok && !filtered) {
         touched.insert(m.model);
         std::lock_guard<std::mutex> lk(mu_);
         ++stats_.messages;
@@ -255,6 +266,7 @@ void UpdateConsumer::Run() {
       if (++since_commit >= std::max<size_t>(1, p_.max_commit_interval)) commit();
     }
   }
+  commit();   // stop seen between polls: everything applied so far is delivered and committed
 }
 
 }  // namespace hps

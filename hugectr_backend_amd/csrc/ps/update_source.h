@@ -67,6 +67,9 @@ class UpdateTransport {
 // receive_buffer_size bounds one message (the reference sizes its Kafka receive buffer with it)
 Status MakeFileTailTransport(const std::string& path, size_t receive_buffer_size, std::unique_ptr<UpdateTransport>* out);
 
+// what ApplyFn returns (with Code::kOk) for a message no update filter selected: dealt with, nothing applied, nothing counted
+constexpr const char* kUpdateFiltered = "filtered";
+
 struct UpdateSourceStats {
   uint64_t messages = 0, keys = 0, dispatches = 0, commits = 0, dispatch_failures = 0, rejected_messages = 0;
 };
@@ -79,6 +82,7 @@ class UpdateConsumer {
   using CommitFn = std::function<void(const std::set<std::string>&)>;
   UpdateConsumer(const UpdateSourceParams& p, std::unique_ptr<UpdateTransport> transport, ApplyFn apply, CommitFn committed);
   ~UpdateConsumer();   // stops the thread (pending messages stay uncommitted: they are replayed after a restart)
+  void Stop();         // the same, explicitly (idempotent); stats() keeps working afterwards
   UpdateSourceStats stats() const;
   // blocks until every message that was in the source when the call started has been applied and committed (tests, tools)
   Status Drain(size_t timeout_ms);
@@ -90,6 +94,7 @@ class UpdateConsumer {
   ApplyFn apply_;
   CommitFn committed_;
   std::thread thread_;
+  std::mutex join_mu_;
   std::atomic<bool> stop_{false};
   mutable std::mutex mu_;
   UpdateSourceStats stats_;

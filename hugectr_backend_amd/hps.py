@@ -136,6 +136,7 @@ def _load() -> C.CDLL:
         "hps_update_message_encode": (C.c_int, [cp, u32, u32, P, P, u64, P, u64, C.POINTER(u64)]),
         "hps_server_update_source_stats": (C.c_int, [P, P]),
         "hps_server_update_source_drain": (C.c_int, [P, u32]),
+        "hps_server_update_source_filtered": (C.c_int, [P, C.POINTER(u64)]),
         "hps_server_update_source_stop": (C.c_int, [P]),
         "hps_shard_owner": (u32, [i64, u32]),
         "hps_shard_bucket_workspace_bytes": (u64, [u64, u32]),
@@ -182,7 +183,7 @@ EXPORTED_SYMBOLS = [
     "hps_server_create_embedding_cache_per_model", "hps_server_destroy_embedding_cache_per_model",
     "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
-    "hps_server_table_data", "hps_update_message_encode", "hps_server_update_source_stats", "hps_server_update_source_drain", "hps_server_update_source_stop",
+    "hps_server_table_data", "hps_update_message_encode", "hps_server_update_source_stats", "hps_server_update_source_drain", "hps_server_update_source_stop", "hps_server_update_source_filtered",
     "hps_cache_on_device", "hps_wake_copy_engines", "hps_session_create_from_cache",
     "hps_shard_unique_id", "hps_shard_session_create", "hps_shard_group_create_local", "hps_shard_group_destroy",
     "hps_shard_session_create_local", "hps_shard_session_lookup", "hps_shard_session_lookup_host", "hps_shard_session_last_timing",
@@ -372,6 +373,11 @@ class HierParameterServer:
         v = (C.c_uint64 * 6)()
         _check(LIB.hps_server_update_source_stats(self._h, v))
         return dict(zip(["messages", "keys", "dispatches", "commits", "dispatch_failures", "rejected_messages"], map(int, v)))
+
+    def filtered_update_count(self) -> int:
+        n = C.c_uint64(0)
+        _check(LIB.hps_server_update_source_filtered(self._h, C.byref(n)))
+        return int(n.value)
 
     def drain_update_source(self, timeout_ms: int = 10000):
         _check(LIB.hps_server_update_source_drain(self._h, int(timeout_ms)))

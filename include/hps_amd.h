@@ -168,12 +168,16 @@ int hps_server_upsert(hps_server_t* server, const char* model, uint32_t table, c
  *   hps_server_update_source_stats   out6 = messages, keys, dispatches, commits, dispatch failures, rejected messages
  *   hps_server_update_source_drain   returns once the source has been found empty twice in a row (tests, tools); an error when
  *                                    the source is unreadable for good (a frame that is not a frame)
- *   hps_server_update_source_stop    stops the consumer thread (orderly shutdown: nothing is applied or committed afterwards;
- *                                    messages not applied yet stay uncommitted and are replayed by the next server); the
- *                                    statistics calls then report HPS_ERR_UNAVAILABLE */
+ *   hps_server_update_source_stop    stops the consumer thread (orderly shutdown): what was applied since the last commit is
+ *                                    delivered to the GPU caches and committed, nothing more is applied; messages not applied
+ *                                    yet stay uncommitted and are replayed by the next server; the statistics calls then
+ *                                    report HPS_ERR_UNAVAILABLE */
 int hps_update_message_encode(const char* model, uint32_t table, uint32_t dim, const int64_t* keys, const float* rows, uint64_t n,
                               void* out, uint64_t out_capacity, uint64_t* out_bytes);
 int hps_server_update_source_stats(hps_server_t* server, uint64_t* out6);
+/* update messages that no update_filters entry selected (volatile_db / persistent_db "update_filters": regular expressions over
+ * "hps_<model>.<table name>"): skipped silently like a message on a topic nobody subscribed to — counted here, not as failures */
+int hps_server_update_source_filtered(hps_server_t* server, uint64_t* out);
 int hps_server_update_source_drain(hps_server_t* server, uint32_t timeout_ms);
 int hps_server_update_source_stop(hps_server_t* server);
 

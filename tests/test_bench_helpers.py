@@ -56,7 +56,7 @@ def _fat_result():
     p = Path(__file__).resolve().parent.parent / "profiles" / "round3" / "r3m" / "bench_default.json"
     res = json.loads(p.read_text())
     # what round 4 adds: the insert kernel priced next to the headline fraction, the near-all-hit legs, the logical C3 leg
-    res["roofline"]["frac_with_insert"] = 0.67
+    res["roofline"]["frac_return_path_kernels"] = 0.75
     res["roofline"]["insert_ms"] = 0.035
     res["roofline"]["insert_on_call_path"] = True
     leg = dict(res["extra_legs"]["all_hit_two_sessions_host_keys"])
@@ -78,7 +78,7 @@ def test_final_line_is_compact_and_round_trips():
         assert k in back, k
     assert back["value"] == res["value"] and back["ms_per_step"] == res["ms_per_step"]
     assert back["config"]["workload"] and len(back["config"]["workload"]) <= 300 and "model" not in back["config"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "frac_with_insert", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "frac_return_path_kernels", "traffic"):
         assert back["roofline"][k] is not None, k
     assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
     for k in ("value", "unit", "cores", "kind", "sample"):

@@ -231,6 +231,39 @@ def test_resident_rows_are_replaced_in_the_gpu_cache_and_absent_keys_stay_out(tm
     sess.close()
 
 
+@pytest.mark.gpu
+def test_stopping_the_consumer_delivers_what_it_applied_to_the_gpu_caches(tmp_path):
+    """Advisor finding of round 4: hps_server_update_source_stop returned without passing the messages applied since the last
+    commit to the GPU caches — the server keeps serving after the stop, and resident keys answered with their OLD rows while
+    the host tier already held the new ones.  A commit interval and a poll timeout the test never reaches keep everything
+    'applied, not committed' until the stop."""
+    import time
+    from hugectr_backend_amd import hps
+    tables = make_tables([(4000, 16)])
+    path = tmp_path / "updates.bin"
+    src = {"type": "file_tail", "brokers": str(path), "poll_timeout_ms": 60000, "max_commit_interval": 100000, "max_batch_size": 256}
+    ps = _server(tmp_path, tables, src, gpucache=True, gpucacheper=0.25, hit_rate_threshold=1.0)
+    ps.create_embedding_cache_per_model("upd")
+    cache = ps.get_embedding_cache("upd", 0)
+    sess = hps.LookupSession.create(ps, "upd", cache)
+    keys = tables[0][0]
+    res = keys[cache.query(0, keys) >= 0][:64]
+    with open(path, "ab") as f:
+        f.write(hps.encode_update_message("upd", 0, res, np.full((res.size, 16), 11.0, np.float32)))
+    t0 = time.time()
+    while ps.update_source_stats()["messages"] < 1 and time.time() - t0 < 20:
+        time.sleep(0.01)
+    st = ps.update_source_stats()
+    assert st["messages"] == 1 and st["commits"] == 0          # applied to the host tier, not committed, caches not told yet
+    ps.stop_update_source()
+    out = sess.lookup(res, [res.size]).cpu().numpy()
+    assert np.all(out == 11.0), "resident keys still answer with the rows from before the update"
+    assert np.all(cache.query(0, res) >= 0)
+    # ... and the offset moved past exactly that message
+    assert int(open(str(path) + ".offset").read()) == path.stat().st_size
+    sess.close()
+
+
 def test_update_filters_decide_which_updates_the_database_layers_take(tmp_path):
     """volatile_db.update_filters / persistent_db.update_filters (docs/hierarchical_parameter_server.md:509-512): regular
     expressions over the update's tag hps_<model>.<table name>.  Round 3 parsed and ignored them."""
@@ -250,17 +283,36 @@ def test_update_filters_decide_which_updates_the_database_layers_take(tmp_path):
         f.write(hps.encode_update_message("upd", 1, tables[1][0][:5], np.full((5, 4), 4.0, np.float32)))   # hps_upd.item: taken
     ps.drain_update_source(10000)
     st = ps.update_source_stats()
-    assert st["messages"] == 1 and st["rejected_messages"] == 1
+    # a message nobody subscribed to is skipped silently (round 4 counted it as a failed dispatch and a rejected message)
+    assert st["messages"] == 1 and st["rejected_messages"] == 0 and st["dispatch_failures"] == 0
+    assert ps.filtered_update_count() == 1
     sess = hps.LookupSession.create(ps, "upd", None)
     out = sess.lookup(np.concatenate([tables[0][0][:5], tables[1][0][:5]]), [5, 5]).reshape(10, 4)
     assert np.array_equal(_bits(out[:5]), _bits(tables[0][1][:5])) and np.all(out[5:] == 4.0)
     sess.close()
     ps.close()
-    # not a regular expression / lists that differ between the layers: refused at start-up, not ignored
+    # not a regular expression: refused at start-up, not ignored
     cfg["volatile_db"]["update_filters"] = ["("]
     with pytest.raises(hps.HpsError, match="regular expression"):
         hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
-    cfg["volatile_db"]["update_filters"] = [".+"]
-    cfg["persistent_db"] = {"type": "rocks_db", "path": str(tmp_path / "store"), "update_filters": ["^hps_a.+$"]}
-    with pytest.raises(hps.HpsError, match="differ"):
+    # lists that differ between the layers are fine (round 4 refused them, even [".+"] against the default "^hps_.+$" which
+    # select the same updates): this build updates both layers in one step, an update is taken when either list selects it
+    cfg["volatile_db"]["update_filters"] = ["^hps_upd\\.item$"]
+    cfg["persistent_db"] = {"type": "rocks_db", "path": str(tmp_path / "store"), "update_filters": ["^hps_upd\\.user$", "("]}
+    with pytest.raises(hps.HpsError, match="persistent_db.update_filters"):
         hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    cfg["persistent_db"]["update_filters"] = ["^hps_upd\\.user$"]
+    for t, (k, r) in enumerate(tables):
+        O_dir = tmp_path / f"files_{t}"
+        from oracle import hps_oracle as O
+        O.np_write_table(O_dir, k, r)
+        cfg["models"][0]["sparse_files"][t] = str(O_dir)
+    path2 = tmp_path / "updates2.bin"
+    cfg["update_source"] = dict(src, brokers=str(path2))
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=True)
+    with open(path2, "ab") as f:
+        f.write(hps.encode_update_message("upd", 0, tables[0][0][:5], np.full((5, 4), 3.0, np.float32)))   # persistent list takes it
+        f.write(hps.encode_update_message("upd", 1, tables[1][0][:5], np.full((5, 4), 4.0, np.float32)))   # volatile list takes it
+    ps.drain_update_source(10000)
+    assert ps.update_source_stats()["messages"] == 2 and ps.filtered_update_count() == 0
+    ps.close()
