@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--mode", choices=["sync", "async"], default="sync",
                     help="sync: exact rows (threshold 1.0); async: misses return default, inserted in background")
     ap.add_argument("--distinct-batches", type=int, default=0, help="0: one fresh batch per step")
-    ap.add_argument("--probe-variant", type=int, default=1002, help="probe kernel variant U + 100*no_dedup + 1000*wide (tools/kbench.py)")
+    ap.add_argument("--probe-variant", type=int, default=1002, help="probe kernel: 1002 (default) or 1102 (no tile-local input dedup)")
     ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
     ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
     ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys narrower when every key of the request fits: 1 = 3-byte packing or uint32, 2 = uint32 only, 0 = off")
@@ -377,7 +377,10 @@ def compact_line(res, limit=COMPACT_LIMIT):
     if sl is not None:
         put("triton_abi_slow_requests_ms", [x[0] if isinstance(x, (list, tuple)) else x for x in sl][:8])
     put("triton_abi_rows_wrong", g(ex, "triton_abi", "rows_wrong"))
+    put("triton_abi_pinned_keys_8B_Glps", _scale(g(ex, "triton_abi", "pinned_keys", "lookups_per_s"), 1e-9))
+    put("triton_abi_pinned_keys_p50_ms", g(ex, "triton_abi", "pinned_keys", "p50_request_ms"))
     put("wide_keys_95_8B_Glps", _scale(g(ex, "wide_keys_95", "lookups_per_s"), 1e-9))
+    put("wide_keys_95_8B_pinned_Glps", _scale(g(ex, "wide_keys_95", "pinned_keys_dma_in_place", "lookups_per_s"), 1e-9))
     put("wide_keys_95_frame_of_ref_Glps", _scale(g(ex, "wide_keys_95", "frame_of_reference_default", "lookups_per_s"), 1e-9))
     put("device_driven_tier_Glps", _scale(g(ex, "device_driven_tier", "lookups_per_s"), 1e-9))
     put("c5_dense_ms", g(ex, "c5_lookup_plus_dense", "dense_kernels_ms"))
@@ -1110,14 +1113,14 @@ def main():
                 "kernel_ms_per_call": hbm_ms,
                 "kernel_times": "each kernel's own start/stop timestamps (hipExtLaunchKernel events on the session's stream), averaged over "
                                 "the timed region's calls — the launch durations rocprofv3 reports for the same command "
-                                "(profiles/round3/ab_kernel_timestamps_vs_event_pairs_vs_rocprofv3.txt); HPS_KERNEL_TIMESTAMPS=0 gives "
-                                "hipEventRecord pairs around the launches instead (+5..8 us of queue hand-offs per kernel)",
+                                "(profiles/round3/ab_kernel_timestamps_vs_event_pairs_vs_rocprofv3.txt: hipEventRecord pairs around the "
+                                "launches read 5..8 us more per kernel, the queue hand-offs)",
                 "probe_ms": probe, "gather_ms": gather, "scatter_ms": scatter,
                 # the cache-insert kernel: since round 4 it is enqueued BEHIND the call (the caller does not wait for it;
                 # HPS_DEFER_INSERT=0 puts it back on the return path).  It still occupies the GPU, so the fraction is also given
                 # with its time added to the three kernels that produce the call's rows.
                 "insert_ms": m["insert_ms"],
-                "insert_on_call_path": os.environ.get("HPS_DEFER_INSERT", "1") == "0",
+                "insert_on_call_path": False,   # (session option defer_insert = 0 puts it back)
                 "frac_with_insert": alg / ((hbm_ms + m["insert_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_probe_plus_gather": alg / ((probe + gather) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 # the gather kernel alone on its own bytes (4 B slot per key + 8D per hit) — the dominant kernel
@@ -1320,7 +1323,7 @@ def triton_abi_leg(a, hb, T, R, D, B):
     """The headline workload through the plugin boundary (two instances, pageable KEYS, device OUTPUT0)."""
     return run_abi_driver(hb, ["--tables", T, "--rows", R, "--dim", D, "--batch", B, "--cache-frac", a.cache_frac, "--hit", a.hit,
                                "--zipf", a.zipf, "--instances", a.sessions, "--steps", 20, "--blocks", 12, "--warmup", 5,
-                               "--direct", int(bool(a.direct))], a.triton_timeout)
+                               "--direct", int(bool(a.direct)), "--also-pinned", 4], a.triton_timeout)
 
 
 def c1_leg(a, hb):
@@ -1535,8 +1538,32 @@ def wide_keys_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
                      "(3 bytes each here: the tables' ids are dense above 2^40)")
         out["frame_of_reference_default"] = o
 
+    def with_pinned_keys(out, ctx):
+        # the same wide keys in PAGE-LOCKED host arrays (Triton's pinned input pool; libtriton_hps.so asks for it): DMA in place at
+        # 8 bytes per key, no staging copy on the host
+        run, sessions = ctx["run"], ctx["sessions"]
+        steps = 40
+        raw = [(x + key0).cpu() for x in make_batches_gpu(torch, ctx["gen"], ctx["resident"], ctx["cdf_d"], R, ctx["C"], B, a.hit, steps + 8)]
+        pinned = [x.pin_memory() for x in raw]
+        del raw
+        hb_ = [(p_, run.pack_host(p_.numpy())) for p_ in pinned]
+        rec = []
+        run.run(hb_, 8, 0, "pinned")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run.run(hb_, steps, 8, "pinned", record=rec)
+        torch.cuda.synchronize()
+        o = summarize(rec, N, D, time.perf_counter() - t1, steps)
+        o["key_bytes_over_pcie_mean"] = float(np.mean([r[11] for r in rec]))
+        o["note"] = "the wide keys in page-locked host arrays: DMA'd in place, 8 bytes per key, never read by a host thread"
+        out["pinned_keys_dma_in_place"] = o
+
+    def both(out, ctx):
+        with_pinned_keys(out, ctx)
+        with_default_narrowing(out, ctx)
+
     out, rec = fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct=bool(a.direct), key0=key0, check_rows=True,
-                                    more=with_default_narrowing, narrow_keys=0)
+                                    more=both, narrow_keys=0)
     uniq = float(np.mean([r[6] for r in rec]))
     bytes_step = uniq * 4 * D + N * out["key_bytes_over_pcie_mean"]
     out.update({

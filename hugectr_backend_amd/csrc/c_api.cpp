@@ -485,10 +485,8 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
     const std::string n(name);
     if (n == "timing") s->s->set_timing(value != 0);
     else if (n == "probe_variant" || n == "probe_unroll") {
-      // U + 100*no_dedup: U bucket lines in flight per 8-lane group of the probe kernel, tile-local input dedup on/off
-      const int u = value % 100;
-      if (value < 0 || (u != 1 && u != 2 && u != 4 && u != 8) || (value / 100) % 10 > 1 || value / 1000 > 1)
-        return Error(Code::kInvalidArg, "probe_variant must be U + 100*no_dedup + 1000*wide with U in {1,2,4,8}");
+      // 1002: tile-local input dedup (default); 1102: without it
+      if (value != 1002 && value != 1102) return Error(Code::kInvalidArg, "probe_variant must be 1002 (default) or 1102 (no tile-local input dedup)");
       s->s->set_probe_variant(value);
     } else if (n == "exclusive_kernels") {
       s->s->set_exclusive_kernels(value != 0);

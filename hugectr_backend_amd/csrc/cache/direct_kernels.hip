@@ -247,23 +247,14 @@ hipError_t LaunchPsFetchDirect(const PsIndexDev* d_index, uint32_t T, const Miss
   // 133-GB page-locked host tier, two sessions (profiles/round3/ab_direct_fetch_grid.txt): 32 blocks x 16 groups x 4 rows in
   // flight move 43 GB/s and leave the other session's probe and gather alone (59 / 214 us); 64 blocks saturate the link
   // (0.70 ms = 53.6 GB/s) but the probe next to them takes 151 us and the gather 241, and the step is no shorter; one
-  // row per group needs 128 blocks for the same rate and disturbs more (probe 190 us).  HPS_DIRECT_FETCH_BLOCKS /
-  // HPS_DIRECT_FETCH_ROWS (1, 2, 4, 8) for A/B.
-  static const int max_blocks = [] {
-    const char* e = getenv("HPS_DIRECT_FETCH_BLOCKS");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 32;
-  }();
-  static const int rows_in_flight = [] {
-    const char* e = getenv("HPS_DIRECT_FETCH_ROWS");   // keys (index lines, then rows) in flight per 16-lane group
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 4;
-  }();
+  // row per group needs 128 blocks for the same rate and disturbs more (probe 190 us).
+  constexpr int max_blocks = 32;
+  constexpr int rows_in_flight = 4;   // keys (index lines, then rows) in flight per 16-lane group
   // grid_blocks < 0: a small request (its whole miss path is tens of microseconds and nothing runs next to it long enough to
   // be disturbed): one key per group, up to 128 workgroups — every row of a few thousand misses on the link at once.  With the
   // big-request shape a 28,672-key W&D request took 0.233 / 0.136 / 0.112 ms at 50 / 90 / 99 % hit instead of 0.166 / 0.120 /
   // 0.100 (tests/tools/bench_configs.py c4 direct).
-  const int rows = grid_blocks < 0 ? 1 : (rows_in_flight >= 8 ? 8 : rows_in_flight >= 4 ? 4 : rows_in_flight >= 2 ? 2 : 1);
+  const int rows = grid_blocks < 0 ? 1 : rows_in_flight;
   const uint64_t per_block = 16ull * (uint64_t)rows;
   uint64_t want = (max_unique + per_block - 1) / per_block;
   // grid_blocks > 0: the caller's own bound (the background inserter runs a small grid: it is in no hurry, and
@@ -271,14 +262,8 @@ hipError_t LaunchPsFetchDirect(const PsIndexDev* d_index, uint32_t T, const Miss
   const uint64_t cap = (uint64_t)(grid_blocks > 0 ? grid_blocks : grid_blocks < 0 ? 128 : max_blocks);
   if (want > cap) want = cap;
   const size_t lds = (size_t)(T + 1) * 8 + (size_t)T * (8 + 8 + sizeof(PsIndexDev)) + 16;
-  if (rows >= 8)
-    hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<8>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
-                       d_uniq_keys, d_staging, d_found);
-  else if (rows >= 4)
+  if (rows >= 4)
     hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<4>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
-                       d_uniq_keys, d_staging, d_found);
-  else if (rows >= 2)
-    hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<2>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,
                        d_uniq_keys, d_staging, d_found);
   else
     hipLaunchKernelGGL(hps_ps_fetch_direct_kernel<1>, dim3((uint32_t)want), dim3(256), (uint32_t)lds, stream, d_index, T, d_md, d_key_start,

@@ -241,11 +241,8 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 0 && v <= 8) { age_shift_ = (uint32_t)v; call_clock_ = true; insert_age_ = 32; }
   }
-  if (const char* e = std::getenv("HPS_LRU_UNITS_PER_TURNOVER")) {
-    const long v = std::strtol(e, nullptr, 10);
-    if (v >= 1 && v <= 4096) units_per_turnover_ = (uint32_t)v;
-  }
   if (!p.cache_admission) admit_log2_ = 0;   // ps.json "gpucache_admission": false
+  small_interval_ = (uint32_t)std::max(1, p.small_miss_insert_interval);
   if (const char* e = std::getenv("HPS_LRU_ADMIT")) {
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 0 && v <= 15) admit_log2_ = (uint32_t)v;
@@ -681,10 +678,9 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
     // instances x 4 shards) kernels that had started stood still for 60-160 ms with the GPU idle until the scheduler's quantum
     // expired — 35 ms per round of requests against 4 ms with normal-priority side streams
     // (profiles/round5/ab_side_priority_many_sessions.txt; rocprofv3: hps_pull16_kernel "running" for 283 ms).
-    static const bool hi = [] { const char* e = std::getenv("HPS_SIDE_PRIORITY"); return !(e && e[0] == '0'); }();
     int least = 0, greatest = 0;
     side_hi_ = false;
-    if (hi && !max_keys_override && device_ >= 0 && device_ < kMaxSideDevices &&
+    if (!max_keys_override && device_ >= 0 && device_ < kMaxSideDevices &&
         hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
       if (g_side_hi[device_].fetch_add(1, std::memory_order_relaxed) < 2) side_hi_ = true;
       else g_side_hi[device_].fetch_sub(1, std::memory_order_relaxed);
@@ -696,17 +692,6 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
     HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   for (hipEvent_t* e : {&ev_t0_, &ev_t1_, &ev_f0_, &ev_f1_, &ev_c1_, &ev_g0_, &ev_g1_, &ev_s0_, &ev_s1_, &ev_i0_, &ev_i1_}) HIP_TRY(hipEventCreate(e));
   for (hipEvent_t& e : ev_lane_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  if (const char* e = std::getenv("HPS_EXCLUSIVE_KERNELS")) exclusive_ = std::strtol(e, nullptr, 10) != 0;
-  if (const char* e = std::getenv("HPS_DIRECT_SPLIT")) direct_split_ = std::strtol(e, nullptr, 10) != 0;
-  if (const char* e = std::getenv("HPS_KEY_FRAME_OF_REFERENCE")) frame_of_reference_ = std::strtol(e, nullptr, 10) != 0;
-  if (const char* e = std::getenv("HPS_FUSED_UNIQUE")) fused_unique_ = std::strtol(e, nullptr, 10) != 0;
-  if (const char* e = std::getenv("HPS_KERNEL_TIMESTAMPS")) kernel_stamps_ = std::strtol(e, nullptr, 10) != 0;
-  if (const char* e = std::getenv("HPS_SPLIT_PROBE")) split_probe_ = std::strtol(e, nullptr, 10) != 0;   // A/B switches
-  if (const char* e = std::getenv("HPS_XCD_WALK")) xcd_walk_ = std::strtol(e, nullptr, 10) != 0;
-  if (const char* e = std::getenv("HPS_PROBE_VARIANT")) probe_variant_ = (int)std::strtol(e, nullptr, 10);
-  if (const char* e = std::getenv("HPS_DEFER_INSERT")) defer_insert_ = std::strtol(e, nullptr, 10) != 0;
-  if (const char* e = std::getenv("HPS_IN_PLACE_KB")) in_place_bytes_ = (size_t)std::max(0l, std::strtol(e, nullptr, 10)) << 10;
-  if (const char* e = std::getenv("HPS_SIDE_SCATTER_MB")) side_bytes_ = (size_t)std::max(0l, std::strtol(e, nullptr, 10)) << 20;
 
   HPS_RETURN_IF_ERROR(PinAlloc(&h_keys_pinned_, max_keys_, hipHostMallocMapped));
   {
@@ -959,7 +944,7 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
       uint8_t* dev8 = reinterpret_cast<uint8_t*>(d_keys_);
       auto body = [&](size_t i) {
         const Task& tk = tasks[i];
-        if (width == 8) { memcpy(h_keys_pinned_ + tk.off, tk.src, tk.n * sizeof(int64_t)); return; }
+        if (width == 8) { CopyKeys64Streaming(tk.src, tk.n, h_keys_pinned_ + tk.off); StreamFence(); return; }
         const uint64_t high = width == 4 ? PackKeys32(tk.src, tk.n, reinterpret_cast<uint32_t*>(dst8) + tk.off, tk.base)
                                          : PackKeys24(tk.src, tk.n, dst8 + 3 * tk.off, tk.base);
         if (high >> (8 * width)) high_or.fetch_or(high, std::memory_order_relaxed);
@@ -1134,7 +1119,7 @@ Status LookupSession::PrepareCall(const int64_t* d_keys_flat, float* const* d_ou
     call_tag_ = 1;
   }
   work_.num_tiles = tiles;
-  { const char* e = std::getenv("HPS_PROBE_XCD_TILES"); work_.xcd_tiles = (tiles >= 64 && (e ? std::strtol(e, nullptr, 10) != 0 : probe_xcd_tiles_)) ? 1u : 0u; }
+  work_.xcd_tiles = (tiles >= 64 && probe_xcd_tiles_) ? 1u : 0u;
   work_.call_tag = call_tag_;
   const size_t block_bytes = block_tiles_off_ + (size_t)tiles * sizeof(TileDesc);
   if (zc_control_) {
@@ -1180,12 +1165,11 @@ Status LookupSession::WaitPushedSeq(uint32_t want, hipEvent_t ev) {
   // poll the sequence word for a while (the usual wait is tens of microseconds), looking at the event now and then so that a
   // failed stream ends the wait; a long wait (a millisecond of uploads ahead of the push) goes to the runtime's own wait
   const auto t0 = std::chrono::steady_clock::now();
-  static const long kSpinUs = [] { const char* e = std::getenv("HPS_WAIT_SPIN_US"); return e ? std::strtol(e, nullptr, 10) : 300l; }();
-  for (uint32_t i = 1; kSpinUs > 0; ++i) {
+  constexpr long kSpinUs = 300;
+  for (uint32_t i = 1;; ++i) {
     if (landed()) return Status::Ok();
     SpinPause();
-    static const bool kYield = [] { const char* e = std::getenv("HPS_POOL_YIELD"); return !(e && e[0] == '0'); }();
-    if ((i & 127u) == 0 && kYield) sched_yield();   // a waiter must not keep a CPU from a pool worker that has work (thread_pool.cpp)
+    if ((i & 127u) == 0) sched_yield();   // a waiter must not keep a CPU from a pool worker that has work (thread_pool.cpp)
     if ((i & 511u) == 0) {
       const hipError_t q = hipEventQuery(ev);
       if (q != hipSuccess && q != hipErrorNotReady) return Error(Code::kInternal, "lookup stream failed: ", hipGetErrorString(q));
@@ -1705,11 +1689,8 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     } else {
       HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, ss));
     }
-    static const size_t kPieceFloats = [] {   // upload piece: HPS_PIECE_MB (A/B switch), default 4 MB
-      const char* e = std::getenv("HPS_PIECE_MB");
-      const long v = e ? std::strtol(e, nullptr, 10) : 0;
-      return (size_t)(v > 0 ? v : 4) * (1u << 20) / sizeof(float);
-    }();
+    // upload piece: 4 MB (8- and 16-MB pieces: no gain, profiles/round4/ab_upload_piece_size_and_sessions.txt)
+    constexpr size_t kPieceFloats = (size_t)4 * (1u << 20) / sizeof(float);
     std::vector<HierParameterServer::FetchJob> jobs;
     size_t piece_begin = SIZE_MAX, piece_end = 0;
     bool used_copy_stream = false;
@@ -1795,6 +1776,17 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       // the call's rows are complete behind this point of the stream: that is what the caller waits for
       if (timing_) (void)hipEventRecord(ev_c1_, stream_);
       HPS_RETURN_IF_ERROR(PushWords(0, ev_done_, &rows_seq));
+    }
+    // Few missed rows (they stayed where the host gathered them): only every n-th such call of the session pays for the writer
+    // window (config.h: gpucache_small_miss_insert_interval); the others return their rows and leave them uncached.
+    // (missed rows that were uploaded but still scattered on the second stream — up to side_scatter_mb, a call at 99 % hit: every
+    //  n/2-th call)
+    const uint32_t ins_every = !(defer && side) ? 1u : in_place ? cache_->small_insert_interval() : std::max(1u, cache_->small_insert_interval() / 2);
+    if (ins_every > 1 && (++small_calls_ % ins_every) != 0) {
+      cache_->AddDropped(uq);
+      HPS_RETURN_IF_ERROR(WaitPushedSeq(rows_seq, ev_done_));
+      if (timing_) (void)hipEventElapsedTime(&last_scatter_ms_, ev_s0_, ev_s1_);
+      return Status::Ok();
     }
     cache_->BeginWrite(stream_);
     tr[2] = since();

@@ -146,6 +146,10 @@ class EmbeddingCache {
     const uint32_t now8 = Stamp8(epoch);
     return now8 | (((now8 + kStampMod - insert_age_) % kStampMod) << 8) | ((epoch & 0xFFu) << 16) | ((admit_log2_ & 15u) << 24);
   }
+  // every n-th small-miss call of a session inserts (InferenceParams::small_miss_insert_interval; 1 when the admission rule is off)
+  uint32_t small_insert_interval() const { return admit_log2_ == 0 ? 1u : small_interval_; }
+  void AddDropped(uint64_t n) { std::lock_guard<std::mutex> lk(stat_mu_); counters_.dropped += n; }
+  uint32_t small_interval_ = 4;
   uint32_t admit_log2_ = 4;   // HPS_LRU_ADMIT: a new key does not take a slot hit more recently than the insert age, except one
                               // new key in 2^this (0 = every new key takes the bucket's oldest slot, rounds 1-3's behaviour)
   uint32_t insert_age_ = 160; // recency units a newly inserted key is aged by (HPS_LRU_INSERT_AGE; 0 = plain LRU insertion),
@@ -388,6 +392,7 @@ class LookupSession {
   Status PushWords(uint32_t words, hipEvent_t ev = nullptr, uint32_t* seq_out = nullptr, hipStream_t on = nullptr);
   Status WaitPushed();                // host: until the last PushWords has landed (or the stream reports an error)
   Status WaitPushedSeq(uint32_t seq, hipEvent_t ev);   // ... until the push that carried `seq` (or a later one) has landed
+  uint32_t small_calls_ = 0;          // small-miss calls of this session so far (every small_insert_interval()-th inserts)
   bool defer_insert_ = true;          // option "defer_insert" / HPS_DEFER_INSERT: the insert kernel is not on the call's return path
   size_t in_place_bytes_ = 1u << 20;  // option "in_place_kb" / HPS_IN_PLACE_KB: missed rows of a chunk up to this size are read by
                                       // the kernels where the host gathered them (page-locked staging), no upload

@@ -958,36 +958,18 @@ hipError_t LaunchProbeTiles(const CallDesc* d_call, const TableCacheDev* d_table
                             bool tail, hipStream_t stream, KTimer kt) {
   if (w.num_tiles == 0) return hipSuccess;
   if (tail && !ProbeTailAvailable(variant)) return hipErrorInvalidValue;
-  // variant = U + 100 * no_dedup + 1000 * wide   (U in {2,4,8}: bucket lines in flight per 16-lane group; wide: 512 threads
-  // per tile instead of 256 — twice the groups probing per workgroup, 32 waves per CU at 4 workgroups)
-  const int U = variant % 100;
+  // variant: 1002 = the default (tile-local input dedup, two bucket lines in flight per 8-lane group, 512 threads per tile);
+  // 1102 = the same without the tile-local dedup (the fallback a deployment can select, session option "probe_variant": every
+  // key probes its bucket itself; 3-5 us slower on Zipf traffic).  Rounds 2-4 carried 24 instantiations (U in {1,2,4,8} x
+  // 256/512 threads x dedup x tail) for the A/B runs recorded in profiles/round2..3/kbench_*.txt; they went with round 5.
   const bool dedup = (variant / 100) % 10 == 0;
-  const bool wide = (variant / 1000) % 10 != 0;
   const uint32_t probe_grid = w.num_tiles;
-#define HPS_PT(DD, UU, TT)                                                                                             \
-  do {                                                                                                                 \
-    if (tail && DD)                                                                                                    \
-      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, UU, TT, DD>), dim3(probe_grid), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);      \
-    else                                                                                                               \
-      hipExtLaunchKernelGGL((hps_probe_tile_kernel<DD, UU, TT, false>), dim3(probe_grid), dim3(TT), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);   \
-  } while (0)
-#define HPS_PT_T(DD, UU)                          \
-  do {                                            \
-    if (wide) HPS_PT(DD, UU, 512);                \
-    else HPS_PT(DD, UU, 256);                     \
-  } while (0)
-#define HPS_PT_U(DD)                              \
-  do {                                            \
-    if (U == 1) HPS_PT_T(DD, 1);                  \
-    else if (U == 2) HPS_PT_T(DD, 2);             \
-    else if (U == 8) HPS_PT_T(DD, 8);             \
-    else HPS_PT_T(DD, 4);                         \
-  } while (0)
-  if (dedup) HPS_PT_U(true);
-  else HPS_PT_U(false);
-#undef HPS_PT_U
-#undef HPS_PT_T
-#undef HPS_PT
+  if (dedup && tail)
+    hipExtLaunchKernelGGL((hps_probe_tile_kernel<true, 2, 512, true>), dim3(probe_grid), dim3(512), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);
+  else if (dedup)
+    hipExtLaunchKernelGGL((hps_probe_tile_kernel<true, 2, 512, false>), dim3(probe_grid), dim3(512), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);
+  else
+    hipExtLaunchKernelGGL((hps_probe_tile_kernel<false, 2, 512, false>), dim3(probe_grid), dim3(512), 0, stream, kt.start, kt.stop, 0, d_call, d_tables, w);
   return hipGetLastError();
 }
 

@@ -5,8 +5,40 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 
 namespace hps {
+
+// 8 bytes per key (ids without structure: hashed 64-bit ids do not narrow): a plain copy into the page-locked staging buffer,
+// with NON-TEMPORAL stores — the staging buffer is written once and read by the DMA engine, never by this core: a cached
+// store would first read every destination line (read-for-ownership), a third of the copy's DRAM traffic.  The caller issues
+// the store fence before it hands the buffer to the copy engine (StreamFence).
+inline void CopyKeys64Streaming(const int64_t* src, size_t n, int64_t* dst) {
+#if defined(__x86_64__)
+  size_t j = 0;
+  while (j < n && ((uintptr_t)(dst + j) & 15u)) { dst[j] = src[j]; ++j; }   // up to the first 16-byte boundary
+  for (; j + 8 <= n; j += 8) {
+    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + j));
+    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + j + 2));
+    const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + j + 4));
+    const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + j + 6));
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + j), a);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + j + 2), b);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + j + 4), c);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + j + 6), d);
+  }
+  for (; j < n; ++j) dst[j] = src[j];
+#else
+  memcpy(dst, src, n * sizeof(int64_t));
+#endif
+}
+inline void StreamFence() {
+#if defined(__x86_64__)
+  _mm_sfence();
+#endif
+}
 
 // Frame of reference: a table's keys are narrowed as offsets from `base` (the table's smallest key, HostTable::min_key — feature
 // ids that carry a per-table offset, or any id space that starts high, narrow like ids that start at 0); a key below the

@@ -666,11 +666,7 @@ Status HierParameterServer::FetchMulti(const std::vector<FetchJob>& jobs) {
   size_t total = 0;
   for (const auto& j : jobs) total += j.n;
   const size_t threads = ThreadPool::Serving().size() + 1;
-  static const size_t tasks_per_thread = [] {
-    const char* e = std::getenv("HPS_FETCH_TASKS_PER_THREAD");
-    const long v = e ? std::strtol(e, nullptr, 10) : 0;
-    return (size_t)(v > 0 ? v : 2);
-  }();
+  constexpr size_t tasks_per_thread = 2;
   size_t chunk = total / (threads * tasks_per_thread);
   chunk = (chunk + 7) & ~(size_t)7;
   chunk = std::min<size_t>(256, std::max<size_t>(64, chunk));

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "../ps/thread_pool.h"
+#include "key_pack.h"
 #include "shard_kernels.h"
 
 namespace hps {
@@ -276,7 +277,7 @@ Status ShardedEntrySession::lookup(const void* const* h_keys_per_table, float* c
     while (g0 < tasks.size()) {
       size_t g1 = g0, keys_in_group = 0;
       while (g1 < tasks.size() && (keys_in_group == 0 || keys_in_group + tasks[g1].n <= kGroupKeys)) keys_in_group += tasks[g1++].n;
-      auto body = [&](size_t i) { const Task& tk = tasks[g0 + i]; memcpy(h_keys_ + tk.off, tk.src, tk.n * sizeof(int64_t)); };
+      auto body = [&](size_t i) { const Task& tk = tasks[g0 + i]; CopyKeys64Streaming(tk.src, tk.n, h_keys_ + tk.off); StreamFence(); };
       if (g1 - g0 <= 2) for (size_t i = 0; i < g1 - g0; ++i) body(i);
       else ThreadPool::Serving().ParallelFor(g1 - g0, body);
       const size_t first = tasks[g0].off, count = tasks[g1 - 1].off + tasks[g1 - 1].n - first;

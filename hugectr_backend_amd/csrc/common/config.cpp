@@ -295,6 +295,9 @@ Status ParseParameterServerJson(const Json& root, ParameterServerConfig* out) {
     HPS_RETURN_IF_ERROR(ParseField(p.enable_pagelock, j, "enable_pagelock", false));
     HPS_RETURN_IF_ERROR(ParseField(p.cache_load_factor, j, "gpucache_load_factor", false));
     HPS_RETURN_IF_ERROR(ParseField(p.cache_admission, j, "gpucache_admission", false));
+    HPS_RETURN_IF_ERROR(ParseField(p.small_miss_insert_interval, j, "gpucache_small_miss_insert_interval", false));
+    if (p.small_miss_insert_interval < 1 || p.small_miss_insert_interval > 1024)
+      return Error(Code::kInvalidArg, "Model '", p.model_name, "': gpucache_small_miss_insert_interval must be in [1, 1024]");
     HPS_RETURN_IF_ERROR(ParseField(p.ps_direct_access, j, "ps_direct_access", false));
     {
       // "table_sharding": "hash" — the model's GPU caches are SHARDS, not replicas: entry s of deployed_device_list holds the

@@ -103,6 +103,15 @@ struct InferenceParams {  // backend.cpp:318-516
   // turnovers (its row is served, it just is not cached on that call; one such key in 16 is let in regardless); false = every
   // missed key is inserted, evicting its bucket's least recently used key — the reference's cache
   bool cache_admission = true;
+  // "gpucache_small_miss_insert_interval": n (default 4; 1 = every call): a synchronous call whose missed rows are FEW (they stay
+  // where the host gathered them: at most in_place_kb, 1 MB) inserts them only every n-th such call of its session; the other
+  // calls serve their missed rows exactly and leave them uncached (counted as `dropped`); calls whose missed rows were uploaded
+  // but still fit the second stream's scatter (side_scatter_mb, 16 MB: a call at 99 % hit) insert every n/2-th time.  Near-all-hit traffic — where a
+  // production cache lives (docs/architecture.md:65-67) — otherwise pays a writer window on every call: the insert kernel waits
+  // for every other session's hit gather and every later probe waits for it (15-35 us of cross-queue hand-off each way,
+  // profiles/round4/timeline_99.9pct_hit_after.txt: 174 us of idle GPU per pair of calls).  A key that keeps being asked for
+  // enters within n calls, like the one-in-16 rule of the admission policy; with gpucache_admission = false every call inserts.
+  int small_miss_insert_interval = 4;
   // "ps_direct_access": the GPU resolves missed keys through a device-resident index of the host tier and reads
   // the rows in place from pinned host memory over PCIe (no host threads, no staging copy).  Needs gpucache.
   bool ps_direct_access = false;

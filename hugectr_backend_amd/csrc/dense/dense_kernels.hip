@@ -377,8 +377,7 @@ hipError_t LaunchDenseMlp(const DenseMlpDesc& d, const float* d_x, uint64_t batc
   //  at once as a K-chunk of layer 2, weights read once per 256 samples: 106 MB of L2 reads per batch instead of 205 — was
   //  measured at the same 235-240 us per forward as this one and withdrawn: below ~200 MB the kernel is no longer bound by the
   //  weight reads but by the serial chain of barriers and LDS round trips of one resident block per CU.)
-  static const bool force64 = [] { const char* e = getenv("HPS_DENSE_MLP_ROWS"); return e && atoi(e) == 64; }();
-  bool fits128 = !force64 && batch > (uint64_t)kMlpRows;
+  bool fits128 = batch > (uint64_t)kMlpRows;
   for (uint32_t l = 0; l < d.num_layers; ++l) fits128 = fits128 && d.dims[l] / 32 <= 8u * kMlp2MaxUnits;
   const size_t lds128 = (size_t)kMlp2Rows * (d.max_dim + kLdsPad) * sizeof(_Float16);
   if (fits128 && lds128 <= (160u << 10)) {
@@ -417,7 +416,6 @@ hipError_t LaunchDenseInteract(const float* d_emb, const void* d_bottom_f16, uin
   const uint64_t cap = (uint64_t)cu_count * per_cu;
   if (want > cap) want = cap;
   const uint32_t per_lane = (T * (D / 4) + 63) / 64;
-  static const bool nt = [] { const char* e = getenv("HPS_DENSE_NT"); return e ? atoi(e) != 0 : true; }();   // A/B switch
   auto go = [&](auto kernel) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -425,18 +423,12 @@ hipError_t LaunchDenseInteract(const float* d_emb, const void* d_bottom_f16, uin
                        batch, T, D, out_stride, reinterpret_cast<_Float16*>(d_out_f16));
     return hipGetLastError();
   };
-  if (nt) {
-    if (per_lane <= 4) return go(hps_dense_interact_kernel<4, true>);
-    if (per_lane <= 8) return go(hps_dense_interact_kernel<8, true>);
-    if (per_lane <= 13) return go(hps_dense_interact_kernel<13, true>);   // T = 26, D = 128: 13 chunks exactly (fewer registers than <16>)
-    if (per_lane <= 16) return go(hps_dense_interact_kernel<16, true>);
-    return go(hps_dense_interact_kernel<0, true>);
-  }
-  if (per_lane <= 4) return go(hps_dense_interact_kernel<4, false>);
-  if (per_lane <= 8) return go(hps_dense_interact_kernel<8, false>);
-  if (per_lane <= 13) return go(hps_dense_interact_kernel<13, false>);
-  if (per_lane <= 16) return go(hps_dense_interact_kernel<16, false>);
-  return go(hps_dense_interact_kernel<0, false>);
+  // (non-temporal row loads: 190 -> 178-186 us under rocprofv3, profiles/round4/ab_dense_interaction_nontemporal_loads.txt)
+  if (per_lane <= 4) return go(hps_dense_interact_kernel<4, true>);
+  if (per_lane <= 8) return go(hps_dense_interact_kernel<8, true>);
+  if (per_lane <= 13) return go(hps_dense_interact_kernel<13, true>);   // T = 26, D = 128: 13 chunks exactly (fewer registers than <16>)
+  if (per_lane <= 16) return go(hps_dense_interact_kernel<16, true>);
+  return go(hps_dense_interact_kernel<0, true>);
 }
 
 }  // namespace hps

@@ -31,10 +31,7 @@ void* SlabAlloc(size_t bytes) {
   const size_t rounded = (bytes + align - 1) / align * align;
   if (posix_memalign(&p, align, rounded) != 0) return nullptr;
 #ifdef MADV_HUGEPAGE
-  // HPS_HOST_THP=0: leave the slab to the system's default page policy (experiment: background huge-page collapse
-  // takes the process's mmap lock)
-  static const bool thp = [] { const char* e = std::getenv("HPS_HOST_THP"); return !(e && e[0] == '0'); }();
-  if (rounded >= kHuge && thp) madvise(p, rounded, MADV_HUGEPAGE);
+  if (rounded >= kHuge) madvise(p, rounded, MADV_HUGEPAGE);
 #endif
   return p;
 }
@@ -509,9 +506,6 @@ Status HostTable::LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, 
   return FinishLoad(pool);
 }
 
-__attribute__((target("avx512f"))) static inline void CopyRowAvx512(const float* src, float* dst, uint32_t D) {
-  for (uint32_t c = 0; c < D; c += 16) _mm512_stream_ps(dst + c, _mm512_loadu_ps(src + c));
-}
 
 int64_t HostTable::FindUnlocked(int64_t key) const {
   if (key == HPS_EMPTY_KEY) return has_sentinel_ ? sentinel_row_ : -1;
@@ -545,28 +539,13 @@ size_t HostTable::Fetch(const int64_t* keys, size_t n, float* out, size_t stride
   // being prefetched.  Rows are written with non-temporal stores when 16-B aligned: the destination
   // (pinned staging / the response buffer) is not read back by this thread, and a regular store would first
   // fetch every destination line (read-for-ownership), doubling the memory traffic of the gather.
-  // B (rows per block) and the prefetch hint are tunable for experiments: HPS_FETCH_BLOCK (1..32), HPS_FETCH_PF
-  // (0 = nta, 1 = t2, 2 = t1, 3 = t0, 4 = no row prefetch), HPS_FETCH_AVX512 (0/1: 64-B loads and streaming stores).
-  constexpr size_t kMaxB = 32;
-  static const size_t B = [] {
-    const char* e = std::getenv("HPS_FETCH_BLOCK");
-    const long v = e ? std::strtol(e, nullptr, 10) : 0;
-    return (size_t)(v >= 1 && v <= (long)kMaxB ? v : 8);
-  }();
-  static const int pf = [] {
-    const char* e = std::getenv("HPS_FETCH_PF");
-    const long v = e ? std::strtol(e, nullptr, 10) : 0;
-    return (int)(v >= 0 && v <= 4 ? v : 0);
-  }();
-  static const bool wide = [] {
-    const char* e = std::getenv("HPS_FETCH_AVX512");
-    const bool want = e ? std::strtol(e, nullptr, 10) != 0 : false;
-    return want && __builtin_cpu_supports("avx512f");
-  }();
+  // Blocks of 8 rows, non-temporal prefetch hint, 16-B streaming stores: measured on the box's EPYC 9575F with tools/host_gather_bench.py
+  // (rounds 2-3, then behind environment switches that went with round 5): 6-16 rows per block and any hint are inside the
+  // run-to-run spread (80-105 GB/s), no row prefetch 53-58 GB/s, blocks of 2 69 GB/s, 64-B AVX-512 copies no gain.
+  constexpr size_t B = 8;
   const size_t nb = (n + B - 1) / B;
-  int64_t row[3][kMaxB];
+  int64_t row[3][B];
   const bool nt_ok = (row_bytes % 16 == 0) && (stride % 4 == 0) && (((uintptr_t)out & 15u) == 0);
-  const bool wide_ok = wide && nt_ok && (row_bytes % 64 == 0) && (stride % 16 == 0) && (((uintptr_t)out & 63u) == 0);
   for (size_t j = 0; j < nb + 2; ++j) {
     if (j < nb) {  // stage A: prefetch index slots of block j
       const size_t base = j * B, m = std::min(B, n - base);
@@ -584,13 +563,7 @@ size_t HostTable::Fetch(const int64_t* keys, size_t n, float* out, size_t stride
         r[i] = FindUnlocked(keys[base + i]);
         if (r[i] >= 0) {
           const char* p = reinterpret_cast<const char*>(rows_ + (size_t)r[i] * D);
-          switch (pf) {
-            case 0: for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(p + o, 0, 0); break;
-            case 1: for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(p + o, 0, 1); break;
-            case 2: for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(p + o, 0, 2); break;
-            case 3: for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(p + o, 0, 3); break;
-            default: break;
-          }
+          for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(p + o, 0, 0);
         }
       }
     }
@@ -601,9 +574,7 @@ size_t HostTable::Fetch(const int64_t* keys, size_t n, float* out, size_t stride
         float* dst = out + (base + i) * stride;
         if (r[i] >= 0) {
           const float* src = rows_ + (size_t)r[i] * D;
-          if (wide_ok) {
-            CopyRowAvx512(src, dst, D);
-          } else if (nt_ok) {
+          if (nt_ok) {
             for (uint32_t c = 0; c < D; c += 4) _mm_stream_ps(dst + c, _mm_loadu_ps(src + c));
           } else {
             memcpy(dst, src, row_bytes);

@@ -73,14 +73,7 @@ ThreadPool& ThreadPool::Serving() {
     // leave two CPUs of the budget to the callers (session threads, HIP runtime threads)
     const size_t c = DefaultConcurrency();
     return std::max<size_t>(1, std::min<size_t>(64, c > 4 ? c - 3 : c / 2));
-  }(), [] {
-    // idle spin of the workers after a job, microseconds (HPS_SERVING_SPIN_US; 0 would turn the lock-free loop slots off)
-    if (const char* e = std::getenv("HPS_SERVING_SPIN_US")) {
-      const long v = std::strtol(e, nullptr, 10);
-      if (v >= 1 && v <= 10000) return (unsigned)v;
-    }
-    return 100u;
-  }());
+  }(), /*idle spin of the workers after a job, microseconds*/ 100u);
   return pool;
 }
 
@@ -114,8 +107,8 @@ void ThreadPool::RunLoop(Loop* l) {
   }
 }
 
-// HPS_POOL_YIELD=0: waiters and idle spinners never yield (A/B of the round-4 change)
-static const bool kPoolYield = [] { const char* e = std::getenv("HPS_POOL_YIELD"); return !(e && e[0] == '0'); }();
+// waiters and idle spinners yield the CPU now and then (round 4: profiles/round4/ab_pool_yield_tail_latency.txt)
+static constexpr bool kPoolYield = true;
 
 static inline void CpuRelax() {
 #if defined(__x86_64__) || defined(__i386__)

@@ -241,7 +241,7 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
  * 1000 = always synchronous insertion, 0 = always asynchronous), "host_gather" (0/1: on a ps_direct_access cache, serve
  * this session's misses the reference's way — host threads gather, hipMemcpyAsync ships — e.g. to compare the two tiers
  * on one deployment), "split_probe" (0/1: read the miss counts back before / after the hit gather), and the kernel A/B
- * switches "probe_variant" (U + 100*no_dedup + 1000*wide, U in {1,2,4,8}), "xcd_walk" (0/1), "exclusive_kernels" (0/1), "fused_unique" (0/1: the
+ * switches "probe_variant" (1002 default; 1102: no tile-local input dedup), "xcd_walk" (0/1), "exclusive_kernels" (0/1), "fused_unique" (0/1: the
  * call-wide unique misses are found in the probe kernel's tail, default 1), "keys_pinned_check" (0/1: DMA flat
  * page-locked key arrays in place instead of staging them), "narrow_keys" (pageable keys cross PCIe at the width the
  * request needs — 0: always 8 bytes; 1 (default): 3 bytes each when every key is in [0, 2^24), uint32 when in [0, 2^32);

@@ -479,11 +479,11 @@ def test_unique_hit_count_over_a_cache_of_several_bitmap_parts():
         cache.wait_async()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 8, 102, 104, 108, 1001, 1002, 1004, 1008, 1102])
+@pytest.mark.parametrize("variant", [1002, 1102, -1002])
 @pytest.mark.parametrize("xcd_walk", [0, 1])
 def test_probe_variants_and_gather_walks_agree(variant, xcd_walk):
-    """Every variant of the probe kernel (bucket lines in flight per group; with and without the tile-local input
-    dedup) and both chunk walks of the gather kernel return the same rows and counts: ragged tables that end inside a
+    """Every instantiation of the probe kernel that ships (with the tile-local input dedup — unique misses in its tail or, -1002,
+    in a launch of their own — and without it) and both chunk walks of the gather kernel return the same rows and counts: ragged tables that end inside a
     tile, tiles full of one key, keys absent everywhere, the sentinel key, an empty table."""
     from oracle import hps_oracle as O
     rng = np.random.default_rng(variant * 2 + xcd_walk)
@@ -491,7 +491,9 @@ def test_probe_variants_and_gather_walks_agree(variant, xcd_walk):
     defaults = [0.5, 1.5, 2.5, 3.5]
     ps, cache, s = _mk(f"var{variant}_{xcd_walk}", tables, maxcat=[2, 1, 1, 1], defaults=defaults, gpucacheper=0.3, max_batch=8192,
                        hit_rate_threshold=0.9)
-    s.set_option("probe_variant", variant)
+    s.set_option("probe_variant", abs(variant))
+    if variant < 0:
+        s.set_option("fused_unique", 0)
     s.set_option("xcd_walk", xcd_walk)
     for it in range(6):
         nk = [int(rng.integers(1, 12000)), int(rng.integers(0, 8000)), int(rng.integers(0, 2100)), 0 if it == 2 else int(rng.integers(1, 3000))]
@@ -845,7 +847,8 @@ def test_insert_left_behind_the_call_is_visible_to_every_later_observer(direct, 
     tables = make_tables([(R, D)] * T)
     # (buckets filled to a quarter: no bucket is full, so that "every missed key is resident afterwards" holds to the key)
     ps, cache, s0 = _mk(f"defer{defer}{int(direct)}_{base_misses}", tables, maxcat=[1] * T, gpucacheper=0.5, max_batch=60000,
-                        extra={"ps_direct_access": direct, "gpucache_load_factor": 0.25})
+                        extra={"ps_direct_access": direct, "gpucache_load_factor": 0.25,
+                               "gpucache_small_miss_insert_interval": 1})   # (every call inserts: this test watches the insert)
     s1 = hps.LookupSession.create(ps, f"defer{defer}{int(direct)}_{base_misses}", cache)
     for s in (s0, s1):
         s.set_option("defer_insert", defer)
@@ -885,6 +888,51 @@ def test_insert_left_behind_the_call_is_visible_to_every_later_observer(direct, 
         assert other.last_stats().misses == 0, it
         assert np.array_equal(_bits(out2), _bits(co.lookup(q2, [m.size for m in missing], [0.0] * T))), it
     assert s0.last_stats().insert_ms >= 0.0
+
+
+@pytest.mark.parametrize("interval,admission", [(4, True), (2, True), (1, True), (4, False)])
+def test_small_miss_calls_insert_every_nth_time(interval, admission):
+    """ps.json gpucache_small_miss_insert_interval (default 4): a big request that missed only a few rows (they are read where the
+    host gathered them) serves them exactly and inserts them only every n-th such call of its session — near-all-hit traffic does
+    not pay a writer window per call.  What is left out is counted as dropped; with the admission rule off every call inserts."""
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(interval)
+    T, R, D = 2, 90000, 64
+    tables = make_tables([(R, D)] * T, seed=77)
+    name = f"smi{interval}{int(admission)}"
+    ps, cache, s0 = _mk(name, tables, maxcat=[1] * T, gpucacheper=0.5, max_batch=80000,
+                        extra={"gpucache_load_factor": 0.25, "gpucache_small_miss_insert_interval": interval, "gpucache_admission": admission})
+    co = O.COracle()
+    for k, r in tables:
+        co.add_table_arrays(k, r)
+    c0 = cache.counters()
+    every = interval if admission else 1
+    expect_inserted = expect_dropped = 0
+    for it in range(1, 9):
+        nk = [75000, 70000]                                # a "big" request (> 128 K keys)
+        parts, missing = [], []
+        for t, ((tk, _), n) in enumerate(zip(tables, nk)):
+            res = tk[cache.query(t, tk) >= 0]
+            cold = tk[cache.query(t, tk) < 0]
+            q = rng.choice(res, n)
+            m = rng.choice(cold, 30 + it, replace=False)
+            q[rng.choice(n, m.size, replace=False)] = m
+            parts.append(q)
+            missing.append(m)
+        q = np.concatenate(parts).astype(np.int64)
+        out = s0.lookup(q, nk).cpu().numpy()
+        assert np.array_equal(_bits(out), _bits(co.lookup(q, nk, [0.0] * T))), it     # exact rows whether inserted or not
+        new = sum(m.size for m in missing)
+        inserts = it % every == 0
+        expect_inserted += new if inserts else 0
+        expect_dropped += 0 if inserts else new
+        for t, m in enumerate(missing):
+            assert bool((cache.query(t, m) >= 0).all()) == inserts and bool((cache.query(t, m) >= 0).any()) == inserts, (it, t)
+        c = cache.counters()
+        assert c["inserted"] - c0["inserted"] == expect_inserted and c["dropped"] - c0["dropped"] == expect_dropped, (it, c)
+        assert c["unique_misses"] - c0["unique_misses"] == expect_inserted + expect_dropped
+    s0.close()
 
 
 def test_two_sessions_near_all_hit_stress_rows_stay_exact():

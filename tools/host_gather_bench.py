@@ -2,7 +2,7 @@
 through hps_server_fetch (the serving pool fans them out), rows written into a reused buffer.  No GPU involved.
 
     python tools/host_gather_bench.py [rows=10000000] [keys=81920] [iters=60]
-Environment knobs of csrc/ps/host_table.cpp (experiments): HPS_FETCH_BLOCK, HPS_FETCH_PF, HPS_FETCH_AVX512.
+(The block size, prefetch hint and copy width this tool swept in rounds 2-3 are constants of csrc/ps/host_table.cpp since round 5.)
 """
 import json
 import os
@@ -42,7 +42,7 @@ def main():
     lat = np.array(lat)
     print(json.dumps({"rows": R, "keys_per_request": n, "p50_ms": float(np.median(lat) * 1e3),
                       "rows_per_s_M": n / float(np.median(lat)) / 1e6, "GB_per_s": n * D * 4 / float(np.median(lat)) / 1e9,
-                      "env": {k: os.environ.get(k) for k in ("HPS_FETCH_BLOCK", "HPS_FETCH_PF", "HPS_FETCH_AVX512", "HPS_SERVING_THREADS")}}))
+                      "env": {k: os.environ.get(k) for k in ("HPS_SERVING_THREADS",)}}))
 
 
 if __name__ == "__main__":

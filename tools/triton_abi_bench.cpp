@@ -46,7 +46,7 @@ namespace {
 
 struct Args {
   std::string lib_dir = "hugectr_backend_amd/lib";
-  int tables = 26, dim = 128, instances = 2, steps = 20, warmup = 5, blocks = 10, direct = 0, pinned_keys = 0;
+  int tables = 26, dim = 128, instances = 2, steps = 20, warmup = 5, blocks = 10, direct = 0, pinned_keys = 0, also_pinned = 0;
   int models = 1, gpucache = 1, uniform = 0;
   std::string dims, per_sample;   // comma lists; empty: `tables` tables of `dim` floats, one key per sample
   long rows = 10000000, batch = 65536;
@@ -94,6 +94,7 @@ int main(int argc, char** argv) {
     else if (k == "--blocks") a.blocks = atoi(v);
     else if (k == "--direct") a.direct = atoi(v);
     else if (k == "--pinned-keys") a.pinned_keys = atoi(v);
+    else if (k == "--also-pinned") a.also_pinned = atoi(v);   // after the measurement: this many more blocks with KEYS in page-locked memory (TRITONSERVER_MEMORY_CPU_PINNED)
     else if (k == "--threshold") a.threshold = atof(v);
     else if (k == "--models") a.models = atoi(v);
     else if (k == "--gpucache") a.gpucache = atoi(v);
@@ -283,6 +284,8 @@ int main(int argc, char** argv) {
   std::atomic<int> failed{0};
   std::vector<std::vector<double>> lat((size_t)W);
   std::vector<long> last_batch((size_t)W, -1);
+  const int64_t* keys_base = keys_all;          // where the requests' KEYS live, and what kind of memory Triton says it is
+  int keys_mtype = a.pinned_keys ? 1 : 0;
   auto run = [&](long first, long count, bool record) {
     next.store(0);
     std::vector<std::thread> th;
@@ -301,8 +304,7 @@ int main(int argc, char** argv) {
           if (i >= count) return;
           const long b = first + i;
           mock_request_t* rq = m.mock_request_new(std::to_string(b).c_str(), 0);
-          m.mock_request_add_input_buffer(rq, "KEYS", 9 /*INT64*/, kshape, 2, keys_all + (size_t)b * N, N * sizeof(int64_t),
-                                          a.pinned_keys ? 1 : 0, 0);
+          m.mock_request_add_input_buffer(rq, "KEYS", 9 /*INT64*/, kshape, 2, keys_base + (size_t)b * N, N * sizeof(int64_t), keys_mtype, 0);
           m.mock_request_add_input_buffer(rq, "NUMKEYS", 8 /*INT32*/, nshape, 2, numkeys.data(), (uint64_t)T * sizeof(int32_t), 0, 0);
           m.mock_request_add_requested_output(rq, "OUTPUT0");
           m.mock_request_set_output_buffer(rq, out_buf[(size_t)w], OUT * sizeof(float), gpu ? 2 /*GPU*/ : 0 /*CPU*/, 0);
@@ -331,6 +333,43 @@ int main(int argc, char** argv) {
     run(a.warmup + (long)blk * a.steps, a.steps, true);
     if (gpu) (void)hipDeviceSynchronize();
     block_s.push_back(now_s() - t0);
+  }
+
+  // ---- (--also-pinned n) the same requests with KEYS in page-locked host memory, as Triton hands them over out of its pinned
+  //      pool when the backend asks for TRITONSERVER_MEMORY_CPU_PINNED (hps.cpp, CollectInput): the lookup DMAs them in place,
+  //      8 bytes per key, no staging copy ----
+  double pinned_lps = 0, pinned_p50 = 0, pinned_p99 = 0;
+  if (a.also_pinned > 0 && !a.pinned_keys && gpu) {
+    const long nb2 = std::min<long>(nbatch, 4 + (long)a.steps * a.also_pinned);
+    int64_t* pk = nullptr;
+    if (hipHostMalloc((void**)&pk, (size_t)nb2 * N * sizeof(int64_t), hipHostMallocDefault) == hipSuccess) {
+      memcpy(pk, keys_all, (size_t)nb2 * N * sizeof(int64_t));
+      std::vector<std::vector<double>> lat_main;
+      lat_main.swap(lat);
+      lat.assign((size_t)W, {});
+      keys_base = pk;
+      keys_mtype = 1;
+      run(0, 4, false);
+      (void)hipDeviceSynchronize();
+      std::vector<double> bs2;
+      for (int blk = 0; blk < a.also_pinned && 4 + (long)(blk + 1) * a.steps <= nb2; ++blk) {
+        const double t0 = now_s();
+        run(4 + (long)blk * a.steps, a.steps, true);
+        (void)hipDeviceSynchronize();
+        bs2.push_back(now_s() - t0);
+      }
+      std::sort(bs2.begin(), bs2.end());
+      if (!bs2.empty()) pinned_lps = (double)a.steps * (double)N / bs2[bs2.size() / 2];
+      std::vector<double> all2;
+      for (auto& v : lat) all2.insert(all2.end(), v.begin(), v.end());
+      std::sort(all2.begin(), all2.end());
+      if (!all2.empty()) { pinned_p50 = all2[all2.size() / 2]; pinned_p99 = all2[std::min(all2.size() - 1, (size_t)(0.99 * (double)all2.size()))]; }
+      lat.swap(lat_main);
+      keys_base = keys_all;
+      keys_mtype = 0;
+      // (the row check below reads keys_all at last_batch: the pinned phase used the same batches at the same indices)
+      (void)hipHostFree(pk);
+    }
   }
 
   dog_stop.store(true);
@@ -385,6 +424,9 @@ int main(int argc, char** argv) {
          pct(0.5), pct(0.99), all.empty() ? 0.0 : all.back(), (unsigned long long)ok_req, (unsigned long long)reports, failed.load(), checked, bad, load_s,
          !gpu ? "CPU parameter server only (gpucache=false)" : a.direct ? "device-driven (ps_direct_access)" : "host gather");
   // requests over 5 ms, and for each the watchdog gaps that overlap it
+  if (pinned_lps > 0)
+    printf("\"pinned_keys\": {\"keys_memory\": \"host, page-locked (TRITONSERVER_MEMORY_CPU_PINNED): DMA in place, 8 bytes per key\", "
+           "\"lookups_per_s\": %.6g, \"p50_request_ms\": %.5g, \"p99_request_ms\": %.5g, \"blocks\": %d}, ", pinned_lps, pinned_p50, pinned_p99, a.also_pinned);
   printf("\"slow_requests_ms\": [");
   int coincide = 0;
   for (size_t i = 0; i < slow_requests.size(); ++i) {
