@@ -486,7 +486,7 @@ def test_probe_variants_and_gather_walks_agree(variant, xcd_walk):
     in a launch of their own — and without it) and both chunk walks of the gather kernel return the same rows and counts: ragged tables that end inside a
     tile, tiles full of one key, keys absent everywhere, the sentinel key, an empty table."""
     from oracle import hps_oracle as O
-    rng = np.random.default_rng(variant * 2 + xcd_walk)
+    rng = np.random.default_rng(abs(variant) * 2 + xcd_walk)
     tables = make_tables([(9000, 128), (5000, 128), (300, 4), (4000, 128)])
     defaults = [0.5, 1.5, 2.5, 3.5]
     ps, cache, s = _mk(f"var{variant}_{xcd_walk}", tables, maxcat=[2, 1, 1, 1], defaults=defaults, gpucacheper=0.3, max_batch=8192,

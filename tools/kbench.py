@@ -22,7 +22,7 @@ import bench as B  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="1001,1002,1004,1102")
+    ap.add_argument("--variants", default="1002,1102")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--tables", type=int, default=26)

@@ -213,7 +213,9 @@ int main(int argc, char** argv) {
     for (long i = 0; i < C; ++i) { acc += 1.0 / std::pow((double)(i + 1), a.zipf); cdf[(size_t)i] = acc; }
     for (long i = 0; i < C; ++i) cdf[(size_t)i] /= acc;
   }
-  const int nbatch = a.warmup + a.steps * a.blocks;
+  // (--also-pinned: its blocks get FRESH batches behind the main measurement's — a replayed batch finds its cold keys inserted)
+  const int nbatch_main = a.warmup + a.steps * a.blocks;
+  const int nbatch = nbatch_main + (a.also_pinned > 0 ? 4 + a.steps * a.also_pinned : 0);
   int64_t* keys_all = nullptr;
   const size_t key_bytes = (size_t)nbatch * N * sizeof(int64_t);
   if (a.pinned_keys) {
@@ -340,10 +342,10 @@ int main(int argc, char** argv) {
   //      8 bytes per key, no staging copy ----
   double pinned_lps = 0, pinned_p50 = 0, pinned_p99 = 0;
   if (a.also_pinned > 0 && !a.pinned_keys && gpu) {
-    const long nb2 = std::min<long>(nbatch, 4 + (long)a.steps * a.also_pinned);
+    const long nb2 = (long)nbatch - nbatch_main;
     int64_t* pk = nullptr;
     if (hipHostMalloc((void**)&pk, (size_t)nb2 * N * sizeof(int64_t), hipHostMallocDefault) == hipSuccess) {
-      memcpy(pk, keys_all, (size_t)nb2 * N * sizeof(int64_t));
+      memcpy(pk, keys_all + (size_t)nbatch_main * N, (size_t)nb2 * N * sizeof(int64_t));
       std::vector<std::vector<double>> lat_main;
       lat_main.swap(lat);
       lat.assign((size_t)W, {});
@@ -367,7 +369,7 @@ int main(int argc, char** argv) {
       lat.swap(lat_main);
       keys_base = keys_all;
       keys_mtype = 0;
-      // (the row check below reads keys_all at last_batch: the pinned phase used the same batches at the same indices)
+      for (auto& b : last_batch) if (b >= 0) b += nbatch_main;   // (the row check below reads keys_all: the pinned phase's batch b is batch nbatch_main + b there)
       (void)hipHostFree(pk);
     }
   }
