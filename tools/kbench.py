@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--zipf", type=float, default=1.05)
     ap.add_argument("--xcd", default="1", help="comma list of 0/1: XCD-aware chunk walk of the gather kernel")
     ap.add_argument("--threshold-permille", type=int, default=1000, help="<1000: the policy needs the unique-key count (K_H: distinct slots in LDS bitmaps)")
+    ap.add_argument("--cache-type", default="dynamic", help="embedding_cache_type: static = no recency stamps written, no inserts")
     ap.add_argument("--env", default="", help="NAME=v1,v2: an environment switch the engine reads per launch, varied like the variants")
     a = ap.parse_args()
     import os
@@ -47,7 +48,7 @@ def main():
            "models": [{"model": "m", "sparse_files": [f"s{t}" for t in range(T)], "num_of_worker_buffer_in_pool": 2,
                        "embedding_vecsize_per_table": [D] * T, "maxnum_catfeature_query_per_table_per_sample": [1] * T,
                        "default_value_for_each_table": [0.0] * T, "deployed_device_list": [0], "max_batch_size": Bn,
-                       "gpucache": True, "gpucacheper": a.cache_frac, "hit_rate_threshold": 1.0}]}
+                       "gpucache": True, "gpucacheper": a.cache_frac, "hit_rate_threshold": 1.0, "embedding_cache_type": a.cache_type}]}
     t0 = time.time()
     ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
     for t in range(T):
