@@ -67,6 +67,33 @@ def test_dense_interaction_matches_torch(num_dense, dims, T, D, B):
     op.close()
 
 
+def test_dense_interaction_at_the_full_config5_batch():
+    """BASELINE config 5 at its own size: 65,536 samples x 26 tables x 128 floats (872 MB of OUTPUT0) against the fp16-rounded
+    PyTorch reference, computed 4,096 samples at a time (the review of round 4: the full batch was only ever compared with
+    itself, fused against separate, in the bench leg).  Same tolerances as above."""
+    import torch
+    from hugectr_backend_amd.dense import DenseInteraction
+    num_dense, dims, T, D, B = 13, [512, 256, 128], 26, 128, 65536
+    ws, bs, x, emb = _make(torch, num_dense, dims, T, D, B, seed=65536)
+    op = DenseInteraction([w.cpu().numpy() for w in ws], [b.cpu().numpy() for b in bs], T, D)
+    out = op.forward(x, emb, B)
+    torch.cuda.synchronize()
+    assert torch.count_nonzero(out[:, op.out_dim:]) == 0
+    emb3 = emb.view(T, B, D)
+    worst_h = worst_f = 0.0
+    for b0 in range(0, B, 4096):
+        b1 = min(B, b0 + 4096)
+        e = emb3[:, b0:b1, :].contiguous().view(-1)
+        got = out[b0:b1, : op.out_dim].float()
+        ref_h = _reference(torch, x[b0:b1], e, ws, bs, T, b1 - b0, D, half_points=True)
+        ref_f = _reference(torch, x[b0:b1], e, ws, bs, T, b1 - b0, D, half_points=False)
+        worst_h = max(worst_h, ((got - ref_h).abs() / ref_h.abs().clamp(min=1.0)).max().item())
+        worst_f = max(worst_f, ((got - ref_f).abs() / ref_f.abs().clamp(min=1.0)).max().item())
+    assert worst_h <= 2e-3, worst_h
+    assert worst_f <= 2e-2, worst_f
+    op.close()
+
+
 def test_dense_consumes_lookup_output_in_place():
     """End to end on the config-5 shape at reduced rows: lookup (HIP, exact rows) -> dense step reading OUTPUT0 where
     the lookup left it; reference = oracle rows through the torch operator."""
