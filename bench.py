@@ -1224,35 +1224,34 @@ def main():
         # replicas (development box): (a) runs with logical shards on the devices there are, (b) with as many RCCL ranks as
         # there are devices.
         entry_rows = min(a.shard_rows, 1 << 26) if not shared_gpu else 1 << 24
-        try:
-            c3e = c3_single_entry_leg(a, torch, hps, devs, entry_rows)
-        except Exception as e:  # noqa: BLE001
-            c3e = {"error": repr(e)[:300]}
-            sys.stderr.write(f"[bench] single-entry config-3 leg stopped: {e!r}\n")
+
+        def guarded(name, fn):
+            """A leg that can hang (kernels storing over peer mappings, RCCL groups — neither has ever run on this project's
+            boxes with more than one GPU) runs on a thread of its own; if it does not come back the line is printed without it."""
+            done, box = threading.Event(), {}
+
+            def body():
+                try:
+                    box["r"] = fn()
+                except Exception as e:  # noqa: BLE001
+                    box["r"] = {"error": repr(e)[:300]}
+                    sys.stderr.write(f"[bench] {name} leg stopped: {e!r}\n")
+                done.set()
+
+            threading.Thread(target=body, daemon=True).start()
+            if done.wait(a.sharded_timeout):
+                return box["r"]
+            res["extra_legs"] = dict(res.get("extra_legs") or {}, **{name: {"error": f"no result within {a.sharded_timeout} s"}})
+            emit(res)
+            os._exit(0)
+
+        c3e = guarded("sharded_c3_single_entry", lambda: c3_single_entry_leg(a, torch, hps, devs, entry_rows))
         res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3_single_entry=c3e)
         gc.collect()
         if world == 1:
             ranks = min(n_rep, ndev)
-            done = threading.Event()
-            box = {}
-
-            def rccl_leg():
-                try:
-                    box["r"] = c3_rccl_threads_leg(a, torch, hps, ranks, entry_rows)
-                except Exception as e:  # noqa: BLE001
-                    box["r"] = {"ranks": ranks, "error": repr(e)[:300]}
-                done.set()
-
-            # a collective that hangs cannot be caught from inside: the leg runs on a thread of its own and the line is
-            # printed without it if it does not come back
-            tl = threading.Thread(target=rccl_leg, daemon=True)
-            tl.start()
-            if done.wait(a.sharded_timeout):
-                res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3=box["r"])
-            else:
-                res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3={"ranks": ranks, "error": f"no result within {a.sharded_timeout} s"})
-                emit(res)
-                os._exit(0)
+            c3r = guarded("sharded_c3", lambda: c3_rccl_threads_leg(a, torch, hps, ranks, entry_rows))
+            res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3=c3r)
     if world > 1:
         dist.barrier()
         if not a.no_sharded_leg:

@@ -46,6 +46,27 @@ def test_two_replicas_in_one_process_share_one_parameter_server(tmp_path):
 
 
 @pytest.mark.gpu
+def test_plain_gpus_2_also_measures_both_config3_variants_and_the_cpu_baseline(tmp_path):
+    """`python bench.py --gpus N` without a launcher (the form of the driver's 1-GPU command): after the replicas measurement the
+    line carries BOTH config-3 variants — the table-sharded model served by entry instances (csrc/cache/shard_entry.h) and the SPMD
+    session over RCCL with one rank per device as threads of the process — and the cpu_baseline (round 4's N > 1 line had neither).
+    On the 1-GPU box: two logical shards on device 0, one RCCL rank."""
+    small = [x for x in SMALL if x not in ("--no-extra-legs", "--no-cpu-baseline")] + ["--cpu-seconds", "1"]
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", *small], capture_output=True, text=True, timeout=900,
+                       cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout, tmp_path)
+    compact = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    legs = compact["legs"]
+    assert legs["c3_single_entry_P"] == 2 and legs["c3_single_entry_parity"] is True and legs["c3_single_entry_Glps"] > 0
+    assert legs["c3_single_entry_all_instances_Glps"] > 0
+    assert legs["c3_rccl_ranks"] == 1 and legs["c3_rccl_parity"] is True and legs["c3_rccl_Glps"] > 0
+    assert compact["cpu_baseline"]["value"] > 0 and compact["cpu_baseline"]["kind"] == "port"
+    e = d["extra_legs"]["sharded_c3_single_entry"]
+    assert e["uniform"]["parity"] and e["zipf"]["parity"] and e["zipf"]["distinct_keys_per_request"] < e["uniform"]["distinct_keys_per_request"]
+
+
+@pytest.mark.gpu
 def test_driver_launch_with_two_ranks_rank0_serves_every_gpu(tmp_path):
     """The driver's N > 1 command line: rank 0 runs the replicas measurement for both GPUs, rank 1 waits and joins the
     sharded-table leg (config 3), here over gloo because the two ranks share the one GPU."""
