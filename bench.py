@@ -91,7 +91,7 @@ def parse_args():
     ap.add_argument("--setup-seconds", type=float, default=150.0,
                     help="N>1: bound on the estimated host-table generation time; rows/table shrinks to meet it")
     ap.add_argument("--sharded-steps", type=int, default=50)
-    ap.add_argument("--sharded-timeout", type=float, default=300.0)
+    ap.add_argument("--sharded-timeout", type=float, default=180.0, help="bound on each config-3 leg (they run on a thread of their own; the line is printed without a leg that does not come back)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs reported next to the headline")
@@ -462,6 +462,13 @@ def emit(res):
         except OSError as e:
             sys.stderr.write(f"[bench] bench_extra.json not written in {d}: {e!r}\n")
     sys.stdout.flush()
+    try:
+        # C stdio of the libraries in this process (RCCL prints a version banner to stdout through it, buffered until exit when
+        # stdout is a pipe): out now, so that the line below stays the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
     print(json.dumps(compact_line(res)), flush=True)
 
 
@@ -1162,6 +1169,32 @@ def main():
     for s in sessions:
         s.close()
 
+    def guarded(name, fn):
+        """A leg that can hang (kernels storing over peer mappings, RCCL groups — neither has ever run on this project's
+        boxes with more than one GPU) runs on a thread of its own; if it does not come back the line is printed without it."""
+        done, box = threading.Event(), {}
+
+        def body():
+            try:
+                box["r"] = fn()
+            except Exception as e:  # noqa: BLE001
+                box["r"] = {"error": repr(e)[:300]}
+                sys.stderr.write(f"[bench] {name} leg stopped: {e!r}\n")
+            done.set()
+
+        threading.Thread(target=body, daemon=True).start()
+        if done.wait(a.sharded_timeout):
+            return box["r"]
+        try:   # where is it stuck?  (every Python thread's stack, to stderr)
+            import faulthandler
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        except Exception:  # noqa: BLE001
+            pass
+        res["extra_legs"] = dict(res.get("extra_legs") or {}, **{name: {"error": f"no result within {a.sharded_timeout} s"}})
+        emit(res)
+        os._exit(0)
+
+
     # ---- one GPU: legs that need the headline's memory back (its tables are 133 GB): the plugin boundary driven by the
     #      native load generator, then the other parameter-server tier ----
     if n_rep == 1 and not a.no_extra_legs:
@@ -1191,19 +1224,11 @@ def main():
         if not a.no_c3_leg:
             gc.collect()
             torch.cuda.empty_cache()
-            try:
-                c3 = c3_logical_leg(a, torch, hps, dev)
-            except Exception as e:  # noqa: BLE001
-                c3 = {"error": repr(e)[:300]}
-                sys.stderr.write(f"[bench] logical config-3 leg stopped: {e!r}\n")
+            c3 = guarded("sharded_c3_logical", lambda: c3_logical_leg(a, torch, hps, dev))
             res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3_logical=c3)
             gc.collect()
             torch.cuda.empty_cache()
-            try:
-                c3e = c3_single_entry_leg(a, torch, hps, [dev] * 4, 1 << 24)
-            except Exception as e:  # noqa: BLE001
-                c3e = {"error": repr(e)[:300]}
-                sys.stderr.write(f"[bench] single-entry config-3 leg stopped: {e!r}\n")
+            c3e = guarded("sharded_c3_single_entry", lambda: c3_single_entry_leg(a, torch, hps, [dev] * 4, 1 << 24))
             res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3_single_entry=c3e)
 
     # ---- BASELINE config 3 leg (only under torch.distributed.run with N > 1 ranks): ONE table sharded over the ranks, one
@@ -1224,26 +1249,6 @@ def main():
         # replicas (development box): (a) runs with logical shards on the devices there are, (b) with as many RCCL ranks as
         # there are devices.
         entry_rows = min(a.shard_rows, 1 << 26) if not shared_gpu else 1 << 24
-
-        def guarded(name, fn):
-            """A leg that can hang (kernels storing over peer mappings, RCCL groups — neither has ever run on this project's
-            boxes with more than one GPU) runs on a thread of its own; if it does not come back the line is printed without it."""
-            done, box = threading.Event(), {}
-
-            def body():
-                try:
-                    box["r"] = fn()
-                except Exception as e:  # noqa: BLE001
-                    box["r"] = {"error": repr(e)[:300]}
-                    sys.stderr.write(f"[bench] {name} leg stopped: {e!r}\n")
-                done.set()
-
-            threading.Thread(target=body, daemon=True).start()
-            if done.wait(a.sharded_timeout):
-                return box["r"]
-            res["extra_legs"] = dict(res.get("extra_legs") or {}, **{name: {"error": f"no result within {a.sharded_timeout} s"}})
-            emit(res)
-            os._exit(0)
 
         c3e = guarded("sharded_c3_single_entry", lambda: c3_single_entry_leg(a, torch, hps, devs, entry_rows))
         res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3_single_entry=c3e)
@@ -1273,6 +1278,10 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # nothing may follow the line on stdout (library destructors print: RCCL's banner): leave without running them
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 def idle_rank(a, dist, rank, world, local_rank):
@@ -1296,6 +1305,9 @@ def idle_rank(a, dist, rank, world, local_rank):
         dog.cancel()
     dist.barrier()
     dist.destroy_process_group()
+    # (this rank's stdout is merged with rank 0's by the launcher: nothing of a library's exit-time output may follow rank 0's line)
+    sys.stderr.flush()
+    os._exit(0)
 
 
 def run_abi_driver(hb, args, timeout):

@@ -58,6 +58,7 @@ def test_plain_gpus_2_also_measures_both_config3_variants_and_the_cpu_baseline(t
     d = _line(r.stdout, tmp_path)
     compact = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     legs = compact["legs"]
+    assert "c3_single_entry_P" in legs, (legs, r.stderr[-2500:])
     assert legs["c3_single_entry_P"] == 2 and legs["c3_single_entry_parity"] is True and legs["c3_single_entry_Glps"] > 0
     assert legs["c3_single_entry_all_instances_Glps"] > 0
     assert legs["c3_rccl_ranks"] == 1 and legs["c3_rccl_parity"] is True and legs["c3_rccl_Glps"] > 0

@@ -13,7 +13,10 @@ def main():
     rl = int(sys.argv[2]) if len(sys.argv) > 2 else 24
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
     sys.argv = sys.argv[:1]
+    import faulthandler
+    faulthandler.dump_traceback_later(int(__import__("os").environ.get("ENTRY_PROBE_DUMP_S", "120")), exit=True)
     a = bench.parse_args()
+    a.batch = int(__import__("os").environ.get("ENTRY_PROBE_BATCH", a.batch))
     import torch
     from hugectr_backend_amd import hps
     ndev = torch.cuda.device_count()
