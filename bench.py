@@ -408,6 +408,10 @@ def compact_line(res, limit=COMPACT_LIMIT):
     put("c3_single_entry_rows_GBps_into_entry", _dig(c3e, ("uniform", "rows_GBps_into_entry_gpu")))
     put("c3_single_entry_parity", c3e.get("parity"))
     put("c3_single_entry_error", (str(c3e["error"])[:120] if c3e.get("error") else None))
+    put("c3_triton_Glps", _scale(g(ex, "c3_sharded_triton", "lookups_per_s"), 1e-9))
+    put("c3_triton_p50_ms", g(ex, "c3_sharded_triton", "p50_request_ms"))
+    put("c3_triton_rows_wrong", g(ex, "c3_sharded_triton", "rows_wrong"))
+    put("c3_triton_error", (str(g(ex, "c3_sharded_triton", "error"))[:100] if g(ex, "c3_sharded_triton", "error") else None))
     c3r = ex.get("sharded_c3") or {}
     put("c3_rccl_Glps", _scale(c3r.get("lookups_per_s"), 1e-9))
     put("c3_rccl_ranks", c3r.get("ranks"))
@@ -1230,6 +1234,8 @@ def main():
             torch.cuda.empty_cache()
             c3e = guarded("sharded_c3_single_entry", lambda: c3_single_entry_leg(a, torch, hps, [dev] * 4, 1 << 24))
             res["extra_legs"] = dict(res["extra_legs"] or {}, sharded_c3_single_entry=c3e)
+            if not a.no_triton_leg:
+                res["extra_legs"] = dict(res["extra_legs"] or {}, c3_sharded_triton=c3_triton_leg(a, hb, 4))
 
     # ---- BASELINE config 3 leg (only under torch.distributed.run with N > 1 ranks): ONE table sharded over the ranks, one
     # rank per GPU, RCCL send/recv inside the engine.  Runs after the headline measurement is complete and its resources are
@@ -1252,6 +1258,8 @@ def main():
 
         c3e = guarded("sharded_c3_single_entry", lambda: c3_single_entry_leg(a, torch, hps, devs, entry_rows))
         res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3_single_entry=c3e)
+        if not a.no_triton_leg:
+            res["extra_legs"] = dict(res.get("extra_legs") or {}, c3_sharded_triton=c3_triton_leg(a, hb, n_rep))
         gc.collect()
         if world == 1:
             ranks = min(n_rep, ndev)
@@ -1335,6 +1343,19 @@ def triton_abi_leg(a, hb, T, R, D, B):
     return run_abi_driver(hb, ["--tables", T, "--rows", R, "--dim", D, "--batch", B, "--cache-frac", a.cache_frac, "--hit", a.hit,
                                "--zipf", a.zipf, "--instances", a.sessions, "--steps", 20, "--blocks", 12, "--warmup", 5,
                                "--direct", int(bool(a.direct)), "--also-pinned", 4], a.triton_timeout)
+
+
+def c3_triton_leg(a, hb, shards):
+    """BASELINE config 3 THROUGH THE PLUGIN: one table-sharded model (ps.json "table_sharding": "hash"), `shards` shards on the visible
+    devices (shard s on device s mod ndev), one instance per device of the pool, requests of the headline's size (1,703,936 uniform
+    keys of one table of 2^24 rows, 100 % resident) through TRITONBACKEND_ModelInstanceExecute — every instance is an entry session
+    (csrc/cache/shard_entry.h).  Native driver, pageable KEYS, device OUTPUT0."""
+    N = a.tables * a.batch
+    out = run_abi_driver(hb, ["--tables", 1, "--rows", 1 << 24, "--dim", a.dim, "--batch", N, "--cache-frac", 1.0, "--uniform", 1,
+                              "--shards", shards, "--instances", 2, "--steps", 20, "--blocks", 4, "--warmup", 4], 180.0)
+    out["config"] = (f"BASELINE configs[2] through the plugin: one table of 2^24 rows x {a.dim} sharded over {shards} shards "
+                     f"(table_sharding hash), requests of {N} uniform keys, two instances per device")
+    return out
 
 
 def c1_leg(a, hb):

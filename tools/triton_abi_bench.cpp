@@ -48,6 +48,7 @@ struct Args {
   std::string lib_dir = "hugectr_backend_amd/lib";
   int tables = 26, dim = 128, instances = 2, steps = 20, warmup = 5, blocks = 10, direct = 0, pinned_keys = 0, also_pinned = 0;
   int models = 1, gpucache = 1, uniform = 0;
+  int shards = 0;   // > 0: ONE table-sharded model (ps.json "table_sharding": "hash"): shard s on device s % (visible devices), instance i on device i % (those)
   std::string dims, per_sample;   // comma lists; empty: `tables` tables of `dim` floats, one key per sample
   long rows = 10000000, batch = 65536;
   double cache_frac = 0.2, hit = 0.957, zipf = 1.05, threshold = 1.0;
@@ -99,6 +100,7 @@ int main(int argc, char** argv) {
     else if (k == "--models") a.models = atoi(v);
     else if (k == "--gpucache") a.gpucache = atoi(v);
     else if (k == "--uniform") a.uniform = atoi(v);
+    else if (k == "--shards") a.shards = atoi(v);
     else if (k == "--dims") a.dims = v;
     else if (k == "--per-sample") a.per_sample = v;
     else die("unknown option", argv[i]);
@@ -129,6 +131,17 @@ int main(int argc, char** argv) {
   }
   const size_t N = key_off[(size_t)T], OUT = out_off[(size_t)T];
   const bool gpu = a.gpucache != 0;
+  // table-sharded deployment (BASELINE config 3 behind the plugin): the devices of the shards and of the instances
+  int ndev = 0;
+  if (gpu && hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+  std::vector<int> shard_dev, inst_dev_pool;
+  if (a.shards > 0) {
+    if (!gpu || ndev <= 0) die("--shards needs a GPU");
+    for (int sdx = 0; sdx < a.shards; ++sdx) shard_dev.push_back(sdx % ndev);
+    for (int d = 0; d < std::min(ndev, a.shards); ++d) inst_dev_pool.push_back(d);
+  } else {
+    inst_dev_pool.push_back(0);
+  }
 
   void* core = dlopen((a.lib_dir + "/libtriton_mock_core.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
   if (!core) die("cannot load the mock core:", dlerror());
@@ -155,7 +168,7 @@ int main(int argc, char** argv) {
       j += std::string(mi ? ", {" : "{") + "\"model\": \"" + names[(size_t)mi] + "\", \"sparse_files\": [";
       for (int t = 0; t < T; ++t)
         j += (t ? ", \"synthetic://" : "\"synthetic://") + std::to_string(R) + "?seed=" + std::to_string(kSeed + (uint64_t)mi) + "\"";
-      j += "], \"num_of_worker_buffer_in_pool\": " + std::to_string(std::max(3, a.instances));
+      j += "], \"num_of_worker_buffer_in_pool\": " + std::to_string(std::max(3, a.instances));   // (instances per device)
       auto list = [&](const char* key, const std::vector<long>* v, const char* all) {
         j += std::string(", \"") + key + "\": [";
         for (int t = 0; t < T; ++t) j += (t ? ", " : "") + (v ? std::to_string((*v)[(size_t)t]) : std::string(all));
@@ -165,9 +178,15 @@ int main(int argc, char** argv) {
       list("maxnum_catfeature_query_per_table_per_sample", &Pt, "");
       list("default_value_for_each_table", nullptr, "0.0");
       char buf[320];
-      snprintf(buf, sizeof buf, ", \"deployed_device_list\": [0], \"max_batch_size\": %ld, \"gpucache\": %s, \"gpucacheper\": %.6f, "
-               "\"hit_rate_threshold\": %.6f, \"ps_direct_access\": %s}", B, gpu ? "true" : "false", a.cache_frac, a.threshold,
-               (a.direct && gpu) ? "true" : "false");
+      std::string devlist = "0";
+      if (a.shards > 0) {
+        devlist.clear();
+        for (size_t sdx = 0; sdx < shard_dev.size(); ++sdx) devlist += (sdx ? ", " : "") + std::to_string(shard_dev[sdx]);
+      }
+      snprintf(buf, sizeof buf, ", \"max_batch_size\": %ld, \"gpucache\": %s, \"gpucacheper\": %.6f, "
+               "\"hit_rate_threshold\": %.6f, \"ps_direct_access\": %s%s}", B, gpu ? "true" : "false", a.cache_frac, a.threshold,
+               (a.direct && gpu) ? "true" : "false", a.shards > 0 ? ", \"table_sharding\": \"hash\", \"gpucache_load_factor\": 0.6" : "");
+      j += ", \"deployed_device_list\": [" + devlist + "]";
       j += buf;
     }
     j += "]}";
@@ -184,23 +203,30 @@ int main(int argc, char** argv) {
     die("TRITONBACKEND_Initialize failed:", m.mock_last_error());
   std::vector<mock_model_t*> model((size_t)M, nullptr);
   std::vector<mock_instance_t*> inst;   // worker w serves model w / instances, instance w % instances
+  std::vector<int> inst_dev;            // ... on this device
   for (int mi = 0; mi < M; ++mi) {
     const std::string model_cfg =
         "{\"name\": \"" + names[(size_t)mi] + "\", \"backend\": \"hps\", \"max_batch_size\": " + std::to_string(B) +
         ", \"input\": [{\"name\": \"KEYS\", \"data_type\": \"TYPE_INT64\", \"dims\": [-1]}, {\"name\": \"NUMKEYS\", \"data_type\": "
         "\"TYPE_INT32\", \"dims\": [-1]}], \"output\": [{\"name\": \"OUTPUT0\", \"data_type\": \"TYPE_FP32\", \"dims\": [-1]}], "
         "\"instance_group\": [{\"count\": " + std::to_string(a.instances) + ", \"kind\": \"" + (gpu ? "KIND_GPU" : "KIND_CPU") +
-        "\", \"gpus\": [" + (gpu ? "0" : "") + "]}]}";
+        "\", \"gpus\": [" + [&] { std::string g; for (size_t d = 0; gpu && d < inst_dev_pool.size(); ++d) g += (d ? ", " : "") + std::to_string(inst_dev_pool[d]); return g; }() + "]}]}";
     if (m.mock_model_load(srv, names[(size_t)mi].c_str(), 1, model_cfg.c_str(), &model[(size_t)mi]) != 0)
       die("ModelInitialize failed:", m.mock_last_error());
-    for (int i = 0; i < a.instances; ++i) {
-      mock_instance_t* h = nullptr;
-      if (m.mock_instance_create(model[(size_t)mi], (names[(size_t)mi] + "_0_" + std::to_string(i)).c_str(), gpu ? 2 : 1, 0, &h) != 0)
-        die("ModelInstanceInitialize failed:", m.mock_last_error());
-      inst.push_back(h);
-    }
+    // (sharded: `instances` per device of the pool, like instance_group { count, gpus })
+    for (size_t dpi = 0; dpi < inst_dev_pool.size(); ++dpi)
+      for (int i = 0; i < a.instances; ++i) {
+        mock_instance_t* h = nullptr;
+        const int d = inst_dev_pool[dpi];
+        if (m.mock_instance_create(model[(size_t)mi], (names[(size_t)mi] + "_" + std::to_string(d) + "_" + std::to_string(i)).c_str(), gpu ? 2 : 1, d, &h) != 0)
+          die("ModelInstanceInitialize failed:", m.mock_last_error());
+        inst.push_back(h);
+        inst_dev.push_back(d);
+      }
   }
-  const int W = (int)inst.size();   // workers = models x instances
+  const int W = (int)inst.size();   // workers = models x instances (x devices of a sharded model)
+  const int per_model = W / M;
+  auto sync_all = [&] { for (int d : inst_dev_pool) { (void)hipSetDevice(d); (void)hipDeviceSynchronize(); } };
   const double load_s = now_s() - t_load0;
 
   // ---- key batches: per table n_t keys; with probability `hit` a Zipf-ranked key of the warmed range [0, C), else uniform
@@ -259,7 +285,7 @@ int main(int argc, char** argv) {
   for (int t = 0; t < T; ++t) numkeys[(size_t)t] = (int32_t)(key_off[(size_t)t + 1] - key_off[(size_t)t]);
   std::vector<float*> out_buf((size_t)W, nullptr);   // device memory for GPU instances, host memory for CPU instances
   for (int i = 0; i < W; ++i) {
-    if (gpu) { if (hipMalloc((void**)&out_buf[(size_t)i], OUT * sizeof(float)) != hipSuccess) die("hipMalloc of OUTPUT0 failed"); }
+    if (gpu) { if (hipSetDevice(inst_dev[(size_t)i]) != hipSuccess || hipMalloc((void**)&out_buf[(size_t)i], OUT * sizeof(float)) != hipSuccess) die("hipMalloc of OUTPUT0 failed"); }
     else if (!(out_buf[(size_t)i] = (float*)malloc(OUT * sizeof(float)))) die("out of memory for OUTPUT0");
   }
 
@@ -293,23 +319,23 @@ int main(int argc, char** argv) {
     std::vector<std::thread> th;
     for (int w = 0; w < W; ++w)
       th.emplace_back([&, w] {
-        if (gpu) (void)hipSetDevice(0);
+        if (gpu) (void)hipSetDevice(inst_dev[(size_t)w]);
         const int64_t kshape[2] = {1, (int64_t)N}, nshape[2] = {1, (int64_t)T};
         // one model: the instances share the requests (whoever is free takes the next, as Triton's scheduler hands them out);
         // several models: every model's instances get that model's own share, so that all of them are under load all the time
-        const int mi = w / a.instances, wi = w % a.instances;
+        const int mi = w / per_model, wi = w % per_model;
         long mine = wi;
         for (;;) {
           long i;
           if (M == 1) i = next.fetch_add(1);
-          else { i = mine * M + mi; mine += a.instances; }
+          else { i = mine * M + mi; mine += per_model; }
           if (i >= count) return;
           const long b = first + i;
           mock_request_t* rq = m.mock_request_new(std::to_string(b).c_str(), 0);
           m.mock_request_add_input_buffer(rq, "KEYS", 9 /*INT64*/, kshape, 2, keys_base + (size_t)b * N, N * sizeof(int64_t), keys_mtype, 0);
           m.mock_request_add_input_buffer(rq, "NUMKEYS", 8 /*INT32*/, nshape, 2, numkeys.data(), (uint64_t)T * sizeof(int32_t), 0, 0);
           m.mock_request_add_requested_output(rq, "OUTPUT0");
-          m.mock_request_set_output_buffer(rq, out_buf[(size_t)w], OUT * sizeof(float), gpu ? 2 /*GPU*/ : 0 /*CPU*/, 0);
+          m.mock_request_set_output_buffer(rq, out_buf[(size_t)w], OUT * sizeof(float), gpu ? 2 /*GPU*/ : 0 /*CPU*/, gpu ? inst_dev[(size_t)w] : 0);
           const double t0 = now_s();
           const int rc = m.mock_instance_execute(inst[(size_t)w], &rq, 1);
           const double dt = now_s() - t0;
@@ -328,12 +354,12 @@ int main(int argc, char** argv) {
     for (auto& x : th) x.join();
   };
   run(0, a.warmup, false);
-  if (gpu) (void)hipDeviceSynchronize();
+  if (gpu) sync_all();
   std::vector<double> block_s;
   for (int blk = 0; blk < a.blocks; ++blk) {
     const double t0 = now_s();
     run(a.warmup + (long)blk * a.steps, a.steps, true);
-    if (gpu) (void)hipDeviceSynchronize();
+    if (gpu) sync_all();
     block_s.push_back(now_s() - t0);
   }
 
@@ -352,12 +378,12 @@ int main(int argc, char** argv) {
       keys_base = pk;
       keys_mtype = 1;
       run(0, 4, false);
-      (void)hipDeviceSynchronize();
+      sync_all();
       std::vector<double> bs2;
       for (int blk = 0; blk < a.also_pinned && 4 + (long)(blk + 1) * a.steps <= nb2; ++blk) {
         const double t0 = now_s();
         run(4 + (long)blk * a.steps, a.steps, true);
-        (void)hipDeviceSynchronize();
+        sync_all();
         bs2.push_back(now_s() - t0);
       }
       std::sort(bs2.begin(), bs2.end());
@@ -382,7 +408,7 @@ int main(int argc, char** argv) {
   long bad = 0, checked = 0;
   for (int w = 0; w < W; ++w) {
     const long b = last_batch[(size_t)w];
-    const uint64_t seed = kSeed + (uint64_t)(w / a.instances);
+    const uint64_t seed = kSeed + (uint64_t)(w / per_model);
     std::vector<float> row;
     for (int s = 0; s < 2048 / W + 1 && b >= 0; ++s) {
       const size_t i = (size_t)(mix(77 + (uint64_t)s + 1000ull * (uint64_t)w) % N);
@@ -415,10 +441,10 @@ int main(int argc, char** argv) {
   const double med = bs.empty() ? 0 : bs[bs.size() / 2];
   auto pct = [&](double p) { return all.empty() ? 0.0 : all[std::min(all.size() - 1, (size_t)(p * (double)all.size()))]; };
   printf("{\"through\": \"TRITONBACKEND_ModelInstanceExecute (libtriton_hps.so) driven by the mock Triton core, native caller\", "
-         "\"keys_memory\": \"%s\", \"output_memory\": \"%s\", \"models\": %d, \"instances\": %d, \"tables\": %d, \"keys_per_request\": %zu, "
+         "\"keys_memory\": \"%s\", \"output_memory\": \"%s\", \"models\": %d, \"instances\": %d, \"shards\": %d, \"visible_devices\": %d, \"tables\": %d, \"keys_per_request\": %zu, "
          "\"floats_per_response\": %zu, \"steps_per_block\": %d, \"blocks\": %d, "
          "\"lookups_per_s\": %.6g, \"requests_per_s\": %.6g, \"ms_per_step\": %.6g, \"block_ms\": [", a.pinned_keys ? "host, page-locked" : "host, pageable",
-         gpu ? "device" : "host", M, a.instances, T, N, OUT, a.steps, a.blocks, med > 0 ? (double)a.steps * (double)N / med : 0.0,
+         gpu ? "device" : "host", M, W / M, a.shards, ndev, T, N, OUT, a.steps, a.blocks, med > 0 ? (double)a.steps * (double)N / med : 0.0,
          med > 0 ? (double)a.steps / med : 0.0, med / a.steps * 1e3);
   for (size_t i = 0; i < block_s.size(); ++i) printf("%s%.4g", i ? ", " : "", block_s[i] * 1e3);
   printf("], \"p50_request_ms\": %.5g, \"p99_request_ms\": %.5g, \"max_request_ms\": %.5g, \"requests_ok_reported_by_backend\": %llu, \"batch_statistics_reports\": %llu, "
