@@ -1128,7 +1128,7 @@ def main():
                                 "launches read 5..8 us more per kernel, the queue hand-offs)",
                 "probe_ms": probe, "gather_ms": gather, "scatter_ms": scatter,
                 # the cache-insert kernel: since round 4 it is enqueued BEHIND the call (the caller does not wait for it;
-                # HPS_DEFER_INSERT=0 puts it back on the return path).  It still occupies the GPU, so the fraction is also given
+                # session option defer_insert 0 puts it back on the return path).  It still occupies the GPU, so the fraction is also given
                 # with its time added to the three kernels that produce the call's rows.
                 "insert_ms": m["insert_ms"],
                 "insert_on_call_path": False,   # (session option defer_insert = 0 puts it back)

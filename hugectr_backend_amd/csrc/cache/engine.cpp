@@ -671,7 +671,7 @@ Status LookupSession::Init(HierParameterServer* ps, const InferenceParams& p, st
     // are placed before the gather's remaining ones — the counts reach the host 50 us earlier (0.23-0.25 against 0.28-0.31 ms),
     // headline 2.03 / 2.05 / 2.08 against 2.01 / 1.69 / 1.92 G lookups/s in three interleaved pairs (the two low ones look like
     // the box's host noise: 2.01 is the fair comparison), p50 1.55-1.58 against 1.61 ms
-    // (profiles/round4/ab_side_stream_priority.txt).  HPS_SIDE_PRIORITY=0: a queue of normal priority.
+    // (profiles/round4/ab_side_stream_priority.txt).
     // Round 5: NOT for more than two sessions per device, and never for the shard sessions of a table-sharded model's entry
     // instances.  A high-priority queue that is merely WAITING (its head is a barrier on another queue's event) makes the
     // hardware scheduler preempt the waves of the normal-priority queue it waits for: with 16 sessions on one GPU (4 entry

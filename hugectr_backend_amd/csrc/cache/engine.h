@@ -154,7 +154,7 @@ class EmbeddingCache {
                               // new key in 2^this (0 = every new key takes the bucket's oldest slot, rounds 1-3's behaviour)
   uint32_t insert_age_ = 160; // recency units a newly inserted key is aged by (HPS_LRU_INSERT_AGE; 0 = plain LRU insertion),
                               // < kAgeSaturate: 2.5 turnovers (call clock: 32 units unless given)
-  uint32_t units_per_turnover_ = 64;   // HPS_LRU_UNITS_PER_TURNOVER: 192 usable units = 3 turnovers of horizon
+  uint32_t units_per_turnover_ = 64;   // 192 usable units = 3 turnovers of horizon
   bool call_clock_ = false;   // HPS_LRU_AGE_SHIFT given: recency unit = 2^age_shift_ calls
   uint32_t age_shift_ = 3;
   uint64_t total_slots_ = 1, rows_per_unit_ = 1, call_start_ = 0;
@@ -393,10 +393,10 @@ class LookupSession {
   Status WaitPushed();                // host: until the last PushWords has landed (or the stream reports an error)
   Status WaitPushedSeq(uint32_t seq, hipEvent_t ev);   // ... until the push that carried `seq` (or a later one) has landed
   uint32_t small_calls_ = 0;          // small-miss calls of this session so far (every small_insert_interval()-th inserts)
-  bool defer_insert_ = true;          // option "defer_insert" / HPS_DEFER_INSERT: the insert kernel is not on the call's return path
-  size_t in_place_bytes_ = 1u << 20;  // option "in_place_kb" / HPS_IN_PLACE_KB: missed rows of a chunk up to this size are read by
+  bool defer_insert_ = true;          // option "defer_insert": the insert kernel is not on the call's return path
+  size_t in_place_bytes_ = 1u << 20;  // option "in_place_kb": missed rows of a chunk up to this size are read by
                                       // the kernels where the host gathered them (page-locked staging), no upload
-  size_t side_bytes_ = 16u << 20;     // HPS_SIDE_SCATTER_MB: missed rows of a call up to this size are uploaded AND scattered on the
+  size_t side_bytes_ = 16u << 20;     // option "side_scatter_mb": missed rows of a call up to this size are uploaded AND scattered on the
                                       // second stream, next to the hit gather and outside the kernel lane
   std::mutex deferred_mu_;
   bool deferred_pending_ = false;     // an insert + statistics push is in flight behind the last call
@@ -412,24 +412,23 @@ class LookupSession {
   float last_gather_ms_ = 0.f;
   bool split_call_ = false;      // the call in progress gathers its hits on stream_ while the miss path runs (copies go down copy_stream_)
   bool split_probe_ = true;      // host-gather tier: start the miss path behind the probe, gather the hits meanwhile (§3.4c);
-                                 // HPS_SPLIT_PROBE=0 / session option split_probe=0: gather first, then the counts
+                                 // session option split_probe=0: gather first, then the counts
   // option "timing": the per-kernel times of a call are the kernels' OWN start / stop timestamps (KTimer, kernels.h), as a
-  // profiler reports them; HPS_KERNEL_TIMESTAMPS=0: hipEventRecord pairs around the launches (they also time two packet
-  // hand-offs per kernel)
+  // profiler reports them (hipEventRecord pairs around the launches also time two packet hand-offs per kernel: round 3's A/B)
   bool kernel_stamps_ = true;
   KTimer Kt(hipEvent_t a, hipEvent_t b) const { return (timing_ && kernel_stamps_) ? KTimer{a, b} : KTimer{}; }
   void Mark(hipEvent_t e, hipStream_t s = nullptr) { if (timing_ && !kernel_stamps_) (void)hipEventRecord(e, s ? s : stream_); }
-  bool fused_unique_ = true;     // the call-wide unique misses are found in the probe kernel's tail (option "fused_unique", HPS_FUSED_UNIQUE)
+  bool fused_unique_ = true;     // the call-wide unique misses are found in the probe kernel's tail (option "fused_unique")
   bool exclusive_ = true;        // the HBM-bound kernels of this session take the cache's lane (option "exclusive_kernels")
   hipEvent_t ev_lane_[4] = {nullptr, nullptr, nullptr, nullptr};   // probe pair, hit gather, miss scatter, insert
-  bool probe_xcd_tiles_ = true;      // probe kernel: XCD x takes the x-th eighth of the tiles (HPS_PROBE_XCD_TILES, read per call)
-  bool frame_of_reference_ = true;   // narrowed keys are offsets from their table's smallest key (HPS_KEY_FRAME_OF_REFERENCE=0: from 0)
+  bool probe_xcd_tiles_ = true;      // probe kernel: XCD x takes the x-th eighth of the tiles (round 3's A/B: profiles/round3/ab_probe_xcd_tiles.txt)
+  bool frame_of_reference_ = true;   // narrowed keys are offsets from their table's smallest key (key_pack.h)
   std::vector<int64_t> key_base_;    // this call's per-table bases
-  bool direct_split_ = true;     // device-driven tier: the fetch kernel runs next to the call's own hit gather (HPS_DIRECT_SPLIT=0: behind it)
+  bool direct_split_ = true;     // device-driven tier: the fetch kernel runs next to the call's own hit gather (round 3: +4 %)
   bool narrow_publish_ = true;   // a narrowed request's unique missed keys come back to the host as uint32 (option "narrow_publish")
   bool uniq_narrow_ = false;     // this call: h_uniq_keys_ holds uint32 keys
   bool chain_gather_ = false;    // other sessions' probes queue behind this session's gather as well as its probe
-  bool xcd_walk_ = true;         // K_G: each XCD sweeps its own eighth of the key range (HPS_XCD_WALK=0: plain grid stride)
+  bool xcd_walk_ = true;         // K_G: each XCD sweeps its own eighth of the key range (option "xcd_walk" 0: plain grid stride)
   MissDesc* h_md_ = nullptr;      // pinned
   const MissDesc* h_md_dev_ = nullptr;     // device views of the pinned miss descriptor / staging rows / found flags (small chunks)
   const float* h_staging_dev_ = nullptr;
