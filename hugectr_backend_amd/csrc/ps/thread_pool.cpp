@@ -218,6 +218,15 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
       // grains: one claim per thread when the caller asked for a cap, else task by task (callers size their tasks)
       const uint32_t grain = max_parallel ? (uint32_t)((num_tasks + threads - 1) / threads) : 1u;
       const uint32_t gen = ++L->gen;
+      // The slot's claim word changes generation BEFORE any parameter of the new loop is stored, with "everything claimed" as
+      // its index.  Round 5 found the window this closes (tools/micro/forkjoin_stress.cpp reproduces it in seconds, 14
+      // callers on 13 workers): a worker still inside RunFast for the slot's PREVIOUS loop — claim word (old generation, n_old)
+      // — read the NEW n before the new claim word was there, took n_old < n_new for unclaimed work, won its compare-and-swap
+      // (the word had not changed yet) and ran tasks of the new loop; the owner then reset the index and every task ran again:
+      // tasks executed twice (rows were still right: staging and gather are idempotent) and `done` overshot n, which the
+      // owner's wait for done == n never survives — the one hang in ~60 bench runs, one in two runs of the sharded stress
+      // driver (9 sessions + 3 entry sessions fork-joining side by side).
+      L->next.store(((uint64_t)gen << 32) | 0xFFFFFFFFu, std::memory_order_seq_cst);
       L->fn.store(&fn, std::memory_order_relaxed);
       L->n.store((uint32_t)num_tasks, std::memory_order_relaxed);
       L->grain.store(grain ? grain : 1u, std::memory_order_relaxed);
@@ -235,7 +244,7 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
       // scheduler slice later — 4 to 6 ms, the 5-to-12-ms requests of rounds 2-3 (HPS_TRACE_TAIL: "pool 4.12 ms" of a
       // 0.15-ms staging loop, "ps fetch 5.56 ms").  The grain cannot be taken over (fn dies with this call), but the CPU
       // can be handed over: after a short spin the waiter yields, and the runnable worker gets it at once.
-      for (uint32_t it = 0; L->done.load(std::memory_order_acquire) != (uint32_t)num_tasks; ++it) {
+      for (uint32_t it = 0; L->done.load(std::memory_order_acquire) < (uint32_t)num_tasks; ++it) {
         if (it < 2048 || !kPoolYield) CpuRelax();
         else sched_yield();
       }

@@ -1,6 +1,8 @@
 // Native (no Python) stress driver over the engine C ABI (include/hps_amd.h), meant to be linked against a
 // ThreadSanitizer or AddressSanitizer build of libhps_amd.so:
-//   abi_driver <cpu|gpu|gpu_direct> [seconds]
+//   abi_driver <cpu|gpu|gpu_direct|gpu_sharded> [seconds]
+// gpu_sharded: the model is table-sharded over three logical shards (ps.json "table_sharding": "hash") and every lookup thread owns an
+// ENTRY session (hps_shard_entry_*: its own worker threads drive one lookup session per shard) instead of a lookup session.
 // Three lookup threads (one session each) query random batches while a fourth thread reloads a table (same content)
 // and, with a GPU cache, refreshes it.  Tables are synthetic (keys 0..R-1), every returned row is recomputed from the
 // recipe in csrc/common/hps_hash.h and compared bit for bit; keys >= R must return the table's default value.
@@ -33,29 +35,34 @@ static const size_t kBatch = 4096;
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "cpu";
   const double seconds = argc > 2 ? atof(argv[2]) : 5.0;
-  const bool gpu = mode != "cpu", direct = mode == "gpu_direct";
+  const bool gpu = mode != "cpu", direct = mode == "gpu_direct", sharded = mode == "gpu_sharded";
   if (gpu && hps_device_count() <= 0) { fprintf(stderr, "no HIP device\n"); return 2; }
   char json[2048];
   snprintf(json, sizeof json,
            "{\"supportlonglong\": true, \"volatile_db\": {\"type\": \"hash_map\", \"num_partitions\": 8}, \"models\": [{"
            "\"model\": \"m\", \"sparse_files\": [\"a\", \"b\", \"c\"], \"num_of_worker_buffer_in_pool\": 3,"
            "\"embedding_vecsize_per_table\": [64, 16, 3], \"maxnum_catfeature_query_per_table_per_sample\": [1, 1, 1],"
-           "\"default_value_for_each_table\": [0.5, -2.0, 7.0], \"deployed_device_list\": [0], \"max_batch_size\": %zu,"
-           "\"gpucache\": %s, \"hit_rate_threshold\": 1.0, \"gpucacheper\": 0.1, \"ps_direct_access\": %s}]}",
-           kBatch, gpu ? "true" : "false", direct ? "true" : "false");
+           "\"default_value_for_each_table\": [0.5, -2.0, 7.0], \"deployed_device_list\": [%s], \"max_batch_size\": %zu,"
+           "\"gpucache\": %s, \"hit_rate_threshold\": 1.0, \"gpucacheper\": 0.1, \"ps_direct_access\": %s%s}]}",
+           sharded ? "0, 0, 0" : "0", kBatch, gpu ? "true" : "false", direct ? "true" : "false",
+           sharded ? ", \"table_sharding\": \"hash\", \"shard_capacity_factor\": 1.0" : "");
   hps_server_t* sv = nullptr;
   CK(hps_server_create_from_text(json, 0, &sv));
   for (int t = 0; t < T; ++t) CK(hps_server_load_table_synthetic(sv, "m", (uint32_t)t, kSeed, 0, R));
   hps_cache_t* cache = nullptr;
   if (gpu) {
     CK(hps_server_create_embedding_cache_per_model(sv, "m"));
-    CK(hps_server_get_embedding_cache(sv, "m", 0, &cache));
+    if (sharded) CK(hps_server_get_shard_cache(sv, "m", 1, &cache));   // (the monitor reads one shard's counters)
+    else CK(hps_server_get_embedding_cache(sv, "m", 0, &cache));
   }
   std::atomic<bool> stop{false};
   std::atomic<long> bad{0}, calls{0};
   auto worker = [&](int id) {
     hps_session_t* s = nullptr;
-    if (hps_session_create(sv, "m", cache, &s) != 0) { bad.fetch_add(1); fprintf(stderr, "session: %s\n", hps_last_error()); return; }
+    hps_shard_entry_t* e = nullptr;
+    if (sharded) {
+      if (hps_shard_entry_create(sv, "m", 0, &e) != 0) { bad.fetch_add(1); fprintf(stderr, "entry session: %s\n", hps_last_error()); return; }
+    } else if (hps_session_create(sv, "m", cache, &s) != 0) { bad.fetch_add(1); fprintf(stderr, "session: %s\n", hps_last_error()); return; }
     std::mt19937_64 rng(100 + id);
     std::vector<int64_t> keys(T * kBatch);
     size_t out_floats = 0;
@@ -79,7 +86,11 @@ int main(int argc, char** argv) {
         ko += n[t];
         vo += n[t] * kDims[t];
       }
-      if (hps_session_lookup(s, kp, vp, n, T) != 0) { fprintf(stderr, "lookup: %s\n", hps_last_error()); bad.fetch_add(1); break; }
+      if ((sharded ? hps_shard_entry_lookup(e, kp, vp, n, T) : hps_session_lookup(s, kp, vp, n, T)) != 0) {
+        fprintf(stderr, "lookup: %s\n", hps_last_error());
+        bad.fetch_add(1);
+        break;
+      }
       if (gpu && hipMemcpy(host_out.data(), dev_out, vo * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { bad.fetch_add(1); break; }
       ko = vo = 0;
       for (int t = 0; t < T; ++t) {
@@ -102,7 +113,8 @@ int main(int argc, char** argv) {
       calls.fetch_add(1);
     }
     if (dev_out) (void)hipFree(dev_out);
-    hps_session_destroy(s);
+    if (s) hps_session_destroy(s);
+    if (e) hps_shard_entry_destroy(e);
   };
   std::vector<std::thread> th;
   for (int i = 0; i < 3; ++i) th.emplace_back(worker, i);

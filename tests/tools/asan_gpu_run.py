@@ -101,6 +101,65 @@ def main():
             print(f"{name}: direct={direct} threshold={thr}: {cache.counters()}")
             cache.release()
             ps.close()
+    # ---- a table-sharded model served by entry sessions (csrc/cache/shard_entry.cpp: worker threads, bucket kernels, indexed
+    #      gather): 3 logical shards, two entry sessions on two threads, uniform and skewed requests, one owner served in passes ----
+    name = "asan_sharded"
+    cfg = ps_config(name, tables, maxcat=[2, 1, 1], defaults=[0.5, -1.0, 2.0], gpucacheper=0.3, max_batch=2048,
+                    extra={"table_sharding": "hash", "shard_capacity_factor": 1.0})
+    cfg["models"][0]["deployed_device_list"] = [0, 0, 0]
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    for t, (k, r) in enumerate(tables):
+        ps.load_table_arrays(name, t, k, r)
+    ps.create_embedding_cache_per_model(name)
+    entries = []
+    for _ in range(2):
+        h = C.c_void_p()
+        hps._check(hps.LIB.hps_shard_entry_create(ps._h, name.encode(), 0, C.byref(h)))
+        entries.append(h)
+
+    def eworker(ei, seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for it in range(10):
+                nk = [int(rng.integers(0, 4097)), int(rng.integers(0, 2049)), int(rng.integers(0, 2049))]
+                parts = []
+                for (keys, _), n in zip(tables, nk):
+                    q = keys[np.minimum(rng.zipf(1.3, n) - 1, keys.size - 1)] if it % 2 else rng.choice(keys, n)
+                    q = np.where(rng.random(n) < 0.05, -1 - rng.integers(0, 1 << 40, n), q)
+                    parts.append(q.astype(np.int64))
+                q = np.concatenate(parts)
+                n_out = sum(n * d for n, d in zip(nk, dims))
+                d_out = dmalloc(n_out * 4)
+                ptrs, off = [], 0
+                for n, d in zip(nk, dims):
+                    ptrs.append((d_out.value or 0) + off * 4)
+                    off += n * d
+                kptrs, koff = [], 0
+                for n in nk:
+                    kptrs.append(q.ctypes.data + koff * 8)
+                    koff += n
+                kp = (C.c_void_p * T)(*kptrs)
+                vp = (C.c_void_p * T)(*ptrs)
+                nkc = (C.c_size_t * T)(*nk)
+                hps._check(hps.LIB.hps_shard_entry_lookup(entries[ei], kp, vp, nkc, T))
+                out = np.empty(n_out, np.float32)
+                if n_out:
+                    assert HIP.hipMemcpy(out.ctypes.data, d_out, n_out * 4, 2) == 0
+                HIP.hipFree(d_out)
+                ref = O.np_lookup(tables, q, nk, [0.5, -1.0, 2.0])
+                if not np.array_equal(out.view(np.uint32), ref.view(np.uint32)):
+                    failures.append((name, ei, it))
+                    return
+        except Exception as e:  # noqa: BLE001
+            failures.append((name, ei, repr(e)))
+
+    th = [threading.Thread(target=eworker, args=(i, 77 + i)) for i in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    for h in entries:
+        hps.LIB.hps_shard_entry_destroy(h)
+    print(f"{name}: 3 logical shards, two entry sessions: {[ps.get_shard_cache(name, s).counters()['keys'] for s in range(3)]} keys per shard")
+    ps.close()
     print("asan_gpu_run:", "FAILED " + repr(failures[:3]) if failures else "ok")
     sys.exit(1 if failures else 0)
 
