@@ -1794,7 +1794,7 @@ def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
             e.lookup(bt[i % 4], [N], out=out)
             lat.append((time.perf_counter() - ts) * 1e3)
             st = e.last_stats()
-            ph.append((st.key_stage_ms, st.bucket_ms, st.lookup_ms, st.expand_ms, st.unique_keys, max(st.shard_ms[:P]), max(st.sent[:P])))
+            ph.append((st.key_stage_ms, st.bucket_ms, st.lookup_ms, st.expand_ms, st.unique_keys, max(st.shard_ms[:P]), max(st.sent[:P]), st.unique_misses))
         sync_all()
         dt = time.perf_counter() - t1
         ok = check(e, out, bt[(steps - 1) % 4])
@@ -1806,7 +1806,7 @@ def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
         one = {"lookups_per_s": N * steps / dt, "ms_per_request": dt / steps * 1e3, "p50_request_ms": float(np.percentile(lat, 50)),
                "p99_request_ms": float(np.percentile(lat, 99)), "parity": ok,
                "phase_ms": {"key_stage": float(pm[0]), "bucket": float(pm[1]), "shard_lookups": float(pm[2]), "expand_repeats": float(pm[3])},
-               "distinct_keys_per_request": float(pm[4]), "slowest_shard_ms": float(pm[5]), "largest_bucket_keys": float(pm[6]),
+               "host_key_bytes_over_pcie": int(st.key_bytes), "distinct_keys_per_request": float(pm[4]), "distinct_misses_per_request": float(pm[7]), "slowest_shard_ms": float(pm[5]), "largest_bucket_keys": float(pm[6]),
                "row_bytes_from_other_gpus_per_request": remote * 4 * D,
                "rows_GBps_into_entry_gpu": remote * 4 * D / (pm[2] * 1e-3) / 1e9 if pm[2] > 0 and remote else None}
         # device keys (an ensemble step upstream holds them in HBM)

@@ -678,6 +678,7 @@ int hps_shard_entry_last_stats(hps_shard_entry_t* e, hps_shard_entry_stats_t* ou
     out->misses = st.misses; out->unique_misses = st.unique_misses;
     out->bucket_ms = st.bucket_ms; out->lookup_ms = st.lookup_ms; out->expand_ms = st.expand_ms; out->key_stage_ms = st.key_stage_ms;
     out->num_shards = e->s->num_shards();
+    out->key_bytes = (uint32_t)st.key_bytes;
     for (uint32_t s = 0; s < e->s->num_shards() && s < 64; ++s) {
       out->sent[s] = st.sent[s]; out->passes[s] = st.passes[s]; out->shard_ms[s] = st.shard_ms[s];
     }

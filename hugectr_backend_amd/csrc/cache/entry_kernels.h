@@ -18,8 +18,13 @@ struct EntryDesc {
   uint32_t first_tile[kMaxTables + 1];   // first tile of table t (tiles never straddle tables); first_tile[T] = num_tiles
   float* out[kMaxTables];                // the request's output slice of table t (entry GPU)
   uint32_t dim[kMaxTables];
+  int64_t key_base[kMaxTables];          // narrowed host keys (hps_entry_widen): key = key_base[t] + what crossed PCIe
 };
 
+// Host keys that crossed PCIe narrowed (3 bytes packed, or uint32, as offsets from their table's smallest key: key_pack.h) ->
+// int64 keys for the bucket kernels and the owners.  key_bytes 3 or 4.
+hipError_t LaunchEntryWiden(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, const void* d_narrow, uint32_t key_bytes,
+                            int64_t* d_keys, hipStream_t stream);
 // d_rep[i] = index of the representative of (table of i, key i): i itself for one key of every distinct pair.
 // d_set: set_mask + 1 (a power of two >= 2 n) words, zeroed once; tag != 0, different from the tags still in the set.
 hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, const int64_t* d_keys, uint64_t n,

@@ -36,6 +36,23 @@ __device__ __forceinline__ int entry_find_table(const uint64_t* ks, int T, uint6
   return lo;
 }
 
+// narrowed host keys -> int64 (one workgroup per tile: the table, and with it the base, is the tile's)
+__global__ __launch_bounds__(kEntryTile) void hps_entry_widen_kernel(const EntryDesc* __restrict__ d, const TileDesc* __restrict__ tiles,
+                                                                    const void* __restrict__ narrow, uint32_t key_bytes,
+                                                                    int64_t* __restrict__ keys) {
+  const TileDesc td = tiles[blockIdx.x];
+  if (threadIdx.x >= td.count) return;
+  const uint64_t i = td.begin + threadIdx.x;
+  const int64_t base = d->key_base[td.table];
+  uint32_t v;
+  if (key_bytes == 4) v = reinterpret_cast<const uint32_t*>(narrow)[i];
+  else {
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(narrow) + 3 * i;
+    v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+  }
+  keys[i] = base + (int64_t)(uint64_t)v;
+}
+
 // rep[i] = index of the representative of (table(i), key(i)).  Two levels, like the probe kernel's input dedup (kernels.hip):
 //   tile   one workgroup per tile of <= 1,024 keys of one table: a 32-bit LDS CAS set gives every key its tile-local
 //          representative — the hot head of a Zipf request (one key = 7 % of 1.7 M keys) collapses to one key per tile HERE, in
@@ -231,6 +248,14 @@ __global__ __launch_bounds__(256) void hps_entry_expand_kernel(const EntryDesc* 
       }
     }
   }
+}
+
+hipError_t LaunchEntryWiden(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, const void* d_narrow, uint32_t key_bytes,
+                            int64_t* d_keys, hipStream_t stream) {
+  if (num_tiles == 0) return hipSuccess;
+  if (key_bytes != 3 && key_bytes != 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(hps_entry_widen_kernel, dim3(num_tiles), dim3(kEntryTile), 0, stream, d_desc, d_tiles, d_narrow, key_bytes, d_keys);
+  return hipGetLastError();
 }
 
 hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, const int64_t* d_keys, uint64_t n,

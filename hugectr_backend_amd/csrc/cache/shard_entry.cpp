@@ -86,6 +86,7 @@ Status ShardedEntrySession::Create(std::shared_ptr<HierParameterServer> ps, cons
   auto tabs = ps->tables_of(model);
   if (tabs.size() != T) return Error(Code::kNotFound, "model '", model, "': tables are not loaded");
   for (size_t t = 0; t < T; ++t) s->dims_.push_back(tabs[t]->dim());
+  s->tables_ = tabs;
 
   // ---- the P shard sessions, each on its shard's device; their kernels read the bucket keys out of, and store the rows
   //      into, the entry device's memory: peer access from every other shard device to the entry device ----
@@ -138,6 +139,7 @@ Status ShardedEntrySession::Create(std::shared_ptr<HierParameterServer> ps, cons
   HPS_RETURN_IF_ERROR(dev_alloc(&s->d_block_, block_bytes));
   HPS_RETURN_IF_ERROR(pin_alloc(&s->h_keys_, N));
   HPS_RETURN_IF_ERROR(dev_alloc(&s->d_keys_, N));
+  HPS_RETURN_IF_ERROR(dev_alloc(&s->d_narrow_, N * 4));
   HPS_RETURN_IF_ERROR(dev_alloc(&s->d_rep_, N));
   uint64_t set_cap = 1024;
   while (set_cap < 2 * (uint64_t)N) set_cap <<= 1;
@@ -176,7 +178,7 @@ ShardedEntrySession::~ShardedEntrySession() {
   (void)hipSetDevice(device_);
   if (stream_) { (void)hipStreamSynchronize(stream_); (void)hipStreamDestroy(stream_); }
   for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
-  for (void* p : {(void*)d_block_, (void*)d_keys_, (void*)d_rep_, (void*)d_set_, (void*)d_hist_, (void*)d_within_, (void*)d_counts_,
+  for (void* p : {(void*)d_block_, (void*)d_keys_, (void*)d_narrow_, (void*)d_rep_, (void*)d_set_, (void*)d_hist_, (void*)d_within_, (void*)d_counts_,
                   (void*)d_bkeys_, (void*)d_bidx_})
     if (p) (void)hipFree(p);
   for (void* p : {(void*)h_block_, (void*)h_keys_, (void*)h_counts_}) if (p) (void)hipHostFree(p);
@@ -224,6 +226,7 @@ Status ShardedEntrySession::lookup_from_device(const int64_t* d_keys_flat, float
   if (!n || !d_out) return Error(Code::kInvalidArg, "null argument");
   HIP_TRY(hipSetDevice(device_));
   stats_.key_stage_ms = 0.f;
+  stats_.key_bytes = 8;
   return Run(d_keys_flat, d_out, n, T);
 }
 
@@ -265,13 +268,63 @@ Status ShardedEntrySession::lookup(const void* const* h_keys_per_table, float* c
     HIP_TRY(hipMemcpyAsync(d_keys_, base, N * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
   } else {
     constexpr size_t kTaskKeys = 32768, kGroupKeys = (4u << 20) / sizeof(int64_t);
-    struct Task { const int64_t* src; size_t off, n; };
+    struct Task { const int64_t* src; size_t off, n; uint64_t base; };
     std::vector<Task> tasks;
     size_t off = 0;
+    key_base_.assign(T, 0);
     for (size_t t = 0; t < T; ++t) {
       const int64_t* p = (const int64_t*)h_keys_per_table[t];
-      for (size_t b = 0; b < n[t]; b += kTaskKeys) tasks.push_back({p + b, off + b, std::min(kTaskKeys, n[t] - b)});
+      key_base_[t] = tables_[t]->min_key();
+      for (size_t b = 0; b < n[t]; b += kTaskKeys) tasks.push_back({p + b, off + b, std::min(kTaskKeys, n[t] - b), (uint64_t)key_base_[t]});
       off += n[t];
+    }
+    // The keys cross PCIe at the width they need, as a replica's do (LookupSession::lookup, key_pack.h): offsets from their
+    // table's smallest key, 3 bytes each (packed) when they all fit 24 bits, uint32 when 32, else 8 bytes as they are; a look at
+    // three keys of every task decides the attempt, the copy loop ORs everything it sees and a key too wide restages the
+    // request at 8 bytes (and narrowing pauses for 256 calls, doubling per failure in a row).  On the entry GPU a small kernel
+    // widens them again (hps_entry_widen) — the bucket kernels and the owners read int64.
+    uint32_t width = 8;
+    if (narrow_backoff_ > 0) --narrow_backoff_;
+    else if (N >= 4 * kTaskKeys) {
+      uint64_t sample = 0;
+      for (const Task& tk : tasks)
+        sample |= ((uint64_t)tk.src[0] - tk.base) | ((uint64_t)tk.src[tk.n / 2] - tk.base) | ((uint64_t)tk.src[tk.n - 1] - tk.base);
+      width = (sample >> 32) ? 8u : (sample >> 24) ? 4u : 3u;
+    }
+    for (; width < 8;) {
+      std::atomic<uint64_t> high_or{0};
+      uint8_t* dst8 = reinterpret_cast<uint8_t*>(h_keys_);
+      bool failed = false;
+      size_t g0n = 0;
+      while (g0n < tasks.size() && !failed) {
+        size_t g1 = g0n, keys_in_group = 0;
+        while (g1 < tasks.size() && (keys_in_group == 0 || keys_in_group + tasks[g1].n <= kGroupKeys)) keys_in_group += tasks[g1++].n;
+        auto body = [&](size_t i) {
+          const Task& tk = tasks[g0n + i];
+          const uint64_t high = width == 4 ? PackKeys32(tk.src, tk.n, reinterpret_cast<uint32_t*>(dst8) + tk.off, tk.base)
+                                           : PackKeys24(tk.src, tk.n, dst8 + 3 * tk.off, tk.base);
+          if (high >> (8 * width)) high_or.fetch_or(high, std::memory_order_relaxed);
+        };
+        if (g1 - g0n <= 2) for (size_t i = 0; i < g1 - g0n; ++i) body(i);
+        else ThreadPool::Serving().ParallelFor(g1 - g0n, body);
+        if (high_or.load(std::memory_order_relaxed) != 0) { failed = true; break; }
+        const size_t first = tasks[g0n].off, count = tasks[g1 - 1].off + tasks[g1 - 1].n - first;
+        HIP_TRY(hipMemcpyAsync(d_narrow_ + first * width, dst8 + first * width, count * width, hipMemcpyHostToDevice, stream_));
+        g0n = g1;
+      }
+      if (!failed) {
+        narrow_streak_ = 0;
+        stats_.key_bytes = (int)width;
+        stats_.key_stage_ms = MsSince(t0);
+        return Run(d_keys_, d_out, n, T, width);
+      }
+      // a key too wide for the attempt: the groups in flight read the staging buffer that is about to be rewritten
+      HIP_TRY(hipStreamSynchronize(stream_));
+      const uint64_t seen = high_or.load(std::memory_order_relaxed);
+      if (width == 3 && (seen >> 32) == 0) { width = 4; continue; }
+      narrow_backoff_ = 256 << (narrow_streak_ < 8 ? narrow_streak_ : 8);
+      if (narrow_streak_ < 8) ++narrow_streak_;
+      width = 8;
     }
     size_t g0 = 0;
     while (g0 < tasks.size()) {
@@ -285,11 +338,12 @@ Status ShardedEntrySession::lookup(const void* const* h_keys_per_table, float* c
       g0 = g1;
     }
   }
+  stats_.key_bytes = 8;
   stats_.key_stage_ms = MsSince(t0);
   return Run(d_keys_, d_out, n, T);
 }
 
-Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
+Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T, uint32_t narrow_bytes) {
   const auto t0 = std::chrono::steady_clock::now();
   EntryDesc& d = *reinterpret_cast<EntryDesc*>(h_block_);
   TileDesc* tiles = reinterpret_cast<TileDesc*>(h_block_ + tiles_off_);
@@ -301,6 +355,7 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
     d.first_tile[t] = nt;
     d.out[t] = d_out[t];
     d.dim[t] = dims_[t];
+    d.key_base[t] = (narrow_bytes && t < key_base_.size()) ? key_base_[t] : 0;
     for (uint64_t b = 0; b < n[t]; b += kTileKeys) tiles[nt++] = TileDesc{N + b, (uint32_t)std::min<uint64_t>(kTileKeys, n[t] - b), (uint32_t)t};
     N += n[t];
   }
@@ -327,6 +382,7 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
   const EntryDesc* dd = reinterpret_cast<const EntryDesc*>(d_block_);
   const TileDesc* dt = reinterpret_cast<const TileDesc*>(d_block_ + tiles_off_);
   HIP_TRY(hipMemcpyAsync(d_block_, h_block_, tiles_off_ + (size_t)nt * sizeof(TileDesc), hipMemcpyHostToDevice, stream_));
+  if (narrow_bytes) HIP_TRY(LaunchEntryWiden(dd, dt, nt, d_narrow_, narrow_bytes, d_keys_, stream_));
   const bool dedup = dedup_;
   if (dedup) {
     if (++set_tag_ == 0) {   // 2^32 requests later: entries of the first ones would look like this one's

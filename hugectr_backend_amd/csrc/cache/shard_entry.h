@@ -54,6 +54,7 @@ struct ShardEntryStats {
   float lookup_ms = 0.f;         // dispatch .. last shard done (wall)
   float expand_ms = 0.f;         // repeated keys' rows (wall, including the synchronisation)
   float key_stage_ms = 0.f;      // host keys: staging + upload enqueue
+  int key_bytes = 8;             // bytes per key that crossed PCIe: 8, 4 (uint32 offsets) or 3 (packed)
   uint64_t misses = 0, unique_misses = 0;   // summed over the shards' lookups
 };
 
@@ -82,7 +83,8 @@ class ShardedEntrySession {
 
  private:
   ShardedEntrySession() = default;
-  Status Run(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T);
+  // narrow_bytes 3 / 4: d_narrow_ holds the request's keys as offsets from key_base_ (they are widened into d_keys_ first)
+  Status Run(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T, uint32_t narrow_bytes = 0);
 
   struct Worker {
     std::thread th;
@@ -118,6 +120,10 @@ class ShardedEntrySession {
   size_t tiles_off_ = 0;
   int64_t* h_keys_ = nullptr;      // pinned staging of host keys
   int64_t* d_keys_ = nullptr;
+  uint8_t* d_narrow_ = nullptr;    // narrowed host keys as they crossed PCIe (4 bytes per key at most)
+  std::vector<std::shared_ptr<HostTable>> tables_;
+  std::vector<int64_t> key_base_;  // this request's per-table bases (frame of reference: the tables' smallest keys)
+  int narrow_backoff_ = 0, narrow_streak_ = 0;   // calls left before narrowing is tried again after a key too wide; failures in a row
   uint32_t* d_rep_ = nullptr;
   unsigned long long* d_set_ = nullptr;
   uint64_t set_mask_ = 0;

@@ -326,7 +326,7 @@ typedef struct hps_shard_entry_stats {
   uint64_t misses, unique_misses;      /* summed over the shards' lookups */
   float bucket_ms, lookup_ms, expand_ms, key_stage_ms;   /* wall clock of the phases of the last request */
   uint32_t num_shards;
-  uint32_t reserved_;
+  uint32_t key_bytes;                  /* host keys: bytes per key that crossed PCIe (8; 4 / 3 = offsets from the table's smallest key) */
   uint64_t sent[64];                   /* keys each shard was asked for */
   uint32_t passes[64];                 /* lookup calls per shard */
   float shard_ms[64];                  /* wall time of each shard's lookups */

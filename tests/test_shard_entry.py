@@ -231,6 +231,62 @@ def test_an_owner_that_gets_more_than_its_session_holds_is_served_in_passes(plai
 
 
 @pytest.mark.gpu
+def test_host_keys_cross_pcie_at_the_width_they_need(plain_lru):
+    """A big request's host keys are staged as offsets from their table's smallest key — 3 bytes each when they all fit 24
+    bits, uint32 when 32 — and widened again on the entry GPU (hps_entry_widen); a key that does not fit restages the request at 8
+    bytes.  Same rows whatever the width; small requests are not narrowed."""
+    import torch
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(8)
+    n0, n1 = 150000, 60000
+    k0 = (5_000_000_000 + rng.permutation(1 << 21)[:n0]).astype(np.int64)           # high base, offsets < 2^24
+    k1 = (7 + rng.permutation(1 << 30)[:n1].astype(np.int64) * 3).astype(np.int64)  # offsets up to ~2^31.6
+    tables = [(k0, rng.standard_normal((n0, 16), dtype=np.float32)), (k1, rng.standard_normal((n1, 4), dtype=np.float32))]
+    ps = _server("w", tables, 2, gpucacheper=0.5, hit_rate_threshold=1.0, maxcat=[2, 1], max_batch=131072, defaults=[0.0, 3.0])
+    try:
+        e = hps.ShardedEntrySession.create(ps, "w", 0)
+
+        def ask(q, nk, want):
+            out = e.lookup(q, nk)
+            torch.cuda.synchronize()
+            assert np.array_equal(_bits(out.cpu().numpy()), _bits(O.np_lookup(tables, q, nk, [0.0, 3.0]))), (nk, want)
+            assert e.last_stats().key_bytes == want, (nk, want, e.last_stats().key_bytes)
+
+        nk = [200000, 0]
+        ask(k0[rng.integers(0, n0, nk[0])], nk, 3)
+        nk = [131072, 100000]
+        q = np.concatenate([k0[rng.integers(0, n0, nk[0])], k1[rng.integers(0, n1, nk[1])]])
+        ask(q, nk, 4)
+        # a key that was never in the table but fits the width travels narrow too (and gets the default row)
+        q2 = q.copy()
+        q2[5] = int(k0.min()) + (1 << 23) + 12345
+        ask(q2, nk, 4)
+        # keys outside the frame (below the base / far above): the sampled look misses them, the copy loop sees them
+        q3 = q.copy()
+        q3[777] = -4
+        q3[nk[0] + 3001] = 1 << 45
+        ask(q3, nk, 8)
+        ask(q, nk, 8)                      # narrowing pauses after a failure ...
+        e2 = hps.ShardedEntrySession.create(ps, "w", 0)
+        nk = [200000, 0]
+        q4 = k0[rng.integers(0, n0, nk[0])]
+        q4[100001] = int(k0.min()) + (1 << 24) + 5          # 25 bits: the 3-byte attempt fails over to uint32
+        out = e2.lookup(q4, nk)
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(O.np_lookup(tables, q4, nk, [0.0, 3.0])))
+        assert e2.last_stats().key_bytes == 4
+        # small requests go as they are
+        nk = [5000, 100]
+        out = e2.lookup(np.concatenate([k0[:5000], k1[:100]]), nk)
+        assert e2.last_stats().key_bytes == 8
+        e.close()
+        e2.close()
+    finally:
+        ps.close()
+
+
+@pytest.mark.gpu
 def test_async_insert_mode_and_refresh_on_a_sharded_model(plain_lru):
     """Insertion policy and refresh work per shard as for any cache: threshold 0 answers misses with the default vector and
     inserts them in the background; afterwards the same keys are served exactly; an updated row reaches the shard that owns it."""
