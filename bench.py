@@ -355,7 +355,7 @@ def compact_line(res, limit=COMPACT_LIMIT):
     put("all_hit_2s_host_keys_Glps", _scale(g(ex, "all_hit_two_sessions_host_keys", "lookups_per_s"), 1e-9))
     put("all_hit_max_call_ms", g(ex, "all_hit_two_sessions_host_keys", "max_call_ms"))
     put("all_hit_call_over_kernel_time", rf.get("all_hit_call_over_kernel_time"))
-    for tag in ("hit_999", "hit_99"):
+    for tag in ("hit_999", "hit_99", "hit_90", "hit_50"):
         put(f"{tag}_2s_host_keys_Glps", _scale(g(ex, f"{tag}_two_sessions_host_keys", "lookups_per_s"), 1e-9))
         put(f"{tag}_max_call_ms", g(ex, f"{tag}_two_sessions_host_keys", "max_call_ms"))
     put("one_session_p50_ms", g(ex, "one_session_host_keys_95", "p50_call_ms"))
@@ -573,6 +573,9 @@ def main():
             "ps_direct_access": bool(a.direct),
         } for m in models],
     }
+    if os.environ.get("BENCH_PS_EXTRA"):          # harness-only: extra ps.json model keys for A/B runs (tools/ab_small_insert.sh)
+        for mm in cfg["models"]:
+            mm.update(json.loads(os.environ["BENCH_PS_EXTRA"]))
 
     def setup():
         """One parameter server: the host tables are generated once, then one cache per (model, device)."""
@@ -921,6 +924,13 @@ def main():
                 "note": f"hps_server_fetch (host tier of this build) on the timed region's own batches, all {T} tables, "
                         f"{reps} passes, rows into pageable host memory"}
             del outc
+            # (7) the rest of SURVEY 8(d)'s hit-rate sweep (h = 1.0 / 0.999 / 0.99 are legs (3) / (3b), 0.957 is the headline): 90 % and
+            #     50 % of the keys resident — 87 MB / 436 MB of missed rows per call over PCIe.  Last, because these calls replace most
+            #     of what the cache holds
+            for tag, h_, st_ in (("hit_90", 0.90, 12), ("hit_50", 0.50, 8)):
+                nb_ = fresh(st_ + 4, h_, resident_now())
+                extra[f"{tag}_two_sessions_host_keys"] = leg(host_form(nb_), st_, "host")
+                del nb_
 
         try:   # the legs are informational: a failure in one of them must not cost the headline line
             run_legs()
