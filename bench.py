@@ -64,6 +64,7 @@ def parse_args():
     ap.add_argument("--distinct-batches", type=int, default=0, help="0: one fresh batch per step")
     ap.add_argument("--probe-variant", type=int, default=1002, help="probe kernel: 1002 (default) or 1102 (no tile-local input dedup)")
     ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
+    ap.add_argument("--probe-in-lane", type=int, default=2, help="K_P and the kernel lane: 1 = always inside, 0 = never, 2 = outside while the session's calls miss little (default)")
     ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
     ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys narrower when every key of the request fits: 1 = 3-byte packing or uint32, 2 = uint32 only, 0 = off")
     ap.add_argument("--direct", type=int, default=-1,
@@ -631,6 +632,7 @@ def main():
                 s.set_option("split_probe", 1 if split else 0)
                 s.set_option("narrow_keys", a.narrow_keys)
                 s.set_option("chain_gather", a.chain_gather)
+                s.set_option("probe_in_lane", a.probe_in_lane)
             # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
             resident = []
             for t in range(T):

@@ -1206,15 +1206,17 @@ Status LookupSession::CollectDeferred() {
 
 // After the accumulator block has come back: per-table unique miss counts, the call's statistics.
 Status LookupSession::ReadBackCounts(size_t T, uint64_t N, bool exact) {
-  uint64_t misses = 0, uniq = 0, uniq_keys = 0;
+  uint64_t misses = 0, uniq = 0, uniq_keys = 0, row_bytes = 0;
   for (size_t t = 0; t < T; ++t) {
     const uint32_t um = h_acc_[AccTableWord((uint32_t)t, kAccUniqMiss)];
     uniq_miss_[t] = um;
     uniq += um;
+    row_bytes += (uint64_t)um * tables_[t]->dim() * sizeof(float);
     misses += h_acc_[AccTableWord((uint32_t)t, kAccSentMiss)];
     if (exact) uniq_keys += (uint64_t)um + h_acc_[AccTableWord((uint32_t)t, kAccUniqHit)];
   }
   last_misses_ = misses;
+  last_miss_row_bytes_ = row_bytes;
   last_unique_ = uniq;
   last_unique_keys_ = uniq_keys;
   cache_->AdvanceClock(uniq);
@@ -1283,7 +1285,15 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
 
   // ---- K_P: tile dedup + probe;  K_M: call-wide unique misses (+ unique hits) ----
   cache_->BeginRead(stream_);
-  if (exclusive_) cache_->LaneEnter(stream_);
+  // The kernel lane keeps the HBM-bound kernels of a cache's sessions from running into each other.  K_P is not one of them
+  // (~120 MB of bucket lines in 42 us), but in the lane it waits for the other session's whole gather — and with it this call's
+  // miss counts, host gather and upload.  While the session's calls miss little (the same bound as the second-stream scatter:
+  // the last call's missed rows fit side_bytes_) the probe therefore runs NEXT TO that gather and only K_G takes a turn: at
+  // 99 % hit the call's chain is 0.73 instead of 0.81 ms and two sessions deliver 4.3 instead of 3.6-3.9 G lookups/s, every key
+  // resident 6.0-6.2 instead of 5.6-5.8 G (profiles/round5/ab_probe_outside_the_lane.txt).  Calls that miss more (the
+  // headline's 37 MB) are bound by PCIe either way and keep the probe in the lane, where it runs in 42 us instead of 50.
+  const bool probe_lane = exclusive_ && (probe_in_lane_ == 1 || (probe_in_lane_ == 2 && last_miss_row_bytes_ > side_bytes_));
+  if (probe_lane) cache_->LaneEnter(stream_);
   Mark(ev_t0_);
   const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_);
   hipError_t e = LaunchProbeTiles(d_call_, cache_->device_tables(), wk, probe_variant_, tail, stream_, Kt(ev_t0_, tail && !exact ? ev_t1_ : nullptr));
@@ -1302,8 +1312,8 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   // (split: the counts leave on the session's SECOND stream, released by the probe's event, so K_G follows K_P on this stream
   //  just the same — round 3 pushed them between the two kernels: two more dependent packets and ~35 us of idle GPU per call)
   const bool side_push = split && zc_control_;
-  const bool hold_lane = exclusive_ && (!split || side_push) && e == hipSuccess;
-  if (exclusive_ && !hold_lane) cache_->LaneLeave(stream_, ev_lane_[0]);
+  const bool hold_lane = probe_lane && (!split || side_push) && e == hipSuccess;
+  if (probe_lane && !hold_lane) cache_->LaneLeave(stream_, ev_lane_[0]);
   // other sessions' probes chain behind ours (K_P, and K_M / K_H where they are launches of their own)
   (void)hipEventRecord(ev_probe_, stream_);
   auto gather = [&]() -> hipError_t {

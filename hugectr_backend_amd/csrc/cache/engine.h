@@ -288,6 +288,7 @@ class LookupSession {
   void set_split_probe(bool b) { split_probe_ = b; }
   void set_xcd_walk(bool b) { xcd_walk_ = b; }
   void set_chain_gather(bool b) { chain_gather_ = b; }
+  void set_probe_in_lane(int v) { probe_in_lane_ = v; }
   void set_narrow_publish(bool b) { narrow_publish_ = b; }
   void set_exclusive_kernels(bool b) { exclusive_ = b; }
   void set_fused_unique(bool b) { fused_unique_ = b; }
@@ -427,6 +428,8 @@ class LookupSession {
   bool direct_split_ = true;     // device-driven tier: the fetch kernel runs next to the call's own hit gather (round 3: +4 %)
   bool narrow_publish_ = true;   // a narrowed request's unique missed keys come back to the host as uint32 (option "narrow_publish")
   bool uniq_narrow_ = false;     // this call: h_uniq_keys_ holds uint32 keys
+  int probe_in_lane_ = 2;        // option "probe_in_lane": 1 = K_P takes its turn in the kernel lane, 0 = it runs next to another session's
+                                 // K_G, 2 (default) = next to it while the session's calls miss little (last call's missed rows <= side_bytes_)
   bool chain_gather_ = false;    // other sessions' probes queue behind this session's gather as well as its probe
   bool xcd_walk_ = true;         // K_G: each XCD sweeps its own eighth of the key range (option "xcd_walk" 0: plain grid stride)
   MissDesc* h_md_ = nullptr;      // pinned
@@ -445,7 +448,7 @@ class LookupSession {
   Status ReadBackCounts(size_t T, uint64_t N, bool exact);
   void AddInsertStats();
 
-  uint64_t last_misses_ = 0, last_unique_ = 0, last_unique_keys_ = 0;
+  uint64_t last_misses_ = 0, last_unique_ = 0, last_unique_keys_ = 0, last_miss_row_bytes_ = 0;
   bool last_async_ = false;
   float last_gpu_ms_ = 0.f;
   float phase_ms_[4] = {0, 0, 0, 0};

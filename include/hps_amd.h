@@ -252,7 +252,10 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
  * "in_place_kb" (default 1024: missed rows of a call up to this many KB are read by the scatter and insert kernels out of
  * the page-locked buffer the host gathered them into, next to the hit gather, instead of being uploaded first),
  * "side_scatter_mb" (default 16: missed rows up to this many MB are uploaded and scattered on the session's second stream,
- * without a turn in the kernel lane; beyond it the scatter takes its turn behind a drained stream) */
+ * without a turn in the kernel lane; beyond it the scatter takes its turn behind a drained stream),
+ * "probe_in_lane" (default 2: the probe kernel runs next to another session's hit gather while this session's calls miss
+ * little — last call's missed rows <= side_scatter_mb — and takes its turn in the kernel lane otherwise; 1: always in the
+ * lane; 0: never) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 /* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------

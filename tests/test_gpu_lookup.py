@@ -935,10 +935,13 @@ def test_small_miss_calls_insert_every_nth_time(interval, admission):
     s0.close()
 
 
-def test_two_sessions_near_all_hit_stress_rows_stay_exact():
+@pytest.mark.parametrize("probe_in_lane", [2, 1, 0], ids=["probe_next_to_the_other_gather_while_missing_little", "probe_in_the_lane", "probe_never_in_the_lane"])
+def test_two_sessions_near_all_hit_stress_rows_stay_exact(probe_in_lane):
     """Two sessions on one cache, big requests that miss a few hundred rows each (the regime of a production cache at
     99.9 % hit): side-stream scatter next to the hit gather, inserts left behind the calls, the other session's probes
-    ordered behind them by the writer event — every row of every call exact, nothing lost from the counters."""
+    ordered behind them by the writer event — every row of every call exact, nothing lost from the counters.
+    Session option "probe_in_lane": where K_P runs relative to the other session's K_G is scheduling only (2, the default:
+    next to it while the session's calls miss little; 1: always behind it; 0: never)."""
     import threading
     from hugectr_backend_amd import hps
     from oracle import hps_oracle as O
@@ -946,6 +949,8 @@ def test_two_sessions_near_all_hit_stress_rows_stay_exact():
     tables = make_tables([(R, D)] * T)
     ps, cache, s0 = _mk("nearhit", tables, maxcat=[1] * T, gpucacheper=0.25, max_batch=100000)
     s1 = hps.LookupSession.create(ps, "nearhit", cache)
+    for s_ in (s0, s1):
+        s_.set_option("probe_in_lane", probe_in_lane)
     co = O.COracle()
     for k, r in tables:
         co.add_table_arrays(k, r)
