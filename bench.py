@@ -1755,7 +1755,7 @@ def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
            "models": [{"model": model, "sparse_files": ["synthetic://one_table"], "num_of_worker_buffer_in_pool": max(2, P),
                        "embedding_vecsize_per_table": [D], "maxnum_catfeature_query_per_table_per_sample": [1],
                        "default_value_for_each_table": [0.0], "deployed_device_list": list(shard_devs), "max_batch_size": N,
-                       "gpucache": True, "gpucacheper": 1.0, "gpucache_load_factor": float(os.environ.get("ENTRY_LOAD_FACTOR", "0.6")),
+                       "gpucache": True, "gpucacheper": 1.0, "gpucache_load_factor": float(os.environ.get("ENTRY_LOAD_FACTOR", "0.5")),
                        "hit_rate_threshold": 1.0, "table_sharding": "hash"}]}
     ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
     ps.load_table_synthetic(model, 0, SEED, 0, rows_total)
@@ -1818,7 +1818,7 @@ def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
         one = {"lookups_per_s": N * steps / dt, "ms_per_request": dt / steps * 1e3, "p50_request_ms": float(np.percentile(lat, 50)),
                "p99_request_ms": float(np.percentile(lat, 99)), "parity": ok,
                "phase_ms": {"key_stage": float(pm[0]), "bucket": float(pm[1]), "shard_lookups": float(pm[2]), "expand_repeats": float(pm[3])},
-               "host_key_bytes_over_pcie": int(st.key_bytes), "distinct_keys_per_request": float(pm[4]), "distinct_misses_per_request": float(pm[7]), "slowest_shard_ms": float(pm[5]), "largest_bucket_keys": float(pm[6]),
+               "host_key_bytes_over_pcie": int(st.key_bytes), "dedup_level": int(st.dedup_level), "distinct_keys_per_request": float(pm[4]), "distinct_misses_per_request": float(pm[7]), "slowest_shard_ms": float(pm[5]), "largest_bucket_keys": float(pm[6]),
                "row_bytes_from_other_gpus_per_request": remote * 4 * D,
                "rows_GBps_into_entry_gpu": remote * 4 * D / (pm[2] * 1e-3) / 1e9 if pm[2] > 0 and remote else None}
         # device keys (an ensemble step upstream holds them in HBM)

@@ -681,6 +681,7 @@ int hps_shard_entry_last_stats(hps_shard_entry_t* e, hps_shard_entry_stats_t* ou
     out->bucket_ms = st.bucket_ms; out->lookup_ms = st.lookup_ms; out->expand_ms = st.expand_ms; out->key_stage_ms = st.key_stage_ms;
     out->num_shards = e->s->num_shards();
     out->key_bytes = (uint32_t)st.key_bytes;
+    out->dedup_level = (uint32_t)st.dedup_level;
     for (uint32_t s = 0; s < e->s->num_shards() && s < 64; ++s) {
       out->sent[s] = st.sent[s]; out->passes[s] = st.passes[s]; out->shard_ms[s] = st.shard_ms[s];
     }
@@ -692,7 +693,7 @@ int hps_shard_entry_set_option(hps_shard_entry_t* e, const char* name, int value
   return Guard([&]() -> Status {
     if (!e || !name) return Error(Code::kInvalidArg, "null argument");
     const std::string n(name);
-    if (n == "dedup") e->s->set_dedup(value != 0);
+    if (n == "dedup") e->s->set_dedup(value < 0 ? 0 : value > 2 ? 2 : value);
     else if (n == "timing") e->s->set_timing(value != 0);
     else return Error(Code::kInvalidArg, "unknown option '", n, "'");
     return Status::Ok();

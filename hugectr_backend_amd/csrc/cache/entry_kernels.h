@@ -25,6 +25,7 @@ struct EntryDesc {
 // int64 keys for the bucket kernels and the owners.  key_bytes 3 or 4.
 hipError_t LaunchEntryWiden(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, const void* d_narrow, uint32_t key_bytes,
                             int64_t* d_keys, hipStream_t stream);
+// (d_set == nullptr: the tile level only — a key that several tiles hold travels once per tile)
 // d_rep[i] = index of the representative of (table of i, key i): i itself for one key of every distinct pair.
 // d_set: set_mask + 1 (a power of two >= 2 n) words, zeroed once; tag != 0, different from the tags still in the set.
 hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, const int64_t* d_keys, uint64_t n,

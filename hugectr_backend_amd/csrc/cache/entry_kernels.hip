@@ -87,7 +87,8 @@ __global__ __launch_bounds__(kEntryTile) void hps_entry_dedup_kernel(const Entry
       e = (e + 1) & (2 * kEntryTile - 1);
     }
   }
-  if (inb && lrep == j) {
+  if (inb && lrep == j && set == nullptr) sh_grep[j] = (uint32_t)i;   // tile level only: the tile's representative travels
+  if (inb && lrep == j && set != nullptr) {
     const uint64_t lo = d->key_start[t], hi = d->key_start[t + 1];
     uint64_t h = (h0 >> 11) & mask;
     const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)i;
@@ -261,7 +262,7 @@ hipError_t LaunchEntryWiden(const EntryDesc* d_desc, const TileDesc* d_tiles, ui
 hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, const int64_t* d_keys, uint64_t n,
                             unsigned long long* d_set, uint64_t set_mask, uint32_t tag, uint32_t* d_rep, hipStream_t stream) {
   if (n == 0 || num_tiles == 0) return hipSuccess;
-  if (tag == 0 || (set_mask & (set_mask + 1)) != 0 || set_mask + 1 < 2 * n) return hipErrorInvalidValue;
+  if (d_set && (tag == 0 || (set_mask & (set_mask + 1)) != 0 || set_mask + 1 < 2 * n)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(hps_entry_dedup_kernel, dim3(num_tiles), dim3(kEntryTile), 0, stream, d_desc, d_tiles, d_keys, d_set, set_mask, tag, d_rep);
   return hipGetLastError();
 }

@@ -73,7 +73,7 @@ Status ShardedEntrySession::Create(std::shared_ptr<HierParameterServer> ps, cons
   s->params_ = p;
   s->P_ = (uint32_t)p.deployed_devices.size();
   s->device_ = entry_device;
-  s->dedup_ = p.shard_dedup;
+  s->dedup_ = p.shard_dedup ? 1 : 0;
   size_t per_sample = 0;
   for (size_t c : p.maxnum_catfeature_query_per_table_per_sample) per_sample += c;
   s->max_keys_ = p.max_batchsize * per_sample;
@@ -201,6 +201,7 @@ void ShardedEntrySession::WorkerMain(uint32_t s) {
       w.has_job = false;
     }
     const auto t0 = std::chrono::steady_clock::now();
+    w.wake_ms = std::chrono::duration<float, std::milli>(t0 - w.posted).count();
     Status st = Status::Ok();
     uint64_t misses = 0, unique = 0;
     for (const ShardPass& pass : w.plan) {
@@ -383,13 +384,22 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
   const TileDesc* dt = reinterpret_cast<const TileDesc*>(d_block_ + tiles_off_);
   HIP_TRY(hipMemcpyAsync(d_block_, h_block_, tiles_off_ + (size_t)nt * sizeof(TileDesc), hipMemcpyHostToDevice, stream_));
   if (narrow_bytes) HIP_TRY(LaunchEntryWiden(dd, dt, nt, d_narrow_, narrow_bytes, d_keys_, stream_));
-  const bool dedup = dedup_;
-  if (dedup) {
+  // Input dedup, two levels (entry_kernels.hip): inside tiles of 1,024 keys (LDS), then call-wide — one device-scope CAS per tile
+  // representative: 1.7 M of them for a request that repeats little, 113 us at the chip's ~15 G atomics/s to spare 5 % of the
+  // rows.  Adaptive (shard_dedup, the default): a big request of which more than 90 % travelled anyway sends the next 31 requests
+  // through the tile level only; one that then finds repeats inside its tiles (< 80 % travel) brings the call-wide level back
+  // at once.  Rows are exact at every level: a key that travels twice is looked up twice.
+  const bool dedup = dedup_ != 0;
+  const int level = !dedup ? 0 : (dedup_ == 1 && tile_only_left_ > 0) ? 1 : 2;
+  stats_.dedup_level = level;
+  if (level == 2) {
     if (++set_tag_ == 0) {   // 2^32 requests later: entries of the first ones would look like this one's
       HIP_TRY(hipMemsetAsync(d_set_, 0, (set_mask_ + 1) * sizeof(unsigned long long), stream_));
       set_tag_ = 1;
     }
     HIP_TRY(LaunchEntryDedup(dd, dt, nt, d_keys_flat, N, d_set_, set_mask_, set_tag_, d_rep_, stream_));
+  } else if (level == 1) {
+    HIP_TRY(LaunchEntryDedup(dd, dt, nt, d_keys_flat, N, nullptr, 0, 0, d_rep_, stream_));
   }
   uint32_t* d_base = d_counts_;
   uint32_t* d_cnt = d_counts_ + (P_ + 1);
@@ -401,6 +411,11 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
   const uint32_t* base = h_counts_;
   const uint32_t* counts = h_counts_ + (P_ + 1);
   stats_.unique_keys = base[P_];
+  if (dedup_ == 1) {
+    constexpr uint64_t kAdaptiveMinKeys = 1u << 16;
+    if (level == 2 && N >= kAdaptiveMinKeys && stats_.unique_keys * 10 > N * 9) tile_only_left_ = 31;
+    else if (level == 1) tile_only_left_ = (stats_.unique_keys * 10 < N * 8) ? 0 : tile_only_left_ - 1;
+  }
 
   // ---- every owner looks its bucket up, all of them side by side; rows land in d_out over the peer mappings ----
   const auto t1 = std::chrono::steady_clock::now();
@@ -417,6 +432,7 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
       w.out = d_out;
       w.done = false;
       w.has_job = true;
+      w.posted = std::chrono::steady_clock::now();
       stats_.passes[s] = (uint32_t)w.plan.size();
     }
     w.cv.notify_all();
@@ -434,6 +450,18 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
   }
   stats_.lookup_ms = MsSince(t1);
   HPS_RETURN_IF_ERROR(first);
+  static const bool kTrace = std::getenv("HPS_TRACE_TAIL") != nullptr;   // the slow-call trace also covers entry requests
+  if (kTrace) {
+    std::string per;
+    char buf[192];
+    for (uint32_t s = 0; s < P_; ++s) {
+      const float* ph = sessions_[s]->last_phase_ms();   // (of the shard's last pass)
+      snprintf(buf, sizeof buf, " [%u: woke %.3f, lookups %.3f (counts on the host %.3f, host gather %.3f, call %.3f)]", s, workers_[s]->wake_ms,
+               workers_[s]->ms, ph[0], ph[1], ph[3]);
+      per += buf;
+    }
+    fprintf(stderr, "[hps entry] bucket %.3f ms, shard lookups %.3f ms:%s\n", stats_.bucket_ms, stats_.lookup_ms, per.c_str());
+  }
 
   // ---- the request's repeated keys take their representative's row (local copy on the entry device) ----
   if (dedup && stats_.unique_keys < N) {

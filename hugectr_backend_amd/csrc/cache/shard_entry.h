@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -46,7 +47,8 @@ std::vector<ShardPass> PlanShardPasses(const uint32_t* counts, size_t num_tables
 
 struct ShardEntryStats {
   uint64_t keys = 0;             // keys of the last request
-  uint64_t unique_keys = 0;      // distinct (table, key) pairs that travelled (= keys without shard_dedup)
+  uint64_t unique_keys = 0;      // keys that travelled: distinct (table, key) pairs (= keys without shard_dedup; per tile when dedup_level is 1)
+  int dedup_level = 2;           // 0: none, 1: within tiles of 1,024 keys only, 2: call-wide
   std::vector<uint64_t> sent;    // keys each shard was asked for
   std::vector<uint32_t> passes;  // lookup calls per shard (1 unless its bucket exceeded the session's capacity)
   std::vector<float> shard_ms;   // wall time of each shard's lookups
@@ -78,7 +80,7 @@ class ShardedEntrySession {
   size_t max_keys() const { return max_keys_; }
   size_t shard_capacity() const { return shard_cap_; }
   LookupSession* shard_session(uint32_t s) { return s < sessions_.size() ? sessions_[s].get() : nullptr; }
-  void set_dedup(bool b) { dedup_ = b; }
+  void set_dedup(int level) { dedup_ = level; tile_only_left_ = 0; }   // 0 off, 1 adaptive (default), 2 always both levels
   void set_timing(bool b);   // forwards to the shard sessions (per-kernel times in their own statistics)
 
  private:
@@ -96,7 +98,8 @@ class ShardedEntrySession {
     float* const* out = nullptr;
     std::vector<ShardPass> plan;
     Status st = Status::Ok();
-    float ms = 0.f;
+    float ms = 0.f, wake_ms = 0.f;   // lookups' wall time; job posted -> worker running
+    std::chrono::steady_clock::time_point posted;
     uint64_t misses = 0, unique = 0;
   };
   void WorkerMain(uint32_t s);
@@ -106,7 +109,8 @@ class ShardedEntrySession {
   uint32_t P_ = 1;
   int device_ = 0;
   size_t max_keys_ = 0, max_tiles_ = 0, shard_cap_ = 0;
-  bool dedup_ = true;
+  int dedup_ = 1;
+  uint32_t tile_only_left_ = 0;    // adaptive dedup: requests left that skip the call-wide level
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_[2] = {nullptr, nullptr};
   std::vector<std::unique_ptr<LookupSession>> sessions_;   // one per shard, on the shard's device

@@ -325,7 +325,7 @@ int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint6
  * repeats travels to its owner once). */
 typedef struct hps_shard_entry hps_shard_entry_t;
 typedef struct hps_shard_entry_stats {
-  uint64_t keys, unique_keys;          /* last request: keys as sent / distinct (table, key) pairs that travelled */
+  uint64_t keys, unique_keys;          /* last request: keys as sent / keys that travelled (dedup_level 2: the distinct (table, key) pairs) */
   uint64_t misses, unique_misses;      /* summed over the shards' lookups */
   float bucket_ms, lookup_ms, expand_ms, key_stage_ms;   /* wall clock of the phases of the last request */
   uint32_t num_shards;
@@ -333,6 +333,8 @@ typedef struct hps_shard_entry_stats {
   uint64_t sent[64];                   /* keys each shard was asked for */
   uint32_t passes[64];                 /* lookup calls per shard */
   float shard_ms[64];                  /* wall time of each shard's lookups */
+  uint32_t dedup_level;                /* input dedup of the last request: 0 none, 1 within tiles of 1,024 keys, 2 call-wide */
+  uint32_t reserved_;
 } hps_shard_entry_stats_t;
 /* the cache of shard s of a table-sharded model (for residency queries, counters); *out = NULL when there is none */
 int hps_server_get_shard_cache(hps_server_t* server, const char* model, uint32_t shard, hps_cache_t** out);
@@ -344,7 +346,9 @@ int hps_shard_entry_lookup(hps_shard_entry_t* entry, const void* const* h_keys_p
 int hps_shard_entry_lookup_device(hps_shard_entry_t* entry, const int64_t* d_keys_flat, float* const* d_vectors_per_table,
                                   const size_t* num_keys_per_table, size_t num_tables);
 int hps_shard_entry_last_stats(hps_shard_entry_t* entry, hps_shard_entry_stats_t* out);
-/* options: "dedup" (0/1), "timing" (0/1: forwarded to the shard sessions) */
+/* options: "dedup" (0: every key travels as sent; 1, the model's default with shard_dedup: adaptive — repeats found within tiles
+ * of 1,024 keys and call-wide, the call-wide level skipped for 31 requests after a big request of which more than 90 %
+ * travelled anyway; 2: always both levels), "timing" (0/1: forwarded to the shard sessions) */
 int hps_shard_entry_set_option(hps_shard_entry_t* entry, const char* name, int value);
 /* keys a shard session of this entry holds per call */
 uint64_t hps_shard_entry_shard_capacity(hps_shard_entry_t* entry);

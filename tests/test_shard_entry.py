@@ -231,6 +231,60 @@ def test_an_owner_that_gets_more_than_its_session_holds_is_served_in_passes(plai
 
 
 @pytest.mark.gpu
+def test_call_wide_dedup_is_skipped_while_big_requests_repeat_little(plain_lru):
+    """shard_dedup is adaptive: a request of >= 65,536 keys of which more than 90 % travelled anyway sends the next 31 requests through
+    the tile level only (one device-scope atomic per key saved); a request that then repeats keys inside its tiles (< 80 % travel)
+    brings the call-wide level back at once.  Option "dedup" 2 pins both levels.  Same rows at every level."""
+    import torch
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    tables = make_tables([(400000, 16), (300000, 4)], seed=12)
+    ps = _server("ad", tables, 2, gpucacheper=0.5, hit_rate_threshold=1.0, maxcat=[2, 1], max_batch=65536)
+    try:
+        e = hps.ShardedEntrySession.create(ps, "ad", 0)
+        rng = np.random.default_rng(2)
+        nk = [100000, 50000]
+
+        def ask(q, level, exact_unique=None):
+            out = e.lookup(q, nk)
+            torch.cuda.synchronize()
+            assert np.array_equal(_bits(out.cpu().numpy()), _bits(O.np_lookup(tables, q, nk, [0.0, 0.0])))
+            st = e.last_stats()
+            assert st.dedup_level == level, (st.dedup_level, level)
+            distinct = np.unique(q[:nk[0]]).size + np.unique(q[nk[0]:]).size
+            if level == 2:
+                assert st.unique_keys == distinct
+            else:
+                assert distinct <= st.unique_keys <= q.size
+            return st
+
+        def uniform():     # permutations: no repeats at all
+            return np.concatenate([rng.permutation(tables[0][0])[:nk[0]], rng.permutation(tables[1][0])[:nk[1]]]).astype(np.int64)
+
+        def zipf():
+            return _draw(rng, tables, nk, zipf=True, absent=0.0)
+
+        ask(zipf(), 2)                      # repeats: both levels stay
+        ask(zipf(), 2)
+        ask(uniform(), 2)                   # > 90 % travelled ...
+        for _ in range(3):
+            ask(uniform(), 1)               # ... so the next ones skip the call-wide level
+        st = ask(zipf(), 1)                 # the first repeating request still runs at the tile level (and finds repeats there)
+        assert st.unique_keys < 0.8 * sum(nk)
+        ask(zipf(), 2)                      # back at once
+        ask(uniform(), 2)
+        for _ in range(31):
+            ask(uniform(), 1)
+        ask(uniform(), 2)                   # re-measured after 31 requests
+        e.set_option("dedup", 2)
+        for _ in range(3):
+            ask(uniform(), 2)
+        e.close()
+    finally:
+        ps.close()
+
+
+@pytest.mark.gpu
 def test_host_keys_cross_pcie_at_the_width_they_need(plain_lru):
     """A big request's host keys are staged as offsets from their table's smallest key — 3 bytes each when they all fit 24
     bits, uint32 when 32 — and widened again on the entry GPU (hps_entry_widen); a key that does not fit restages the request at 8
