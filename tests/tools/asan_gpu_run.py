@@ -160,6 +160,51 @@ def main():
         hps.LIB.hps_shard_entry_destroy(h)
     print(f"{name}: 3 logical shards, two entry sessions: {[ps.get_shard_cache(name, s).counters()['keys'] for s in range(3)]} keys per shard")
     ps.close()
+    # ---- big requests on a sharded model: host keys staged narrow (3-byte / uint32 offsets, the widen kernel), the fail-over to 8
+    #      bytes, and the adaptive input dedup (tile level only after a request that repeated little) ----
+    name = "asan_sharded_big"
+    rng = np.random.default_rng(5)
+    kb = (5_000_000_000 + rng.permutation(1 << 21)[:300000]).astype(np.int64)
+    kc = (3 + rng.permutation(1 << 29)[:200000].astype(np.int64) * 5).astype(np.int64)
+    big = [(kb, rng.standard_normal((kb.size, 8), dtype=np.float32)), (kc, rng.standard_normal((kc.size, 4), dtype=np.float32))]
+    bdims = [8, 4]
+    cfg = ps_config(name, big, maxcat=[1, 1], defaults=[0.0, 9.0], gpucacheper=0.5, max_batch=100000, extra={"table_sharding": "hash"})
+    cfg["models"][0]["deployed_device_list"] = [0, 0]
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
+    for t, (k, r) in enumerate(big):
+        ps.load_table_arrays(name, t, k, r)
+    ps.create_embedding_cache_per_model(name)
+    h = C.c_void_p()
+    hps._check(hps.LIB.hps_shard_entry_create(ps._h, name.encode(), 0, C.byref(h)))
+    seen = []
+    for it in range(7):
+        nk = [100000, 60000] if it != 1 else [150000, 0]
+        if it in (5,):     # skewed: repeats inside tiles
+            parts = [k[np.minimum(rng.zipf(1.2, n) - 1, k.size - 1)] for (k, _), n in zip(big, nk)]
+        else:              # no repeats
+            parts = [rng.permutation(k)[:n] for (k, _), n in zip(big, nk)]
+        q = np.concatenate(parts).astype(np.int64)
+        if it == 3:
+            q[70001] = -17                       # outside every frame: the request is restaged at 8 bytes
+        n_out = sum(n * d for n, d in zip(nk, bdims))
+        d_out = dmalloc(n_out * 4)
+        kp = (C.c_void_p * 2)(q.ctypes.data, q.ctypes.data + nk[0] * 8)
+        vp = (C.c_void_p * 2)(d_out.value, (d_out.value or 0) + nk[0] * bdims[0] * 4)
+        nkc = (C.c_size_t * 2)(*nk)
+        hps._check(hps.LIB.hps_shard_entry_lookup(h, kp, vp, nkc, 2))
+        st = hps.ShardEntryStats()
+        hps._check(hps.LIB.hps_shard_entry_last_stats(h, C.byref(st)))
+        seen.append((int(st.key_bytes), int(st.dedup_level)))
+        out = np.empty(n_out, np.float32)
+        assert HIP.hipMemcpy(out.ctypes.data, d_out, n_out * 4, 2) == 0
+        HIP.hipFree(d_out)
+        if not np.array_equal(out.view(np.uint32), O.np_lookup(big, q, nk, [0.0, 9.0]).view(np.uint32)):
+            failures.append((name, it))
+    hps.LIB.hps_shard_entry_destroy(h)
+    ps.close()
+    print(f"{name}: (key bytes over PCIe, dedup level) per request: {seen}")
+    if seen != [(4, 2), (3, 1), (4, 1), (8, 1), (8, 1), (8, 1), (8, 2)]:
+        failures.append((name, "widths / dedup levels", seen))
     print("asan_gpu_run:", "FAILED " + repr(failures[:3]) if failures else "ok")
     sys.exit(1 if failures else 0)
 
