@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -1298,10 +1299,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    # nothing may follow the line on stdout (library destructors print: RCCL's banner): leave without running them
+    silence_stdout_for_exit()
+
+
+def silence_stdout_for_exit():
+    """Nothing may follow the result line on stdout, and libraries print when they are torn down (RCCL's version banner; under
+    torch.distributed.run every rank's stdout is merged with rank 0's).  The process still has to exit the normal way — a
+    profiler's tool library (rocprofv3) writes its results from its exit handlers; round 5's first answer, os._exit, left
+    `rocprofv3 -- python bench.py` without an output directory — so file descriptor 1 is pointed at /dev/null instead."""
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
+    try:
+        ctypes.CDLL(None).fflush(None)
+        dn = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(dn, 1)
+        os.close(dn)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def idle_rank(a, dist, rank, world, local_rank):
@@ -1325,9 +1339,7 @@ def idle_rank(a, dist, rank, world, local_rank):
         dog.cancel()
     dist.barrier()
     dist.destroy_process_group()
-    # (this rank's stdout is merged with rank 0's by the launcher: nothing of a library's exit-time output may follow rank 0's line)
-    sys.stderr.flush()
-    os._exit(0)
+    silence_stdout_for_exit()
 
 
 def run_abi_driver(hb, args, timeout):

@@ -57,6 +57,17 @@ def _native_libs():
     _b.build()
     from oracle import hps_oracle
     hps_oracle.build()
+    # On a box with a GPU: bring torch and the ROCm libraries into the page cache HERE, where nothing times it.  The first
+    # `import torch` on a fresh box takes minutes while the image pages in (2.7 x longer than usual on one box of round 5, where the
+    # suite's first GPU test — a subprocess with a 300-s limit — was killed inside exactly that import).
+    try:
+        from hugectr_backend_amd import hps
+        if hps.device_count() > 0:
+            import torch
+            if torch.cuda.is_available():
+                torch.zeros(1, device="cuda").cpu()
+    except Exception:  # noqa: BLE001
+        pass
 
 
 @pytest.fixture

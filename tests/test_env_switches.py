@@ -13,7 +13,7 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _run(code, env, timeout=300):
+def _run(code, env, timeout=900):
     e = dict(os.environ)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
