@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--probe-variant", type=int, default=1002, help="probe kernel: 1002 (default) or 1102 (no tile-local input dedup)")
     ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
     ap.add_argument("--probe-in-lane", type=int, default=2, help="K_P and the kernel lane: 1 = always inside, 0 = never, 2 = outside while the session's calls miss little (default)")
+    ap.add_argument("--numa-bind", type=int, default=1, help="1: bind this process to the NUMA node of its GPU(s) when they share one (numactl --cpunodebind); 0: leave it alone")
     ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
     ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys narrower when every key of the request fits: 1 = 3-byte packing or uint32, 2 = uint32 only, 0 = off")
     ap.add_argument("--direct", type=int, default=-1,
@@ -518,8 +519,19 @@ def main():
     # throttled time in exactly the leg with the 86.7-ms call).  torch is this harness's plumbing, not the product: keep it
     # inside the quota.
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, effective_cpus() // 2))))
-    from hugectr_backend_amd.gpu_wait import wait_for_gpu
+    from hugectr_backend_amd.gpu_wait import bind_process_to_numa_node, gpu_numa_nodes, wait_for_gpu
     wait_for_gpu(30.0)   # a device that another process has just released can be invisible for a moment
+    # Two-socket host: this process (its session threads, the HIP runtime's threads, the request buffers it allocates) stays on the
+    # socket its GPU hangs off, as a deployment does with `numactl --cpunodebind`: unbound, the same binary gave 1.50-2.09 G lookups/s
+    # from run to run on one box (key staging 0.19-0.50 ms and host gather 0.43-0.85 ms per call, wherever threads and pages had
+    # landed), under `taskset` to ONE node 2.03-2.06 G in every run (profiles/round5/numa_one_node.txt).  Only when every GPU of
+    # the run hangs off the same node; --numa-bind 0 leaves the process alone.  Before HIP starts: its threads inherit the mask.
+    bound_node = -1
+    if a.numa_bind and os.path.exists("/sys/devices/system/node/node1"):
+        nodes = gpu_numa_nodes()
+        used = {nodes[g % len(nodes)] for g in range(n_rep)} if nodes else set()
+        if len(used) == 1 and min(used) >= 0 and bind_process_to_numa_node(min(used)):
+            bound_node = min(used)
     import torch
     torch.set_num_threads(max(1, min(8, effective_cpus() // 2)))
     from hugectr_backend_amd import build as hb
@@ -1114,7 +1126,7 @@ def main():
             # ms inside the host gather calls, ms of upload tail + scatter + insert, ms of the whole call inside the engine]
             "slowest_calls_ms": [[round(l, 3)] + [round(x, 3) for x in p] for l, p in
                                  sorted(zip(lat.tolist(), ph.tolist()), key=lambda t: -t[0])[:5]],
-            "host": {"cpus": ncpu, "numa": numa_note,
+            "host": {"cpus": ncpu, "numa": numa_note, "numa_node_of_worker_pools": hps.pool_numa_node(), "process_bound_to_numa_node": bound_node,
                      "cpu_quota_throttled_periods_in_timed_region": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
                      "cpu_quota_throttled_ms_in_timed_region": (thr1[1] - thr0[1]) / 1e3 if thr0 and thr1 else None,
                      "hypervisor_steal_ms_in_timed_region": (ct1[0] - ct0[0]) * 1e3 if ct0[0] is not None and ct1[0] is not None else None,

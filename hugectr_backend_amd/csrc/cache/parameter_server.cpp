@@ -1,7 +1,11 @@
 // HierParameterServer + the background insert path of EmbeddingCache.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cctype>
 #include <cstdlib>
 #include <filesystem>
 #include <cstring>
@@ -140,6 +144,48 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
 // =================================================================================================
 // HierParameterServer
 // =================================================================================================
+namespace {
+// The NUMA node the host tier's worker pools (and with them the tables they load) should live on (thread_pool.h): the node the
+// deployed GPUs hang off when they share one, the caller's own node for a deployment without GPU caches, -1 (no binding) when the
+// GPUs span nodes or the machine has one node.
+int NumaNodeOfCpu(int cpu) {
+  for (int n = 0; n < 64; ++n) {
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpu%d", n, cpu);
+    if (access(path, F_OK) == 0) return n;
+  }
+  return -1;
+}
+int PreferredNumaNode(const ParameterServerConfig& cfg) {
+  if (access("/sys/devices/system/node/node1", F_OK) != 0) return -1;
+  std::vector<int> devs;
+  for (const auto& kv : cfg.models)
+    if (kv.second.use_gpu_embedding_cache)
+      for (int d : kv.second.deployed_devices) if (std::find(devs.begin(), devs.end(), d) == devs.end()) devs.push_back(d);
+  if (devs.empty()) return NumaNodeOfCpu(sched_getcpu());
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  int node = -1;
+  for (int d : devs) {
+    if (d < 0 || d >= ndev) return -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    int n = -1;
+    const bool ok = fscanf(f, "%d", &n) == 1;
+    fclose(f);
+    if (!ok || n < 0) return -1;
+    if (node >= 0 && n != node) return -1;     // replicas on both sockets: the one host tier serves them all
+    node = n;
+  }
+  return node;
+}
+}  // namespace
+
 HierParameterServer::~HierParameterServer() {
   {
     std::shared_ptr<UpdateConsumer> u;
@@ -166,6 +212,7 @@ Status HierParameterServer::create_from_config(const ParameterServerConfig& cfg,
                                                std::shared_ptr<HierParameterServer>* out) {
   std::shared_ptr<HierParameterServer> ps(new HierParameterServer());
   ps->cfg_ = cfg;
+  ThreadPool::BindToNumaNode(PreferredNumaNode(cfg));   // (before the pools start; the first server of the process decides)
   ps->pool_ = &ThreadPool::Global();
   if (!cfg.support_int64_key)
     return Error(Code::kUnsupported,

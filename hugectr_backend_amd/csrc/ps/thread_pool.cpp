@@ -1,5 +1,6 @@
 #include "thread_pool.h"
 
+#include <pthread.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -44,6 +45,61 @@ static size_t EffectiveCpus() {
   return n;
 }
 
+// ---- NUMA node of the pools' workers ----
+namespace {
+std::atomic<int> g_numa_node{-2};        // -2: not decided yet, -1: none
+std::atomic<bool> g_pool_started{false};
+cpu_set_t g_numa_cpus;                   // valid when g_numa_node >= 0
+
+// the CPUs of `node` this process may run on (sysfs cpulist: "0-63,128-191"); false when there are fewer than two
+bool NodeCpus(int node, cpu_set_t* out) {
+  char path[96];
+  snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return false;
+  char buf[4096] = {0};
+  const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+  fclose(f);
+  if (!ok) return false;
+  cpu_set_t allowed;
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+  CPU_ZERO(out);
+  for (char* p = buf; *p;) {
+    char* e = nullptr;
+    const long a = strtol(p, &e, 10);
+    if (e == p) break;
+    long b = a;
+    if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+      if (c >= 0 && CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, out);
+    p = (*e == ',') ? e + 1 : e;
+    if (*e != ',' ) break;
+  }
+  return CPU_COUNT(out) >= 2;
+}
+}  // namespace
+
+void ThreadPool::BindToNumaNode(int node) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (g_pool_started.load(std::memory_order_acquire) || g_numa_node.load(std::memory_order_acquire) != -2) return;
+  int expect = -2;
+  if (const char* e = std::getenv("HPS_NUMA_NODE")) {
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    node = (end != e && v >= 0) ? (int)v : -1;      // "off", "-1", anything that is not a node number: no binding
+  }
+  cpu_set_t set;
+  if (node >= 0 && !NodeCpus(node, &set)) node = -1;
+  if (node >= 0) g_numa_cpus = set;                 // (published by the store below; read only after g_numa_node >= 0 is seen)
+  g_numa_node.compare_exchange_strong(expect, node, std::memory_order_acq_rel);
+}
+
+int ThreadPool::NumaNode() {
+  const int n = g_numa_node.load(std::memory_order_acquire);
+  return n < 0 ? -1 : n;
+}
+
 size_t ThreadPool::DefaultConcurrency() {
   // thread_pool.cpp:25-41 of the reference: env override, else hardware_concurrency (here: the CPUs the
   // process is really allowed to use).
@@ -78,6 +134,7 @@ ThreadPool& ThreadPool::Serving() {
 }
 
 ThreadPool::ThreadPool(size_t num_workers, unsigned spin_us) : spin_us_(spin_us) {
+  g_pool_started.store(true, std::memory_order_release);
   workers_.reserve(num_workers);
   for (size_t i = 0; i < num_workers; ++i) workers_.emplace_back([this] { WorkerMain(); });
 }
@@ -147,6 +204,8 @@ bool ThreadPool::HelpFastLoops() {
 }
 
 void ThreadPool::WorkerMain() {
+  (void)pthread_setname_np(pthread_self(), spin_us_ ? "hps-serving" : "hps-pool");
+  if (g_numa_node.load(std::memory_order_acquire) >= 0) (void)pthread_setaffinity_np(pthread_self(), sizeof g_numa_cpus, &g_numa_cpus);
   uint64_t seen = 0;
   for (;;) {
     std::shared_ptr<Loop> loop;

@@ -34,6 +34,16 @@ class ThreadPool {
   static ThreadPool& Serving();         // lazily built, min(32, cores/2) workers, spin 200 us
   static size_t DefaultConcurrency();   // HCTR_DEFAULT_CONCURRENCY env, else hardware_concurrency
 
+  // NUMA placement of the two pools' workers (and, through first touch, of the host tables they load).  On a two-socket box the
+  // scheduler spreads the workers over both sockets and the tables end up wherever their loaders happened to run: round 5's
+  // headline was 1.59-2.01 G lookups/s from run to run on one box (key staging 0.19-0.50 ms, host gather 0.43-0.85 ms per
+  // call) and 2.03-2.06 G in every run confined to ONE node — either one (profiles/round5/numa_one_node.txt).
+  // BindToNumaNode is called once, before the pools start (HierParameterServer: the node of the deployed GPUs when they share
+  // one, the caller's own node for a CPU-only deployment, none when the GPUs span nodes); HPS_NUMA_NODE=<n> names the node,
+  // HPS_NUMA_NODE=off leaves the workers where the scheduler puts them.  The callers' threads are never touched.
+  static void BindToNumaNode(int node);   // -1: none.  Ignored once a pool exists or a node has been chosen
+  static int NumaNode();                  // the node the workers are bound to, -1 when they are not
+
   size_t size() const { return workers_.size(); }
 
   // fn(task_index) for task_index in [0, num_tasks); returns when all are done.  max_parallel caps the

@@ -214,6 +214,11 @@ int hps_cache_wait_async(hps_cache_t* cache);
  * inside some request's hipMemcpyAsync, 7-12 ms during which every HIP call of the process waits).  Writes a one-line report
  * ("16 engines host->device, 16 device->host, 140 ms") into buf; returns the number of engines that took a copy. */
 int hps_wake_copy_engines(int device, char* buf, uint64_t cap);
+/* The NUMA node the host tier's worker pools are bound to, -1 when they are not (csrc/ps/thread_pool.h).  The first server of the
+ * process decides, before the pools start: the node of the deployed GPUs when they hang off one, the caller's node for a
+ * deployment without GPU caches, none when the GPUs span nodes or the machine has one node; environment HPS_NUMA_NODE=<n> names
+ * the node, HPS_NUMA_NODE=off switches the binding off.  Threads of the caller (Triton's instance threads) are never touched. */
+int hps_pool_numa_node(void);
 /* drop this handle's reference (the shared_ptr copy the shell holds)         src/model_instance_state.cpp:158 */
 void hps_cache_release(hps_cache_t* cache);
 

@@ -56,6 +56,48 @@ def test_pool_sizes_follow_the_environment():
     assert after - before == 2, (before, after)
 
 
+_POOL_THREADS = """
+    import os
+    def pool_threads():
+        out = {}
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                name = open(f"/proc/self/task/{tid}/comm").read().strip()
+                if name in ("hps-pool", "hps-serving"):
+                    allowed = [l.split(":")[1].strip() for l in open(f"/proc/self/task/{tid}/status") if l.startswith("Cpus_allowed_list")][0]
+                    out.setdefault(name, set()).add(allowed)
+            except OSError:
+                pass
+        return out
+    def cpus(spec):
+        s = set()
+        for part in spec.split(","):
+            a, _, b = part.partition("-")
+            s.update(range(int(a), int(b or a) + 1))
+        return s
+    mine = cpus([l.split(":")[1].strip() for l in open("/proc/self/status") if l.startswith("Cpus_allowed_list")][0])
+"""
+
+
+def test_worker_pools_can_be_bound_to_a_numa_node_or_left_alone():
+    """HPS_NUMA_NODE=<n>: the workers of both pools run on the CPUs of that node (and the tables they load are first touched
+    there); HPS_NUMA_NODE=off: wherever the scheduler puts them.  Unset: the first server of the process decides (the node of the
+    deployed GPUs when they share one, the caller's node without GPU caches, none on a one-node machine) — the GPU test below."""
+    code = _HOST_LOOKUP + _POOL_THREADS + """
+    node0 = cpus(open("/sys/devices/system/node/node0/cpulist").read().strip()) & mine
+    th = pool_threads()
+    assert set(th) == {"hps-pool", "hps-serving"}, th
+    print("NODE", hps.pool_numa_node())
+    for name, lists in th.items():
+        for l in lists:
+            assert cpus(l) == (node0 if BOUND else mine), (name, l, sorted(node0)[:4], BOUND)
+    """
+    r = _run("BOUND = True\n" + textwrap.dedent(code), {"HPS_NUMA_NODE": 0, "HPS_SERVING_THREADS": 3, "HCTR_DEFAULT_CONCURRENCY": 4})
+    assert "NODE 0" in r.stdout
+    r = _run("BOUND = False\n" + textwrap.dedent(code), {"HPS_NUMA_NODE": "off", "HPS_SERVING_THREADS": 3, "HCTR_DEFAULT_CONCURRENCY": 4})
+    assert "NODE -1" in r.stdout
+
+
 def test_roctx_ranges_can_be_switched_on_without_a_profiler():
     """HPS_ENABLE_ROCTX=1: roctx ranges around the plugin's phases (the reference's NVTX ranges, hps.cc:375,671).  With no profiler
     attached — and on a box without the library — the requests are served all the same."""
@@ -108,6 +150,30 @@ _GPU_LOOKUP = """
     st = s.last_stats()
     print("STATS", st.probe_gather_ms, st.phase_ms[3])
 """
+
+
+@pytest.mark.gpu
+def test_worker_pools_follow_the_gpu_to_its_numa_node():
+    """No HPS_NUMA_NODE: on a machine with several NUMA nodes the pools of a one-GPU deployment are bound to the node the GPU hangs
+    off; on a one-node machine they are not bound at all.  Rows exact either way."""
+    code = "EXTRA = {}\n" + textwrap.dedent(_GPU_LOOKUP) + textwrap.dedent(_POOL_THREADS) + textwrap.dedent("""
+        import ctypes as C, glob
+        hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        b = C.create_string_buffer(64)
+        assert hip.hipDeviceGetPCIBusId(b, 64, 0) == 0
+        gpu_node = int(open(f"/sys/bus/pci/devices/{b.value.decode().lower()}/numa_node").read())
+        nodes = len(glob.glob("/sys/devices/system/node/node[0-9]*"))
+        node = hps.pool_numa_node()
+        if nodes > 1 and gpu_node >= 0:
+            assert node == gpu_node, (node, gpu_node)
+            want = cpus(open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()) & mine
+            for name, lists in pool_threads().items():
+                assert all(cpus(l) == want for l in lists), (name, lists)
+        else:
+            assert node == -1
+        print("POOLS ON NODE", node, "OF", nodes)
+    """)
+    assert "POOLS ON NODE" in _run(code, {}).stdout
 
 
 @pytest.mark.gpu
