@@ -67,6 +67,7 @@ def parse_args():
     ap.add_argument("--xcd-walk", type=int, default=1, help="gather kernel: each XCD sweeps its own eighth of the keys")
     ap.add_argument("--probe-in-lane", type=int, default=2, help="K_P and the kernel lane: 1 = always inside, 0 = never, 2 = outside while the session's calls miss little (default)")
     ap.add_argument("--numa-bind", type=int, default=1, help="1: bind this process to the NUMA node of its GPU(s) when they share one (numactl --cpunodebind); 0: leave it alone")
+    ap.add_argument("--keys-by-kernel", type=int, default=2, help="staged keys pulled into HBM by a kernel instead of copy-engine copies: 0 never, 1 always, 2 while the session's calls miss much (default)")
     ap.add_argument("--chain-gather", type=int, default=0, help="other sessions' probes wait for a session's gather kernel too")
     ap.add_argument("--narrow-keys", type=int, default=1, help="stage host keys narrower when every key of the request fits: 1 = 3-byte packing or uint32, 2 = uint32 only, 0 = off")
     ap.add_argument("--direct", type=int, default=-1,
@@ -646,6 +647,7 @@ def main():
                 s.set_option("narrow_keys", a.narrow_keys)
                 s.set_option("chain_gather", a.chain_gather)
                 s.set_option("probe_in_lane", a.probe_in_lane)
+                s.set_option("keys_by_kernel", a.keys_by_kernel)
             # resident set = what the warm-up actually placed (first C rows in file order minus over-full buckets)
             resident = []
             for t in range(T):
@@ -1580,6 +1582,7 @@ def wide_keys_leg(a, torch, hps, T, R, D, B, N, dev, cfg):
         run, sessions = ctx["run"], ctx["sessions"]
         for s in sessions:
             s.set_option("narrow_keys", a.narrow_keys)
+            s.set_option("keys_by_kernel", a.keys_by_kernel)
         steps = 40
         hb_ = [((x + key0).cpu().numpy(),) for x in make_batches_gpu(torch, ctx["gen"], ctx["resident"], ctx["cdf_d"], R, ctx["C"], B, a.hit, steps + 8)]
         hb_ = [(x[0], run.pack_host(x[0])) for x in hb_]

@@ -496,6 +496,8 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       s->s->set_fused_unique(value != 0);
     } else if (n == "narrow_publish") {
       s->s->set_narrow_publish(value != 0);
+    } else if (n == "keys_by_kernel") {
+      s->s->set_keys_by_kernel(value);
     } else if (n == "probe_in_lane") {
       s->s->set_probe_in_lane(value);
     } else if (n == "chain_gather") {

@@ -937,6 +937,15 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     // running behind that call, waiting for the other session's hit gather to release the cache), and nothing of this
     // upload depends on it.  The probe waits for the event behind the last piece.
     hipStream_t ks = copy_stream_;
+    // ... by copy-engine copies, or read out of the staging buffer by a kernel (hps_pull_bytes).  While the session's calls miss
+    // much, the link is full of the OTHER session's 4-MB row copies, and a key copy queues behind them: the probe started 0.3 ms
+    // late, the two sessions' uploads stopped overlapping (one session's copies alone move 34 GB/s, two overlapping 51), and the
+    // sessions stayed in that step for whole blocks — 20 steps in 20.3 ms instead of 16.3, in 1-5 blocks of 12
+    // (profiles/round5/slow_blocks_keys_behind_the_other_sessions_rows.txt).  The kernel's reads share the link packet by packet:
+    // no such block in 72, counts on the host after 0.20 instead of 0.22-0.29 ms.  While calls miss little it is the other way
+    // round — nothing is on the link, and a kernel would wait for CUs behind the other session's gather (every key resident
+    // 6.35 -> 5.4 G lookups/s): copies.  Same bound as the second-stream scatter and the probe's place in the lane.
+    const bool pull_keys = h_keys_dev_ && (keys_by_kernel_ == 1 || (keys_by_kernel_ == 2 && last_miss_row_bytes_ > side_bytes_));
     uint64_t seen = 0;
     auto stage = [&](int width) -> Status {
       std::atomic<uint64_t> high_or{0};
@@ -959,7 +968,10 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
         const auto tp1 = std::chrono::steady_clock::now();
         if (width < 8 && (seen = high_or.load(std::memory_order_relaxed)) != 0) return Status::Ok();   // caller restages wider
         const size_t first = tasks[g0].off, count = tasks[g1 - 1].off + tasks[g1 - 1].n - first;
-        HIP_TRY(hipMemcpyAsync(dev8 + first * (size_t)width, dst8 + first * (size_t)width, count * (size_t)width, hipMemcpyHostToDevice, ks));
+        if (pull_keys)
+          HIP_TRY(LaunchPullBytes(reinterpret_cast<const uint8_t*>(h_keys_dev_) + first * (size_t)width, dev8 + first * (size_t)width, count * (size_t)width, ks));
+        else
+          HIP_TRY(hipMemcpyAsync(dev8 + first * (size_t)width, dst8 + first * (size_t)width, count * (size_t)width, hipMemcpyHostToDevice, ks));
         const auto tp2 = std::chrono::steady_clock::now();
         stage_pool_ms_ += std::chrono::duration<float, std::milli>(tp1 - tp0).count();
         stage_enqueue_ms_ += std::chrono::duration<float, std::milli>(tp2 - tp1).count();
@@ -1004,8 +1016,9 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
   if (kTraceCallsMs > 0.f) {
     const float all = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tk0).count();
     if (all > kTraceCallsMs)
-      fprintf(stderr, "[hps call] %.2f ms: key staging %.2f (pool %.2f, H2D enqueue %.2f, event %.2f), counts on host %.2f, ps fetch %.2f, tail %.2f, engine call %.2f, GPU span %.2f (direct_dma %d narrow %d)\n",
-              all, key_stage_ms_, stage_pool_ms_, stage_enqueue_ms_, stage_event_ms_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3], last_gpu_call_ms_, (int)direct_dma, (int)keys_narrow_);
+      fprintf(stderr, "[hps call] %.2f ms: key staging %.2f (pool %.2f, H2D enqueue %.2f, event %.2f), counts on host %.2f, ps fetch %.2f, tail %.2f, engine call %.2f, GPU span %.2f (direct_dma %d narrow %d) session %p began at %.3f ms\n",
+              all, key_stage_ms_, stage_pool_ms_, stage_enqueue_ms_, stage_event_ms_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3], last_gpu_call_ms_, (int)direct_dma, (int)keys_narrow_,
+              (void*)this, std::chrono::duration<double, std::milli>(tk0.time_since_epoch()).count());
   }
   return st_;
 }

@@ -289,6 +289,7 @@ class LookupSession {
   void set_xcd_walk(bool b) { xcd_walk_ = b; }
   void set_chain_gather(bool b) { chain_gather_ = b; }
   void set_probe_in_lane(int v) { probe_in_lane_ = v; }
+  void set_keys_by_kernel(int v) { keys_by_kernel_ = v; }
   void set_narrow_publish(bool b) { narrow_publish_ = b; }
   void set_exclusive_kernels(bool b) { exclusive_ = b; }
   void set_fused_unique(bool b) { fused_unique_ = b; }
@@ -428,6 +429,8 @@ class LookupSession {
   bool direct_split_ = true;     // device-driven tier: the fetch kernel runs next to the call's own hit gather (round 3: +4 %)
   bool narrow_publish_ = true;   // a narrowed request's unique missed keys come back to the host as uint32 (option "narrow_publish")
   bool uniq_narrow_ = false;     // this call: h_uniq_keys_ holds uint32 keys
+  int keys_by_kernel_ = 2;       // option "keys_by_kernel": staged keys are pulled into HBM by a kernel instead of copy-engine copies:
+                                 // 0 never, 1 always, 2 (default) while the session's calls miss much (last call's missed rows > side_bytes_)
   int probe_in_lane_ = 2;        // option "probe_in_lane": 1 = K_P takes its turn in the kernel lane, 0 = it runs next to another session's
                                  // K_G, 2 (default) = next to it while the session's calls miss little (last call's missed rows <= side_bytes_)
   bool chain_gather_ = false;    // other sessions' probes queue behind this session's gather as well as its probe

@@ -49,6 +49,8 @@ hipError_t LaunchCacheInsert(const TableCacheDev* d_tables, uint32_t T, const Mi
 // control words over the compute queue (kernels.hip): call block host -> HBM (bytes rounded up to 16), accumulator words
 // HBM -> host followed by a sequence word
 hipError_t LaunchPull16(const void* src_host_devptr, void* dst, size_t bytes, hipStream_t stream);
+// a range of any size and alignment out of page-locked host memory (src and dst equally misaligned to 16 B): staged KEYS, see engine.cpp
+hipError_t LaunchPullBytes(const void* src_host_devptr, void* dst, size_t bytes, hipStream_t stream);
 hipError_t LaunchPushWords(const uint32_t* src, uint32_t* dst_host_devptr, uint32_t words, uint32_t* seq_host_devptr, uint32_t seq,
                            hipStream_t stream);
 // every key slot of the bucket lines EMPTY, every recency stamp = stamp8

@@ -1055,6 +1055,27 @@ __global__ __launch_bounds__(256) void hps_pull16_kernel(const uint4* __restrict
   if (i < n16) dst[i] = src_host[i];
 }
 
+// Staged keys, page-locked host memory -> HBM, read by the compute units instead of a copy engine: a request's keys then share
+// the link with the other session's row uploads packet by packet instead of queueing behind its 4-MB copies (engine.cpp, stage()).
+// Grid-stride, four 16-B loads in flight per lane; head and tail of a range that does not start / end on 16 B go byte by byte.
+__global__ __launch_bounds__(256) void hps_pull_bytes_kernel(const uint8_t* __restrict__ src_host, uint8_t* __restrict__ dst, uint64_t bytes) {
+  const uint64_t head = min<uint64_t>(bytes, (16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u);
+  const uint64_t n16 = (bytes - head) / 16;
+  const uint64_t tail0 = head + n16 * 16;
+  const uint64_t tid = (uint64_t)blockIdx.x * 256u + threadIdx.x, nthr = (uint64_t)gridDim.x * 256u;
+  if (tid < head) dst[tid] = src_host[tid];
+  if (tid < bytes - tail0) dst[tail0 + tid] = src_host[tail0 + tid];
+  const u64x2* s = reinterpret_cast<const u64x2*>(src_host + head);
+  u64x2* d = reinterpret_cast<u64x2*>(dst + head);
+  uint64_t i = tid;
+  for (; i + 3 * nthr < n16; i += 4 * nthr) {
+    const u64x2 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + nthr),
+                c = __builtin_nontemporal_load(s + i + 2 * nthr), e = __builtin_nontemporal_load(s + i + 3 * nthr);
+    d[i] = a; d[i + nthr] = b; d[i + 2 * nthr] = c; d[i + 3 * nthr] = e;
+  }
+  for (; i < n16; i += nthr) d[i] = __builtin_nontemporal_load(s + i);
+}
+
 __global__ __launch_bounds__(256) void hps_push_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst_host,
                                                              uint32_t words, uint32_t* __restrict__ seq_host, uint32_t seq) {
   for (uint32_t i = threadIdx.x; i < words; i += 256u) dst_host[i] = src[i];
@@ -1067,6 +1088,16 @@ hipError_t LaunchPull16(const void* src_host_devptr, void* dst, size_t bytes, hi
   const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
   if (n16 == 0) return hipSuccess;
   hipLaunchKernelGGL(hps_pull16_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, (const uint4*)src_host_devptr, (uint4*)dst, n16);
+  return hipGetLastError();
+}
+
+hipError_t LaunchPullBytes(const void* src_host_devptr, void* dst, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(src_host_devptr) & 15u) != (reinterpret_cast<uintptr_t>(dst) & 15u)) return hipErrorInvalidValue;
+  uint64_t blocks = (bytes / 16 + 1023) / 1024;   // up to four 16-B units per lane
+  if (blocks > 96) blocks = 96;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(hps_pull_bytes_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, (const uint8_t*)src_host_devptr, (uint8_t*)dst, (uint64_t)bytes);
   return hipGetLastError();
 }
 

@@ -258,6 +258,9 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
  * the page-locked buffer the host gathered them into, next to the hit gather, instead of being uploaded first),
  * "side_scatter_mb" (default 16: missed rows up to this many MB are uploaded and scattered on the session's second stream,
  * without a turn in the kernel lane; beyond it the scatter takes its turn behind a drained stream),
+ * "keys_by_kernel" (default 2: the staged keys of a big request are read out of the page-locked staging buffer by a kernel
+ * while this session's calls miss much — last call's missed rows > side_scatter_mb — so that they do not queue behind the other
+ * session's row copies, and go up as copy-engine copies otherwise; 1: always by kernel; 0: never),
  * "probe_in_lane" (default 2: the probe kernel runs next to another session's hit gather while this session's calls miss
  * little — last call's missed rows <= side_scatter_mb — and takes its turn in the kernel lane otherwise; 1: always in the
  * lane; 0: never) */

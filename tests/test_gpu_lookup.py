@@ -935,6 +935,35 @@ def test_small_miss_calls_insert_every_nth_time(interval, admission):
     s0.close()
 
 
+def test_staged_keys_pulled_by_a_kernel_at_every_width_and_alignment():
+    """Session option "keys_by_kernel": the staged keys of a big request are read out of the page-locked staging buffer by a kernel
+    (hps_pull_bytes) instead of copy-engine copies.  Ragged tables (group offsets that are not multiples of 16 bytes at 3 bytes per
+    key), 3-byte / uint32 / 8-byte keys: same rows as the oracle and as the copies."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(77)
+    sizes = [(90001, 8), (70003, 4), (50000, 16)]
+    k0 = rng.permutation(1 << 20)[:sizes[0][0]].astype(np.int64)
+    k1 = (1 << 33) + rng.permutation(1 << 22)[:sizes[1][0]].astype(np.int64)           # high base, small offsets
+    k2 = rng.permutation(1 << 28)[:sizes[2][0]].astype(np.int64) * 9                       # offsets beyond 24 bits
+    tables = [(k, rng.standard_normal((k.size, d), dtype=np.float32)) for k, (_, d) in zip((k0, k1, k2), sizes)]
+    ps, cache, s = _mk("pullkeys", tables, maxcat=[1, 1, 1], gpucacheper=0.5, max_batch=100000)
+    try:
+        for by_kernel in (1, 0, 2):
+            s.set_option("keys_by_kernel", by_kernel)
+            for nk, wide in (([70001, 65537, 0], 3), ([33333, 70003, 40001], 4), ([99999, 1, 50000], 8)):
+                q = np.concatenate([rng.choice(tables[t][0], nk[t]) for t in range(3)]).astype(np.int64)
+                if wide == 8:
+                    q[12345] = -3
+                    s.set_option("narrow_keys", 0)
+                out = s.lookup(q, nk).cpu().numpy()
+                s.set_option("narrow_keys", 1)
+                assert s.last_stats().key_bytes == wide, (nk, wide, s.last_stats().key_bytes)
+                assert np.array_equal(_bits(out), _bits(O.np_lookup(tables, q, nk, [0.0] * 3))), (by_kernel, nk, wide)
+    finally:
+        s.close()
+        ps.close()
+
+
 @pytest.mark.parametrize("probe_in_lane", [2, 1, 0], ids=["probe_next_to_the_other_gather_while_missing_little", "probe_in_the_lane", "probe_never_in_the_lane"])
 def test_two_sessions_near_all_hit_stress_rows_stay_exact(probe_in_lane):
     """Two sessions on one cache, big requests that miss a few hundred rows each (the regime of a production cache at
