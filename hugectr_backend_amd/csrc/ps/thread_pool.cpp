@@ -95,6 +95,25 @@ void ThreadPool::BindToNumaNode(int node) {
   g_numa_node.compare_exchange_strong(expect, node, std::memory_order_acq_rel);
 }
 
+bool ThreadPool::BindCallingThread() {
+  if (g_numa_node.load(std::memory_order_acquire) < 0) return false;
+  cpu_set_t cur;
+  if (pthread_getaffinity_np(pthread_self(), sizeof cur, &cur) != 0) return false;
+  // already inside one node (somebody placed this thread on purpose)?
+  for (int n = 0; n < 64; ++n) {
+    cpu_set_t node;
+    if (!NodeCpus(n, &node)) { if (n > 0) break; else continue; }
+    cpu_set_t outside;
+    CPU_XOR(&outside, &cur, &node);          // bits in exactly one of the two
+    CPU_AND(&outside, &outside, &cur);       // ... that are in cur: cur \ node
+    if (CPU_COUNT(&outside) == 0) return false;
+  }
+  cpu_set_t want;
+  CPU_AND(&want, &cur, &g_numa_cpus);
+  if (CPU_COUNT(&want) == 0) return false;
+  return pthread_setaffinity_np(pthread_self(), sizeof want, &want) == 0;
+}
+
 int ThreadPool::NumaNode() {
   const int n = g_numa_node.load(std::memory_order_acquire);
   return n < 0 ? -1 : n;

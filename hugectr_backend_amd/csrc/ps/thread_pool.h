@@ -43,6 +43,12 @@ class ThreadPool {
   // HPS_NUMA_NODE=off leaves the workers where the scheduler puts them.  The callers' threads are never touched.
   static void BindToNumaNode(int node);   // -1: none.  Ignored once a pool exists or a node has been chosen
   static int NumaNode();                  // the node the workers are bound to, -1 when they are not
+  // The calling thread joins the workers' node — for the threads that drive lookups (the plugin does it for every Triton
+  // instance thread at its first request: through the plugin boundary 1.57-2.04 G lookups/s from process to process with the
+  // instance threads left alone, 1.99-2.04 G with them bound, profiles/round5/triton_abi_numa_bound_vs_free.txt).  A thread
+  // whose affinity mask already lies inside ONE node (numactl, Triton's host policy, taskset) is left as it is.
+  // false: nothing changed (workers not bound, or the thread already placed).
+  static bool BindCallingThread();
 
   size_t size() const { return workers_.size(); }
 

@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "../ps/thread_pool.h"
 #include "backend_state.h"
 #include "model_instance_state.h"
 #include "model_state.h"
@@ -377,6 +378,12 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInstanceExecute(TRITONBACKEND_ModelInstan
   ModelInstanceState* instance_state;
   RETURN_IF_ERROR(TRITONBACKEND_ModelInstanceState(instance, reinterpret_cast<void**>(&instance_state)));
   ModelState* model_state = instance_state->StateForModel();
+  {
+    // the instance's thread joins the host tier's worker pools on the GPUs' NUMA node (thread_pool.h; HPS_NUMA_NODE=off: nobody is
+    // bound; a thread that a host policy or numactl has already placed inside one node is left alone)
+    thread_local bool placed = false;
+    if (!placed) { placed = true; (void)hps::ThreadPool::BindCallingThread(); }
+  }
   HPS_TRITON_LOG(VERBOSE, "model ", model_state->Name(), ", instance ", instance_state->Name(), ", executing ",
                  request_count, " requests");
   HPS_ROCTX_RANGE(roctx_execute, "ModelInstanceExecute " + instance_state->Name());     // hps.cc:375

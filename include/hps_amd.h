@@ -219,6 +219,10 @@ int hps_wake_copy_engines(int device, char* buf, uint64_t cap);
  * deployment without GPU caches, none when the GPUs span nodes or the machine has one node; environment HPS_NUMA_NODE=<n> names
  * the node, HPS_NUMA_NODE=off switches the binding off.  Threads of the caller (Triton's instance threads) are never touched. */
 int hps_pool_numa_node(void);
+/* The calling thread joins the worker pools' node — for the application's threads that drive lookups (libtriton_hps.so calls it for
+ * every Triton instance thread at its first request).  A thread whose affinity mask already lies inside one NUMA node is left as
+ * it is.  Returns 1 when the thread's affinity was changed, 0 otherwise (pools not bound, thread already placed). */
+int hps_bind_calling_thread(void);
 /* drop this handle's reference (the shared_ptr copy the shell holds)         src/model_instance_state.cpp:158 */
 void hps_cache_release(hps_cache_t* cache);
 

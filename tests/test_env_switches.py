@@ -171,6 +171,17 @@ def test_worker_pools_follow_the_gpu_to_its_numa_node():
                 assert all(cpus(l) == want for l in lists), (name, lists)
         else:
             assert node == -1
+        import threading
+        res = {}
+        def t():
+            res["first"] = hps.bind_calling_thread(); res["aff"] = os.sched_getaffinity(0); res["second"] = hps.bind_calling_thread()
+        th = threading.Thread(target=t); th.start(); th.join()
+        # (a process that was started inside one node already — numactl, or a parent whose thread the plugin had placed — stays as it is)
+        inside_one = any(mine <= cpus(open(p).read().strip()) for p in glob.glob("/sys/devices/system/node/node[0-9]*/cpulist"))
+        if nodes > 1 and gpu_node >= 0 and not inside_one:
+            assert res["first"] and set(res["aff"]) == want and not res["second"], res
+        else:
+            assert not res["first"]
         print("POOLS ON NODE", node, "OF", nodes)
     """)
     assert "POOLS ON NODE" in _run(code, {}).stdout

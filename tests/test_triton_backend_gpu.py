@@ -85,6 +85,68 @@ def test_wdl_gpu_cache_device_output_exact(tmp_path):
         srv.shutdown()
 
 
+def test_an_instance_thread_joins_the_worker_pools_on_the_gpus_numa_node(tmp_path):
+    """On a host with several NUMA nodes the plugin places the thread that executes an instance's requests on the node of the deployed GPU
+    (where the worker pools and the tables are: csrc/ps/thread_pool.h) at its first request — unless somebody placed that thread inside one
+    node already.  One-node host: nothing is touched.  Rows exact either way."""
+    import glob
+    import os
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    tables = make_tables([(5000, 8)])
+    srv, _ = _deploy(tmp_path, {"numa": (tables, [4], [0.0])}, gpucacheper=0.5, hit_rate_threshold=1.0)
+    got = {}
+
+    def cpus(spec):
+        out = set()
+        for part in spec.split(","):
+            a, _, b = part.partition("-")
+            out.update(range(int(a), int(b or a) + 1))
+        return out
+
+    try:
+        inst = srv.load_model("numa", tm.model_config("numa", gpus=[0])).create_instance("numa_0", tm.KIND_GPU, 0)
+        rng = np.random.default_rng(4)
+
+        def serve(tag, preset=None):
+            if preset is not None:
+                os.sched_setaffinity(0, preset)
+            before = os.sched_getaffinity(0)
+            nk = [400]
+            q = rng.choice(tables[0][0], nk[0]).astype(np.int64)
+            req, out = _request(q, nk, nk[0] * 8)
+            inst.execute([req])
+            assert req.error_code == -1, req.error_message
+            assert np.array_equal(_bits(_result(req, out, nk[0] * 8)), _bits(O.np_lookup(tables, q, nk, [0.0])))
+            got[tag] = (before, os.sched_getaffinity(0))
+
+        node = hps.pool_numa_node()
+        nodes = len(glob.glob("/sys/devices/system/node/node[0-9]*"))
+        th = threading.Thread(target=serve, args=("free",))
+        th.start(); th.join()
+        before, after = got["free"]
+        if nodes > 1 and node >= 0:
+            want = cpus(open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()) & before
+            assert after == want, (sorted(after)[:4], sorted(want)[:4])
+            # a thread somebody confined to a few CPUs of the OTHER node keeps them
+            # (the thread may set any CPU its cgroup allows, whatever mask it inherited)
+            other = cpus(open(f"/sys/devices/system/node/node{1 - node if node < 2 else 0}/cpulist").read().strip())
+            preset = set(sorted(other)[:3])
+            try:
+                os.sched_setaffinity(0, preset)
+                os.sched_setaffinity(0, before | after)
+            except OSError:
+                preset = None      # a cpuset that does not include the other node: nothing to show
+            if preset:
+                th = threading.Thread(target=serve, args=("placed", preset))
+                th.start(); th.join()
+                assert got["placed"][1] == preset
+        else:
+            assert after == before
+    finally:
+        srv.shutdown()
+
+
 @pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
 def test_two_models_share_the_device_concurrently(tmp_path, direct):
     """BASELINE config 4 shape: two W&D models (D=[1,16], keys/sample [2,26], batch 1024), two instances each,
