@@ -945,7 +945,8 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     // no such block in 72, counts on the host after 0.20 instead of 0.22-0.29 ms.  While calls miss little it is the other way
     // round — nothing is on the link, and a kernel would wait for CUs behind the other session's gather (every key resident
     // 6.35 -> 5.4 G lookups/s): copies.  Same bound as the second-stream scatter and the probe's place in the lane.
-    const bool pull_keys = h_keys_dev_ && (keys_by_kernel_ == 1 || (keys_by_kernel_ == 2 && last_miss_row_bytes_ > side_bytes_));
+    // (HPS_ZC_CONTROL=0 — no kernel of this library reads or writes host memory — keeps the copies)
+    const bool pull_keys = zc_control_ && h_keys_dev_ && (keys_by_kernel_ == 1 || (keys_by_kernel_ == 2 && last_miss_row_bytes_ > side_bytes_));
     uint64_t seen = 0;
     auto stage = [&](int width) -> Status {
       std::atomic<uint64_t> high_or{0};
