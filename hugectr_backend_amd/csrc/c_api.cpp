@@ -367,6 +367,7 @@ int hps_cache_num_tables(hps_cache_t* c) {
 int hps_cache_on_device(hps_cache_t* c) { return c && c->cache ? 1 : 0; }
 
 int hps_pool_numa_node(void) { return ThreadPool::NumaNode(); }
+uint64_t hps_pool_fast_overruns(void) { return ThreadPool::FastOverruns(); }
 int hps_bind_calling_thread(void) { return ThreadPool::BindCallingThread() ? 1 : 0; }
 
 int hps_wake_copy_engines(int device, char* buf, uint64_t cap) {

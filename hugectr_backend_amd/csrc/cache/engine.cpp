@@ -1805,7 +1805,11 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     // window (config.h: gpucache_small_miss_insert_interval); the others return their rows and leave them uncached.
     // (missed rows that were uploaded but still scattered on the second stream — up to side_scatter_mb, a call at 99 % hit: every
     //  n/2-th call)
-    const uint32_t ins_every = !(defer && side) ? 1u : in_place ? cache_->small_insert_interval() : std::max(1u, cache_->small_insert_interval() / 2);
+    // Only NEAR-ALL-HIT calls skip (at most one key in 64 missed): a cold or low-hit-rate cache — small online requests whose missed
+    // rows fit in_place_kb whatever the hit rate — inserts on every call, as the reference does below its hit_rate_threshold
+    // (docs/architecture.md:65-67).
+    const bool near_all_hit = last_misses_ * 64 <= N;
+    const uint32_t ins_every = !(defer && side && near_all_hit) ? 1u : in_place ? cache_->small_insert_interval() : std::max(1u, cache_->small_insert_interval() / 2);
     if (ins_every > 1 && (++small_calls_ % ins_every) != 0) {
       cache_->AddDropped(uq);
       HPS_RETURN_IF_ERROR(WaitPushedSeq(rows_seq, ev_done_));

@@ -497,7 +497,8 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
 
   // table injection without files
   // online update hook: insert-or-overwrite rows of one table (fences ps_direct_access caches like a reload)
-  Status upsert_table(const std::string& model, size_t table, const int64_t* keys, const float* rows, size_t n);
+  Status upsert_table(const std::string& model, size_t table, const int64_t* keys, const float* rows, size_t n,
+                      unsigned layers = HostTable::kLayerVolatile | HostTable::kLayerPersistent);
   Status load_table_from_arrays(const std::string& model, size_t table, const int64_t* keys, const float* rows,
                                 size_t R, bool borrow);
   Status load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0, size_t R,
@@ -556,7 +557,10 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   std::map<std::tuple<std::string, int, int>, std::shared_ptr<EmbeddingCache>> caches_;
   std::mutex upd_mu_;
   std::map<std::string, std::vector<std::vector<int64_t>>> updated_keys_;   // model -> per table: keys applied since the last commit
-  std::vector<std::regex> update_filters_;    // volatile_db.update_filters, compiled (set before the consumer starts, then read-only)
+  // volatile_db.update_filters / persistent_db.update_filters, compiled (set before the consumer starts, then read-only): each
+  // layer takes the updates ITS list selects (backend.cpp:207-216, 250-259)
+  std::vector<std::regex> update_filters_, persistent_update_filters_;
+  bool persistent_subscribes_ = false;        // a persistent database is configured
   // filtered: update messages no update_filters entry selected (skipped silently, as a subscription filter does)
   std::atomic<uint64_t> filtered_updates_{0};
   mutable std::mutex updates_mu_;             // guards the POINTER: stats / drain take a reference under it, stop moves it out

@@ -162,7 +162,9 @@ int PreferredNumaNode(const ParameterServerConfig& cfg) {
   for (const auto& kv : cfg.models)
     if (kv.second.use_gpu_embedding_cache)
       for (int d : kv.second.deployed_devices) if (std::find(devs.begin(), devs.end(), d) == devs.end()) devs.push_back(d);
-  if (devs.empty()) return NumaNodeOfCpu(sched_getcpu());
+  // a CPU-only deployment is not bound: its host tier is all there is, and one node's CPUs would halve it (HPS_NUMA_NODE=<n>
+  // still binds on request — ThreadPool::BindToNumaNode reads it)
+  if (devs.empty()) return -1;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return -1; }
   int node = -1;
@@ -240,19 +242,19 @@ Status HierParameterServer::create_from_config(const ParameterServerConfig& cfg,
   HPS_RETURN_IF_ERROR(ps->Build(load_tables));
   if (cfg.update_source.type == UpdateSourceType::FileTail) {
     // update_filters (docs/hierarchical_parameter_server.md:509-512, 570-573; parsed at backend.cpp:207-216, 250-259): regular
-    // expressions over the update's tag "hps_<model>.<table name>" that decide which updates a database layer takes.  This
-    // build writes an update through both layers in one step (HostTable::Upsert): an update is taken when EITHER layer's list
-    // selects it (round 4 refused configurations whose two lists differed textually — e.g. [".+"] against the default
-    // "^hps_.+$", which select the same updates).
-    std::vector<std::pair<const char*, const std::vector<std::string>*>> lists{{"volatile_db", &cfg.volatile_db.update_filters}};
-    if (cfg.persistent_db.type != DatabaseType::Disabled && cfg.persistent_db.update_filters != cfg.volatile_db.update_filters)
-      lists.push_back({"persistent_db", &cfg.persistent_db.update_filters});
+    // expressions over the update's tag "hps_<model>.<table name>" that decide which updates a database layer takes.  Each layer
+    // subscribes with its OWN list, as in the reference: an update only the persistent list selects goes to the row store and
+    // leaves the volatile tier and the GPU caches as they are (round 5 merged the two lists into one).
+    ps->persistent_subscribes_ = cfg.persistent_db.type != DatabaseType::Disabled;
+    std::vector<std::tuple<const char*, const std::vector<std::string>*, std::vector<std::regex>*>> lists{
+        {"volatile_db", &cfg.volatile_db.update_filters, &ps->update_filters_}};
+    if (ps->persistent_subscribes_) lists.push_back({"persistent_db", &cfg.persistent_db.update_filters, &ps->persistent_update_filters_});
     for (const auto& l : lists) {
-      for (const std::string& f : *l.second) {
+      for (const std::string& f : *std::get<1>(l)) {
         try {
-          ps->update_filters_.emplace_back(f, std::regex::ECMAScript | std::regex::optimize);
+          std::get<2>(l)->emplace_back(f, std::regex::ECMAScript | std::regex::optimize);
         } catch (const std::regex_error& e) {
-          return Error(Code::kInvalidArg, l.first, ".update_filters: '", f, "' is not a regular expression (", e.what(), ")");
+          return Error(Code::kInvalidArg, std::get<0>(l), ".update_filters: '", f, "' is not a regular expression (", e.what(), ")");
         }
       }
     }
@@ -273,19 +275,23 @@ Status HierParameterServer::ApplyUpdate(const std::string& model, uint32_t table
   if (table >= tabs.size()) return Error(Code::kNotFound, "update for model '", model, "' table ", table, ": no such table in this server");
   if (tabs[table]->dim() != dim)
     return Error(Code::kInvalidArg, "update for model '", model, "' table ", table, ": rows are ", dim, " wide, the table is ", tabs[table]->dim());
+  unsigned layers = 0;
   {
     // the layers take an update only if its tag matches one of their update_filters (default "^hps_.+$": every model)
     std::string tag = "hps_" + model + ".";
     InferenceParams ip;
     if (model_params(model, &ip) && table < ip.embedding_table_names.size()) tag += ip.embedding_table_names[table];
     else tag += "sparse_embedding" + std::to_string(table + 1);
-    bool take = false;
-    for (const std::regex& f : update_filters_) take = take || std::regex_search(tag, f);
+    for (const std::regex& f : update_filters_) if (std::regex_search(tag, f)) { layers |= HostTable::kLayerVolatile; break; }
+    if (persistent_subscribes_)
+      for (const std::regex& f : persistent_update_filters_) if (std::regex_search(tag, f)) { layers |= HostTable::kLayerPersistent; break; }
     // not subscribed to: skipped silently, like a message on a topic nobody listens to (the consumer counts the message as dealt
     // with; hps_server_update_source_filtered says how many there were)
-    if (!take) { filtered_updates_.fetch_add(1, std::memory_order_relaxed); return Status(Code::kOk, kUpdateFiltered); }
+    if (!layers) { filtered_updates_.fetch_add(1, std::memory_order_relaxed); return Status(Code::kOk, kUpdateFiltered); }
   }
-  HPS_RETURN_IF_ERROR(upsert_table(model, table, keys, rows, n));
+  HPS_RETURN_IF_ERROR(upsert_table(model, table, keys, rows, n, layers));
+  // the GPU caches follow the volatile layer: an update only the persistent database subscribed to is not pushed into them
+  if (!(layers & HostTable::kLayerVolatile)) return Status::Ok();
   std::lock_guard<std::mutex> lk(upd_mu_);
   auto& per_table = updated_keys_[model];
   if (per_table.size() < tabs.size()) per_table.resize(tabs.size());
@@ -672,10 +678,10 @@ Status HierParameterServer::load_table_from_arrays(const std::string& model, siz
 }
 
 Status HierParameterServer::upsert_table(const std::string& model, size_t table, const int64_t* keys, const float* rows,
-                                         size_t n) {
+                                         size_t n, unsigned layers) {
   auto tabs = tables_of(model);
   if (table >= tabs.size()) return Error(Code::kNotFound, "model '", model, "' has no table ", table);
-  return MutateTables(model, [&]() { return tabs[table]->Upsert(keys, rows, n); });
+  return MutateTables(model, [&]() { return tabs[table]->Upsert(keys, rows, n, layers); });
 }
 
 Status HierParameterServer::load_table_synthetic(const std::string& model, size_t table, uint64_t seed, int64_t key0,

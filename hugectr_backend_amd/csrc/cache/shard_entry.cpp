@@ -350,6 +350,12 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
   TileDesc* tiles = reinterpret_cast<TileDesc*>(h_block_ + tiles_off_);
   uint64_t N = 0;
   uint32_t nt = 0;
+  // (before any tile descriptor is written: the page-locked block holds max_tiles_ of them)
+  for (size_t t = 0; t < T; ++t) N += n[t];
+  if (N > max_keys_)
+    return Error(Code::kInvalidArg, "lookup: ", N, " keys exceed the request capacity of ", max_keys_,
+                 " (max_batch_size x sum(maxnum_catfeature_query_per_table_per_sample))");
+  N = 0;
   for (size_t t = 0; t < T; ++t) {
     if (n[t] && !d_out[t]) return Error(Code::kInvalidArg, "lookup: null output pointer for table ", t);
     d.key_start[t] = N;
@@ -360,9 +366,6 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
     for (uint64_t b = 0; b < n[t]; b += kTileKeys) tiles[nt++] = TileDesc{N + b, (uint32_t)std::min<uint64_t>(kTileKeys, n[t] - b), (uint32_t)t};
     N += n[t];
   }
-  if (N > max_keys_)
-    return Error(Code::kInvalidArg, "lookup: ", N, " keys exceed the request capacity of ", max_keys_,
-                 " (max_batch_size x sum(maxnum_catfeature_query_per_table_per_sample))");
   d.key_start[T] = N;
   d.first_tile[T] = nt;
   d.num_tables = (uint32_t)T;

@@ -103,7 +103,8 @@ struct InferenceParams {  // backend.cpp:318-516
   // turnovers (its row is served, it just is not cached on that call; one such key in 16 is let in regardless); false = every
   // missed key is inserted, evicting its bucket's least recently used key — the reference's cache
   bool cache_admission = true;
-  // "gpucache_small_miss_insert_interval": n (default 4; 1 = every call): a synchronous call whose missed rows are FEW (they stay
+  // "gpucache_small_miss_insert_interval": n (default 4; 1 = every call): a synchronous NEAR-ALL-HIT call (at most one key in 64
+  // missed; a cold or low-hit-rate cache inserts on every call) whose missed rows are FEW (they stay
   // where the host gathered them: at most in_place_kb, 1 MB) inserts them only every n-th such call of its session; the other
   // calls serve their missed rows exactly and leave them uncached (counted as `dropped`); calls whose missed rows were uploaded
   // but still fit the second stream's scatter (side_scatter_mb, 16 MB: a call at 99 % hit) insert every n/2-th time.  Near-all-hit traffic — where a

@@ -591,9 +591,10 @@ size_t HostTable::Fetch(const int64_t* keys, size_t n, float* out, size_t stride
   return nfound;
 }
 
-Status HostTable::Upsert(const int64_t* keys, const float* rows, size_t n) {
+Status HostTable::Upsert(const int64_t* keys, const float* rows, size_t n, unsigned layers) {
+  if ((layers & (kLayerVolatile | kLayerPersistent)) == 0) return Status::Ok();
   WriteLock lk(*this);
-  if (vt_) return UpsertTiered(keys, rows, n);
+  if (vt_) return UpsertTiered(keys, rows, n, layers);
   const uint32_t D = dim_;
   // overwrite existing, collect new
   std::vector<size_t> fresh;
@@ -703,24 +704,27 @@ Status HostTable::IndexAppended(size_t first_new) {
 // Online update with a bounded volatile tier.  With a persistent database behind it the row store is the database of
 // record (written through unless read_only) and a cached copy is refreshed in place; without one the volatile tier IS
 // the database and takes the rows, pruning by its overflow policy like any other insert.
-Status HostTable::UpsertTiered(const int64_t* keys, const float* rows, size_t n) {
+Status HostTable::UpsertTiered(const int64_t* keys, const float* rows, size_t n, unsigned layers) {
   const uint32_t D = dim_;
   const uint64_t now = clock_.fetch_add(1, std::memory_order_relaxed) + 1;
+  // without a persistent database behind it the volatile tier is the only layer there is
+  const bool vol = (layers & kLayerVolatile) != 0 || !tier_opt_.persistent;
+  const bool per = (layers & kLayerPersistent) != 0 && tier_opt_.persistent;
   std::vector<size_t> fresh;
   // (the table's writer lock is held: no lookup is inside the tier, its partition locks are not needed)
   for (size_t i = 0; i < n; ++i) {
     const int64_t r = FindUnlocked(keys[i]);
-    if (r >= 0 && rows_writable_ && tier_opt_.persistent) memcpy(rows_ + (size_t)r * D, rows + i * D, (size_t)D * sizeof(float));
+    if (r >= 0 && rows_writable_ && per) memcpy(rows_ + (size_t)r * D, rows + i * D, (size_t)D * sizeof(float));
     if (r < 0) fresh.push_back(i);
+    if (!vol) continue;
     const size_t p = PartitionOf(keys[i]);
     if (tier_opt_.persistent) vt_->Overwrite(p, keys[i], rows + i * D);
     else vt_->Insert(p, keys[i], rows + i * D, now);
   }
-  if (fresh.empty() || !tier_opt_.persistent) return Status::Ok();
+  if (fresh.empty() || !per) return Status::Ok();
   if (!rows_writable_)
     return Error(Code::kUnsupported, "host table '", name_, "': the persistent database is read_only, new keys cannot be added");
   return AppendRows(keys, rows, fresh);
 }
 
 }  // namespace hps
-

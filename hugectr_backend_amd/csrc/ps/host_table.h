@@ -68,7 +68,11 @@ class HostTable {
   Status LoadSynthetic(uint64_t seed, uint32_t table_id, int64_t key0, size_t R, ThreadPool* pool, uint32_t shard = 0,
                        uint32_t num_shards = 1);
   // Insert-or-overwrite rows (online update path; duplicate keys: last wins).
-  Status Upsert(const int64_t* keys, const float* rows, size_t n);
+  // layers: which database layers take the update (each layer subscribes with its own update_filters, backend.cpp:207-216,
+  // 250-259) — kLayerVolatile the in-memory tier, kLayerPersistent the row store behind it.  A table that is ONE store (the whole
+  // table in memory, no volatile tier in front of a persistent database) is updated when either bit is set.
+  static constexpr unsigned kLayerVolatile = 1u, kLayerPersistent = 2u;
+  Status Upsert(const int64_t* keys, const float* rows, size_t n, unsigned layers = kLayerVolatile | kLayerPersistent);
 
   const std::string& name() const { return name_; }
   uint32_t dim() const { return dim_; }
@@ -103,7 +107,7 @@ class HostTable {
   void SetupTier();
   Status FinishLoad(ThreadPool* pool);
   size_t FetchTiered(const int64_t* keys, size_t n, float* out, size_t stride, float default_value, uint8_t* found) const;
-  Status UpsertTiered(const int64_t* keys, const float* rows, size_t n);
+  Status UpsertTiered(const int64_t* keys, const float* rows, size_t n, unsigned layers);
   Status AppendRows(const int64_t* keys, const float* rows, const std::vector<size_t>& fresh);
   Status IndexAppended(size_t first_new);
   double index_headroom_ = 1.0;   // AllocPartitions sizes the index for this many times the keys it is given

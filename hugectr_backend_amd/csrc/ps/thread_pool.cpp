@@ -50,6 +50,7 @@ namespace {
 std::atomic<int> g_numa_node{-2};        // -2: not decided yet, -1: none
 std::atomic<bool> g_pool_started{false};
 cpu_set_t g_numa_cpus;                   // valid when g_numa_node >= 0
+std::atomic<uint64_t> g_fast_overruns{0};   // fork-joins of the lock-free path whose tasks ran more often than once each
 
 // the CPUs of `node` this process may run on (sysfs cpulist: "0-63,128-191"); false when there are fewer than two
 bool NodeCpus(int node, cpu_set_t* out) {
@@ -114,6 +115,8 @@ bool ThreadPool::BindCallingThread() {
   return pthread_setaffinity_np(pthread_self(), sizeof want, &want) == 0;
 }
 
+uint64_t ThreadPool::FastOverruns() { return g_fast_overruns.load(std::memory_order_relaxed); }
+
 int ThreadPool::NumaNode() {
   const int n = g_numa_node.load(std::memory_order_acquire);
   return n < 0 ? -1 : n;
@@ -127,6 +130,12 @@ size_t ThreadPool::DefaultConcurrency() {
     if (v > 0) return (size_t)v;
   }
   static const size_t n = EffectiveCpus();
+  // workers bound to one NUMA node (BindToNumaNode) share that node's CPUs: on a two-socket box without a tight quota the
+  // machine-wide count would put twice as many spinning workers on them as there are CPUs
+  if (g_numa_node.load(std::memory_order_acquire) >= 0) {
+    const int c = CPU_COUNT(&g_numa_cpus);
+    if (c > 0 && (size_t)c < n) return (size_t)c;
+  }
   return n;
 }
 
@@ -198,13 +207,16 @@ uint32_t ThreadPool::RunFast(FastLoop& L, uint32_t gen) {
     uint64_t cur = L.next.load(std::memory_order_acquire);
     if ((uint32_t)(cur >> 32) != gen) break;                 // the slot moved on to another loop
     const uint32_t idx = (uint32_t)cur;
-    const uint32_t n = L.n.load(std::memory_order_relaxed);
+    // (acquire, paired with the owner's release stores: a thread that sees a NEW loop's n / grain / fn has the new claim word —
+    //  stored before them — ordered before its compare-and-swap below, which therefore fails against an old `cur`.  On x86 this
+    //  costs nothing; round 5's fix relied on TSO for it.)
+    const uint32_t n = L.n.load(std::memory_order_acquire);
     if (idx >= n) break;                                     // everything claimed
-    const uint32_t g = L.grain.load(std::memory_order_relaxed);
+    const uint32_t g = L.grain.load(std::memory_order_acquire);
     const uint32_t end = idx + g < n ? idx + g : n;
     // the generation in the word makes the claim fail if the parameters just read belong to an older loop
     if (!L.next.compare_exchange_weak(cur, ((uint64_t)gen << 32) | end, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
-    const std::function<void(size_t)>* fn = L.fn.load(std::memory_order_relaxed);
+    const std::function<void(size_t)>* fn = L.fn.load(std::memory_order_acquire);
     for (uint32_t i = idx; i < end; ++i) (*fn)(i);
     ran += end - idx;
     L.done.fetch_add(end - idx, std::memory_order_acq_rel);   // the owner returns (and fn dies) only after this
@@ -305,9 +317,9 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
       // owner's wait for done == n never survives — the one hang in ~60 bench runs, one in two runs of the sharded stress
       // driver (9 sessions + 3 entry sessions fork-joining side by side).
       L->next.store(((uint64_t)gen << 32) | 0xFFFFFFFFu, std::memory_order_seq_cst);
-      L->fn.store(&fn, std::memory_order_relaxed);
-      L->n.store((uint32_t)num_tasks, std::memory_order_relaxed);
-      L->grain.store(grain ? grain : 1u, std::memory_order_relaxed);
+      L->fn.store(&fn, std::memory_order_release);
+      L->n.store((uint32_t)num_tasks, std::memory_order_release);
+      L->grain.store(grain ? grain : 1u, std::memory_order_release);
       L->done.store(0, std::memory_order_relaxed);
       L->next.store((uint64_t)gen << 32, std::memory_order_release);
       L->state.store(1, std::memory_order_release);
@@ -326,6 +338,8 @@ void ThreadPool::ParallelFor(size_t num_tasks, const std::function<void(size_t)>
         if (it < 2048 || !kPoolYield) CpuRelax();
         else sched_yield();
       }
+      // a task that ran twice shows here (the wait above is `<`, so it would not hang any more): counted, never silent
+      if (L->done.load(std::memory_order_acquire) > (uint32_t)num_tasks) g_fast_overruns.fetch_add(1, std::memory_order_relaxed);
       L->state.store(0, std::memory_order_release);
       return;
     }

@@ -39,7 +39,7 @@ class ThreadPool {
   // headline was 1.59-2.01 G lookups/s from run to run on one box (key staging 0.19-0.50 ms, host gather 0.43-0.85 ms per
   // call) and 2.03-2.06 G in every run confined to ONE node — either one (profiles/round5/numa_one_node.txt).
   // BindToNumaNode is called once, before the pools start (HierParameterServer: the node of the deployed GPUs when they share
-  // one, the caller's own node for a CPU-only deployment, none when the GPUs span nodes); HPS_NUMA_NODE=<n> names the node,
+  // one, none for a CPU-only deployment or when the GPUs span nodes; bound pools are sized for that node's CPUs); HPS_NUMA_NODE=<n> names the node,
   // HPS_NUMA_NODE=off leaves the workers where the scheduler puts them.  The callers' threads are never touched.
   static void BindToNumaNode(int node);   // -1: none.  Ignored once a pool exists or a node has been chosen
   static int NumaNode();                  // the node the workers are bound to, -1 when they are not
@@ -51,6 +51,9 @@ class ThreadPool {
   static bool BindCallingThread();
 
   size_t size() const { return workers_.size(); }
+  // fork-joins (lock-free path, all pools of the process) in which a task ran more than once: 0 unless the slot-reuse race of
+  // round 5 is back (tools/micro/forkjoin_stress.cpp checks it; hps_pool_fast_overruns in the C ABI)
+  static uint64_t FastOverruns();
 
   // fn(task_index) for task_index in [0, num_tasks); returns when all are done.  max_parallel caps the
   // number of threads (including the caller) that work on this loop; 0 = no cap.

@@ -122,6 +122,7 @@ def _load() -> C.CDLL:
         "hps_cache_on_device": (C.c_int, [P]),
         "hps_wake_copy_engines": (C.c_int, [C.c_int, C.c_char_p, u64]),
         "hps_pool_numa_node": (C.c_int, []),
+        "hps_pool_fast_overruns": (u64, []),
         "hps_bind_calling_thread": (C.c_int, []),
         "hps_session_create_from_cache": (C.c_int, [P, C.POINTER(P)]),
         "hps_cache_table_info": (C.c_int, [P, u32, C.POINTER(CacheTableInfo)]),
@@ -186,7 +187,7 @@ EXPORTED_SYMBOLS = [
     "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
     "hps_server_table_data", "hps_update_message_encode", "hps_server_update_source_stats", "hps_server_update_source_drain", "hps_server_update_source_stop", "hps_server_update_source_filtered",
-    "hps_cache_on_device", "hps_wake_copy_engines", "hps_pool_numa_node", "hps_bind_calling_thread", "hps_session_create_from_cache",
+    "hps_cache_on_device", "hps_wake_copy_engines", "hps_pool_numa_node", "hps_pool_fast_overruns", "hps_bind_calling_thread", "hps_session_create_from_cache",
     "hps_shard_unique_id", "hps_shard_session_create", "hps_shard_group_create_local", "hps_shard_group_destroy",
     "hps_shard_session_create_local", "hps_shard_session_lookup", "hps_shard_session_lookup_host", "hps_shard_session_last_timing",
     "hps_shard_session_last_stats", "hps_shard_session_destroy",
@@ -214,6 +215,11 @@ def device_count() -> int:
 def pool_numa_node() -> int:
     """NUMA node the host tier's worker pools are bound to (-1: not bound); decided by the first server of the process."""
     return int(LIB.hps_pool_numa_node())
+
+
+def pool_fast_overruns() -> int:
+    """Fork-joins of the lock-free pool path whose tasks ran more than once (0 unless round 5's slot-reuse race is back)."""
+    return int(LIB.hps_pool_fast_overruns())
 
 
 def bind_calling_thread() -> bool:

@@ -215,10 +215,13 @@ int hps_cache_wait_async(hps_cache_t* cache);
  * ("16 engines host->device, 16 device->host, 140 ms") into buf; returns the number of engines that took a copy. */
 int hps_wake_copy_engines(int device, char* buf, uint64_t cap);
 /* The NUMA node the host tier's worker pools are bound to, -1 when they are not (csrc/ps/thread_pool.h).  The first server of the
- * process decides, before the pools start: the node of the deployed GPUs when they hang off one, the caller's node for a
- * deployment without GPU caches, none when the GPUs span nodes or the machine has one node; environment HPS_NUMA_NODE=<n> names
+ * process decides, before the pools start: the node of the deployed GPUs when they hang off one (the pools are then sized
+ * for that node's CPUs), none for a deployment without GPU caches, when the GPUs span nodes or the machine has one node; environment HPS_NUMA_NODE=<n> names
  * the node, HPS_NUMA_NODE=off switches the binding off.  Threads of the caller (Triton's instance threads) are never touched. */
 int hps_pool_numa_node(void);
+/* Fork-joins of the host tier's lock-free pool path in which a task ran more than once since the process started: 0 unless
+ * the slot-reuse race round 5 fixed is back (csrc/ps/thread_pool.h; soak and stress drivers assert it). */
+uint64_t hps_pool_fast_overruns(void);
 /* The calling thread joins the worker pools' node — for the application's threads that drive lookups (libtriton_hps.so calls it for
  * every Triton instance thread at its first request).  A thread whose affinity mask already lies inside one NUMA node is left as
  * it is.  Returns 1 when the thread's affinity was changed, 0 otherwise (pools not bound, thread already placed). */

@@ -82,7 +82,7 @@ _POOL_THREADS = """
 def test_worker_pools_can_be_bound_to_a_numa_node_or_left_alone():
     """HPS_NUMA_NODE=<n>: the workers of both pools run on the CPUs of that node (and the tables they load are first touched
     there); HPS_NUMA_NODE=off: wherever the scheduler puts them.  Unset: the first server of the process decides (the node of the
-    deployed GPUs when they share one, the caller's node without GPU caches, none on a one-node machine) — the GPU test below."""
+    deployed GPUs when they share one, none without GPU caches or on a one-node machine) — the GPU test below."""
     code = _HOST_LOOKUP + _POOL_THREADS + """
     node0 = cpus(open("/sys/devices/system/node/node0/cpulist").read().strip()) & mine
     th = pool_threads()

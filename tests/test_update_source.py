@@ -296,7 +296,8 @@ def test_update_filters_decide_which_updates_the_database_layers_take(tmp_path):
     with pytest.raises(hps.HpsError, match="regular expression"):
         hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
     # lists that differ between the layers are fine (round 4 refused them, even [".+"] against the default "^hps_.+$" which
-    # select the same updates): this build updates both layers in one step, an update is taken when either list selects it
+    # select the same updates): every layer takes the updates its own list selects (the next test); a table that is ONE store —
+    # here: the whole table in memory, unbounded volatile database — is updated when either list selects it
     cfg["volatile_db"]["update_filters"] = ["^hps_upd\\.item$"]
     cfg["persistent_db"] = {"type": "rocks_db", "path": str(tmp_path / "store"), "update_filters": ["^hps_upd\\.user$", "("]}
     with pytest.raises(hps.HpsError, match="persistent_db.update_filters"):
@@ -316,3 +317,48 @@ def test_update_filters_decide_which_updates_the_database_layers_take(tmp_path):
     ps.drain_update_source(10000)
     assert ps.update_source_stats()["messages"] == 2 and ps.filtered_update_count() == 0
     ps.close()
+
+
+def test_each_database_layer_subscribes_with_its_own_update_filters(tmp_path):
+    """Advisor finding of round 5: differing volatile_db / persistent_db update_filters were merged — an update only the persistent
+    database subscribed to also changed the volatile tier (and the GPU caches).  In the reference each layer subscribes with its
+    own filter (backend.cpp:207-216, 250-259).  Bounded volatile tier in front of a writable row store, every key cached at load
+    time: a persistent-only update lands in the row store and the volatile tier keeps answering with the row it holds; a
+    volatile-only update is served at once and never reaches the row store."""
+    from hugectr_backend_amd import hps
+    from oracle import hps_oracle as O
+    tables = make_tables([(60, 4), (60, 4)])
+    path = tmp_path / "updates.bin"
+    cfg = ps_config("upd", tables, gpucache=False)
+    cfg["update_source"] = {"type": "file_tail", "brokers": str(path), "poll_timeout_ms": 20, "failure_backoff_ms": 5}
+    cfg["models"][0]["embedding_table_names"] = ["user", "item"]
+    cfg["volatile_db"].update({"overflow_margin": 1000, "overflow_policy": "evict_oldest", "initial_cache_rate": 1.0,
+                               "update_filters": ["^hps_upd\\.item$"]})
+    cfg["persistent_db"] = {"type": "rocks_db", "path": str(tmp_path / "store"), "update_filters": ["^hps_upd\\.user$"]}
+    for t, (k, r) in enumerate(tables):
+        O.np_write_table(tmp_path / f"files_{t}", k, r)
+        cfg["models"][0]["sparse_files"][t] = str(tmp_path / f"files_{t}")
+    ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=True)
+    assert ps.host_tier_stats("upd", 0)["tiered"] == 1
+    ku, ki = tables[0][0][:5], tables[1][0][:5]
+    with open(path, "ab") as f:
+        f.write(hps.encode_update_message("upd", 0, ku, np.full((5, 4), 3.0, np.float32)))   # hps_upd.user: persistent layer only
+        f.write(hps.encode_update_message("upd", 1, ki, np.full((5, 4), 4.0, np.float32)))   # hps_upd.item: volatile layer only
+    ps.drain_update_source(10000)
+    assert ps.update_source_stats()["messages"] == 2 and ps.filtered_update_count() == 0
+    sess = hps.LookupSession.create(ps, "upd", None)
+    out = sess.lookup(np.concatenate([ku, ki]), [5, 5]).reshape(10, 4)
+    assert np.array_equal(_bits(out[:5]), _bits(tables[0][1][:5])), "the volatile tier took an update it did not subscribe to"
+    assert np.all(out[5:] == 4.0)
+    sess.close()
+    ps.close()
+    # what is on disk afterwards: the row store of `user` has the new rows, the one of `item` the old ones
+    rows = {}
+    for ev in (tmp_path / "store").rglob("emb_vector"):
+        k = np.fromfile(ev.parent / "key", np.int64)
+        r = np.fromfile(ev, np.float32).reshape(k.size, 4)
+        rows[str(ev.parent)] = dict(zip(k.tolist(), r))
+    user = [m for m in rows.values() if int(ku[0]) in m and np.all(m[int(ku[0])] == 3.0)]
+    item_old = [m for m in rows.values() if int(ki[0]) in m and np.array_equal(m[int(ki[0])], tables[1][1][0])]
+    assert user, "the persistent layer did not take the update it subscribed to"
+    assert item_old, "the persistent layer took an update only the volatile database subscribed to"

@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
   }
   stop.store(true);
   for (auto& t : th) t.join();
+  if (hps::ThreadPool::FastOverruns()) { printf("OVERRUN %llu\n", (unsigned long long)hps::ThreadPool::FastOverruns()); _exit(4); }
   printf("ok\n");
   return 0;
 }
