@@ -688,8 +688,11 @@ int hps_shard_entry_last_stats(hps_shard_entry_t* e, hps_shard_entry_stats_t* ou
     out->num_shards = e->s->num_shards();
     out->key_bytes = (uint32_t)st.key_bytes;
     out->dedup_level = (uint32_t)st.dedup_level;
+    out->transport = (uint32_t)st.transport;
+    out->copied_bytes = st.copied_bytes;
     for (uint32_t s = 0; s < e->s->num_shards() && s < 64; ++s) {
       out->sent[s] = st.sent[s]; out->passes[s] = st.passes[s]; out->shard_ms[s] = st.shard_ms[s];
+      out->copy_wait_ms[s] = st.copy_wait_ms[s];
     }
     return Status::Ok();
   });
@@ -701,6 +704,11 @@ int hps_shard_entry_set_option(hps_shard_entry_t* e, const char* name, int value
     const std::string n(name);
     if (n == "dedup") e->s->set_dedup(value < 0 ? 0 : value > 2 ? 2 : value);
     else if (n == "timing") e->s->set_timing(value != 0);
+    else if (n == "transport") return e->s->set_transport(value);
+    else if (n == "copy_piece_keys") {
+      if (value < 1024) return Error(Code::kInvalidArg, "copy_piece_keys must be >= 1024");
+      e->s->set_piece_keys((size_t)value);
+    }
     else return Error(Code::kInvalidArg, "unknown option '", n, "'");
     return Status::Ok();
   });

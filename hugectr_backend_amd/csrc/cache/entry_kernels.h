@@ -39,6 +39,20 @@ hipError_t LaunchEntryDedup(const EntryDesc* d_desc, const TileDesc* d_tiles, ui
 hipError_t LaunchEntryBucket(const EntryDesc* d_desc, const TileDesc* d_tiles, uint32_t num_tiles, uint32_t num_shards,
                              const int64_t* d_keys, const uint32_t* d_rep, uint32_t* d_hist, uint32_t* d_within, uint32_t* d_base,
                              uint32_t* d_counts, int64_t* d_bkeys, uint32_t* d_bidx, hipStream_t stream);
+// "staged_copy" transport (shard_entry.h): an owner gathered the rows of one PIECE of its bucket into a local block — table-major,
+// every table's rows starting on a 16-byte boundary — and a copy engine shipped the block into the entry GPU's receive buffer.
+// This kernel puts every row where it belongs: out[table][d_bidx[j]] = block row of bucket key j.  One launch covers up to
+// kPlaceMaxSegments non-empty tables of the piece (by-value argument block; a piece with more takes several launches).
+constexpr int kPlaceMaxSegments = 64;
+struct PlaceArgs {
+  uint32_t num_segments;
+  uint32_t num_keys;                            // keys of this launch
+  uint32_t start[kPlaceMaxSegments + 1];        // segment g covers launch keys [start[g], start[g + 1])
+  uint32_t table[kPlaceMaxSegments];            // its table
+  uint32_t src_off[kPlaceMaxSegments];          // float offset of its first row in the block (a multiple of 4)
+};
+// d_bidx: the launch's slice of the bucket index array; d_block: the piece's block in the receive buffer
+hipError_t LaunchEntryPlace(const EntryDesc* d_desc, const PlaceArgs& args, const uint32_t* d_bidx, const float* d_block, hipStream_t stream);
 // out[i] = out[d_rep[i]] where d_rep[i] != i
 hipError_t LaunchEntryExpand(const EntryDesc* d_desc, const uint32_t* d_rep, uint64_t n, hipStream_t stream);
 

@@ -216,6 +216,32 @@ __global__ __launch_bounds__(kEntryTile) void hps_entry_scatter_kernel(const Ent
   }
 }
 
+// "staged_copy" transport: rows of one piece of an owner's bucket, shipped into the entry GPU by a copy engine, go to their places
+// in OUTPUT0.  A 16-lane group moves one row (a 512-B row = two float4 per lane); 512 B read + 512 B written + 4 B of index per
+// key at D = 128, all local HBM of the entry GPU.
+__global__ __launch_bounds__(256) void hps_entry_place_kernel(const EntryDesc* __restrict__ d, const PlaceArgs a,
+                                                              const uint32_t* __restrict__ bidx, const float* __restrict__ block) {
+  const int lig = threadIdx.x & 15;
+  const uint32_t groups = gridDim.x * (blockDim.x / 16);
+  for (uint32_t j = blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4); j < a.num_keys; j += groups) {
+    int lo = 0, hi = (int)a.num_segments;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.start[mid] <= j) lo = mid; else hi = mid;
+    }
+    const uint32_t t = a.table[lo];
+    const uint32_t D = d->dim[t];
+    const float* s = block + a.src_off[lo] + (uint64_t)(j - a.start[lo]) * D;
+    float* o = d->out[t] + (uint64_t)bidx[j] * D;
+    if ((D & 3u) == 0 && (((uintptr_t)d->out[t]) & 15u) == 0) {
+      for (uint32_t e = (uint32_t)lig * 4; e < D; e += 64)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f4e*>(s + e)), reinterpret_cast<f4e*>(o + e));
+    } else {
+      for (uint32_t e = (uint32_t)lig; e < D; e += 16) o[e] = s[e];
+    }
+  }
+}
+
 // out[i] = out[rep[i]] for the keys the request repeats (their representative's row has arrived from its owner by now).
 // A wave takes 64 keys (one coalesced load of their rep words), each 16-lane group copies the repeated ones among its 16.
 __global__ __launch_bounds__(256) void hps_entry_expand_kernel(const EntryDesc* __restrict__ d, const uint32_t* __restrict__ rep) {
@@ -277,6 +303,15 @@ hipError_t LaunchEntryBucket(const EntryDesc* d_desc, const TileDesc* d_tiles, u
   if (num_tiles)
     hipLaunchKernelGGL(hps_entry_scatter_kernel, dim3(num_tiles), dim3(kEntryTile), 0, stream, d_desc, d_tiles, d_keys, d_rep, d_within,
                        d_base, d_bkeys, d_bidx);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEntryPlace(const EntryDesc* d_desc, const PlaceArgs& args, const uint32_t* d_bidx, const float* d_block, hipStream_t stream) {
+  if (args.num_keys == 0) return hipSuccess;
+  if (args.num_segments == 0 || args.num_segments > (uint32_t)kPlaceMaxSegments) return hipErrorInvalidValue;
+  uint32_t want = (args.num_keys + 15) / 16;
+  if (want > 8192) want = 8192;
+  hipLaunchKernelGGL(hps_entry_place_kernel, dim3(want), dim3(256), 0, stream, d_desc, args, d_bidx, d_block);
   return hipGetLastError();
 }
 

@@ -74,6 +74,8 @@ Status ShardedEntrySession::Create(std::shared_ptr<HierParameterServer> ps, cons
   s->P_ = (uint32_t)p.deployed_devices.size();
   s->device_ = entry_device;
   s->dedup_ = p.shard_dedup ? 1 : 0;
+  s->transport_ = p.shard_transport_staged ? 1 : 0;
+  s->piece_keys_ = p.shard_copy_piece_keys;
   size_t per_sample = 0;
   for (size_t c : p.maxnum_catfeature_query_per_table_per_sample) per_sample += c;
   s->max_keys_ = p.max_batchsize * per_sample;
@@ -100,13 +102,19 @@ Status ShardedEntrySession::Create(std::shared_ptr<HierParameterServer> ps, cons
       HIP_TRY(hipSetDevice(dev));
       int can = 0;
       HIP_TRY(hipDeviceCanAccessPeer(&can, dev, entry_device));
-      if (!can)
-        return Error(Code::kUnavailable, "model '", model, "': device ", dev, " (shard ", sh, ") cannot access device ", entry_device,
-                     " as a peer; the table-sharded lookup needs peer access between the deployed devices");
-      const hipError_t pe = hipDeviceEnablePeerAccess(entry_device, 0);
-      if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
-        return Error(Code::kInternal, "hipDeviceEnablePeerAccess(", entry_device, ") from device ", dev, " failed: ", hipGetErrorString(pe));
-      (void)hipGetLastError();
+      if (!can) {
+        // the staged_copy transport moves keys and rows with copies only and does without the mapping
+        if (s->transport_ == 0)
+          return Error(Code::kUnavailable, "model '", model, "': device ", dev, " (shard ", sh, ") cannot access device ", entry_device,
+                       " as a peer; the peer_store transport of the table-sharded lookup needs peer access between the deployed devices"
+                       " (ps.json \"shard_transport\": \"staged_copy\" does not)");
+        s->peers_ok_ = false;
+      } else {
+        const hipError_t pe = hipDeviceEnablePeerAccess(entry_device, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+          return Error(Code::kInternal, "hipDeviceEnablePeerAccess(", entry_device, ") from device ", dev, " failed: ", hipGetErrorString(pe));
+        (void)hipGetLastError();
+      }
     }
     std::unique_ptr<LookupSession> ls;
     HPS_RETURN_IF_ERROR(ps->create_lookup_session_sized(model, cache, s->shard_cap_, &ls));
@@ -160,6 +168,7 @@ Status ShardedEntrySession::Create(std::shared_ptr<HierParameterServer> ps, cons
   s->stats_.sent.assign(P, 0);
   s->stats_.passes.assign(P, 0);
   s->stats_.shard_ms.assign(P, 0.f);
+  s->stats_.copy_wait_ms.assign(P, 0.f);
   *out = std::move(s);
   return Status::Ok();
 }
@@ -174,6 +183,7 @@ ShardedEntrySession::~ShardedEntrySession() {
     w->cv.notify_all();
   }
   for (auto& w : workers_) if (w && w->th.joinable()) w->th.join();
+  FreeStaged();
   sessions_.clear();
   (void)hipSetDevice(device_);
   if (stream_) { (void)hipStreamSynchronize(stream_); (void)hipStreamDestroy(stream_); }
@@ -204,11 +214,15 @@ void ShardedEntrySession::WorkerMain(uint32_t s) {
     w.wake_ms = std::chrono::duration<float, std::milli>(t0 - w.posted).count();
     Status st = Status::Ok();
     uint64_t misses = 0, unique = 0;
-    for (const ShardPass& pass : w.plan) {
-      st = sessions_[s]->lookup_from_device_indexed(w.keys + pass.offset, w.idx + pass.offset, w.out, pass.n.data(), T);
-      if (!st.ok()) break;
-      misses += sessions_[s]->last_miss_count();
-      unique += sessions_[s]->last_unique_miss_count();
+    if (w.staged) {
+      st = ServeStaged(s, w, &misses, &unique);
+    } else {
+      for (const ShardPass& pass : w.plan) {
+        st = sessions_[s]->lookup_from_device_indexed(w.keys + pass.offset, w.idx + pass.offset, w.out, pass.n.data(), T);
+        if (!st.ok()) break;
+        misses += sessions_[s]->last_miss_count();
+        unique += sessions_[s]->last_unique_miss_count();
+      }
     }
     {
       std::lock_guard<std::mutex> lk(w.mu);
@@ -220,6 +234,154 @@ void ShardedEntrySession::WorkerMain(uint32_t s) {
     }
     w.cv.notify_all();
   }
+}
+
+Status ShardedEntrySession::set_transport(int transport) {
+  if (transport != 0 && transport != 1) return Error(Code::kInvalidArg, "transport must be 0 (peer_store) or 1 (staged_copy)");
+  if (transport == 0 && !peers_ok_)
+    return Error(Code::kUnavailable, "model '", params_.model_name, "': the peer_store transport needs peer access from every shard's device to device ",
+                 device_, ", which this machine does not grant");
+  transport_ = transport;
+  return Status::Ok();
+}
+
+// floats of one piece's block: table-major, every table's rows on a 16-byte boundary (the gather kernels' float4 path)
+size_t ShardedEntrySession::PieceFloats(const ShardPass& pass, const std::vector<uint32_t>& dims) {
+  size_t fl = 0;
+  for (size_t t = 0; t < dims.size(); ++t) fl = ((fl + 3) & ~(size_t)3) + pass.n[t] * dims[t];
+  return (fl + 3) & ~(size_t)3;
+}
+
+Status ShardedEntrySession::EnsureStaged() {
+  uint32_t maxd = 1;
+  for (uint32_t d : dims_) maxd = std::max(maxd, d);
+  const size_t want = piece_keys_ * maxd + 4 * dims_.size() + 4;
+  if (staged_.size() == P_ && staged_[0].stage_floats >= want) return Status::Ok();
+  FreeStaged();
+  staged_.resize(P_);
+  for (uint32_t s = 0; s < P_; ++s) {
+    StagedShard& g = staged_[s];
+    HIP_TRY(hipSetDevice(shard_device_[s]));
+    for (int b = 0; b < 2; ++b) {
+      void* v = nullptr;
+      if (hipMalloc(&v, want * sizeof(float)) != hipSuccess) return Error(Code::kInternal, "sharded entry session: out of device memory (piece blocks)");
+      g.stage[b] = (float*)v;
+      HIP_TRY(hipEventCreateWithFlags(&g.copied[b], hipEventDisableTiming));
+    }
+    g.stage_floats = want;
+    void* v = nullptr;
+    if (hipMalloc(&v, max_keys_ * sizeof(int64_t)) != hipSuccess) return Error(Code::kInternal, "sharded entry session: out of device memory (bucket keys)");
+    g.okeys = (int64_t*)v;
+    HIP_TRY(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipStreamCreateWithFlags(&g.place_stream, hipStreamNonBlocking));
+  }
+  HIP_TRY(hipSetDevice(device_));
+  return Status::Ok();
+}
+
+void ShardedEntrySession::FreeStaged() {
+  for (uint32_t s = 0; s < staged_.size(); ++s) {
+    StagedShard& g = staged_[s];
+    (void)hipSetDevice(shard_device_[s]);
+    if (g.copy_stream) { (void)hipStreamSynchronize(g.copy_stream); (void)hipStreamDestroy(g.copy_stream); }
+    for (int b = 0; b < 2; ++b) {
+      if (g.copied[b]) (void)hipEventDestroy(g.copied[b]);
+      if (g.stage[b]) (void)hipFree(g.stage[b]);
+    }
+    if (g.okeys) (void)hipFree(g.okeys);
+    (void)hipSetDevice(device_);
+    if (g.place_stream) { (void)hipStreamSynchronize(g.place_stream); (void)hipStreamDestroy(g.place_stream); }
+  }
+  staged_.clear();
+  (void)hipSetDevice(device_);
+  if (d_recv_) { (void)hipFree(d_recv_); d_recv_ = nullptr; recv_floats_ = 0; }
+}
+
+// staged_copy, one owner's side (runs on the owner's worker thread): the bucket's keys come over in one copy; then piece by
+// piece — ordinary lookup into a local block, the block shipped by a copy engine while the next piece is looked up, and the
+// rows of a delivered block put into OUTPUT0 by a kernel on the entry GPU.
+Status ShardedEntrySession::ServeStaged(uint32_t s, Worker& w, uint64_t* misses, uint64_t* unique) {
+  StagedShard& g = staged_[s];
+  const int dev = shard_device_[s];
+  const size_t T = dims_.size();
+  auto ship = [&](void* dst, int dst_dev, const void* src, int src_dev, size_t bytes) -> hipError_t {
+    if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g.copy_stream);
+    return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, g.copy_stream);
+  };
+  HIP_TRY(hipSetDevice(dev));
+  HIP_TRY(ship(g.okeys, dev, w.keys, device_, (size_t)w.total * sizeof(int64_t)));
+  HIP_TRY(hipStreamSynchronize(g.copy_stream));
+  struct Shipped { bool valid = false; int buf = 0; const ShardPass* pass = nullptr; size_t recv_off = 0; } prev;
+  float wait_ms = 0.f;
+  // the rows of a shipped block go to their places in OUTPUT0 (entry GPU) once the copy has landed
+  auto deliver = [&](const Shipped& x) -> Status {
+    const auto tw = std::chrono::steady_clock::now();
+    HIP_TRY(hipEventSynchronize(g.copied[x.buf]));
+    wait_ms += MsSince(tw);
+    HIP_TRY(hipSetDevice(device_));
+    PlaceArgs a;
+    a.num_segments = 0;
+    a.num_keys = 0;
+    size_t fl = 0, first_key = x.pass->offset;
+    auto flush = [&]() -> Status {
+      if (a.num_segments == 0) return Status::Ok();
+      a.start[a.num_segments] = a.num_keys;
+      const hipError_t e = LaunchEntryPlace(w.desc, a, w.idx + first_key, w.recv + x.recv_off, g.place_stream);
+      if (e != hipSuccess) return Error(Code::kInternal, "row placement launch failed: ", hipGetErrorString(e));
+      first_key += a.num_keys;
+      a.num_segments = 0;
+      a.num_keys = 0;
+      return Status::Ok();
+    };
+    for (size_t t = 0; t < T; ++t) {
+      fl = (fl + 3) & ~(size_t)3;
+      const size_t nt = x.pass->n[t];
+      if (nt == 0) continue;
+      if (a.num_segments == (uint32_t)kPlaceMaxSegments) HPS_RETURN_IF_ERROR(flush());
+      a.start[a.num_segments] = a.num_keys;
+      a.table[a.num_segments] = (uint32_t)t;
+      a.src_off[a.num_segments] = (uint32_t)fl;
+      ++a.num_segments;
+      a.num_keys += (uint32_t)nt;
+      fl += nt * dims_[t];
+    }
+    HPS_RETURN_IF_ERROR(flush());
+    HIP_TRY(hipSetDevice(dev));
+    return Status::Ok();
+  };
+  size_t recv_off = 0;
+  std::vector<float*> outs(T, nullptr);
+  uint32_t p = 0;
+  for (const ShardPass& pass : w.plan) {
+    const int b = (int)(p & 1u);
+    size_t fl = 0;
+    for (size_t t = 0; t < T; ++t) {
+      fl = (fl + 3) & ~(size_t)3;
+      outs[t] = g.stage[b] + fl;
+      fl += pass.n[t] * dims_[t];
+    }
+    fl = (fl + 3) & ~(size_t)3;
+    if (fl > g.stage_floats) return Error(Code::kInternal, "staged_copy: a piece of ", fl, " floats does not fit its block of ", g.stage_floats);
+    // (block b's previous copy — piece p - 2 — was waited for when that piece was delivered)
+    HPS_RETURN_IF_ERROR(sessions_[s]->lookup_from_device(g.okeys + pass.offset, outs.data(), pass.n.data(), T));
+    *misses += sessions_[s]->last_miss_count();
+    *unique += sessions_[s]->last_unique_miss_count();
+    HIP_TRY(hipSetDevice(dev));
+    HIP_TRY(ship(w.recv + recv_off, device_, g.stage[b], dev, fl * sizeof(float)));
+    HIP_TRY(hipEventRecord(g.copied[b], g.copy_stream));
+    w.copied_bytes += fl * sizeof(float);
+    if (prev.valid) HPS_RETURN_IF_ERROR(deliver(prev));
+    prev.valid = true; prev.buf = b; prev.pass = &pass; prev.recv_off = recv_off;
+    recv_off += fl;
+    ++p;
+  }
+  if (prev.valid) HPS_RETURN_IF_ERROR(deliver(prev));
+  HIP_TRY(hipSetDevice(device_));
+  HIP_TRY(hipStreamSynchronize(g.place_stream));
+  HIP_TRY(hipSetDevice(dev));
+  w.copy_wait_ms = wait_ms;
+  return Status::Ok();
 }
 
 Status ShardedEntrySession::lookup_from_device(const int64_t* d_keys_flat, float* const* d_out, const size_t* n, size_t T) {
@@ -379,6 +541,9 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
   std::fill(stats_.sent.begin(), stats_.sent.end(), 0);
   std::fill(stats_.passes.begin(), stats_.passes.end(), 0);
   std::fill(stats_.shard_ms.begin(), stats_.shard_ms.end(), 0.f);
+  std::fill(stats_.copy_wait_ms.begin(), stats_.copy_wait_ms.end(), 0.f);
+  stats_.transport = transport_;
+  stats_.copied_bytes = 0;
   if (N == 0) return Status::Ok();
   if (!d_keys_flat) return Error(Code::kInvalidArg, "lookup: null key pointer");
 
@@ -420,8 +585,31 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
     else if (level == 1) tile_only_left_ = (stats_.unique_keys * 10 < N * 8) ? 0 : tile_only_left_ - 1;
   }
 
-  // ---- every owner looks its bucket up, all of them side by side; rows land in d_out over the peer mappings ----
+  // ---- every owner looks its bucket up, all of them side by side; rows land in d_out over the peer mappings (peer_store) or
+  //      come over block by block through the receive buffer (staged_copy) ----
   const auto t1 = std::chrono::steady_clock::now();
+  const bool staged = transport_ == 1;
+  std::vector<std::vector<ShardPass>> plans(P_);
+  std::vector<size_t> recv_base(P_ + 1, 0);
+  for (uint32_t s = 0; s < P_; ++s) {
+    const uint32_t total = base[s + 1] - base[s];
+    if (total) plans[s] = PlanShardPasses(counts + (size_t)s * T, T, staged ? std::min(sessions_[s]->max_keys(), piece_keys_) : sessions_[s]->max_keys());
+    size_t fl = 0;
+    if (staged) for (const ShardPass& pass : plans[s]) fl += PieceFloats(pass, dims_);
+    recv_base[s + 1] = recv_base[s] + fl;
+  }
+  if (staged) {
+    HPS_RETURN_IF_ERROR(EnsureStaged());
+    if (recv_base[P_] > recv_floats_) {
+      // (grows with the largest request seen; nothing of an earlier request is in flight here)
+      if (d_recv_) { HIP_TRY(hipFree(d_recv_)); d_recv_ = nullptr; recv_floats_ = 0; }
+      const size_t want = recv_base[P_] + recv_base[P_] / 8 + 1024;
+      void* v = nullptr;
+      if (hipMalloc(&v, want * sizeof(float)) != hipSuccess) return Error(Code::kInternal, "sharded entry session: out of device memory (receive buffer)");
+      d_recv_ = (float*)v;
+      recv_floats_ = want;
+    }
+  }
   for (uint32_t s = 0; s < P_; ++s) {
     const uint32_t total = base[s + 1] - base[s];
     stats_.sent[s] = total;
@@ -429,10 +617,16 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
     Worker& w = *workers_[s];
     {
       std::lock_guard<std::mutex> lk(w.mu);
-      w.plan = PlanShardPasses(counts + (size_t)s * T, T, sessions_[s]->max_keys());
+      w.plan = std::move(plans[s]);
       w.keys = d_bkeys_ + base[s];
       w.idx = d_bidx_ + base[s];
       w.out = d_out;
+      w.staged = staged;
+      w.total = total;
+      w.recv = staged ? d_recv_ + recv_base[s] : nullptr;
+      w.desc = dd;
+      w.copy_wait_ms = 0.f;
+      w.copied_bytes = 0;
       w.done = false;
       w.has_job = true;
       w.posted = std::chrono::steady_clock::now();
@@ -448,6 +642,8 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
     w.cv.wait(lk, [&] { return w.done; });
     if (!w.st.ok() && first.ok()) first = Error(w.st.code(), "shard ", s, " (device ", shard_device_[s], "): ", w.st.message());
     stats_.shard_ms[s] = w.ms;
+    stats_.copy_wait_ms[s] = w.copy_wait_ms;
+    stats_.copied_bytes += w.copied_bytes;
     stats_.misses += w.misses;
     stats_.unique_misses += w.unique;
   }

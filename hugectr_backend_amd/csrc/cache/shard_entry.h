@@ -18,6 +18,18 @@
 // the sessions of all instances as they order any sessions (EmbeddingCache::BeginRead / BeginWrite).  The SPMD variant — one
 // process per GPU, RCCL send/recv groups — is shard_session.h.
 //
+// TWO TRANSPORTS for the rows (ps.json "shard_transport", session option "transport"; chosen per session, both bit-exact):
+//   "peer_store" (default)  the owners' kernels store each row straight into the entry GPU's OUTPUT0 through peer-mapped pointers
+//                           (fine-grained xGMI stores, no extra copy of any row, needs peer access between the devices)
+//   "staged_copy"           an owner gathers a PIECE of its bucket (<= shard_copy_piece_keys keys) into a LOCAL block with an ordinary
+//                           lookup, a copy engine ships the block to the entry GPU's receive buffer (hipMemcpyPeerAsync: SDMA over
+//                           xGMI, bulk transfers) while the owner already gathers the next piece, and hps_entry_place puts the rows of
+//                           a delivered block into OUTPUT0 (local HBM of the entry GPU).  The bucket keys travel the same way, in one
+//                           copy: no kernel of this transport touches another GPU's memory, so it also works where peer access
+//                           is not available (the runtime then stages the copies itself).
+// Which one fills the entry GPU's seven inbound links better is for the first multi-GPU run to say (bench.py runs both on the same
+// requests); on one GPU staged_copy costs one more pass over the rows.
+//
 // One host round trip sits between the bucket step and the lookups (P x T counts, ~20 us): exact bucket sizes mean no
 // padding, no overflow/retry, any number of tables.  An owner that gets more keys than its session holds (skew; the session is
 // sized shard_capacity_factor x request capacity / P) is served in several passes (PlanShardPasses).
@@ -58,6 +70,9 @@ struct ShardEntryStats {
   float key_stage_ms = 0.f;      // host keys: staging + upload enqueue
   int key_bytes = 8;             // bytes per key that crossed PCIe: 8, 4 (uint32 offsets) or 3 (packed)
   uint64_t misses = 0, unique_misses = 0;   // summed over the shards' lookups
+  int transport = 0;             // 0 peer_store, 1 staged_copy
+  uint64_t copied_bytes = 0;     // staged_copy: row bytes the copy engines shipped into the entry GPU
+  std::vector<float> copy_wait_ms;   // staged_copy: time each shard's worker spent waiting for its copies to land
 };
 
 class ShardedEntrySession {
@@ -81,6 +96,10 @@ class ShardedEntrySession {
   size_t shard_capacity() const { return shard_cap_; }
   LookupSession* shard_session(uint32_t s) { return s < sessions_.size() ? sessions_[s].get() : nullptr; }
   void set_dedup(int level) { dedup_ = level; tile_only_left_ = 0; }   // 0 off, 1 adaptive (default), 2 always both levels
+  // 0 peer_store, 1 staged_copy; peer_store is refused when a shard's device cannot store into the entry device
+  Status set_transport(int transport);
+  int transport() const { return transport_; }
+  void set_piece_keys(size_t keys) { if (keys >= 1024) piece_keys_ = keys; }   // staged_copy: keys per piece (from the next request on)
   void set_timing(bool b);   // forwards to the shard sessions (per-kernel times in their own statistics)
 
  private:
@@ -101,8 +120,35 @@ class ShardedEntrySession {
     float ms = 0.f, wake_ms = 0.f;   // lookups' wall time; job posted -> worker running
     std::chrono::steady_clock::time_point posted;
     uint64_t misses = 0, unique = 0;
+    // staged_copy
+    bool staged = false;
+    uint64_t total = 0;              // keys of the bucket
+    float* recv = nullptr;           // this shard's region of the entry GPU's receive buffer
+    const EntryDesc* desc = nullptr; // the request's descriptor on the entry GPU
+    float copy_wait_ms = 0.f;
+    uint64_t copied_bytes = 0;
   };
   void WorkerMain(uint32_t s);
+  Status ServeStaged(uint32_t s, Worker& w, uint64_t* misses, uint64_t* unique);
+
+  // staged_copy: what one shard needs on its own device and on the entry device (allocated at the first staged request)
+  struct StagedShard {
+    float* stage[2] = {nullptr, nullptr};   // shard device: two blocks of piece rows
+    size_t stage_floats = 0;
+    int64_t* okeys = nullptr;                // shard device: the bucket's keys
+    hipStream_t copy_stream = nullptr;       // shard device
+    hipEvent_t copied[2] = {nullptr, nullptr};
+    hipStream_t place_stream = nullptr;      // entry device
+  };
+  Status EnsureStaged();
+  void FreeStaged();
+  static size_t PieceFloats(const ShardPass& pass, const std::vector<uint32_t>& dims);
+  std::vector<StagedShard> staged_;
+  float* d_recv_ = nullptr;         // entry device: the shards' blocks, shard-major, piece by piece
+  size_t recv_floats_ = 0;
+  size_t piece_keys_ = 65536;
+  int transport_ = 0;
+  bool peers_ok_ = true;            // every shard device can store into the entry device
 
   std::shared_ptr<HierParameterServer> ps_;
   InferenceParams params_;

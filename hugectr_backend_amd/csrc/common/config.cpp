@@ -310,6 +310,15 @@ Status ParseParameterServerJson(const Json& root, ParameterServerConfig* out) {
         return Error(Code::kInvalidArg, "Model '", p.model_name, "': table_sharding must be \"hash\" or \"none\", got '", sharding, "'");
       HPS_RETURN_IF_ERROR(ParseField(p.shard_capacity_factor, j, "shard_capacity_factor", false));
       HPS_RETURN_IF_ERROR(ParseField(p.shard_dedup, j, "shard_dedup", false));
+      std::string transport;
+      HPS_RETURN_IF_ERROR(ParseField(transport, j, "shard_transport", false));
+      transport = Normalised(transport, false);
+      if (transport == "staged_copy") p.shard_transport_staged = true;
+      else if (!(transport.empty() || transport == "peer_store"))
+        return Error(Code::kInvalidArg, "Model '", p.model_name, "': shard_transport must be \"peer_store\" or \"staged_copy\", got '", transport, "'");
+      HPS_RETURN_IF_ERROR(ParseField(p.shard_copy_piece_keys, j, "shard_copy_piece_keys", false));
+      if (p.shard_copy_piece_keys < 1024 || p.shard_copy_piece_keys > (1u << 24))
+        return Error(Code::kInvalidArg, "Model '", p.model_name, "': shard_copy_piece_keys must be in [1024, 16777216]");
       if (p.table_sharding) {
         if (!p.use_gpu_embedding_cache)
           return Error(Code::kInvalidArg, "Model '", p.model_name, "': table_sharding shards the GPU caches and needs gpucache = true");

@@ -82,7 +82,8 @@ class ShardEntryStats(C.Structure):
     _fields_ = [("keys", C.c_uint64), ("unique_keys", C.c_uint64), ("misses", C.c_uint64), ("unique_misses", C.c_uint64),
                 ("bucket_ms", C.c_float), ("lookup_ms", C.c_float), ("expand_ms", C.c_float), ("key_stage_ms", C.c_float),
                 ("num_shards", C.c_uint32), ("key_bytes", C.c_uint32), ("sent", C.c_uint64 * 64), ("passes", C.c_uint32 * 64),
-                ("shard_ms", C.c_float * 64), ("dedup_level", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("shard_ms", C.c_float * 64), ("dedup_level", C.c_uint32), ("transport", C.c_uint32), ("copied_bytes", C.c_uint64),
+                ("copy_wait_ms", C.c_float * 64)]
 
 
 def _load() -> C.CDLL:

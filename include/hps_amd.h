@@ -337,7 +337,11 @@ int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint6
  * collective, no lock-step between instances (csrc/cache/shard_entry.h).  libtriton_hps.so creates one entry session per
  * model instance of such a model.  Optional keys: "shard_capacity_factor" (default 2.0: a shard session holds that many
  * times its fair share of a full request; more is served in several passes), "shard_dedup" (default true: a key the request
- * repeats travels to its owner once). */
+ * repeats travels to its owner once), "shard_transport" ("peer_store", the default: as above | "staged_copy": every owner
+ * gathers pieces of "shard_copy_piece_keys" (default 65,536) keys into local blocks with ordinary lookups, copy engines ship
+ * the blocks into the entry device's receive buffer — hipMemcpyPeerAsync, SDMA over xGMI — while the next piece is gathered,
+ * and a kernel on the entry device puts the delivered rows into OUTPUT0; the bucket keys travel by copy too, so no kernel
+ * touches another device's memory and peer access is not needed).  Same rows either way. */
 typedef struct hps_shard_entry hps_shard_entry_t;
 typedef struct hps_shard_entry_stats {
   uint64_t keys, unique_keys;          /* last request: keys as sent / keys that travelled (dedup_level 2: the distinct (table, key) pairs) */
@@ -349,7 +353,9 @@ typedef struct hps_shard_entry_stats {
   uint32_t passes[64];                 /* lookup calls per shard */
   float shard_ms[64];                  /* wall time of each shard's lookups */
   uint32_t dedup_level;                /* input dedup of the last request: 0 none, 1 within tiles of 1,024 keys, 2 call-wide */
-  uint32_t reserved_;
+  uint32_t transport;                  /* how the rows reached the entry GPU: 0 peer_store, 1 staged_copy */
+  uint64_t copied_bytes;               /* staged_copy: row bytes the copy engines shipped into the entry GPU */
+  float copy_wait_ms[64];              /* staged_copy: time each shard's worker waited for its copies to land */
 } hps_shard_entry_stats_t;
 /* the cache of shard s of a table-sharded model (for residency queries, counters); *out = NULL when there is none */
 int hps_server_get_shard_cache(hps_server_t* server, const char* model, uint32_t shard, hps_cache_t** out);
@@ -363,7 +369,9 @@ int hps_shard_entry_lookup_device(hps_shard_entry_t* entry, const int64_t* d_key
 int hps_shard_entry_last_stats(hps_shard_entry_t* entry, hps_shard_entry_stats_t* out);
 /* options: "dedup" (0: every key travels as sent; 1, the model's default with shard_dedup: adaptive — repeats found within tiles
  * of 1,024 keys and call-wide, the call-wide level skipped for 31 requests after a big request of which more than 90 %
- * travelled anyway; 2: always both levels), "timing" (0/1: forwarded to the shard sessions) */
+ * travelled anyway; 2: always both levels), "timing" (0/1: forwarded to the shard sessions), "transport" (0 peer_store,
+ * 1 staged_copy: from the next request on; 0 is refused where peer access is not available), "copy_piece_keys" (staged_copy:
+ * keys per piece, >= 1024) */
 int hps_shard_entry_set_option(hps_shard_entry_t* entry, const char* name, int value);
 /* keys a shard session of this entry holds per call */
 uint64_t hps_shard_entry_shard_capacity(hps_shard_entry_t* entry);

@@ -935,6 +935,36 @@ def test_small_miss_calls_insert_every_nth_time(interval, admission):
     s0.close()
 
 
+def test_calls_that_miss_much_insert_every_time_whatever_the_interval():
+    """Advisor finding of round 5: the small-miss interval looked only at the BYTES a call missed.  Narrow rows (16 B) make 14,000
+    missed rows of a 140,000-key request 'few' (224 KB, read in place) — a call at 90 % hit inserted every 4th time and warmed the
+    cache four times slower than the reference, which inserts every missing key below its hit_rate_threshold
+    (docs/architecture.md:65-67).  Only near-all-hit calls (at most one key in 64 missed) skip now."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(5)
+    R, D = 400000, 4
+    tables = make_tables([(R, D)], seed=78)
+    ps, cache, s0 = _mk("coldins", tables, maxcat=[1], gpucacheper=0.3, max_batch=150000, extra={"gpucache_load_factor": 0.25})
+    co = O.COracle()
+    co.add_table_arrays(*tables[0])
+    tk = tables[0][0]
+    c0 = cache.counters()
+    for it in range(1, 5):
+        res = tk[cache.query(0, tk) >= 0]
+        cold = tk[cache.query(0, tk) < 0]
+        n = 140000
+        q = rng.choice(res, n)
+        m = rng.choice(cold, 14000, replace=False)
+        q[rng.choice(n, m.size, replace=False)] = m
+        out = s0.lookup(q.astype(np.int64), [n]).cpu().numpy()
+        assert np.array_equal(_bits(out), _bits(co.lookup(q.astype(np.int64), [n], [0.0]))), it
+        # (a key whose bucket is full of recently hit keys stays out under the admission rule: a handful, not three calls in four)
+        assert (cache.query(0, m) >= 0).mean() > 0.98, f"call {it}: missed keys of a call at 90 % hit were left uncached"
+        c = cache.counters()
+        assert c["inserted"] - c0["inserted"] > 0.98 * 14000 * it and c["dropped"] - c0["dropped"] < 0.02 * 14000 * it, (it, c)
+    s0.close()
+
+
 def test_staged_keys_pulled_by_a_kernel_at_every_width_and_alignment():
     """Session option "keys_by_kernel": the staged keys of a big request are read out of the page-locked staging buffer by a kernel
     (hps_pull_bytes) instead of copy-engine copies.  Ragged tables (group offsets that are not multiples of 16 bytes at 3 bytes per

@@ -38,7 +38,8 @@ def test_table_sharding_configuration_is_parsed_and_checked():
     ps = hps.HierParameterServer.create_from_dict(ok, load_tables=False)
     assert ps.model_info("m").num_deployed_devices == 4
     ps.close()
-    for bad, what in [({"table_sharding": "ring"}, "table_sharding"), ({"shard_capacity_factor": 0.5}, "shard_capacity_factor")]:
+    for bad, what in [({"table_sharding": "ring"}, "table_sharding"), ({"shard_capacity_factor": 0.5}, "shard_capacity_factor"),
+                      ({"shard_transport": "carrier_pigeon"}, "shard_transport"), ({"shard_copy_piece_keys": 10}, "shard_copy_piece_keys")]:
         cfg = _sharded_cfg("m", tables, 2, extra=bad)
         with pytest.raises(hps.HpsError) as e:
             hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
@@ -49,6 +50,8 @@ def test_table_sharding_configuration_is_parsed_and_checked():
     with pytest.raises(hps.HpsError) as e:
         hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
     assert "gpucache" in e.value.msg
+    for ok_extra in ({"shard_transport": "staged_copy", "shard_copy_piece_keys": 4096}, {"shard_transport": "peer_store"}):
+        hps.HierParameterServer.create_from_dict(_sharded_cfg("m", tables, 2, extra=ok_extra), load_tables=False).close()
     # "none" / "replicas" / absent: an ordinary model
     for v in ("none", "replicas"):
         cfg = _sharded_cfg("m", tables, 1, extra={"table_sharding": v})
@@ -128,16 +131,20 @@ def _draw(rng, tables, nk, zipf=False, absent=0.05):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["peer_store", "staged_copy"])
 @pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
 @pytest.mark.parametrize("P", [2, 4])
-def test_entry_session_over_logical_shards_is_bit_exact(P, direct, plain_lru):
+def test_entry_session_over_logical_shards_is_bit_exact(P, direct, transport, plain_lru):
+    """Both transports of the rows (shard_entry.h): peer_store — the owners' kernels store into the entry GPU's output — and
+    staged_copy — owners gather pieces into local blocks, copy engines ship them, hps_entry_place puts the rows in place."""
     import torch
     from hugectr_backend_amd import hps, sharded
     from oracle import hps_oracle as O
     tables = make_tables([(30000, 128), (9000, 16), (4000, 5)], seed=21)
     defaults = [0.0, 1.5, -2.0]
+    staged = transport == "staged_copy"
     ps = _server("c3", tables, P, gpucacheper=0.4, hit_rate_threshold=1.0, defaults=defaults, maxcat=[4, 2, 1], max_batch=8192,
-                 extra={"ps_direct_access": direct})
+                 extra={"ps_direct_access": direct, "shard_transport": transport, "shard_copy_piece_keys": 2048})
     try:
         # the shards partition the table: what a shard holds after warm-up is owned by it, and it holds its share
         resident = 0
@@ -179,6 +186,25 @@ def test_entry_session_over_logical_shards_is_bit_exact(P, direct, plain_lru):
                     distinct += np.unique(q[off:off + n]).size
                     off += n
                 assert st.unique_keys == distinct
+                assert st.transport == int(staged)
+                if staged:
+                    # every travelling key's row crossed in a block, in pieces of at most 2,048 keys (the last of an owner short)
+                    assert [st.passes[s] for s in range(P)] == [(st.sent[s] + 2047) // 2048 for s in range(P)]
+                    dims = [128, 16, 5]
+                    lo = sum(np.unique(q[o:o + n]).size * d * 4 for o, n, d in zip(np.cumsum([0] + nk[:-1]), nk, dims))
+                    assert lo <= st.copied_bytes <= lo + 16 * 3 * sum(st.passes[:P]) + 16 * sum(st.passes[:P])
+                else:
+                    assert st.copied_bytes == 0
+        # the other transport on the same session, then back (session option "transport"): same rows
+        nk = [6000, 3000, 500]
+        q = _draw(rng, tables, nk, True)
+        ref = O.np_lookup(tables, q, nk, defaults)
+        for tr in (1 - int(staged), int(staged)):
+            e0.set_option("transport", tr)
+            out = e0.lookup(q, nk)
+            torch.cuda.synchronize()
+            assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref)), tr
+            assert e0.last_stats().transport == tr
         # without the input dedup every key travels as sent; same rows
         e0.set_option("dedup", 0)
         nk = [8192, 4096, 100]
@@ -193,7 +219,8 @@ def test_entry_session_over_logical_shards_is_bit_exact(P, direct, plain_lru):
 
 
 @pytest.mark.gpu
-def test_an_owner_that_gets_more_than_its_session_holds_is_served_in_passes(plain_lru):
+@pytest.mark.parametrize("transport", ["peer_store", "staged_copy"])
+def test_an_owner_that_gets_more_than_its_session_holds_is_served_in_passes(transport, plain_lru):
     """shard_capacity_factor 1.0: a shard session holds request capacity / P (+ 1,024) keys.  A request whose keys all belong
     to ONE owner is then several times that: the entry serves that owner in consecutive passes — exact rows, no error."""
     import torch
@@ -203,7 +230,7 @@ def test_an_owner_that_gets_more_than_its_session_holds_is_served_in_passes(plai
     P = 4
     tables = make_tables([(40000, 32), (40000, 8)], seed=4)
     ps = _server("skew", tables, P, gpucacheper=0.5, hit_rate_threshold=1.0, maxcat=[3, 1], max_batch=4096,
-                 extra={"shard_capacity_factor": 1.0})
+                 extra={"shard_capacity_factor": 1.0, "shard_transport": transport})   # (pieces of 65,536 keys: the session's capacity binds)
     try:
         e = hps.ShardedEntrySession.create(ps, "skew", 0)
         cap = e.shard_capacity
@@ -389,8 +416,9 @@ def _write_tables(tmp_path, name, tables):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["peer_store", "staged_copy"])
 @pytest.mark.parametrize("P", [2, 4])
-def test_sharded_model_through_the_triton_plugin_a_request_on_every_instance_at_once(tmp_path, P):
+def test_sharded_model_through_the_triton_plugin_a_request_on_every_instance_at_once(tmp_path, P, transport):
     """config.pbtxt + ps.json with "table_sharding": "hash" through TRITONBACKEND_ModelInstanceExecute (mock core): every
     instance is an entry session; P instances execute requests concurrently; bit-exact; response parameters as always."""
     import torch
@@ -399,7 +427,7 @@ def test_sharded_model_through_the_triton_plugin_a_request_on_every_instance_at_
     tables = make_tables([(20000, 128), (6000, 16)], seed=31)
     dirs = _write_tables(tmp_path, "c3t", tables)
     cfg = _sharded_cfg("c3t", tables, P, dirs=dirs, gpucacheper=0.5, hit_rate_threshold=1.0, defaults=[0.0, 0.5], maxcat=[3, 1],
-                       max_batch=4096)
+                       max_batch=4096, extra={"shard_transport": transport, "shard_copy_piece_keys": 1500})
     cfg["models"][0]["num_of_worker_buffer_in_pool"] = P
     ps_path = tmp_path / "ps.json"
     ps_path.write_text(json.dumps(cfg))
