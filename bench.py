@@ -56,8 +56,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=65536, help="samples per batch; one key per table per sample")
     ap.add_argument("--cache-frac", type=float, default=0.2, help="gpucacheper")
     ap.add_argument("--hit", type=float, default=0.957,
-                    help="probability that a key is drawn from the set resident after warm-up (0.957 gives a MEASURED hit "
-                         "rate of 0.95: inserting each batch's cold keys evicts a little of the hot tail)")
+                    help="probability that a key is drawn from the set resident after warm-up.  The MEASURED hit rate is what the "
+                         "line reports (measured_hit_rate, config.measured_hit_rate): 0.957 here measures ~0.957 since the admission "
+                         "rule of round 4 (before it, evictions of the hot tail brought it to 0.95); the leg hit_950 runs the same two "
+                         "sessions at a draw probability tuned to a measured 0.950 +- 0.001")
     ap.add_argument("--zipf", type=float, default=1.05)
     ap.add_argument("--sessions", type=int, default=2, help="concurrent lookup sessions (Triton instance count)")
     ap.add_argument("--mode", choices=["sync", "async"], default="sync",
@@ -92,8 +94,9 @@ def parse_args():
                     help="N>1: skip the BASELINE config 3 leg (one table sharded over the ranks, RCCL all-to-all)")
     ap.add_argument("--shard-rows", type=int, default=1 << 28,
                     help="rows of the sharded table in total (config 3 names 1e9 = 512 GB; default 2^28 = 137 GB)")
-    ap.add_argument("--setup-seconds", type=float, default=150.0,
-                    help="N>1: bound on the estimated host-table generation time; rows/table shrinks to meet it")
+    ap.add_argument("--copy-piece-keys", type=int, default=65536, help="config 3, staged_copy transport: keys per piece an owner gathers and ships")
+    ap.add_argument("--selftest-timeout", type=float, default=20.0, help="N>1: deadline of the multi-GPU first-contact self-test (peer access, 4-KB peer stores, per-pair GB/s, one RCCL all-reduce)")
+    ap.add_argument("--no-selftest", action="store_true", help="N>1: skip the multi-GPU self-test")
     ap.add_argument("--sharded-steps", type=int, default=50)
     ap.add_argument("--sharded-timeout", type=float, default=180.0, help="bound on each config-3 leg (they run on a thread of their own; the line is printed without a leg that does not come back)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
@@ -332,16 +335,31 @@ def compact_line(res, limit=COMPACT_LIMIT):
     rf = res.get("roofline") or {}
     cfg = res.get("config") or {}
     out = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                                   "scaling", "vs_baseline", "dtype", "data")}
-    out["config"] = {"workload": str(cfg.get("workload", ""))[:300], "parallelism": str(cfg.get("parallelism", ""))[:120],
+                                   "scaling", "vs_baseline", "dtype", "data", "value_mean", "value_min", "value_max", "slow_blocks")}
+    # (the two facts the headline leans on come BEFORE the workload text, which is cut at 300 characters)
+    out["config"] = {"measured_hit_rate": cfg.get("measured_hit_rate"), "key_bytes_over_pcie": cfg.get("key_bytes_over_pcie"),
+                     "workload": str(cfg.get("workload", ""))[:300], "parallelism": str(cfg.get("parallelism", ""))[:120],
                      "ps_tier": str(cfg.get("ps_tier", ""))[:80], "blocks": cfg.get("blocks"), "value_is": cfg.get("value_is"),
                      "resident_draw_probability": cfg.get("resident_draw_probability")}
+    stt = res.get("multi_gpu_selftest")
+    if stt:
+        flat = lambda m_: [v for row in (m_ or []) for v in row if v is not None]   # noqa: E731
+        out["multi_gpu_selftest"] = {
+            "devices": stt.get("devices"), "timeout": stt.get("timeout"), "stuck_in": (str(stt["stuck_in"])[:100] if stt.get("stuck_in") else None),
+            "error": (str(stt["error"])[:100] if stt.get("error") else None),
+            "peer_access_all": (all(v == 1 for v in flat(stt.get("peer_access"))) if stt.get("peer_access") is not None else None),
+            "store_4k_all_ok": (all(v == 1 for v in flat(stt.get("store_4k_ok"))) if stt.get("store_4k_ok") is not None else None),
+            "rccl_allreduce_ok": _dig(stt, ("rccl_allreduce", "ok")), "rccl_allreduce_ms": _dig(stt, ("rccl_allreduce", "ms")),
+            "seconds": stt.get("wall_seconds")}
+        out["xgmi_pair_GBps_min"] = stt.get("pair_GBps_min")
+        out["xgmi_pair_GBps_median"] = stt.get("pair_GBps_median")
     for k in ("p50_batch_latency_ms", "p99_batch_latency_ms", "measured_hit_rate"):
         out[k] = res.get(k)
-    out["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_return_path_kernels", "traffic",
+    out["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_return_path_kernels", "traffic", "traffic_source",
                                                "algorithmic_bytes_per_call", "probe_ms", "gather_ms", "scatter_ms", "insert_ms",
                                                "insert_on_call_path", "frac_kernels_alone", "box_d2d_copy_GBps")}
     out["roofline"]["kernel"] = str(rf.get("kernel", ""))[:160]
+    out["roofline"]["excluded"] = (str(rf["excluded"])[:110] if rf.get("excluded") else None)
     out["roofline_pcie"] = {"frac": g(res, "roofline_pcie", "frac"), "achieved": g(res, "roofline_pcie", "achieved"),
                             "peak": g(res, "roofline_pcie", "peak"), "unit": "GB/s"}
     cb = res.get("cpu_baseline")
@@ -359,6 +377,8 @@ def compact_line(res, limit=COMPACT_LIMIT):
     put("all_hit_2s_host_keys_Glps", _scale(g(ex, "all_hit_two_sessions_host_keys", "lookups_per_s"), 1e-9))
     put("all_hit_max_call_ms", g(ex, "all_hit_two_sessions_host_keys", "max_call_ms"))
     put("all_hit_call_over_kernel_time", rf.get("all_hit_call_over_kernel_time"))
+    put("hit_950_Glps", _scale(g(ex, "hit_950_two_sessions_host_keys", "lookups_per_s"), 1e-9))
+    put("hit_950_measured_hit_rate", g(ex, "hit_950_two_sessions_host_keys", "measured_hit_rate"))
     for tag in ("hit_999", "hit_99", "hit_90", "hit_50"):
         put(f"{tag}_2s_host_keys_Glps", _scale(g(ex, f"{tag}_two_sessions_host_keys", "lookups_per_s"), 1e-9))
         put(f"{tag}_max_call_ms", g(ex, f"{tag}_two_sessions_host_keys", "max_call_ms"))
@@ -379,7 +399,7 @@ def compact_line(res, limit=COMPACT_LIMIT):
     put("triton_abi_max_ms", g(ex, "triton_abi", "max_request_ms"))
     sl = g(ex, "triton_abi", "slow_requests_ms")
     if sl is not None:
-        put("triton_abi_slow_requests_ms", [x[0] if isinstance(x, (list, tuple)) else x for x in sl][:8])
+        put("triton_abi_slow_requests_ms", [x[0] if isinstance(x, (list, tuple)) else x for x in sl][:4])
     put("triton_abi_rows_wrong", g(ex, "triton_abi", "rows_wrong"))
     put("triton_abi_pinned_keys_8B_Glps", _scale(g(ex, "triton_abi", "pinned_keys", "lookups_per_s"), 1e-9))
     put("triton_abi_pinned_keys_p50_ms", g(ex, "triton_abi", "pinned_keys", "p50_request_ms"))
@@ -408,8 +428,11 @@ def compact_line(res, limit=COMPACT_LIMIT):
     put("c3_single_entry_Glps", _scale(c3e.get("lookups_per_s"), 1e-9))
     put("c3_single_entry_p50_ms", _dig(c3e, ("uniform", "p50_request_ms")))
     put("c3_single_entry_zipf_Glps", _scale(_dig(c3e, ("zipf", "lookups_per_s")), 1e-9))
-    put("c3_single_entry_all_instances_Glps", _scale(_dig(c3e, ("uniform", "all_instances_at_once", "lookups_per_s")), 1e-9))
-    put("c3_single_entry_rows_GBps_into_entry", _dig(c3e, ("uniform", "rows_GBps_into_entry_gpu")))
+    for tr_, tag_ in (("peer_store", "store"), ("staged_copy", "copy")):
+        bt_ = _dig(c3e, ("by_transport", tr_, "uniform")) or {}
+        put(f"c3_single_entry_{tag_}_Glps", _scale(bt_.get("lookups_per_s"), 1e-9))
+        put(f"c3_single_entry_{tag_}_rows_GBps_into_entry", bt_.get("rows_GBps_into_entry_gpu"))
+        put(f"c3_single_entry_{tag_}_all_instances_Glps", _scale(_dig(bt_, ("all_instances_at_once", "lookups_per_s")), 1e-9))
     put("c3_single_entry_parity", c3e.get("parity"))
     put("c3_single_entry_error", (str(c3e["error"])[:120] if c3e.get("error") else None))
     put("c3_triton_Glps", _scale(g(ex, "c3_sharded_triton", "lookups_per_s"), 1e-9))
@@ -548,6 +571,34 @@ def main():
     numa_note = None
     hb.build()
     from hugectr_backend_amd import hps
+
+    # ---- N > 1: first contact with the machine's links, BEFORE anything is trusted with them (hps_multi_gpu_selftest): peer access
+    # matrix, one 4-KB peer store + read-back per ordered pair, GB/s per pair of kernel stores over the peer mapping and of
+    # hipMemcpyPeerAsync (the two transports of the table-sharded lookup), one RCCL all-reduce of one word with one rank per GPU —
+    # behind a deadline, so that a hang is ATTRIBUTED (the report names the step) before the legs start.  What it finds decides
+    # which config-3 legs run: no peer stores -> staged_copy only; RCCL stuck -> no RCCL leg.
+    selftest = None
+    c3_transports = ("peer_store", "staged_copy")
+    rccl_usable = True
+    if n_rep > 1 and not a.no_selftest:
+        t_st = time.time()
+        try:
+            selftest = hps.multi_gpu_selftest(sorted(set(devs)), 64 << 20, a.selftest_timeout, with_rccl=not a.no_c3_leg)
+        except Exception as e:  # noqa: BLE001
+            selftest = {"error": repr(e)[:200]}
+        selftest["wall_seconds"] = time.time() - t_st
+        stuck = str(selftest.get("stuck_in") or "")
+        flat = lambda m: [v for row in (m or []) for v in row if v is not None]   # noqa: E731
+        stores_ok = not selftest.get("timeout") and not selftest.get("error") and all(v == 1 for v in flat(selftest.get("peer_access"))) \
+            and all(v == 1 for v in flat(selftest.get("store_4k_ok")))
+        if not stores_ok and (len(set(devs)) > 1):
+            c3_transports = ("staged_copy",)
+        if stuck.startswith("RCCL") or (selftest.get("rccl_allreduce") or {}).get("ok") is False:
+            rccl_usable = False
+        if selftest.get("timeout") and not stuck.startswith("RCCL"):
+            # a peer store or a peer copy did not come back: the device it ran on is in an unknown state — report and stop here
+            sys.stderr.write(f"[bench] multi-GPU self-test stuck in: {stuck}\n")
+        sys.stderr.write(f"[bench] multi_gpu_selftest: {json.dumps(selftest)[:1500]}\n")
 
     T, R, D, B = a.tables, a.rows, a.dim, a.batch
     N = T * B
@@ -853,6 +904,18 @@ def main():
             extra["one_session_host_keys_95"] = leg(one, 24, "host", [0])
             extra["one_session_host_keys_95"]["note"] = "same workload, a single lookup session: request latency without a second session on the GPU and the link"
             del one
+            # (2c) the headline's two sessions at a MEASURED hit rate of 0.950 +- 0.001 (the headline itself measures ~0.957: "at
+            #      least 95 %" — this leg is the rate at exactly 95.0 %).  The draw probability is corrected by what a first pass measured.
+            h_try, r_ = 0.950, None
+            for attempt in range(3):
+                nb_ = fresh(28, h_try, resident_now())
+                r_ = leg(host_form(nb_), 24, "host")
+                del nb_
+                got_ = r_["measured_hit_rate"]
+                if abs(got_ - 0.950) <= 0.001:
+                    break
+                h_try = min(1.0, max(0.0, h_try + 0.950 - got_))
+            extra["hit_950_two_sessions_host_keys"] = dict(r_, resident_draw_probability=h_try, passes=attempt + 1)
             # (3) every key resident: the GPU-side ceiling of the path, one session (kernels run alone)
             #     TRUE all-hit: the keys are drawn from what is resident at this moment (round 3 drew them from the set resident
             #     after warm-up; a few hundred of those had been evicted by then and the "all-hit" legs measured a miss path)
@@ -1110,11 +1173,19 @@ def main():
                 "ps_tier": "device-driven (ps_direct_access)" if a.direct else
                            ("host gather" + (f" [{direct_note}]" if direct_note else "")),
                 "blocks": blocks, "value_is": "median block", "resident_draw_probability": a.hit,
+                "measured_hit_rate": m["measured_hit_rate"],
+                "key_bytes_over_pcie": float(np.mean([r[11] for r in main_rec])),
                 "timed_region": f"{blocks} blocks of exactly {K} steps per GPU (every device synchronised on both sides; a block ends when "
                                 f"the last GPU has finished its {K} steps = max over GPUs), every step a fresh batch; value = the MEDIAN block",
             },
             "block_ms": [b * 1e3 for b in block_s],
             "value_min_max_over_blocks": [n_rep * K * N / max(block_s), n_rep * K * N / min(block_s)],
+            # the spread the median hides: mean / slowest / fastest block, and how many blocks took more than 1.15 x the median
+            "value_mean": n_rep * K * N * len(block_s) / sum(block_s),
+            "value_min": n_rep * K * N / max(block_s),
+            "value_max": n_rep * K * N / min(block_s),
+            "slow_blocks": int(sum(1 for b in block_s if b > 1.15 * float(np.median(block_s)))),
+            "multi_gpu_selftest": selftest,
             "p50_batch_latency_ms": float(np.percentile(lat, 50)),
             "p99_batch_latency_ms": float(np.percentile(lat, 99)),
             # GPU side of a batch (HIP events on the session's stream: probe start to the last kernel of the call)
@@ -1146,7 +1217,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "frac_return_path_kernels": achieved_rows / HBM_PEAK_GBS,   # probe + gather + scatter: what the caller waits for
                 "traffic": traffic,
-                "traffic_source": traffic_src,
+                # NOT measured in this run (bench.py cannot run the profiler on itself): copied from the committed PMC passes
+                "traffic_source": (f"profiles/pmc_latest.json <- {traffic_src}" if traffic_src else None),
+                "excluded": "hps_pull_bytes_kernel (staged keys pulled over PCIe: link-bound, ~4 launches x ~39 us per call while calls miss "
+                            "much), hps_pull16 / hps_push_words (control words)",
                 "algorithmic_bytes_per_call": alg,
                 "kernel_ms_per_call": hbm_ms,
                 "kernel_times": "each kernel's own start/stop timestamps (hipExtLaunchKernel events on the session's stream), averaged over "
@@ -1283,12 +1357,14 @@ def main():
         # there are devices.
         entry_rows = min(a.shard_rows, 1 << 26) if not shared_gpu else 1 << 24
 
-        c3e = guarded("sharded_c3_single_entry", lambda: c3_single_entry_leg(a, torch, hps, devs, entry_rows))
+        c3e = guarded("sharded_c3_single_entry", lambda: c3_single_entry_leg(a, torch, hps, devs, entry_rows, transports=c3_transports))
         res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3_single_entry=c3e)
         if not a.no_triton_leg:
             res["extra_legs"] = dict(res.get("extra_legs") or {}, c3_sharded_triton=c3_triton_leg(a, hb, n_rep))
         gc.collect()
-        if world == 1:
+        if world == 1 and not rccl_usable:
+            res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3={"error": "skipped: the self-test's RCCL all-reduce did not come back"})
+        elif world == 1:
             ranks = min(n_rep, ndev)
             c3r = guarded("sharded_c3", lambda: c3_rccl_threads_leg(a, torch, hps, ranks, entry_rows))
             res["extra_legs"] = dict(res.get("extra_legs") or {}, sharded_c3=c3r)
@@ -1765,7 +1841,7 @@ def c3_logical_leg(a, torch, hps, dev, P=4, rows_total=1 << 24, steps=30):
     return res
 
 
-def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
+def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30, transports=("peer_store", "staged_copy")):
     """BASELINE configs[2] BEHIND THE PLUGIN'S CONTRACT (one blocking call per request on one instance, hps.cc:353-369): one
     table-sharded model (ps.json "table_sharding": "hash", csrc/cache/shard_entry.h) — ONE server, the host tier whole, shard s
     = entry s of deployed_device_list with 100 % of the keys it owns resident; an ENTRY session per instance buckets a request of
@@ -1783,7 +1859,8 @@ def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
                        "embedding_vecsize_per_table": [D], "maxnum_catfeature_query_per_table_per_sample": [1],
                        "default_value_for_each_table": [0.0], "deployed_device_list": list(shard_devs), "max_batch_size": N,
                        "gpucache": True, "gpucacheper": 1.0, "gpucache_load_factor": float(os.environ.get("ENTRY_LOAD_FACTOR", "0.5")),
-                       "hit_rate_threshold": 1.0, "table_sharding": "hash"}]}
+                       "hit_rate_threshold": 1.0, "table_sharding": "hash",
+                       "shard_transport": transports[0], "shard_copy_piece_keys": a.copy_piece_keys}]}
     ps = hps.HierParameterServer.create_from_dict(cfg, load_tables=False)
     ps.load_table_synthetic(model, 0, SEED, 0, rows_total)
     t_table = time.time() - t0
@@ -1820,8 +1897,18 @@ def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
         return bool(np.array_equal(got.view(np.uint32), exp.view(np.uint32)))
 
     ok_all = True
-    for kind in ("uniform", "zipf"):
-        bt = batches(kind, 4)
+    # Both transports of the rows on the SAME requests (csrc/cache/shard_entry.h): "peer_store" — the owners' kernels store into the
+    # entry GPU's output over peer mappings — with uniform and Zipf keys, then "staged_copy" — owners gather pieces into local
+    # blocks, hipMemcpyPeerAsync ships them, a kernel on the entry GPU puts the rows in place — with the uniform requests.
+    # `transports`: what the self-test left standing (a machine without peer access, or whose peer stores hung, runs staged_copy only).
+    plan = [(tr, kind) for tr in transports for kind in (("uniform", "zipf") if tr == transports[0] else ("uniform",))]
+    saved = {}
+    for tr, kind in plan:
+        for e_ in entries:
+            e_.set_option("transport", 1 if tr == "staged_copy" else 0)
+        if kind not in saved:
+            saved[kind] = batches(kind, 4)
+        bt = saved[kind]
         e, out = entries[0], outs[0]
         for i in range(4):
             e.lookup(bt[i % 4], [N], out=out)
@@ -1833,7 +1920,8 @@ def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
             e.lookup(bt[i % 4], [N], out=out)
             lat.append((time.perf_counter() - ts) * 1e3)
             st = e.last_stats()
-            ph.append((st.key_stage_ms, st.bucket_ms, st.lookup_ms, st.expand_ms, st.unique_keys, max(st.shard_ms[:P]), max(st.sent[:P]), st.unique_misses))
+            ph.append((st.key_stage_ms, st.bucket_ms, st.lookup_ms, st.expand_ms, st.unique_keys, max(st.shard_ms[:P]), max(st.sent[:P]), st.unique_misses,
+                       max(st.copy_wait_ms[:P]), st.copied_bytes))
         sync_all()
         dt = time.perf_counter() - t1
         ok = check(e, out, bt[(steps - 1) % 4])
@@ -1842,7 +1930,9 @@ def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
         own_dev = entry_devs[0]
         st = e.last_stats()
         remote = float(sum(st.sent[s] for s in range(P) if shard_devs[s] != own_dev))
-        one = {"lookups_per_s": N * steps / dt, "ms_per_request": dt / steps * 1e3, "p50_request_ms": float(np.percentile(lat, 50)),
+        one = {"transport": tr, "pieces_per_shard": [int(x) for x in st.passes[:P]], "copy_wait_ms_slowest_shard": float(pm[8]),
+               "row_bytes_copied_per_request": float(pm[9]),
+               "lookups_per_s": N * steps / dt, "ms_per_request": dt / steps * 1e3, "p50_request_ms": float(np.percentile(lat, 50)),
                "p99_request_ms": float(np.percentile(lat, 99)), "parity": ok,
                "phase_ms": {"key_stage": float(pm[0]), "bucket": float(pm[1]), "shard_lookups": float(pm[2]), "expand_repeats": float(pm[3])},
                "host_key_bytes_over_pcie": int(st.key_bytes), "dedup_level": int(st.dedup_level), "distinct_keys_per_request": float(pm[4]), "distinct_misses_per_request": float(pm[7]), "slowest_shard_ms": float(pm[5]), "largest_bucket_keys": float(pm[6]),
@@ -1900,7 +1990,10 @@ def c3_single_entry_leg(a, torch, hps, shard_devs, rows_total, steps=30):
             ok_all &= okc
             one["all_instances_at_once"] = {"instances": P, "lookups_per_s": P * N * steps / dtc, "ms_per_round": dtc / steps * 1e3, "parity": okc,
                                             "cpu_quota_throttled_ms": (thr1[1] - thr0[1]) / 1e3 if thr0 and thr1 else None}
-        res[kind] = one
+        if tr == transports[0]:
+            res[kind] = one
+        res.setdefault("by_transport", {}).setdefault(tr, {})[kind] = one
+    res["transports"] = list(transports)
     res["lookups_per_s"] = (res.get("uniform") or {}).get("lookups_per_s")
     res["parity"] = bool(ok_all)
     for e in entries:

@@ -45,6 +45,8 @@ ENGINE_SRCS = [
     "cache/shard_entry.cpp",
     "cache/direct_kernels.hip",
     "cache/copy_engines.cpp",
+    "cache/probe_kernels.hip",
+    "cache/multi_gpu_probe.cpp",
     "cache/engine.cpp",
     "cache/parameter_server.cpp",
     "dense/dense_kernels.hip",

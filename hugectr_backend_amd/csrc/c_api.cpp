@@ -16,6 +16,7 @@
 #include "cache/engine.h"
 #include "cache/shard_kernels.h"
 #include "cache/shard_entry.h"
+#include "cache/multi_gpu_probe.h"
 #include "cache/shard_session.h"
 #include "dense/dense.h"
 
@@ -729,6 +730,24 @@ uint64_t hps_shard_plan_passes(const uint32_t* counts, uint32_t num_tables, uint
   } catch (...) {
     return 0;
   }
+}
+
+int hps_multi_gpu_selftest(const int32_t* devices, uint32_t n, uint64_t probe_bytes, uint32_t timeout_ms, int32_t with_rccl, char* buf,
+                           uint64_t cap) {
+  return Guard([&]() -> Status {
+    if (!devices || n == 0 || !buf || cap == 0) return Error(Code::kInvalidArg, "null argument");
+    std::vector<int> devs(devices, devices + n);
+    for (uint32_t i = 0; i < n; ++i)
+      for (uint32_t k = 0; k < i; ++k)
+        if (devs[i] == devs[k]) return Error(Code::kInvalidArg, "device ", devs[i], " is listed twice");
+    std::string json;
+    const bool ok = MultiGpuSelfTest(devs, probe_bytes, timeout_ms, with_rccl != 0, &json);
+    const size_t m = std::min<size_t>(json.size(), (size_t)cap - 1);
+    memcpy(buf, json.data(), m);
+    buf[m] = 0;
+    if (!ok) return Error(Code::kUnavailable, "multi-GPU self-test did not finish within ", timeout_ms, " ms: ", json);
+    return Status::Ok();
+  });
 }
 
 int hps_dense_create(int device, uint32_t num_dense, uint32_t num_layers, const uint32_t* layer_dims, const float* const* weights,

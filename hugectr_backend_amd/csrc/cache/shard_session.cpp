@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <thread>
 
 #include "../ps/thread_pool.h"
 #include "key_pack.h"
@@ -40,6 +42,7 @@ struct RcclApi {
   int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
   int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;   // (self-test only)
   std::string load_error;
 
   static RcclApi& Get() {
@@ -58,6 +61,7 @@ struct RcclApi {
       a.Send = (decltype(a.Send))sym("ncclSend");
       a.Recv = (decltype(a.Recv))sym("ncclRecv");
       a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+      a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");   // optional
       return a;
     }();
     return api;
@@ -112,6 +116,58 @@ Status ShardUniqueId(uint8_t out[128]) {
   RcclApi::UniqueId id;
   RCCL_TRY(api, api.GetUniqueId(&id));
   memcpy(out, id.internal, 128);
+  return Status::Ok();
+}
+
+Status RcclAllReduceSelfTest(const std::vector<int>& devices, std::atomic<int>* phase, float* ms) {
+  RcclApi& api = RcclApi::Get();
+  HPS_RETURN_IF_ERROR(api.Ready());
+  if (!api.AllReduce) return Error(Code::kUnavailable, "librccl has no ncclAllReduce");
+  const int n = (int)devices.size();
+  if (n == 0) return Error(Code::kInvalidArg, "no devices");
+  RcclApi::UniqueId id;
+  RCCL_TRY(api, api.GetUniqueId(&id));
+  std::vector<Status> st(n, Status::Ok());
+  std::vector<float> took(n, 0.f);
+  std::vector<std::thread> th;
+  for (int r = 0; r < n; ++r) {
+    th.emplace_back([&, r]() {
+      st[r] = [&]() -> Status {
+        const auto t0 = std::chrono::steady_clock::now();
+        HIP_TRY(hipSetDevice(devices[r]));
+        if (phase) phase[r].store(1);
+        RcclApi::Comm comm = nullptr;
+        RCCL_TRY(api, api.CommInitRank(&comm, n, id, r));
+        hipStream_t s = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        int32_t* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, sizeof(int32_t)));
+        const int32_t mine = r + 1;
+        HIP_TRY(hipMemcpyAsync(d, &mine, sizeof mine, hipMemcpyHostToDevice, s));
+        constexpr int kNcclInt32 = 2, kNcclSum = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
+        RCCL_TRY(api, api.AllReduce(d, d, 1, kNcclInt32, kNcclSum, comm, s));
+        if (phase) phase[r].store(2);
+        int32_t got = 0;
+        HIP_TRY(hipMemcpyAsync(&got, d, sizeof got, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (got != n * (n + 1) / 2) return Error(Code::kInternal, "all-reduce over ", n, " ranks gave ", got, " on rank ", r, ", expected ", n * (n + 1) / 2);
+        took[r] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (phase) phase[r].store(3);
+        (void)hipFree(d);
+        (void)hipStreamDestroy(s);
+        (void)api.CommDestroy(comm);
+        if (phase) phase[r].store(4);
+        return Status::Ok();
+      }();
+    });
+  }
+  for (auto& t : th) t.join();
+  float worst = 0.f;
+  for (int r = 0; r < n; ++r) {
+    if (!st[r].ok()) return Error(st[r].code(), "rank ", r, " (device ", devices[r], "): ", st[r].message());
+    worst = std::max(worst, took[r]);
+  }
+  if (ms) *ms = worst;
   return Status::Ok();
 }
 

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <condition_variable>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -47,6 +48,11 @@ class ShardTransport {
 // caller (torch.distributed broadcast, a file, MPI ...).
 Status ShardUniqueId(uint8_t out[128]);
 Status MakeRcclTransport(uint32_t rank, uint32_t world, const uint8_t unique_id[128], int device, std::unique_ptr<ShardTransport>* out);
+// First contact (multi_gpu_probe.h): one communicator over `devices` — one rank per entry, the ranks being threads of this
+// process — and one all-reduce of one word.  `phase` (devices.size() words) is written as the ranks advance: 1 communicator
+// being created, 2 all-reduce enqueued, 3 result back and right, 4 communicator destroyed; a caller watching from another
+// thread can tell where a hang sits.  *ms: the slowest rank's time from entering ncclCommInitRank to the checked result.
+Status RcclAllReduceSelfTest(const std::vector<int>& devices, std::atomic<int>* phase, float* ms);
 
 // P endpoints inside ONE process on one device, for tests and single-process deployments: blocks are copied device to
 // device on the callers' streams, ordered by events; the P callers must run on P threads (the exchange is a rendezvous).

@@ -166,6 +166,7 @@ def _load() -> C.CDLL:
         "hps_shard_entry_set_option": (C.c_int, [P, cp, C.c_int]),
         "hps_shard_entry_shard_capacity": (u64, [P]),
         "hps_shard_plan_passes": (u64, [P, u32, u64, P, u64]),
+        "hps_multi_gpu_selftest": (C.c_int, [P, u32, u64, u32, i32, C.c_char_p, u64]),
         "hps_dense_create": (C.c_int, [C.c_int, u32, u32, P, P, P, u32, u32, C.POINTER(P)]),
         "hps_dense_destroy": (None, [P]),
         "hps_dense_out_dim": (u32, [P]),
@@ -200,7 +201,7 @@ EXPORTED_SYMBOLS = [
     "hps_dense_forward", "hps_session_lookup_interact_device",
     "hps_server_get_shard_cache", "hps_shard_entry_create", "hps_shard_entry_destroy", "hps_shard_entry_lookup",
     "hps_shard_entry_lookup_device", "hps_shard_entry_last_stats", "hps_shard_entry_set_option", "hps_shard_entry_shard_capacity",
-    "hps_shard_plan_passes",
+    "hps_shard_plan_passes", "hps_multi_gpu_selftest",
 ]
 
 
@@ -226,6 +227,25 @@ def pool_fast_overruns() -> int:
 def bind_calling_thread() -> bool:
     """The calling thread joins the worker pools' NUMA node (no-op when the pools are not bound or the thread is already placed)."""
     return bool(LIB.hps_bind_calling_thread())
+
+
+def multi_gpu_selftest(devices, probe_bytes: int = 64 << 20, timeout_s: float = 20.0, with_rccl: bool = True) -> dict:
+    """First contact with a multi-GPU machine (include/hps_amd.h: hps_multi_gpu_selftest): peer access matrix, a 4-KB peer store
+    per ordered pair, GB/s per pair of kernel stores and of copy-engine copies, one RCCL all-reduce of one word — behind a
+    deadline.  Always returns the report (dict); "timeout": True + "stuck_in" when a step did not come back."""
+    import json
+    devs = [int(d) for d in devices]
+    arr = (C.c_int32 * len(devs))(*devs)
+    buf = C.create_string_buffer(1 << 16)
+    rc = int(LIB.hps_multi_gpu_selftest(arr, len(devs), int(probe_bytes), int(timeout_s * 1000), 1 if with_rccl else 0, buf, len(buf)))
+    text = buf.value.decode(errors="replace")
+    try:
+        rep = json.loads(text) if text else {}
+    except ValueError:
+        rep = {"unparsed": text[:300]}
+    if rc != 0 and not rep.get("timeout"):
+        _check(rc)
+    return rep
 
 
 def wake_copy_engines(device: int = 0):

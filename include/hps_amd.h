@@ -380,6 +380,16 @@ uint64_t hps_shard_entry_shard_capacity(hps_shard_entry_t* entry);
  * passes needed (which may exceed max_passes). */
 uint64_t hps_shard_plan_passes(const uint32_t* counts, uint32_t num_tables, uint64_t capacity, uint64_t* out, uint64_t max_passes);
 
+/* First contact with a multi-GPU machine, before the table-sharded legs are trusted with it (csrc/cache/multi_gpu_probe.h): for
+ * every ordered pair of the `n` DISTINCT devices — may a kernel on `from` address memory of `to` (hipDeviceCanAccessPeer), does a
+ * 4-KB peer store arrive intact, GB/s of kernel stores over the peer mapping (the peer_store transport's mechanism) and of
+ * hipMemcpyPeerAsync (staged_copy's), probe_bytes per transfer; then (with_rccl != 0) one RCCL all-reduce of one word with one
+ * rank per device.  Runs behind a deadline on a thread of its own: a step that does not come back within timeout_ms is named in
+ * the report ("timeout": true, "stuck_in": "...") and the call returns HPS_ERR_UNAVAILABLE — its thread stays behind.  Writes one
+ * JSON object into buf (truncated to cap - 1 bytes). */
+int hps_multi_gpu_selftest(const int32_t* devices, uint32_t n, uint64_t probe_bytes, uint32_t timeout_ms, int32_t with_rccl,
+                           char* buf, uint64_t cap);
+
 /* ---- dense step of BASELINE config 5: DLRM bottom MLP + pairwise dot interaction, consuming OUTPUT0 in place ------
  * Not in the reference backend: there the dense model is another Triton backend reached through an ensemble
  * hand-off (samples/hps-triton-ensemble); here it runs on the GPU that holds the lookup's output.

@@ -91,6 +91,65 @@ def test_final_line_is_compact_and_round_trips():
         assert k in legs, k
 
 
+def test_final_line_says_what_was_measured():
+    """Round 5's review: the line gave a median with no spread, and the two facts the headline leans on — the MEASURED hit rate and
+    the bytes per key over PCIe — sat behind the 300-character cut of the workload text."""
+    import json
+    res = _fat_result()
+    res.update({"value_mean": 2.0e9, "value_min": 1.6e9, "value_max": 2.1e9, "slow_blocks": 2})
+    res["config"].update({"measured_hit_rate": 0.9573, "key_bytes_over_pcie": 3.0})
+    res["roofline"].update({"traffic_source": "profiles/pmc_latest.json <- profiles/round5/r5z", "excluded": "hps_pull_bytes_kernel (link-bound, 4 x 39 us)"})
+    leg = dict(res["extra_legs"]["all_hit_two_sessions_host_keys"], measured_hit_rate=0.9502)
+    res["extra_legs"]["hit_950_two_sessions_host_keys"] = leg
+    line = json.dumps(bench.compact_line(res))
+    assert len(line) < 4096
+    back = json.loads(line)
+    assert back["legs"]["hit_950_Glps"] > 0 and abs(back["legs"]["hit_950_measured_hit_rate"] - 0.950) <= 0.001
+    # ---- a --gpus 2 line: no one-GPU legs, the self-test and both transports of config 3 instead
+    for k in list(res["extra_legs"]):
+        if not k.startswith("sharded_c3"):
+            del res["extra_legs"][k]
+    res["n_gpus"] = 2
+    res["multi_gpu_selftest"] = {"devices": [0, 1], "peer_access": [[None, 1], [1, None]], "store_4k_ok": [[None, 1], [1, None]],
+                                 "store_GBps": [[None, 48.1], [47.9, None]], "copy_GBps": [[None, 50.2], [50.0, None]],
+                                 "pair_GBps_min": {"store": 47.9, "copy": 50.0}, "pair_GBps_median": {"store": 48.1, "copy": 50.2},
+                                 "rccl_allreduce": {"ranks": 2, "ok": True, "ms": 812.0, "error": None}, "timeout": False, "stuck_in": None,
+                                 "wall_seconds": 3.2}
+    res["extra_legs"]["sharded_c3_single_entry"] = {
+        "shards": 2, "shard_devices": [0, 1], "lookups_per_s": 1.5e9, "parity": True, "transports": ["peer_store", "staged_copy"],
+        "uniform": {"lookups_per_s": 1.5e9, "p50_request_ms": 1.1, "rows_GBps_into_entry_gpu": 300.0},
+        "by_transport": {"peer_store": {"uniform": {"lookups_per_s": 1.5e9, "rows_GBps_into_entry_gpu": 300.0, "all_instances_at_once": {"lookups_per_s": 2.5e9}}},
+                         "staged_copy": {"uniform": {"lookups_per_s": 1.2e9, "rows_GBps_into_entry_gpu": 250.0, "all_instances_at_once": {"lookups_per_s": 2.0e9}}}}}
+    line = json.dumps(bench.compact_line(res))
+    assert len(line) < 4096
+    back = json.loads(line)
+    for k in ("value_mean", "value_min", "value_max", "slow_blocks"):
+        assert back[k] is not None, k
+    keys = list(back["config"])
+    assert keys.index("measured_hit_rate") < keys.index("workload") and keys.index("key_bytes_over_pcie") < keys.index("workload")
+    assert back["config"]["measured_hit_rate"] == 0.9573 and back["config"]["key_bytes_over_pcie"] == 3.0
+    assert back["roofline"]["traffic_source"].startswith("profiles/") and "hps_pull_bytes_kernel" in back["roofline"]["excluded"]
+    st = back["multi_gpu_selftest"]
+    assert st["peer_access_all"] is True and st["store_4k_all_ok"] is True and st["rccl_allreduce_ok"] is True and st["timeout"] is False
+    assert back["xgmi_pair_GBps_min"] == {"store": 47.9, "copy": 50.0} and back["xgmi_pair_GBps_median"]["copy"] == 50.2
+    for k in ("c3_single_entry_store_Glps", "c3_single_entry_copy_Glps", "c3_single_entry_store_rows_GBps_into_entry",
+              "c3_single_entry_copy_rows_GBps_into_entry", "c3_single_entry_store_all_instances_Glps", "c3_single_entry_copy_all_instances_Glps"):
+        assert back["legs"][k] > 0, k
+    # a self-test that did not come back is named, not dropped
+    res["multi_gpu_selftest"] = {"timeout": True, "stuck_in": "4-KB peer store 2->5", "seconds": 20.0, "wall_seconds": 20.0}
+    back = json.loads(json.dumps(bench.compact_line(res)))
+    assert back["multi_gpu_selftest"]["timeout"] is True and "2->5" in back["multi_gpu_selftest"]["stuck_in"]
+
+
+def test_no_stale_flags():
+    import subprocess, sys
+    from pathlib import Path
+    root = Path(bench.__file__).resolve().parent
+    h = subprocess.run([sys.executable, str(root / "bench.py"), "--help"], capture_output=True, text=True, timeout=120).stdout
+    assert "--setup-seconds" not in h and "--selftest-timeout" in h and "--copy-piece-keys" in h
+    assert "gives a MEASURED hit rate of 0.95" not in " ".join(h.split())
+
+
 def test_final_line_stays_under_the_limit_whatever_the_legs_hold():
     import json
     res = _fat_result()

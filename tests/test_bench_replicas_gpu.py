@@ -60,7 +60,18 @@ def test_plain_gpus_2_also_measures_both_config3_variants_and_the_cpu_baseline(t
     legs = compact["legs"]
     assert "c3_single_entry_P" in legs, (legs, r.stderr[-2500:])
     assert legs["c3_single_entry_P"] == 2 and legs["c3_single_entry_parity"] is True and legs["c3_single_entry_Glps"] > 0
-    assert legs["c3_single_entry_all_instances_Glps"] > 0
+    # both transports of the rows on the same requests (csrc/cache/shard_entry.h), and the first-contact self-test in front of them
+    for tag in ("store", "copy"):
+        assert legs[f"c3_single_entry_{tag}_Glps"] > 0 and legs[f"c3_single_entry_{tag}_all_instances_Glps"] > 0, tag
+    st = compact["multi_gpu_selftest"]
+    assert st["devices"] == [0] and st["timeout"] is False and st["error"] is None and st["rccl_allreduce_ok"] is True, st
+    assert "xgmi_pair_GBps_min" in compact and "xgmi_pair_GBps_median" in compact       # (no pair on a one-GPU box: nulls)
+    bt = d["extra_legs"]["sharded_c3_single_entry"]["by_transport"]
+    assert bt["staged_copy"]["uniform"]["parity"] and bt["staged_copy"]["uniform"]["row_bytes_copied_per_request"] > 0
+    assert bt["peer_store"]["uniform"]["row_bytes_copied_per_request"] == 0
+    for k in ("value_mean", "value_min", "value_max", "slow_blocks"):
+        assert compact[k] is not None, k
+    assert compact["config"]["measured_hit_rate"] > 0 and compact["config"]["key_bytes_over_pcie"] in (3.0, 4.0, 8.0)
     assert legs["c3_rccl_ranks"] == 1 and legs["c3_rccl_parity"] is True and legs["c3_rccl_Glps"] > 0
     assert compact["cpu_baseline"]["value"] > 0 and compact["cpu_baseline"]["kind"] == "port"
     e = d["extra_legs"]["sharded_c3_single_entry"]
