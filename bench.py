@@ -393,6 +393,10 @@ def compact_line(res, limit=COMPACT_LIMIT):
         if isinstance(v, dict):
             put("c4@" + k.replace("target_hit_", "") + "_p50_ms", v.get("p50_request_ms"))
             put("c4@" + k.replace("target_hit_", "") + "_Mlps", _scale(v.get("lookups_per_s"), 1e-6))
+    b8 = g(ex, "c4_two_models_triton", "batched8_target_hit_0.9") or {}
+    put("c4_batched8_Mlps", _scale(b8.get("lookups_per_s"), 1e-6))
+    put("c4_batched8_p50_execute_ms", b8.get("p50_execute_ms"))
+    put("c4_batched8_one_lookup_per_execute", (b8.get("instances_whose_last_execute_was_one_lookup") == 2) if b8 else None)
     put("triton_abi_Glps", _scale(g(ex, "triton_abi", "lookups_per_s"), 1e-9))
     put("triton_abi_p50_ms", g(ex, "triton_abi", "p50_request_ms"))
     put("triton_abi_p99_ms", g(ex, "triton_abi", "p99_request_ms"))
@@ -1491,9 +1495,15 @@ def c4_leg(a, hb):
             hb, ["--models", 2, "--dims", "1,16", "--per-sample", "2,26", "--rows", 1_000_000, "--batch", 1024, "--instances", 1,
                  "--cache-frac", 0.2, "--hit", hit, "--zipf", a.zipf, "--steps", 100, "--blocks", 6, "--warmup", 50,
                  "--direct", int(bool(a.direct))], 120.0)
+    # the same requests as a dynamic batcher hands them over: EIGHT per TRITONBACKEND_ModelInstanceExecute call (max_batch_size 8,192).
+    # The reference runs one blocking lookup per request (hps.cc:406); here the eight go as one engine call (csrc/triton/hps.cpp).
+    batched = run_abi_driver(
+        hb, ["--models", 2, "--dims", "1,16", "--per-sample", "2,26", "--rows", 1_000_000, "--batch", 1024, "--instances", 1,
+             "--cache-frac", 0.2, "--hit", 0.9, "--zipf", a.zipf, "--steps", 40, "--blocks", 6, "--warmup", 20,
+             "--direct", int(bool(a.direct)), "--requests-per-execute", 8], 120.0)
     return {"config": "BASELINE configs[3]: two W&D models (2 tables each, 1,000,000 rows x [1,16] fp32, keys/sample [2,26], batch 1,024 = "
                       "28,672 keys per request), one GPU instance each, concurrent Execute, sync insert, pageable KEYS, device OUTPUT0",
-            "results": res}
+            "results": res, "batched8_target_hit_0.9": batched}
 
 
 def fresh_deployment_leg(a, torch, hps, T, R, D, B, N, dev, cfg, direct, key0=0, check_rows=False, more=None, narrow_keys=None):

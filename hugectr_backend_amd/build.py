@@ -45,6 +45,7 @@ ENGINE_SRCS = [
     "cache/shard_entry.cpp",
     "cache/direct_kernels.hip",
     "cache/copy_engines.cpp",
+    "cache/segcopy_kernels.hip",
     "cache/probe_kernels.hip",
     "cache/multi_gpu_probe.cpp",
     "cache/engine.cpp",

@@ -92,6 +92,7 @@ class ShardedEntrySession {
   const ShardEntryStats& last_stats() const { return stats_; }
   uint32_t num_shards() const { return P_; }
   int device() const { return device_; }
+  hipStream_t stream() const { return stream_; }   // the entry device's stream (idle between requests)
   size_t max_keys() const { return max_keys_; }
   size_t shard_capacity() const { return shard_cap_; }
   LookupSession* shard_session(uint32_t s) { return s < sessions_.size() ? sessions_[s].get() : nullptr; }

@@ -10,6 +10,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -44,7 +45,8 @@ struct TRITONBACKEND_ModelInstance {
   TRITONBACKEND_Model* model = nullptr;
   void* state = nullptr;
   std::mutex mu;
-  mock_instance_stats_t stats{0, 0, 0, 0};
+  mock_instance_stats_t stats{0, 0, 0, 0, 0};
+  std::set<uint64_t> compute_starts;   // of the successful requests since the last batch report
 };
 
 struct InputBuf { const void* ptr; uint64_t bytes; TRITONSERVER_MemoryType mt; int64_t mt_id; };
@@ -228,10 +230,10 @@ API TRITONBACKEND_ModelInstanceModel(TRITONBACKEND_ModelInstance* i, TRITONBACKE
 API TRITONBACKEND_ModelInstanceState(TRITONBACKEND_ModelInstance* i, void** state) { NEED(i, "instance"); *state = i->state; return nullptr; }
 API TRITONBACKEND_ModelInstanceSetState(TRITONBACKEND_ModelInstance* i, void* state) { NEED(i, "instance"); i->state = state; return nullptr; }
 API TRITONBACKEND_ModelInstanceReportStatistics(TRITONBACKEND_ModelInstance* i, TRITONBACKEND_Request* request, const bool success,
-                                                const uint64_t, const uint64_t, const uint64_t, const uint64_t) {
+                                                const uint64_t, const uint64_t compute_start_ns, const uint64_t, const uint64_t) {
   NEED(i && request, "instance/request");
   std::lock_guard<std::mutex> lk(i->mu);
-  if (success) i->stats.success_requests++; else i->stats.failed_requests++;
+  if (success) { i->stats.success_requests++; i->compute_starts.insert(compute_start_ns); } else i->stats.failed_requests++;
   return nullptr;
 }
 API TRITONBACKEND_ModelInstanceReportBatchStatistics(TRITONBACKEND_ModelInstance* i, const uint64_t batch_size, const uint64_t,
@@ -240,6 +242,8 @@ API TRITONBACKEND_ModelInstanceReportBatchStatistics(TRITONBACKEND_ModelInstance
   std::lock_guard<std::mutex> lk(i->mu);
   i->stats.batch_reports++;
   i->stats.last_batch_size = batch_size;
+  i->stats.last_distinct_compute_starts = i->compute_starts.size();
+  i->compute_starts.clear();
   return nullptr;
 }
 

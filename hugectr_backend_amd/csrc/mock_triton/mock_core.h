@@ -78,6 +78,9 @@ int mock_request_response_int_param(mock_request_t* request, const char* name, i
 /* ---- statistics the backend reported for an instance ---- */
 typedef struct mock_instance_stats {
   uint64_t success_requests, failed_requests, batch_reports, last_batch_size;
+  /* distinct compute-start times among the successful requests of the last Execute call: 1 when the backend served them
+   * with one lookup, the number of requests when it ran one lookup each */
+  uint64_t last_distinct_compute_starts;
 } mock_instance_stats_t;
 int mock_instance_get_stats(mock_instance_t* instance, mock_instance_stats_t* out);
 

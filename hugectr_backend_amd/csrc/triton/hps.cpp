@@ -110,9 +110,20 @@ TRITONSERVER_Error* OpenTensor(TRITONBACKEND_Request* request, const char* name,
   return nullptr;
 }
 
-// Everything that can fail for one request; any error becomes that request's error response.
-TRITONSERVER_Error* ExecuteOne(ModelInstanceState* instance_state, ModelState* model_state, TRITONBACKEND_Request* request,
-                               TRITONBACKEND_Response* response, int64_t* num_of_samples, uint64_t* exec_start_ns) {
+// One request after validation: where its keys are, how they split over the tables, where its rows go.
+struct Prepared {
+  bool wants_output = false;      // false: nothing to produce (an empty success response, hps.cc:555)
+  const int64_t* keys = nullptr;
+  bool keys_on_device = false;
+  ModelInstanceState::RequestSlice slice;   // keys (when on the host), keys per table, output buffer
+  int64_t num_of_samples = 0;
+};
+
+// Everything that can fail for one request BEFORE the lookup; any error becomes that request's error response.
+// staging_offset: this request's place in the instance's key staging (reserved for all requests of the call up front).
+TRITONSERVER_Error* PrepareOne(ModelInstanceState* instance_state, ModelState* model_state, TRITONBACKEND_Request* request,
+                               TRITONBACKEND_Response* response, size_t staging_offset, Prepared* prep) {
+  int64_t* num_of_samples = &prep->num_of_samples;
   const char* request_id = "";
   RETURN_IF_ERROR(TRITONBACKEND_RequestId(request, &request_id));                       // hps.cc:410-412
   uint64_t correlation_id = 0;
@@ -174,7 +185,7 @@ TRITONSERVER_Error* ExecuteOne(ModelInstanceState* instance_state, ModelState* m
   const void* key_data = nullptr;
   bool keys_on_device = false;
   RETURN_IF_ERROR(CollectInput(keys_in.handle, keys_in.buffers, keys_in.bytes, gpucache, instance_state->DeviceId(),
-                               instance_state->KeyStaging((size_t)std::max<int64_t>(num_keys, 1)), &key_data, &keys_on_device));
+                               instance_state->KeyStagingAt(staging_offset), &key_data, &keys_on_device));
 
   // ---- output tensor (hps.cc:626-660) ----
   TRITONBACKEND_Output* output = nullptr;
@@ -189,11 +200,25 @@ TRITONSERVER_Error* ExecuteOne(ModelInstanceState* instance_state, ModelState* m
     return HPS_TRITON_ERROR(UNSUPPORTED, "the output buffer is on device ", output_memory_id, ", the instance on device ",
                             instance_state->DeviceId());
 
-  // ---- lookup (hps.cc:663-691) ----
-  *exec_start_ns = NowNs();
-  HPS_ROCTX_RANGE(roctx_process, "ProcessRequest " + instance_state->Name());           // hps.cc:671
-  return instance_state->ProcessRequest(reinterpret_cast<const int64_t*>(key_data), keys_on_device, keys_per_table,
-                                        reinterpret_cast<float*>(output_buffer), out_on_device, (size_t)output_elems);
+  prep->wants_output = true;
+  prep->keys = reinterpret_cast<const int64_t*>(key_data);
+  prep->keys_on_device = keys_on_device;
+  prep->slice.keys = keys_on_device ? nullptr : prep->keys;
+  prep->slice.num_keys_per_table = std::move(keys_per_table);
+  prep->slice.out = reinterpret_cast<float*>(output_buffer);
+  prep->slice.out_on_device = out_on_device;
+  prep->slice.out_elems = (size_t)output_elems;
+  return nullptr;
+}
+
+// KEYS of a request in int64 elements, 0 when the request has no such input (the real check comes in PrepareOne)
+size_t KeyCountOf(TRITONBACKEND_Request* request) {
+  TRITONBACKEND_Input* in = nullptr;
+  TRITONSERVER_Error* e = TRITONBACKEND_RequestInput(request, "KEYS", &in);
+  uint64_t bytes = 0;
+  if (e == nullptr) e = TRITONBACKEND_InputProperties(in, nullptr, nullptr, nullptr, nullptr, &bytes, nullptr);
+  if (e != nullptr) { TRITONSERVER_ErrorDelete(e); return 0; }
+  return (size_t)(bytes / sizeof(int64_t));
 }
 
 // No C++ exception may cross the C ABI (std::bad_alloc from a vector, anything a dependency throws): every entry point
@@ -406,16 +431,63 @@ TRITONSERVER_Error* TRITONBACKEND_ModelInstanceExecute(TRITONBACKEND_ModelInstan
   uint64_t max_exec_end_ns = 0;
   uint64_t total_batch_size = 0;
 
-  for (uint32_t r = 0; r < request_count; ++r) {                                         // hps.cc:406
-    TRITONBACKEND_Request* request = requests[r];
-    uint64_t exec_start_ns = NowNs();
-    int64_t num_of_samples = 0;
-    GUARDED_RESPOND_IF_ERROR(responses, r,
-                             ExecuteOne(instance_state, model_state, request, responses[r], &num_of_samples, &exec_start_ns));
-    if (responses[r] == nullptr) {
-      HPS_TRITON_LOG(ERROR, "request ", r, ": failed, error response sent");
-      continue;
+  // ---- validate every request and find its buffers (hps.cc:406-660, per request) ----
+  std::vector<Prepared> prep(request_count);
+  std::vector<uint64_t> started(request_count, 0);
+  {
+    std::vector<size_t> staging_at(request_count, 0);
+    size_t staging = 0;
+    for (uint32_t r = 0; r < request_count; ++r) { staging_at[r] = staging; staging += std::max<size_t>(KeyCountOf(requests[r]), 1); }
+    instance_state->ReserveKeyStaging(staging);
+    for (uint32_t r = 0; r < request_count; ++r) {
+      started[r] = NowNs();
+      GUARDED_RESPOND_IF_ERROR(responses, r, PrepareOne(instance_state, model_state, requests[r], responses[r], staging_at[r], &prep[r]));
+      if (responses[r] == nullptr) HPS_TRITON_LOG(ERROR, "request ", r, ": failed, error response sent");
     }
+  }
+
+  // ---- the lookups.  The reference runs one blocking lookup per request (hps.cc:406, 663-691).  Several SMALL requests in one
+  //      Execute call (Triton's dynamic batcher hands them over together) go as ONE engine call instead — the call overhead
+  //      (~0.1 ms: descriptor upload, count read-back, launches, the final synchronisation) is paid once, and the requests'
+  //      keys share one probe / gather / miss path.  Requests that failed validation have their error response already and take
+  //      no part; if the joint call fails, the requests are run one by one so that each gets its own verdict. ----
+  std::vector<uint32_t> live;
+  for (uint32_t r = 0; r < request_count; ++r)
+    if (responses[r] != nullptr && prep[r].wants_output) live.push_back(r);
+  bool joint = false;
+  if (live.size() >= 2) {
+    std::vector<const ModelInstanceState::RequestSlice*> slices;
+    bool host_keys = true;
+    for (uint32_t r : live) { slices.push_back(&prep[r].slice); host_keys &= !prep[r].keys_on_device; }
+    if (host_keys && instance_state->CanCoalesce(slices)) {
+      const uint64_t t0 = NowNs();
+      HPS_ROCTX_RANGE(roctx_process, "ProcessCoalesced " + instance_state->Name());
+      TRITONSERVER_Error* err = instance_state->ProcessCoalesced(slices);
+      if (err == nullptr) {
+        joint = true;
+        for (uint32_t r : live) started[r] = t0;
+      } else {
+        HPS_TRITON_LOG(WARN, "one call for ", live.size(), " requests failed (", TRITONSERVER_ErrorMessage(err), "): running them one by one");
+        TRITONSERVER_ErrorDelete(err);
+      }
+    }
+  }
+  if (!joint) {
+    for (uint32_t r : live) {
+      started[r] = NowNs();
+      HPS_ROCTX_RANGE(roctx_process, "ProcessRequest " + instance_state->Name());         // hps.cc:671
+      GUARDED_RESPOND_IF_ERROR(responses, r,
+                               instance_state->ProcessRequest(prep[r].keys, prep[r].keys_on_device, prep[r].slice.num_keys_per_table,
+                                                              prep[r].slice.out, prep[r].slice.out_on_device, prep[r].slice.out_elems));
+      if (responses[r] == nullptr) HPS_TRITON_LOG(ERROR, "request ", r, ": failed, error response sent");
+    }
+  }
+
+  for (uint32_t r = 0; r < request_count; ++r) {
+    if (responses[r] == nullptr) continue;
+    TRITONBACKEND_Request* request = requests[r];
+    const uint64_t exec_start_ns = started[r];
+    const int64_t num_of_samples = prep[r].num_of_samples;
     min_exec_start_ns = std::min(min_exec_start_ns, exec_start_ns);
     total_batch_size += (uint64_t)num_of_samples;
 

@@ -2,6 +2,10 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cstring>
+
+#include "../cache/segcopy_kernels.h"
+
 namespace hps { namespace triton {
 
 TRITONSERVER_Error* ModelInstanceState::Create(ModelState* model_state,
@@ -30,6 +34,7 @@ ModelInstanceState::~ModelInstanceState() {
     (void)hipSetDevice(device_id_);
     (void)hipFree(d_result_);
   }
+  if (h_result_) (void)hipHostFree(h_result_);
 }
 
 TRITONSERVER_Error* ModelInstanceState::LoadHPSInstance() {
@@ -59,6 +64,133 @@ int64_t* ModelInstanceState::KeyStaging(size_t count) {
   return key_staging_.data();
 }
 
+TRITONSERVER_Error* ModelInstanceState::EnsureDeviceResult(size_t elems) {
+  if (d_result_elems_ >= elems) return nullptr;
+  const InferenceParams& p = model_state_->Params();
+  if (hipSetDevice(device_id_) != hipSuccess) return HPS_TRITON_ERROR(INTERNAL, "hipSetDevice(", device_id_, ") failed");
+  if (d_result_) (void)hipFree(d_result_);
+  d_result_ = nullptr;
+  d_result_elems_ = 0;
+  size_t full = 0;   // a full request's output
+  for (size_t t = 0; t < p.num_tables(); ++t) full += p.embedding_vecsize_per_table[t] * p.maxnum_catfeature_query_per_table_per_sample[t];
+  const size_t want = std::max(elems, (size_t)model_state_->MaxBatch() * full);
+  if (hipMalloc((void**)&d_result_, want * sizeof(float)) != hipSuccess)
+    return HPS_TRITON_ERROR(INTERNAL, "failed to allocate the lookup result buffer (", want * sizeof(float), " bytes)");
+  d_result_elems_ = want;
+  return nullptr;
+}
+
+bool ModelInstanceState::CanCoalesce(const std::vector<const RequestSlice*>& slices) const {
+  if (slices.size() < 2) return false;
+  const size_t capacity = (size_t)model_state_->MaxBatch() * (size_t)model_state_->KeysPerSample();
+  size_t keys = 0, elems = 0;
+  const bool gpu = model_state_->UsesGpuCache();
+  for (const RequestSlice* s : slices) {
+    for (size_t n : s->num_keys_per_table) keys += n;
+    elems += s->out_elems;
+    if (!gpu && s->out_on_device) return false;
+  }
+  if (keys == 0 || keys > capacity) return false;
+  // every row makes one more trip through memory (result buffer -> the request's output): worth it while that costs less
+  // than the engine calls it saves (~0.1 ms each; 64 MB move in ~25 us)
+  return elems * sizeof(float) <= (slices.size() - 1) * ((size_t)64 << 20);
+}
+
+TRITONSERVER_Error* ModelInstanceState::ProcessCoalesced(const std::vector<const RequestSlice*>& slices) {
+  const InferenceParams& p = model_state_->Params();
+  const size_t T = p.num_tables(), R = slices.size();
+  const bool gpu = model_state_->UsesGpuCache();
+  // ---- keys: table by table, request by request; rows come back in the same order ----
+  std::vector<size_t> n(T, 0);
+  size_t total_keys = 0, total_elems = 0;
+  for (const RequestSlice* s : slices)
+    for (size_t t = 0; t < T; ++t) { n[t] += s->num_keys_per_table[t]; total_keys += s->num_keys_per_table[t]; }
+  for (size_t t = 0; t < T; ++t) total_elems += n[t] * p.embedding_vecsize_per_table[t];
+  if (merged_keys_.size() < total_keys) merged_keys_.resize(total_keys);
+  std::vector<const void*> keys_per_table(T);
+  {
+    size_t w = 0;
+    std::vector<size_t> roff(R, 0);   // read offset inside each request's flat KEYS
+    for (size_t t = 0; t < T; ++t) {
+      keys_per_table[t] = merged_keys_.data() + w;
+      for (size_t r = 0; r < R; ++r) {
+        const size_t c = slices[r]->num_keys_per_table[t];
+        if (c) memcpy(merged_keys_.data() + w, slices[r]->keys + roff[r], c * sizeof(int64_t));
+        roff[r] += c;
+        w += c;
+      }
+    }
+  }
+  // ---- one lookup into the instance's result buffer ----
+  float* result = nullptr;
+  if (gpu) {
+    RETURN_IF_ERROR(EnsureDeviceResult(total_elems));
+    result = d_result_;
+  } else {
+    if (cpu_result_.size() < total_elems) cpu_result_.resize(total_elems);
+    result = cpu_result_.data();
+  }
+  std::vector<float*> out_per_table(T);
+  {
+    size_t o = 0;
+    for (size_t t = 0; t < T; ++t) { out_per_table[t] = result + o; o += n[t] * p.embedding_vecsize_per_table[t]; }
+  }
+  if (sharded_entry_) RETURN_IF_STATUS_ERROR(sharded_entry_->lookup(keys_per_table.data(), out_per_table.data(), n.data(), T));
+  else RETURN_IF_STATUS_ERROR(lookupsession_->lookup(keys_per_table.data(), out_per_table.data(), n.data(), T));
+  ++coalesced_calls_;
+  // ---- every request's rows to its own output buffer (request r: table-major, as for a call of its own) ----
+  bool any_host_out = false;
+  for (const RequestSlice* s : slices) any_host_out |= gpu && !s->out_on_device && s->out_elems;
+  const float* host_view = result;   // where host copies read from
+  if (any_host_out) {
+    if (h_result_elems_ < total_elems) {
+      if (h_result_) (void)hipHostFree(h_result_);
+      h_result_ = nullptr;
+      h_result_elems_ = 0;
+      if (hipHostMalloc((void**)&h_result_, total_elems * sizeof(float), hipHostMallocDefault) != hipSuccess)
+        return HPS_TRITON_ERROR(INTERNAL, "failed to allocate the page-locked result buffer (", total_elems * sizeof(float), " bytes)");
+      h_result_elems_ = total_elems;
+    }
+    if (hipSetDevice(device_id_) != hipSuccess ||
+        hipMemcpy(h_result_, d_result_, total_elems * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+      return HPS_TRITON_ERROR(INTERNAL, "failed to copy the lookup result to host memory");
+    host_view = h_result_;
+  }
+  std::vector<const void*> seg_src;
+  std::vector<void*> seg_dst;
+  std::vector<uint64_t> seg_bytes;
+  std::vector<size_t> woff(R, 0);     // write offset inside each request's OUTPUT0
+  size_t table_base = 0;
+  for (size_t t = 0; t < T; ++t) {
+    const size_t D = p.embedding_vecsize_per_table[t];
+    size_t in_table = 0;
+    for (size_t r = 0; r < R; ++r) {
+      const size_t elems = slices[r]->num_keys_per_table[t] * D;
+      if (elems) {
+        const size_t from = table_base + in_table;
+        if (gpu && slices[r]->out_on_device) {
+          seg_src.push_back(d_result_ + from);
+          seg_dst.push_back(slices[r]->out + woff[r]);
+          seg_bytes.push_back(elems * sizeof(float));
+        } else {
+          memcpy(slices[r]->out + woff[r], host_view + from, elems * sizeof(float));
+        }
+      }
+      woff[r] += elems;
+      in_table += elems;
+    }
+    table_base += n[t] * D;
+  }
+  if (!seg_src.empty()) {
+    if (hipSetDevice(device_id_) != hipSuccess) return HPS_TRITON_ERROR(INTERNAL, "hipSetDevice(", device_id_, ") failed");
+    hipStream_t st = sharded_entry_ ? sharded_entry_->stream() : lookupsession_->stream();
+    hipError_t e = LaunchSegmentedCopy(seg_src.data(), seg_dst.data(), seg_bytes.data(), seg_src.size(), st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return HPS_TRITON_ERROR(INTERNAL, "failed to move a coalesced call's rows to the requests' output buffers: ", hipGetErrorString(e));
+  }
+  return nullptr;
+}
+
 TRITONSERVER_Error* ModelInstanceState::ProcessRequest(const int64_t* keys, bool keys_on_device,
                                                        const std::vector<size_t>& num_keys_per_table, float* out,
                                                        bool out_on_device, size_t out_elems) {
@@ -70,16 +202,7 @@ TRITONSERVER_Error* ModelInstanceState::ProcessRequest(const int64_t* keys, bool
   if (gpu && !out_on_device) {
     // Triton gave host memory for the output of a GPU-cache model: look up into the instance's device
     // buffer, then one D2H copy (the reference always does this extra hop, hps.cc:676-691).
-    if (d_result_elems_ < out_elems) {
-      if (hipSetDevice(device_id_) != hipSuccess) return HPS_TRITON_ERROR(INTERNAL, "hipSetDevice(", device_id_, ") failed");
-      if (d_result_) (void)hipFree(d_result_);
-      d_result_ = nullptr;
-      const size_t want = std::max(out_elems, (size_t)model_state_->MaxBatch() *
-                                                  [&] { size_t s = 0; for (size_t t = 0; t < p.num_tables(); ++t) s += p.embedding_vecsize_per_table[t] * p.maxnum_catfeature_query_per_table_per_sample[t]; return s; }());
-      if (hipMalloc((void**)&d_result_, want * sizeof(float)) != hipSuccess)
-        return HPS_TRITON_ERROR(INTERNAL, "failed to allocate the lookup result buffer (", want * sizeof(float), " bytes)");
-      d_result_elems_ = want;
-    }
+    RETURN_IF_ERROR(EnsureDeviceResult(out_elems));
     result = d_result_;
   }
   if (!gpu && out_on_device)

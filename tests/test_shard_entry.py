@@ -467,6 +467,26 @@ def test_sharded_model_through_the_triton_plugin_a_request_on_every_instance_at_
         [t.start() for t in ths]
         [t.join() for t in ths]
         assert not errs, errs[:3]
+        # three requests in ONE Execute call: the entry session serves them with one bucketed lookup (csrc/triton/hps.cpp)
+        rng = np.random.default_rng(9)
+        trio = []
+        for i in range(3):
+            batch = int(rng.integers(1, 1000))
+            nk = [batch * 3, batch]
+            q = _draw(rng, tables, nk, zipf=bool(i % 2))
+            n = nk[0] * 128 + nk[1] * 16
+            req = tm.Request(f"trio-{i}")
+            req.add_input("KEYS", q.reshape(1, -1)).add_input("NUMKEYS", np.asarray([nk], np.int32)).request_output("OUTPUT0")
+            out = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            req.set_output_buffer(out.data_ptr(), n * 4, tm.MEM_GPU, 0, keep=out)
+            trio.append((req, out, O.np_lookup(tables, q, nk, [0.0, 0.5])))
+        insts[0].execute([t[0] for t in trio])
+        torch.cuda.synchronize()
+        for req, out, ref in trio:
+            assert req.error_code == -1, req.error_message
+            assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref)), req.id
+        assert insts[0].stats().last_distinct_compute_starts == 1
         # host output buffer (Triton gave CPU memory): the instance's device buffer + one D2H copy
         rng = np.random.default_rng(7)
         nk = [300, 100]

@@ -96,8 +96,62 @@ def test_several_requests_in_one_execute_call_and_missing_keys_get_default(tmp_p
             assert np.array_equal(_bits(out), _bits(ref))
             assert (out.reshape(-1, 16)[0] == 1.0).all()
         assert inst.stats().success_requests == 4
+        # the four small requests were served by ONE lookup (the reference: one blocking lookup per request, hps.cc:406)
+        assert inst.stats().last_distinct_compute_starts == 1
     finally:
         srv.shutdown()
+
+
+def test_requests_of_one_execute_call_share_one_lookup_and_keep_their_own_verdicts(wdl_server):
+    """Several requests in one TRITONBACKEND_ModelInstanceExecute call (Triton's dynamic batcher): the valid ones are served by
+    ONE engine call — keys concatenated table by table, every request's rows delivered to its own OUTPUT0 in its own order —, a
+    request that fails validation in the middle gets its error response and takes no part, a request that wants no output gets its
+    empty response; exactly one final response and one release each.  Two tables of different widths, mixed sizes, an empty
+    request, keys split over several buffers."""
+    from oracle import hps_oracle as O
+    srv, tables, _, _ = wdl_server
+    inst = srv.load_model("hps_wdl", tm.model_config("hps_wdl", kind="KIND_CPU", gpus=[])).create_instance("i", tm.KIND_CPU)
+    rng = np.random.default_rng(11)
+    for count in (1, 3, 8):
+        reqs, want = [], []
+        for i in range(count):
+            batch = int(rng.integers(1, 40))
+            r, q, nk = _wdl_request(rng, tables, batch=batch, rid=f"{count}-{i}")
+            reqs.append(r)
+            want.append(O.np_lookup(tables, q, nk, [0.0, 0.0]))
+        extra = []
+        if count >= 3:
+            # in the middle: NUMKEYS that does not add up; a request that wants no output; an empty request; keys in three buffers
+            _, q, nk = _wdl_request(rng, tables, batch=4, rid="x")
+            bad = tm.Request("bad").add_input("KEYS", q.reshape(1, -1)).add_input("NUMKEYS", np.array([[nk[0], nk[1] - 1]], np.int32)).request_output()
+            silent = tm.Request("silent").add_input("KEYS", q.reshape(1, -1)).add_input("NUMKEYS", np.array([nk], np.int32))
+            empty = tm.Request("empty").add_input("KEYS", np.zeros((1, 0), np.int64)).add_input("NUMKEYS", np.array([[0, 0]], np.int32)).request_output()
+            split = tm.Request("split")
+            pieces = [q[:3].copy(), q[3:50].copy(), q[50:].copy()]
+            for piece in pieces:
+                split.add_input_raw("KEYS", tm.TYPE_INT64, [1, q.size], piece.ctypes.data, piece.nbytes, tm.MEM_CPU)
+            split._keep += pieces
+            split.add_input("NUMKEYS", np.array([nk], np.int32)).request_output()
+            reqs[1:1] = [bad, silent]
+            want[1:1] = [None, None]
+            reqs += [empty, split]
+            want += [np.zeros(0, np.float32), O.np_lookup(tables, q, nk, [0.0, 0.0])]
+            extra = [bad, silent]
+        before = inst.stats()
+        inst.execute(reqs)
+        for r, ref in zip(reqs, want):
+            assert (r.response_count, r.release_count, r.final) == (1, 1, True), r.id
+            if r in extra:
+                continue
+            assert r.error_code == -1, (r.id, r.error_message)
+            assert np.array_equal(_bits(r.output_numpy()), _bits(ref)), (count, r.id)
+        st = inst.stats()
+        if extra:
+            assert extra[0].error_code == tm.ERR["INVALID_ARG"] and extra[1].error_code == -1 and extra[1].output_count == 0
+        assert st.failed_requests - before.failed_requests == (1 if extra else 0)
+        assert st.success_requests - before.success_requests == len(reqs) - (1 if extra else 0)
+        # one lookup for all requests that had rows to fetch (the silent one is answered without one and keeps its own start time)
+        assert st.last_distinct_compute_starts == (1 if count == 1 else 2 if extra else 1), (count, st.last_distinct_compute_starts)
 
 
 def test_keys_delivered_in_several_buffers_are_concatenated(wdl_server):
@@ -331,3 +385,13 @@ def test_native_driver_config1_cpu_parameter_server_through_the_plugin():
         assert d["failed"] == 0 and d["rows_wrong"] == 0 and d["rows_checked_against_recipe"] >= 2048
         assert d["keys_per_request"] == nkeys and d["floats_per_response"] == nout and d["output_memory"] == "host"
         assert d["requests_ok_reported_by_backend"] == d["batch_statistics_reports"] == 45
+    # --requests-per-execute 4: four requests per TRITONBACKEND_ModelInstanceExecute call (a dynamic batcher's hand-over), served
+    # by one lookup each time; the LAST request's rows of the last call are the ones checked against the recipe
+    r = subprocess.run([str(exe), "--lib-dir", str(hb.LIB), "--models", "2", "--rows", "50000", "--dims", "1,16", "--per-sample", "2,26",
+                        "--batch", "64", "--gpucache", "0", "--instances", "1", "--steps", "10", "--blocks", "2", "--warmup", "3",
+                        "--requests-per-execute", "4"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["failed"] == 0 and d["rows_wrong"] == 0 and d["requests_per_execute"] == 4
+    assert d["requests_ok_reported_by_backend"] == 4 * 23 and d["batch_statistics_reports"] == 23
+    assert d["instances_whose_last_execute_was_one_lookup"] == 2

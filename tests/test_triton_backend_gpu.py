@@ -189,6 +189,72 @@ def test_two_models_share_the_device_concurrently(tmp_path, direct):
 
 
 @pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
+def test_requests_of_one_execute_call_are_served_by_one_engine_call(tmp_path, direct):
+    """TRITONBACKEND_ModelInstanceExecute with 1 / 3 / 8 requests (Triton's dynamic batcher hands small requests over together; the
+    reference runs one blocking lookup per request, hps.cc:406): the valid requests go as ONE engine call — one probe / gather /
+    miss path for all their keys — and every request's rows land in its own output buffer, device or host, in its own table-major
+    order; an invalid request in the middle gets its error response and takes no part; requests whose KEYS are already on the
+    device, or that are too big together, are served one by one as before.  Bit-exact, one final response and one release each."""
+    import torch
+    from oracle import hps_oracle as O
+    tables = make_tables([(30000, 1), (20000, 16), (5000, 7)], seed=5)
+    defaults = [0.0, 0.25, -1.0]
+    srv, _ = _deploy(tmp_path, {"mr": (tables, [2, 26, 3], defaults)}, gpucacheper=0.2, hit_rate_threshold=1.0, max_batch=1024,
+                     extra={"ps_direct_access": direct})
+    try:
+        inst = srv.load_model("mr", tm.model_config("mr", gpus=[0], max_batch_size=1024)).create_instance("mr_0", tm.KIND_GPU, 0)
+        rng = np.random.default_rng(17 + direct)
+
+        def make(batch, device_out, device_keys=False, rid="r"):
+            nk = [batch * 2, batch * 26, batch * 3]
+            q = np.concatenate([rng.choice(k, n) for (k, _), n in zip(tables, nk)]).astype(np.int64)
+            q[::9] = -7 - rng.integers(0, 1 << 30, q[::9].size)          # keys that exist nowhere -> the table's default
+            n = nk[0] * 1 + nk[1] * 16 + nk[2] * 7
+            req, out = _request(q, nk, n, device_out, device_keys, rid=rid)
+            return req, out, n, O.np_lookup(tables, q, nk, defaults), batch
+
+        for count in (1, 3, 8):
+            for trial in range(3):
+                items = [make(int(rng.integers(1, 1024 // count + 1)), bool((i + trial) % 3), rid=f"{count}.{trial}.{i}") for i in range(count)]
+                bad = None
+                if count >= 3:
+                    # NUMKEYS with one table too few, in the middle of the call
+                    qb = np.zeros(10, np.int64)
+                    bad = tm.Request("bad").add_input("KEYS", qb.reshape(1, -1)).add_input("NUMKEYS", np.asarray([[4, 6]], np.int32)).request_output()
+                reqs = [it[0] for it in items]
+                if bad is not None:
+                    reqs.insert(count // 2, bad)
+                before = inst.stats()
+                inst.execute(reqs)
+                for req, out, n, ref, batch in items:
+                    assert (req.response_count, req.release_count, req.final, req.error_code) == (1, 1, True, -1), (req.id, req.error_message)
+                    assert np.array_equal(_bits(_result(req, out, n)), _bits(ref)), (count, trial, req.id)
+                    assert req.int_param("NumSample") == batch and req.int_param("DeviceID") == 0
+                    assert req.output(0)[5] == (tm.MEM_GPU if out is not None else tm.MEM_CPU)
+                st = inst.stats()
+                assert st.last_batch_size == sum(it[4] for it in items)
+                assert st.last_distinct_compute_starts == 1, (count, st.last_distinct_compute_starts)      # ONE lookup
+                if bad is not None:
+                    assert (bad.response_count, bad.release_count, bad.final) == (1, 1, True) and bad.error_code == tm.ERR["INVALID_ARG"]
+                    assert st.failed_requests - before.failed_requests == 1
+        # KEYS already in device memory: such requests are served one by one (no host copy of the keys exists to merge)
+        items = [make(20, True, device_keys=(i == 1), rid=f"dk{i}") for i in range(3)]
+        inst.execute([it[0] for it in items])
+        for req, out, n, ref, _ in items:
+            assert req.error_code == -1 and np.array_equal(_bits(_result(req, out, n)), _bits(ref)), req.id
+        assert inst.stats().last_distinct_compute_starts == 3
+        # together more samples than one call holds (max_batch_size): one by one
+        items = [make(700, True, rid=f"big{i}") for i in range(2)]
+        inst.execute([it[0] for it in items])
+        for req, out, n, ref, _ in items:
+            assert req.error_code == -1 and np.array_equal(_bits(_result(req, out, n)), _bits(ref)), req.id
+        assert inst.stats().last_distinct_compute_starts == 2
+        torch.cuda.synchronize()
+    finally:
+        srv.shutdown()
+
+
+@pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
 def test_new_model_version_refreshes_the_cache(tmp_path, direct):
     """Loading version 2 of a served model re-reads the sparse files and refreshes the device cache
     asynchronously (hps.cc:207-226, model_state.cpp:124-142,413-418)."""

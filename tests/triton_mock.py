@@ -31,7 +31,7 @@ EXPORTS = ["TRITONBACKEND_Initialize", "TRITONBACKEND_Finalize", "TRITONBACKEND_
 
 class InstanceStats(C.Structure):
     _fields_ = [("success_requests", C.c_uint64), ("failed_requests", C.c_uint64), ("batch_reports", C.c_uint64),
-                ("last_batch_size", C.c_uint64)]
+                ("last_batch_size", C.c_uint64), ("last_distinct_compute_starts", C.c_uint64)]
 
 
 class TritonError(RuntimeError):
@@ -109,6 +109,7 @@ class Request:
     def __init__(self, rid="1", correlation_id=0):
         self.L = lib()
         self._h = self.L.mock_request_new(str(rid).encode(), correlation_id)
+        self.id = str(rid)
         self._keep = []
 
     def add_input(self, name, array: np.ndarray, shape=None, dtype_code=None):

@@ -20,6 +20,10 @@
 //       gpucache=false model, KIND_CPU instance, OUTPUT0 in host memory, keys uniform over the table
 //   config 4 (README.md:148-152: W&D, D = [1,16], keys per sample [2,26]; two models served side by side on one GPU):
 //       --models 2 --dims 1,16 --per-sample 2,26 --rows 1000000 --batch 1024 --instances 1 --hit 0.9
+//   dynamic batching (Triton hands several queued requests to ONE TRITONBACKEND_ModelInstanceExecute call; the reference then runs one
+//   blocking lookup per request, hps.cc:406; this build serves them with one engine call):
+//       --requests-per-execute 8   every Execute call carries 8 requests of --batch samples each; the model's max_batch_size is
+//       8 x --batch (what a dynamic batcher needs to merge them); a "step" is then one Execute call
 // --dims / --per-sample are comma lists (one entry per table; --tables N --dim D is the short form of N equal tables);
 // --models M deploys the model M times (own tables: seed + model index) and drives all of them concurrently.
 #include <dlfcn.h>
@@ -48,6 +52,7 @@ struct Args {
   std::string lib_dir = "hugectr_backend_amd/lib";
   int tables = 26, dim = 128, instances = 2, steps = 20, warmup = 5, blocks = 10, direct = 0, pinned_keys = 0, also_pinned = 0;
   int models = 1, gpucache = 1, uniform = 0;
+  int rpe = 1;      // requests per TRITONBACKEND_ModelInstanceExecute call
   int shards = 0;   // > 0: ONE table-sharded model (ps.json "table_sharding": "hash"): shard s on device s % (visible devices), instance i on device i % (those)
   std::string dims, per_sample;   // comma lists; empty: `tables` tables of `dim` floats, one key per sample
   long rows = 10000000, batch = 65536;
@@ -101,6 +106,7 @@ int main(int argc, char** argv) {
     else if (k == "--gpucache") a.gpucache = atoi(v);
     else if (k == "--uniform") a.uniform = atoi(v);
     else if (k == "--shards") a.shards = atoi(v);
+    else if (k == "--requests-per-execute") a.rpe = std::max(1, atoi(v));
     else if (k == "--dims") a.dims = v;
     else if (k == "--per-sample") a.per_sample = v;
     else die("unknown option", argv[i]);
@@ -184,7 +190,7 @@ int main(int argc, char** argv) {
         for (size_t sdx = 0; sdx < shard_dev.size(); ++sdx) devlist += (sdx ? ", " : "") + std::to_string(shard_dev[sdx]);
       }
       snprintf(buf, sizeof buf, ", \"max_batch_size\": %ld, \"gpucache\": %s, \"gpucacheper\": %.6f, "
-               "\"hit_rate_threshold\": %.6f, \"ps_direct_access\": %s%s}", B, gpu ? "true" : "false", a.cache_frac, a.threshold,
+               "\"hit_rate_threshold\": %.6f, \"ps_direct_access\": %s%s}", B * a.rpe, gpu ? "true" : "false", a.cache_frac, a.threshold,
                (a.direct && gpu) ? "true" : "false", a.shards > 0 ? ", \"table_sharding\": \"hash\", \"gpucache_load_factor\": 0.6" : "");
       j += ", \"deployed_device_list\": [" + devlist + "]";
       j += buf;
@@ -206,7 +212,7 @@ int main(int argc, char** argv) {
   std::vector<int> inst_dev;            // ... on this device
   for (int mi = 0; mi < M; ++mi) {
     const std::string model_cfg =
-        "{\"name\": \"" + names[(size_t)mi] + "\", \"backend\": \"hps\", \"max_batch_size\": " + std::to_string(B) +
+        "{\"name\": \"" + names[(size_t)mi] + "\", \"backend\": \"hps\", \"max_batch_size\": " + std::to_string(B * a.rpe) +
         ", \"input\": [{\"name\": \"KEYS\", \"data_type\": \"TYPE_INT64\", \"dims\": [-1]}, {\"name\": \"NUMKEYS\", \"data_type\": "
         "\"TYPE_INT32\", \"dims\": [-1]}], \"output\": [{\"name\": \"OUTPUT0\", \"data_type\": \"TYPE_FP32\", \"dims\": [-1]}], "
         "\"instance_group\": [{\"count\": " + std::to_string(a.instances) + ", \"kind\": \"" + (gpu ? "KIND_GPU" : "KIND_CPU") +
@@ -240,8 +246,9 @@ int main(int argc, char** argv) {
     for (long i = 0; i < C; ++i) cdf[(size_t)i] /= acc;
   }
   // (--also-pinned: its blocks get FRESH batches behind the main measurement's — a replayed batch finds its cold keys inserted)
-  const int nbatch_main = a.warmup + a.steps * a.blocks;
-  const int nbatch = nbatch_main + (a.also_pinned > 0 ? 4 + a.steps * a.also_pinned : 0);
+  const int Q = a.rpe;
+  const int nbatch_main = (a.warmup + a.steps * a.blocks) * Q;
+  const int nbatch = nbatch_main + (a.also_pinned > 0 ? (4 + a.steps * a.also_pinned) * Q : 0);
   int64_t* keys_all = nullptr;
   const size_t key_bytes = (size_t)nbatch * N * sizeof(int64_t);
   if (a.pinned_keys) {
@@ -285,8 +292,8 @@ int main(int argc, char** argv) {
   for (int t = 0; t < T; ++t) numkeys[(size_t)t] = (int32_t)(key_off[(size_t)t + 1] - key_off[(size_t)t]);
   std::vector<float*> out_buf((size_t)W, nullptr);   // device memory for GPU instances, host memory for CPU instances
   for (int i = 0; i < W; ++i) {
-    if (gpu) { if (hipSetDevice(inst_dev[(size_t)i]) != hipSuccess || hipMalloc((void**)&out_buf[(size_t)i], OUT * sizeof(float)) != hipSuccess) die("hipMalloc of OUTPUT0 failed"); }
-    else if (!(out_buf[(size_t)i] = (float*)malloc(OUT * sizeof(float)))) die("out of memory for OUTPUT0");
+    if (gpu) { if (hipSetDevice(inst_dev[(size_t)i]) != hipSuccess || hipMalloc((void**)&out_buf[(size_t)i], (size_t)Q * OUT * sizeof(float)) != hipSuccess) die("hipMalloc of OUTPUT0 failed"); }
+    else if (!(out_buf[(size_t)i] = (float*)malloc((size_t)Q * OUT * sizeof(float)))) die("out of memory for OUTPUT0");
   }
 
   // ---- stall watchdog: a thread that does nothing but sleep 200 us at a time and notes every wake-up that comes more than
@@ -330,25 +337,32 @@ int main(int argc, char** argv) {
           if (M == 1) i = next.fetch_add(1);
           else { i = mine * M + mi; mine += per_model; }
           if (i >= count) return;
-          const long b = first + i;
-          mock_request_t* rq = m.mock_request_new(std::to_string(b).c_str(), 0);
-          m.mock_request_add_input_buffer(rq, "KEYS", 9 /*INT64*/, kshape, 2, keys_base + (size_t)b * N, N * sizeof(int64_t), keys_mtype, 0);
-          m.mock_request_add_input_buffer(rq, "NUMKEYS", 8 /*INT32*/, nshape, 2, numkeys.data(), (uint64_t)T * sizeof(int32_t), 0, 0);
-          m.mock_request_add_requested_output(rq, "OUTPUT0");
-          m.mock_request_set_output_buffer(rq, out_buf[(size_t)w], OUT * sizeof(float), gpu ? 2 /*GPU*/ : 0 /*CPU*/, gpu ? inst_dev[(size_t)w] : 0);
+          // (Q requests per Execute call: batches (first + i) * Q .. + Q - 1, each with its own output buffer)
+          const long b0 = (first + i) * Q;
+          std::vector<mock_request_t*> rqs((size_t)Q, nullptr);
+          for (int j = 0; j < Q; ++j) {
+            const long b = b0 + j;
+            mock_request_t* rq = rqs[(size_t)j] = m.mock_request_new(std::to_string(b).c_str(), 0);
+            m.mock_request_add_input_buffer(rq, "KEYS", 9 /*INT64*/, kshape, 2, keys_base + (size_t)b * N, N * sizeof(int64_t), keys_mtype, 0);
+            m.mock_request_add_input_buffer(rq, "NUMKEYS", 8 /*INT32*/, nshape, 2, numkeys.data(), (uint64_t)T * sizeof(int32_t), 0, 0);
+            m.mock_request_add_requested_output(rq, "OUTPUT0");
+            m.mock_request_set_output_buffer(rq, out_buf[(size_t)w] + (size_t)j * OUT, OUT * sizeof(float), gpu ? 2 /*GPU*/ : 0 /*CPU*/, gpu ? inst_dev[(size_t)w] : 0);
+          }
           const double t0 = now_s();
-          const int rc = m.mock_instance_execute(inst[(size_t)w], &rq, 1);
+          const int rc = m.mock_instance_execute(inst[(size_t)w], rqs.data(), (uint32_t)Q);
           const double dt = now_s() - t0;
-          if (rc != 0 || m.mock_request_error_code(rq) != -1 || m.mock_request_response_count(rq) != 1 ||
-              m.mock_request_release_count(rq) != 1) {
-            if (!failed.exchange(1))
-              fprintf(stderr, "request %ld failed: rc=%d code=%d %s\n", b, rc, m.mock_request_error_code(rq),
-                      m.mock_request_error_message(rq) ? m.mock_request_error_message(rq) : "");
+          for (mock_request_t* rq : rqs) {
+            if (rc != 0 || m.mock_request_error_code(rq) != -1 || m.mock_request_response_count(rq) != 1 ||
+                m.mock_request_release_count(rq) != 1) {
+              if (!failed.exchange(1))
+                fprintf(stderr, "request of execute %ld failed: rc=%d code=%d %s\n", first + i, rc, m.mock_request_error_code(rq),
+                        m.mock_request_error_message(rq) ? m.mock_request_error_message(rq) : "");
+            }
           }
           if (record) lat[(size_t)w].push_back(dt * 1e3);
           if (record && dt > 0.005) { std::lock_guard<std::mutex> lk(slow_mu); slow_requests.emplace_back(t0 - dog_t0, dt * 1e3); }
-          last_batch[(size_t)w] = b;
-          m.mock_request_delete(rq);
+          last_batch[(size_t)w] = b0 + Q - 1;     // (checked below: the LAST request of the call, in the last output buffer)
+          for (mock_request_t* rq : rqs) m.mock_request_delete(rq);
         }
       });
     for (auto& x : th) x.join();
@@ -380,14 +394,14 @@ int main(int argc, char** argv) {
       run(0, 4, false);
       sync_all();
       std::vector<double> bs2;
-      for (int blk = 0; blk < a.also_pinned && 4 + (long)(blk + 1) * a.steps <= nb2; ++blk) {
+      for (int blk = 0; blk < a.also_pinned && (4 + (long)(blk + 1) * a.steps) * Q <= nb2; ++blk) {
         const double t0 = now_s();
         run(4 + (long)blk * a.steps, a.steps, true);
         sync_all();
         bs2.push_back(now_s() - t0);
       }
       std::sort(bs2.begin(), bs2.end());
-      if (!bs2.empty()) pinned_lps = (double)a.steps * (double)N / bs2[bs2.size() / 2];
+      if (!bs2.empty()) pinned_lps = (double)a.steps * (double)Q * (double)N / bs2[bs2.size() / 2];
       std::vector<double> all2;
       for (auto& v : lat) all2.insert(all2.end(), v.begin(), v.end());
       std::sort(all2.begin(), all2.end());
@@ -416,7 +430,7 @@ int main(int argc, char** argv) {
       while (i >= key_off[(size_t)t + 1]) ++t;
       const size_t D = (size_t)Dt[(size_t)t];
       const int64_t key = keys_all[(size_t)b * N + i];
-      const float* src = out_buf[(size_t)w] + out_off[(size_t)t] + (i - key_off[(size_t)t]) * D;
+      const float* src = out_buf[(size_t)w] + (size_t)(Q - 1) * OUT + out_off[(size_t)t] + (i - key_off[(size_t)t]) * D;
       row.resize(D);
       if (gpu) { if (hipMemcpy(row.data(), src, D * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { ++bad; continue; } }
       else memcpy(row.data(), src, D * sizeof(float));
@@ -444,10 +458,15 @@ int main(int argc, char** argv) {
          "\"keys_memory\": \"%s\", \"output_memory\": \"%s\", \"models\": %d, \"instances\": %d, \"shards\": %d, \"visible_devices\": %d, \"tables\": %d, \"keys_per_request\": %zu, "
          "\"floats_per_response\": %zu, \"steps_per_block\": %d, \"blocks\": %d, "
          "\"lookups_per_s\": %.6g, \"requests_per_s\": %.6g, \"ms_per_step\": %.6g, \"block_ms\": [", a.pinned_keys ? "host, page-locked" : "host, pageable",
-         gpu ? "device" : "host", M, W / M, a.shards, ndev, T, N, OUT, a.steps, a.blocks, med > 0 ? (double)a.steps * (double)N / med : 0.0,
-         med > 0 ? (double)a.steps / med : 0.0, med / a.steps * 1e3);
+         gpu ? "device" : "host", M, W / M, a.shards, ndev, T, N, OUT, a.steps, a.blocks, med > 0 ? (double)a.steps * (double)Q * (double)N / med : 0.0,
+         med > 0 ? (double)a.steps * (double)Q / med : 0.0, med / a.steps * 1e3);
   for (size_t i = 0; i < block_s.size(); ++i) printf("%s%.4g", i ? ", " : "", block_s[i] * 1e3);
-  printf("], \"p50_request_ms\": %.5g, \"p99_request_ms\": %.5g, \"max_request_ms\": %.5g, \"requests_ok_reported_by_backend\": %llu, \"batch_statistics_reports\": %llu, "
+  {
+    uint64_t one_lookup = 0;
+    for (int i = 0; i < W; ++i) { mock_instance_stats_t s2{}; m.mock_instance_get_stats(inst[(size_t)i], &s2); one_lookup += s2.last_distinct_compute_starts == 1; }
+    printf("], \"requests_per_execute\": %d, \"instances_whose_last_execute_was_one_lookup\": %llu, \"p50_execute_ms\": %.5g, ", Q, (unsigned long long)one_lookup, pct(0.5));
+  }
+  printf("\"p50_request_ms\": %.5g, \"p99_request_ms\": %.5g, \"max_request_ms\": %.5g, \"requests_ok_reported_by_backend\": %llu, \"batch_statistics_reports\": %llu, "
          "\"failed\": %d, \"rows_checked_against_recipe\": %ld, \"rows_wrong\": %ld, \"model_load_seconds\": %.4g, \"ps_tier\": \"%s\", ",
          pct(0.5), pct(0.99), all.empty() ? 0.0 : all.back(), (unsigned long long)ok_req, (unsigned long long)reports, failed.load(), checked, bad, load_s,
          !gpu ? "CPU parameter server only (gpucache=false)" : a.direct ? "device-driven (ps_direct_access)" : "host gather");
