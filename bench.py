@@ -377,6 +377,11 @@ def compact_line(res, limit=COMPACT_LIMIT):
     put("all_hit_2s_host_keys_Glps", _scale(g(ex, "all_hit_two_sessions_host_keys", "lookups_per_s"), 1e-9))
     put("all_hit_max_call_ms", g(ex, "all_hit_two_sessions_host_keys", "max_call_ms"))
     put("all_hit_call_over_kernel_time", rf.get("all_hit_call_over_kernel_time"))
+    for tag_, leg_ in (("headline", "headline_under_refresh"), ("hit_999", "hit_999_under_refresh")):
+        put(f"{tag_}_under_refresh_Glps", _scale(g(ex, leg_, "lookups_per_s"), 1e-9))
+        put(f"{tag_}_under_refresh_p50_p99_max_ms", [g(ex, leg_, k_) for k_ in ("p50_call_ms", "p99_call_ms", "max_call_ms")] if g(ex, leg_, "p50_call_ms") is not None else None)
+        put(f"{tag_}_under_refresh_refresh_GBps", g(ex, leg_, "refresh_GBps_during_leg"))
+    put("unchanged_refresh_row_bytes", g(ex, "unchanged_refresh", "row_bytes"))
     put("hit_950_Glps", _scale(g(ex, "hit_950_two_sessions_host_keys", "lookups_per_s"), 1e-9))
     put("hit_950_measured_hit_rate", g(ex, "hit_950_two_sessions_host_keys", "measured_hit_rate"))
     for tag in ("hit_999", "hit_99", "hit_90", "hit_50"):
@@ -920,6 +925,47 @@ def main():
                     break
                 h_try = min(1.0, max(0.0, h_try + 0.950 - got_))
             extra["hit_950_two_sessions_host_keys"] = dict(r_, resident_draw_probability=h_try, passes=attempt + 1)
+            # (2d) SERVING UNDER A CACHE REFRESH (the reference runs refresh_embedding_cache on a timer next to the lookups:
+            #      model_state.cpp:125-178, 413-427).  A thread loops FULL refreshes of this cache — every resident row re-read from the
+            #      host tier and uploaded, the reference's behaviour, 26.6 GB here — while the two sessions serve fresh batches at the
+            #      headline's hit rate, then at 99.9 %.  (The default refresh takes only rows that can differ: nothing at all for these
+            #      unchanged tables — its cost is the unchanged_refresh figure.)
+            def under_refresh(batches, steps):
+                stop, acc = threading.Event(), {"passes": 0, "row_bytes": 0, "seconds": 0.0}
+                def bg():
+                    try:
+                        while not stop.is_set():
+                            st_ = ps.refresh_embedding_cache(model, dev, full=True)
+                            acc["passes"] += 1
+                            acc["row_bytes"] += st_["row_bytes"]
+                            acc["seconds"] += st_["seconds"]
+                    except Exception as e_:  # noqa: BLE001
+                        acc["error"] = repr(e_)[:200]
+                c0 = cache.counters()["refreshed"]
+                th_ = threading.Thread(target=bg, daemon=True)
+                th_.start()
+                t_w = time.time()
+                while cache.counters()["refreshed"] == c0 and time.time() - t_w < 20 and "error" not in acc:
+                    time.sleep(0.01)      # (the pass starts with a read-back of the resident keys)
+                c1, t1_ = cache.counters()["refreshed"], time.perf_counter()
+                r_ = leg(batches, steps, "host")
+                c2, t2_ = cache.counters()["refreshed"], time.perf_counter()
+                stop.set()
+                th_.join(60)
+                r_["refresh_rows_during_leg"] = int(c2 - c1)
+                r_["refresh_GBps_during_leg"] = (c2 - c1) * 4 * D / max(t2_ - t1_, 1e-9) / 1e9
+                r_["refresh_passes_completed"] = acc["passes"]
+                r_["refresh_GBps_whole_passes"] = acc["row_bytes"] / acc["seconds"] / 1e9 if acc["seconds"] > 0 else None
+                if "error" in acc:
+                    r_["refresh_error"] = acc["error"]
+                return r_
+
+            t_u = time.perf_counter()
+            st_u = ps.refresh_embedding_cache(model, dev)
+            extra["unchanged_refresh"] = dict(st_u, wall_ms=(time.perf_counter() - t_u) * 1e3,
+                                              note="default refresh of a cache whose tables did not change: nothing is re-read or uploaded")
+            extra["headline_under_refresh"] = under_refresh(host_form(fresh(64)), 60)
+            extra["hit_999_under_refresh"] = under_refresh(host_form(fresh(64, 0.999, resident_now())), 60)
             # (3) every key resident: the GPU-side ceiling of the path, one session (kernels run alone)
             #     TRUE all-hit: the keys are drawn from what is resident at this moment (round 3 drew them from the set resident
             #     after warm-up; a few hundred of those had been evicted by then and the "all-hit" legs measured a miss path)

@@ -205,6 +205,20 @@ int hps_server_refresh_embedding_cache(hps_server_t* sv, const char* model, int3
   });
 }
 
+int hps_server_refresh_embedding_cache_ex(hps_server_t* sv, const char* model, int32_t device, int32_t full, hps_refresh_stats_t* out) {
+  return Guard([&]() -> Status {
+    if (!sv || !model) return Error(Code::kInvalidArg, "null argument");
+    HierParameterServer::RefreshStats st;
+    HPS_RETURN_IF_ERROR(sv->ps->refresh_embedding_cache(model, device, full != 0, &st));
+    if (out) {
+      out->tables = st.tables; out->tables_unchanged = st.tables_unchanged; out->tables_full = st.tables_full;
+      out->keys_dumped = st.keys_dumped; out->keys_changed = st.keys_changed;
+      out->rows_refreshed = st.rows_refreshed; out->row_bytes = st.row_bytes; out->seconds = st.seconds;
+    }
+    return Status::Ok();
+  });
+}
+
 int hps_server_get_embedding_cache(hps_server_t* sv, const char* model, int32_t device, hps_cache_t** out) {
   return Guard([&]() -> Status {
     if (!sv || !model || !out) return Error(Code::kInvalidArg, "null argument");

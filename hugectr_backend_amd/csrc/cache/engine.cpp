@@ -256,6 +256,14 @@ Status EmbeddingCache::Init(const std::string& model, const InferenceParams& p,
   cfg_.use_gpu_embedding_cache_ = true;
   cfg_.device_id_ = device;
   h_tables_.resize(T);
+  {
+    // where the host tables stand BEFORE the warm-up reads them: the refresh replays what changed since (HostTable::ChangeMark)
+    std::lock_guard<std::mutex> rlk(refresh_mu_);
+    seen_epoch_.assign(T, 0);
+    seen_prev_.assign(T, 0);
+    for (size_t t = 0; t < T; ++t) tables[t]->ChangeMark(&seen_epoch_[t], &seen_prev_[t]);
+    seen_last_ = seen_prev_;
+  }
   HIP_TRY(hipEventCreateWithFlags(&last_write_, hipEventDisableTiming));
 
   for (size_t t = 0; t < T; ++t) {

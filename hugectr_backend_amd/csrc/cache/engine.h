@@ -86,7 +86,13 @@ class EmbeddingCache {
   // Fetch `keys_per_table` from the parameter server and insert them (keys already resident get their
   // row refreshed in place).  Used by the async-insert path and by refresh_embedding_cache; runs on
   // the cache's own stream and staging buffers, serialised by a mutex.
-  Status InsertKeys(HierParameterServer* ps, const std::vector<std::vector<int64_t>>& keys_per_table);
+  // pacing (refresh): pieces of at most piece_keys keys; while lookup sessions are calling, a piece that took t is followed by a
+  // pause of t x (1 / link_share - 1) — the refresh takes link_share of the PCIe link and of the writer windows, the sessions
+  // the rest — and the host gather runs on at most max_threads threads of the serving pool.  *row_bytes: bytes uploaded.
+  struct InsertPacing { size_t piece_keys = 0; double link_share = 1.0; size_t max_threads = 0; };
+  Status InsertKeys(HierParameterServer* ps, const std::vector<std::vector<int64_t>>& keys_per_table, const InsertPacing* pacing = nullptr,
+                    uint64_t* row_bytes = nullptr);
+  uint64_t calls_so_far() const { return calls_.load(std::memory_order_relaxed); }   // lookup calls of all sessions (the refresh paces itself by it)
   // blocks until every queued async insertion has finished
   void WaitAsync();
 
@@ -94,6 +100,10 @@ class EmbeddingCache {
   friend class HierParameterServer;
   friend class LookupSession;
   EmbeddingCache() = default;
+  // refresh bookkeeping (HierParameterServer::RefreshOne; guarded by refresh_mu_): per table the host table's load epoch and the
+  // positions in its change log as of the warm-up / the last two refreshes (HostTable::ChangeMark)
+  std::mutex refresh_mu_;
+  std::vector<uint64_t> seen_epoch_, seen_prev_, seen_last_;
   // shard >= 0: this cache is shard `shard` of `num_shards` of a table-sharded model (ps.json "table_sharding": "hash"): it
   // is sized for, warmed with and only ever asked for the keys with mix64(key) mod num_shards == shard
   Status Init(const std::string& model, const InferenceParams& p, const std::vector<std::shared_ptr<HostTable>>& tables,
@@ -487,7 +497,20 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   Status update_database_per_model(const InferenceParams& p);          // (re)load sparse files into the host tier
   Status create_embedding_cache_per_model(const InferenceParams& p);   // build caches on deployed_devices
   Status destory_embedding_cache_per_model(const std::string& model);  // [sic] reference spelling
-  Status refresh_embedding_cache(const std::string& model, int device);
+  // Rows of resident keys are taken again from the parameter server (docs/hierarchical_parameter_server.md:234-238, 259-265).
+  // By default only rows that CAN differ: a table that was neither reloaded nor updated since the cache last looked costs
+  // nothing, an updated one costs its changed keys that are resident (HostTable's change log; every change is replayed by two
+  // consecutive refreshes, which closes the race with a lookup that fetched the old row just before the update and inserts it
+  // just after the refresh).  full = true (or ps.json "gpucache_refresh_changed_only": false): every resident row, as the
+  // reference does.  Either way the upload is paced (InsertPacing) while sessions are serving.
+  struct RefreshStats {
+    uint64_t tables = 0, tables_unchanged = 0, tables_full = 0;
+    uint64_t keys_dumped = 0;      // resident keys read back for a full pass
+    uint64_t keys_changed = 0;     // change-log entries looked at
+    uint64_t rows_refreshed = 0, row_bytes = 0;
+    double seconds = 0.0;
+  };
+  Status refresh_embedding_cache(const std::string& model, int device, bool full = false, RefreshStats* stats = nullptr);
   Status add_model(const InferenceParams& p);  // online deployment: register a model parsed later
   // Re-read ps.json and (re)register every model in it (HPSBackend::ParseParameterServer, hps.cc:210-219)
   Status parse_config(const std::string& ps_json_config_file);
@@ -521,7 +544,7 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
     const uint32_t* keys32 = nullptr;  // when `keys` is null: the same keys as uint32 offsets (widened task by task)
     int64_t key_base = 0;              // ... from this base
   };
-  Status FetchMulti(const std::vector<FetchJob>& jobs);
+  Status FetchMulti(const std::vector<FetchJob>& jobs, size_t max_threads = 0);   // max_threads 0: the whole serving pool
 
   // async-insert mode: queue "fetch these keys and insert them" for a cache; dropped (best effort)
   // when more than number_of_worker_buffers_in_pool jobs are already waiting.
@@ -547,7 +570,7 @@ class HierParameterServer : public std::enable_shared_from_this<HierParameterSer
   Status Build(bool load_tables);
   Status EnsureTables(const InferenceParams& p, bool load);
   Status MutateTables(const std::string& model, const std::function<Status()>& fn);
-  Status RefreshOne(const std::string& model, const std::shared_ptr<EmbeddingCache>& cache);
+  Status RefreshOne(const std::string& model, const std::shared_ptr<EmbeddingCache>& cache, bool full, RefreshStats* stats);
 
   ParameterServerConfig cfg_;
   ThreadPool* pool_ = nullptr;

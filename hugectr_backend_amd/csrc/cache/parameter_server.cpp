@@ -1,6 +1,9 @@
 // HierParameterServer + the background insert path of EmbeddingCache.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <thread>
+
 #include <sched.h>
 #include <unistd.h>
 
@@ -64,7 +67,8 @@ void EmbeddingCache::WaitAsync() {
   pend_cv_.wait(lk, [&] { return pending_async_ == 0; });
 }
 
-Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std::vector<int64_t>>& keys_per_table) {
+Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std::vector<int64_t>>& keys_per_table, const InsertPacing* pacing,
+                                  uint64_t* row_bytes) {
   const size_t T = num_tables();
   if (keys_per_table.size() != T) return Error(Code::kInvalidArg, "InsertKeys: table count mismatch");
   if (static_) return Status::Ok();
@@ -96,7 +100,10 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
   Inserter& I = *ins_;
   std::vector<size_t> done(T, 0);
   HIP_TRY(hipMemsetAsync(I.d_stats, 0, (size_t)kStatLines * kAccStride * sizeof(uint32_t), I.stream));
+  const size_t piece_cap = (pacing && pacing->piece_keys) ? std::min(I.cap_keys, std::max<size_t>(pacing->piece_keys, 256)) : I.cap_keys;
+  uint64_t calls_seen = calls_so_far();
   for (;;) {
+    const auto piece_t0 = std::chrono::steady_clock::now();
     MissDesc& md = *I.h_md;
     size_t uq = 0, fl = 0;
     std::vector<HierParameterServer::FetchJob> jobs;
@@ -107,7 +114,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
       I.h_ks[t] = uq;
       md.chunk_lo[t] = 0;
       md.stage_off[t] = fl;
-      const size_t take = std::min(keys_per_table[t].size() - done[t], I.cap_keys - uq);
+      const size_t take = std::min(keys_per_table[t].size() - done[t], piece_cap - uq);
       md.chunk_hi[t] = (uint32_t)take;
       if (take) {
         memcpy(I.h_keys + uq, keys_per_table[t].data() + done[t], take * sizeof(int64_t));
@@ -120,7 +127,8 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
     md.useg_start[T] = uq;
     I.h_ks[T] = uq;
     if (uq == 0) break;
-    HPS_RETURN_IF_ERROR(ps->FetchMulti(jobs));
+    HPS_RETURN_IF_ERROR(ps->FetchMulti(jobs, pacing ? pacing->max_threads : 0));
+    if (row_bytes) *row_bytes += fl * sizeof(float);
     HIP_TRY(hipMemcpyAsync(I.d_md, I.h_md, sizeof(MissDesc), hipMemcpyHostToDevice, I.stream));
     HIP_TRY(hipMemcpyAsync(I.d_ks, I.h_ks, sizeof(uint64_t) * (T + 1), hipMemcpyHostToDevice, I.stream));
     HIP_TRY(hipMemcpyAsync(I.d_keys, I.h_keys, uq * sizeof(int64_t), hipMemcpyHostToDevice, I.stream));
@@ -134,6 +142,16 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
     EndWrite(I.stream);
     if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
     HIP_TRY(hipStreamSynchronize(I.stream));
+    if (pacing && pacing->link_share < 1.0) {
+      // sessions called since the last piece: they are serving — leave them their share of the link, the CPUs and the cache
+      const uint64_t calls_now = calls_so_far();
+      if (calls_now != calls_seen) {
+        const double took = std::chrono::duration<double>(std::chrono::steady_clock::now() - piece_t0).count();
+        const double pause = std::min(0.05, took * (1.0 / pacing->link_share - 1.0));
+        std::this_thread::sleep_for(std::chrono::duration<double>(pause));
+      }
+      calls_seen = calls_so_far();
+    }
   }
   HIP_TRY(hipMemcpyAsync(I.h_stats, I.d_stats, (size_t)kStatLines * kAccStride * sizeof(uint32_t), hipMemcpyDeviceToHost, I.stream));
   HIP_TRY(hipStreamSynchronize(I.stream));
@@ -600,7 +618,7 @@ Status HierParameterServer::destory_embedding_cache_per_model(const std::string&
   return Status::Ok();  // device memory goes when the last session drops its reference
 }
 
-Status HierParameterServer::refresh_embedding_cache(const std::string& model, int device) {
+Status HierParameterServer::refresh_embedding_cache(const std::string& model, int device, bool full, RefreshStats* stats) {
   std::vector<std::shared_ptr<EmbeddingCache>> on_device;   // one replica, or every shard of a table-sharded model on that device
   {
     std::lock_guard<std::mutex> lk(mu_);
@@ -608,11 +626,14 @@ Status HierParameterServer::refresh_embedding_cache(const std::string& model, in
       if (std::get<0>(kv.first) == model && std::get<1>(kv.first) == device) on_device.push_back(kv.second);
   }
   if (on_device.empty()) return Error(Code::kNotFound, "no embedding cache for model '", model, "' on device ", device);
-  for (auto& c : on_device) HPS_RETURN_IF_ERROR(RefreshOne(model, c));
+  const auto t0 = std::chrono::steady_clock::now();
+  if (stats) *stats = RefreshStats();
+  for (auto& c : on_device) HPS_RETURN_IF_ERROR(RefreshOne(model, c, full, stats));
+  if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return Status::Ok();
 }
 
-Status HierParameterServer::RefreshOne(const std::string& model, const std::shared_ptr<EmbeddingCache>& cache) {
+Status HierParameterServer::RefreshOne(const std::string& model, const std::shared_ptr<EmbeddingCache>& cache, bool full, RefreshStats* stats) {
   InferenceParams p;
   {
     std::lock_guard<std::mutex> lk(mu_);
@@ -620,26 +641,77 @@ Status HierParameterServer::RefreshOne(const std::string& model, const std::shar
     if (it == cfg_.models.end()) return Error(Code::kNotFound, "model '", model, "' is not configured");
     p = it->second;
   }
-  // Re-read the resident keys' vectors from the parameter server, a fraction of the cache per
-  // iteration (docs/hierarchical_parameter_server.md:234-238).
+  auto tabs = tables_of(model);
   const size_t T = cache->num_tables();
-  std::vector<std::vector<int64_t>> resident(T);
-  for (size_t t = 0; t < T; ++t) HPS_RETURN_IF_ERROR(cache->DumpKeys((uint32_t)t, &resident[t]));
+  if (tabs.size() != T) return Error(Code::kNotFound, "model '", model, "': tables are not loaded");
+  std::lock_guard<std::mutex> rlk(cache->refresh_mu_);   // one refresh of a cache at a time
+  if (!p.refresh_changed_only) full = true;
+  if (cache->seen_epoch_.size() != T) full = true;         // (a cache that never recorded its marks)
+  // ---- which keys to take again: per table either every resident key (reloaded table, log overrun, full pass) or the
+  //      resident ones among the keys the table's change log names since the refresh BEFORE the last one ----
+  std::vector<std::vector<int64_t>> todo(T);
+  std::vector<uint64_t> mark_epoch(T, 0), mark_seq(T, 0);
+  std::vector<uint8_t> whole_table(T, 0);
+  RefreshStats local;
+  for (size_t t = 0; t < T; ++t) {
+    ++local.tables;
+    std::vector<int64_t> changed;
+    bool whole = full;
+    if (!whole) whole = !tabs[t]->ChangesSince(cache->seen_epoch_[t], cache->seen_prev_[t], &changed, &mark_epoch[t], &mark_seq[t]);
+    else tabs[t]->ChangeMark(&mark_epoch[t], &mark_seq[t]);     // (before the rows are read)
+    whole_table[t] = whole ? 1 : 0;
+    if (whole) {
+      ++local.tables_full;
+      HPS_RETURN_IF_ERROR(cache->DumpKeys((uint32_t)t, &todo[t]));
+      local.keys_dumped += todo[t].size();
+      continue;
+    }
+    if (changed.empty()) { ++local.tables_unchanged; continue; }
+    local.keys_changed += changed.size();
+    std::sort(changed.begin(), changed.end());
+    changed.erase(std::unique(changed.begin(), changed.end()), changed.end());
+    // only what is resident: an updated row nobody has asked for does not displace a row somebody has
+    std::vector<int32_t> slots(changed.size());
+    HPS_RETURN_IF_ERROR(cache->Query((uint32_t)t, changed.data(), changed.size(), slots.data()));
+    for (size_t i = 0; i < changed.size(); ++i) if (slots[i] >= 0) todo[t].push_back(changed[i]);
+  }
+  // Re-read the vectors from the parameter server, a fraction of the CACHE per iteration
+  // (cache_refresh_percentage_per_iteration, docs/hierarchical_parameter_server.md:234-238), in paced pieces.
   double frac = p.cache_refresh_percentage_per_iteration;
   if (!(frac > 0.0) || frac > 1.0) frac = 1.0;
+  EmbeddingCache::InsertPacing pacing;   // (link share 1.0: unpaced — 262,144-row pieces, the whole serving pool, as before round 6)
+  if (p.refresh_link_share < 1.0) {
+    pacing.piece_keys = 32768;
+    pacing.link_share = p.refresh_link_share;
+    pacing.max_threads = 4;
+  }
   std::vector<size_t> done(T, 0);
   for (;;) {
     std::vector<std::vector<int64_t>> part(T);
     bool any = false;
     for (size_t t = 0; t < T; ++t) {
-      const size_t step = std::max<size_t>(1, (size_t)((double)resident[t].size() * frac + 0.999999));
-      const size_t n = std::min(step, resident[t].size() - done[t]);
-      part[t].assign(resident[t].begin() + done[t], resident[t].begin() + done[t] + n);
+      const size_t step = std::max<size_t>(1, (size_t)((double)cache->get_cache_config().capacity_rows_[t] * frac + 0.999999));
+      const size_t n = std::min(step, todo[t].size() - done[t]);
+      part[t].assign(todo[t].begin() + done[t], todo[t].begin() + done[t] + n);
       done[t] += n;
+      local.rows_refreshed += n;
       any |= n > 0;
     }
     if (!any) break;
-    HPS_RETURN_IF_ERROR(cache->InsertKeys(this, part));
+    HPS_RETURN_IF_ERROR(cache->InsertKeys(this, part, &pacing, &local.row_bytes));
+  }
+  // the marks move only after the rows are in: a refresh that failed half-way is repeated from where the last good one stood
+  const bool had_marks = cache->seen_last_.size() == T && cache->seen_prev_.size() == T;
+  std::vector<uint64_t> prev(T);
+  for (size_t t = 0; t < T; ++t)   // (a whole-table pass has seen everything up to its mark)
+    prev[t] = (whole_table[t] || !had_marks) ? mark_seq[t] : cache->seen_last_[t];
+  cache->seen_epoch_ = mark_epoch;
+  cache->seen_prev_ = std::move(prev);
+  cache->seen_last_ = mark_seq;
+  if (stats) {
+    stats->tables += local.tables; stats->tables_unchanged += local.tables_unchanged; stats->tables_full += local.tables_full;
+    stats->keys_dumped += local.keys_dumped; stats->keys_changed += local.keys_changed;
+    stats->rows_refreshed += local.rows_refreshed; stats->row_bytes += local.row_bytes;
   }
   return Status::Ok();
 }
@@ -710,7 +782,7 @@ Status HierParameterServer::Fetch(const HostTable& tb, const int64_t* keys, size
   return Status::Ok();
 }
 
-Status HierParameterServer::FetchMulti(const std::vector<FetchJob>& jobs) {
+Status HierParameterServer::FetchMulti(const std::vector<FetchJob>& jobs, size_t max_threads) {
   struct Task { uint32_t job; size_t begin, end; };
   // Task size: about two tasks per thread — enough to even out the last round (a 4,096-key request cut into 256-key
   // tasks leaves two of 14 threads with a second task) without paying a contended claim per 100 keys (each claim is a
@@ -737,7 +809,7 @@ Status HierParameterServer::FetchMulti(const std::vector<FetchJob>& jobs) {
                    J.found ? J.found + k.begin : nullptr);
   };
   if (tasks.size() <= 1) { if (!tasks.empty()) body(0); }
-  else ThreadPool::Serving().ParallelFor(tasks.size(), body);
+  else ThreadPool::Serving().ParallelFor(tasks.size(), body, max_threads);
   return Status::Ok();
 }
 

@@ -299,6 +299,10 @@ Status ParseParameterServerJson(const Json& root, ParameterServerConfig* out) {
     if (p.small_miss_insert_interval < 1 || p.small_miss_insert_interval > 1024)
       return Error(Code::kInvalidArg, "Model '", p.model_name, "': gpucache_small_miss_insert_interval must be in [1, 1024]");
     HPS_RETURN_IF_ERROR(ParseField(p.ps_direct_access, j, "ps_direct_access", false));
+    HPS_RETURN_IF_ERROR(ParseField(p.refresh_changed_only, j, "gpucache_refresh_changed_only", false));
+    HPS_RETURN_IF_ERROR(ParseField(p.refresh_link_share, j, "gpucache_refresh_link_share", false));
+    if (!(p.refresh_link_share > 0.0) || p.refresh_link_share > 1.0)
+      return Error(Code::kInvalidArg, "Model '", p.model_name, "': gpucache_refresh_link_share must be in (0, 1]");
     {
       // "table_sharding": "hash" — the model's GPU caches are SHARDS, not replicas: entry s of deployed_device_list holds the
       // keys with mix64(key) mod P == s (P = the length of the list; a device may appear more than once: logical shards)

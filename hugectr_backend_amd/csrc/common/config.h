@@ -113,6 +113,12 @@ struct InferenceParams {  // backend.cpp:318-516
   // profiles/round4/timeline_99.9pct_hit_after.txt: 174 us of idle GPU per pair of calls).  A key that keeps being asked for
   // enters within n calls, like the one-in-16 rule of the admission policy; with gpucache_admission = false every call inserts.
   int small_miss_insert_interval = 4;
+  // "gpucache_refresh_changed_only" (default true): refresh_embedding_cache re-reads only rows that can differ from the host tier's
+  // (tables reloaded or keys updated since the cache last looked); false: every resident row on every refresh, as the reference.
+  // "gpucache_refresh_link_share" (default 0.15, in (0, 1]): the share of the PCIe link (and of the cache's writer windows) a
+  // refresh takes while lookup sessions are serving; with nobody serving it runs at full speed.
+  bool refresh_changed_only = true;
+  double refresh_link_share = 0.15;
   // "ps_direct_access": the GPU resolves missed keys through a device-resident index of the host tier and reads
   // the rows in place from pinned host memory over PCIe (no host threads, no staging copy).  Needs gpucache.
   bool ps_direct_access = false;

@@ -289,7 +289,45 @@ Status HostTable::LoadFromDir(const std::string& dir, ThreadPool* pool) {
 Status HostTable::FinishLoad(ThreadPool* pool) {
   HPS_RETURN_IF_ERROR(BuildIndex(pool));
   SetupTier();
+  {
+    // a new load epoch: whoever holds copies of rows of the previous contents has to take them all again
+    std::lock_guard<std::mutex> lk(log_mu_);
+    ++load_epoch_;
+    log_base_ += change_log_.size();
+    change_log_.clear();
+  }
   return Status::Ok();
+}
+
+void HostTable::LogChanges(const int64_t* keys, size_t n) {
+  std::lock_guard<std::mutex> lk(log_mu_);
+  if (n >= kChangeLogMax) {   // more than the log holds in one go: nothing older is worth keeping
+    log_base_ += change_log_.size() + n;
+    change_log_.clear();
+    return;
+  }
+  if (change_log_.size() + n > kChangeLogMax) {
+    const size_t drop = std::max(change_log_.size() / 2, change_log_.size() + n - kChangeLogMax);
+    change_log_.erase(change_log_.begin(), change_log_.begin() + drop);
+    log_base_ += drop;
+  }
+  change_log_.insert(change_log_.end(), keys, keys + n);
+}
+
+void HostTable::ChangeMark(uint64_t* load_epoch, uint64_t* log_seq) const {
+  std::lock_guard<std::mutex> lk(log_mu_);
+  *load_epoch = load_epoch_;
+  *log_seq = log_base_ + change_log_.size();
+}
+
+bool HostTable::ChangesSince(uint64_t load_epoch, uint64_t log_seq, std::vector<int64_t>* keys, uint64_t* new_epoch, uint64_t* new_seq) const {
+  std::lock_guard<std::mutex> lk(log_mu_);
+  *new_epoch = load_epoch_;
+  *new_seq = log_base_ + change_log_.size();
+  keys->clear();
+  if (load_epoch != load_epoch_ || log_seq < log_base_ || log_seq > *new_seq) return false;
+  keys->assign(change_log_.begin() + (log_seq - log_base_), change_log_.end());
+  return true;
 }
 
 // Builds the volatile tier over the freshly indexed row store and caches the first initial_cache_rate * R rows in
@@ -594,6 +632,8 @@ size_t HostTable::Fetch(const int64_t* keys, size_t n, float* out, size_t stride
 Status HostTable::Upsert(const int64_t* keys, const float* rows, size_t n, unsigned layers) {
   if ((layers & (kLayerVolatile | kLayerPersistent)) == 0) return Status::Ok();
   WriteLock lk(*this);
+  // logged before the rows change (and whatever the outcome): a holder that reads a half-applied update finds its keys in the log
+  LogChanges(keys, n);
   if (vt_) return UpsertTiered(keys, rows, n, layers);
   const uint32_t D = dim_;
   // overwrite existing, collect new

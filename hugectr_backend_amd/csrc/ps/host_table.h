@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <shared_mutex>
 #include <string>
 #include <vector>
@@ -53,6 +54,17 @@ class HostTable {
   bool pinned() const { return pinned_; }
   // bumped by every (re)load / growing upsert: device-side indexes built from this table compare it
   uint64_t generation() const { return generation_.load(std::memory_order_acquire); }
+  // ---- what changed, for whoever holds copies of rows (the GPU caches' refresh, cache/parameter_server.cpp) ----
+  // Every (re)load starts a new load epoch; every Upsert appends its keys to a bounded change log.  A holder remembers
+  // (load epoch, log position) as of the moment its copies were taken:
+  //   ChangeMark(&e, &s)                       the current position (take it BEFORE reading rows: changes racing with the read
+  //                                            are then replayed, never lost)
+  //   ChangesSince(e, s, &keys, &e2, &s2)      true: `keys` = every key upserted since (e, s) (duplicates possible), (e2, s2) the
+  //                                            new mark; false: the table was reloaded since, or the log no longer reaches back
+  //                                            that far — every row may differ
+  void ChangeMark(uint64_t* load_epoch, uint64_t* log_seq) const;
+  bool ChangesSince(uint64_t load_epoch, uint64_t log_seq, std::vector<int64_t>* keys, uint64_t* new_epoch, uint64_t* new_seq) const;
+  static constexpr size_t kChangeLogMax = (size_t)4 << 20;   // keys kept (32 MB); older entries are dropped, their holders refresh fully
   ~HostTable();
   HostTable(const HostTable&) = delete;
   HostTable& operator=(const HostTable&) = delete;
@@ -115,6 +127,11 @@ class HostTable {
   void DataFree(void* p);
   bool pinned_ = false;
   std::atomic<uint64_t> generation_{0};
+  mutable std::mutex log_mu_;
+  uint64_t load_epoch_ = 0;            // (re)loads so far
+  uint64_t log_base_ = 0;              // sequence number of change_log_[0]
+  std::vector<int64_t> change_log_;    // keys of the upserts since log_base_
+  void LogChanges(const int64_t* keys, size_t n);
   std::atomic<int64_t> min_key_{0};
   Status BuildIndex(ThreadPool* pool);
   Status AllocPartitions(const std::vector<size_t>& counts);

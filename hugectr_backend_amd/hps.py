@@ -78,6 +78,11 @@ class LookupStats(C.Structure):
                 ("scatter_ms", C.c_float), ("insert_ms", C.c_float), ("keys_narrowed", C.c_int32), ("key_bytes", C.c_int32)]
 
 
+class RefreshStats(C.Structure):
+    _fields_ = [("tables", C.c_uint64), ("tables_unchanged", C.c_uint64), ("tables_full", C.c_uint64), ("keys_dumped", C.c_uint64),
+                ("keys_changed", C.c_uint64), ("rows_refreshed", C.c_uint64), ("row_bytes", C.c_uint64), ("seconds", C.c_double)]
+
+
 class ShardEntryStats(C.Structure):
     _fields_ = [("keys", C.c_uint64), ("unique_keys", C.c_uint64), ("misses", C.c_uint64), ("unique_misses", C.c_uint64),
                 ("bucket_ms", C.c_float), ("lookup_ms", C.c_float), ("expand_ms", C.c_float), ("key_stage_ms", C.c_float),
@@ -109,6 +114,7 @@ def _load() -> C.CDLL:
         "hps_server_create_embedding_cache_per_model": (C.c_int, [P, cp]),
         "hps_server_destroy_embedding_cache_per_model": (C.c_int, [P, cp]),
         "hps_server_refresh_embedding_cache": (C.c_int, [P, cp, i32]),
+        "hps_server_refresh_embedding_cache_ex": (C.c_int, [P, cp, i32, i32, C.POINTER(RefreshStats)]),
         "hps_server_get_embedding_cache": (C.c_int, [P, cp, i32, C.POINTER(P)]),
         "hps_server_load_table_arrays": (C.c_int, [P, cp, u32, P, P, u64, C.c_int]),
         "hps_server_load_table_synthetic": (C.c_int, [P, cp, u32, u64, i64, u64]),
@@ -186,7 +192,7 @@ EXPORTED_SYMBOLS = [
     "hps_server_model_count", "hps_server_model_name", "hps_server_model_info", "hps_server_table_info",
     "hps_server_deployed_device", "hps_server_parse_config", "hps_server_update_database_per_model",
     "hps_server_create_embedding_cache_per_model", "hps_server_destroy_embedding_cache_per_model",
-    "hps_server_refresh_embedding_cache", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
+    "hps_server_refresh_embedding_cache", "hps_server_refresh_embedding_cache_ex", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
     "hps_server_table_data", "hps_update_message_encode", "hps_server_update_source_stats", "hps_server_update_source_drain", "hps_server_update_source_stop", "hps_server_update_source_filtered",
     "hps_cache_on_device", "hps_wake_copy_engines", "hps_pool_numa_node", "hps_pool_fast_overruns", "hps_bind_calling_thread", "hps_session_create_from_cache",
@@ -346,8 +352,12 @@ class HierParameterServer:
     def destory_embedding_cache_per_model(self, model: str):  # [sic] reference spelling
         _check(LIB.hps_server_destroy_embedding_cache_per_model(self._h, model.encode()))
 
-    def refresh_embedding_cache(self, model: str, device: int):
-        _check(LIB.hps_server_refresh_embedding_cache(self._h, model.encode(), device))
+    def refresh_embedding_cache(self, model: str, device: int, full: bool = False) -> dict:
+        """Rows of resident keys are taken again from the host tier — by default only those that can differ (tables reloaded or
+        keys updated since the cache last looked); full=True: every resident row, as the reference does.  Returns what it did."""
+        st = RefreshStats()
+        _check(LIB.hps_server_refresh_embedding_cache_ex(self._h, model.encode(), device, 1 if full else 0, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in RefreshStats._fields_}
 
     def get_embedding_cache(self, model: str, device: int):
         h = C.c_void_p()

@@ -124,6 +124,19 @@ int hps_server_create_embedding_cache_per_model(hps_server_t* server, const char
 int hps_server_destroy_embedding_cache_per_model(hps_server_t* server, const char* model);
 /* refresh_embedding_cache(model, device)                                     src/model_state.cpp:135,160 */
 int hps_server_refresh_embedding_cache(hps_server_t* server, const char* model, int32_t device);
+/* The same with a choice and an account of what it did.  By default a refresh re-reads only rows that CAN differ from the host
+ * tier's: nothing for a table that was neither reloaded nor updated since the cache last looked, the resident ones among the
+ * updated keys otherwise (ps.json "gpucache_refresh_changed_only": false, or full != 0 here: every resident row of every table,
+ * as the reference does: docs/hierarchical_parameter_server.md:234-238).  While lookup sessions are serving, the upload takes
+ * "gpucache_refresh_link_share" (default 0.15) of the link and of the cache's writer windows, in pieces of 32,768 rows. */
+typedef struct hps_refresh_stats {
+  uint64_t tables, tables_unchanged, tables_full;   /* tables looked at / skipped as unchanged / refreshed row by row in full */
+  uint64_t keys_dumped;                             /* resident keys read back from the GPU for the full passes */
+  uint64_t keys_changed;                            /* change-log entries examined */
+  uint64_t rows_refreshed, row_bytes;               /* rows re-read from the parameter server and uploaded, their bytes */
+  double seconds;
+} hps_refresh_stats_t;
+int hps_server_refresh_embedding_cache_ex(hps_server_t* server, const char* model, int32_t device, int32_t full, hps_refresh_stats_t* out);
 /* get_embedding_cache(model, device): *out = NULL (and HPS_OK) when there is none (unknown model, or a GPU-cache model
  * without a cache on that device), like the reference's nullptr.  A model that runs without GPU cache gets a handle too —
  * the reference hands out a cache object with use_gpu_embedding_cache = false there — so that the shell's

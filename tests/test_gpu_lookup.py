@@ -278,6 +278,132 @@ def test_refresh_drops_keys_that_left_the_parameter_server():
     assert (out2.reshape(600, 16)[100:300] == 9.0).all()
 
 
+def test_refresh_takes_only_rows_that_can_differ():
+    """refresh_embedding_cache (docs/hierarchical_parameter_server.md:234-238; model_state.cpp:125-178 runs it on a timer next to
+    the lookups) re-uploaded the WHOLE cache — 26.6 GB for config 2 — whether or not a row had changed.  Now: a table that was neither
+    reloaded nor updated since the cache last looked costs nothing; an updated one its changed keys that are resident (each change
+    replayed by two consecutive refreshes); a reloaded one a full pass; full=True and ps.json gpucache_refresh_changed_only=false
+    give the reference's behaviour."""
+    from oracle import hps_oracle as O
+    tables = make_tables([(6000, 16), (4000, 8), (3000, 4)], seed=91)
+    ps, cache, s = _mk("rf", tables, maxcat=[1, 1, 1], gpucacheper=0.5, max_batch=4096)
+    T = 3
+    resident = [k[cache.query(t, k) >= 0] for t, (k, _) in enumerate(tables)]
+    cold = [k[cache.query(t, k) < 0] for t, (k, _) in enumerate(tables)]
+    assert all(r.size > 500 for r in resident) and all(c.size > 500 for c in cold)
+    # (1) nothing changed: nothing moves
+    st = ps.refresh_embedding_cache("rf", 0)
+    assert (st["tables"], st["tables_unchanged"], st["tables_full"]) == (T, T, 0), st
+    assert st["row_bytes"] == 0 and st["keys_dumped"] == 0 and st["rows_refreshed"] == 0
+    # (2) an online update of 300 resident + 200 cold keys of table 1: exactly the 300 go up, and the lookups see the new rows
+    upd = np.concatenate([resident[1][:300], cold[1][:200]])
+    new_rows = np.full((upd.size, 8), 5.5, np.float32)
+    ps.upsert("rf", 1, upd, new_rows)
+    st = ps.refresh_embedding_cache("rf", 0)
+    assert (st["tables_unchanged"], st["tables_full"]) == (2, 0) and st["keys_changed"] == 500
+    assert st["rows_refreshed"] == 300 and st["row_bytes"] >= 300 * 8 * 4 and st["row_bytes"] < 300 * 8 * 4 + 64
+    before = cache.counters()["misses"]
+    out = s.lookup(np.concatenate([tables[0][0][:0], resident[1][:300], tables[2][0][:0]]).astype(np.int64), [0, 300, 0]).cpu().numpy()
+    assert np.all(out == 5.5) and cache.counters()["misses"] == before            # served from the cache, new rows
+    assert (cache.query(1, cold[1][:200]) < 0).all()                              # an update is not a request: cold keys stay out
+    # ... replayed once more by the next refresh (the race with a lookup that fetched the old row just before the update), then done
+    st = ps.refresh_embedding_cache("rf", 0)
+    assert st["rows_refreshed"] == 300 and st["tables_unchanged"] == 2
+    st = ps.refresh_embedding_cache("rf", 0)
+    assert st["rows_refreshed"] == 0 and st["tables_unchanged"] == 3
+    # (3) a reloaded table takes a full pass, the others nothing
+    k2, r2 = tables[2]
+    ps.load_table_arrays("rf", 2, k2, (r2 + 1.0).astype(np.float32))
+    n_res2 = int((cache.query(2, k2) >= 0).sum())
+    st = ps.refresh_embedding_cache("rf", 0)
+    assert (st["tables_unchanged"], st["tables_full"]) == (2, 1) and st["keys_dumped"] == n_res2 and st["rows_refreshed"] == n_res2
+    q = np.concatenate([resident[2][:256]]).astype(np.int64)
+    out = s.lookup(q, [0, 0, 256]).cpu().numpy()
+    ref = O.np_lookup([tables[0], tables[1], (k2, (r2 + 1.0).astype(np.float32))], q, [0, 0, 256], [0.0] * 3)
+    assert np.array_equal(_bits(out), _bits(ref))
+    st = ps.refresh_embedding_cache("rf", 0)
+    assert st["tables_unchanged"] == 3 and st["row_bytes"] == 0
+    # (4) full=True: every resident row of every table, as the reference does
+    n_res = [int((cache.query(t, k) >= 0).sum()) for t, (k, _) in enumerate(tables)]
+    st = ps.refresh_embedding_cache("rf", 0, full=True)
+    assert st["tables_full"] == 3 and st["rows_refreshed"] == sum(n_res) == st["keys_dumped"]
+    assert st["row_bytes"] >= n_res[0] * 64 + n_res[1] * 32 + n_res[2] * 16
+    s.close()
+    ps.close()
+    # (5) ps.json gpucache_refresh_changed_only = false: every refresh is a full one
+    ps, cache, s = _mk("rf2", tables[:1], maxcat=[1], gpucacheper=0.5, max_batch=4096, extra={"gpucache_refresh_changed_only": False})
+    st = ps.refresh_embedding_cache("rf2", 0)
+    assert st["tables_full"] == 1 and st["rows_refreshed"] == int((cache.query(0, tables[0][0]) >= 0).sum()) > 0
+    s.close()
+
+
+def test_lookups_are_served_exactly_while_a_full_refresh_runs():
+    """Two sessions keep calling while a thread loops FULL refreshes (paced pieces, gpucache_refresh_link_share) and another one
+    upserts rows: every returned row is the table's row before or after the update of its key — never torn, never another key's."""
+    import threading
+    tables = make_tables([(60000, 32), (40000, 16)], seed=92)
+    ps, cache, s0 = _mk("rfl", tables, maxcat=[1, 1], gpucacheper=0.4, max_batch=20000)
+    from hugectr_backend_amd import hps
+    s1 = hps.LookupSession.create(ps, "rfl", cache)
+    stop = threading.Event()
+    errs, passes = [], [0]
+    base = [r.copy() for _, r in tables]
+
+    def refresher():
+        try:
+            while not stop.is_set():
+                st = ps.refresh_embedding_cache("rfl", 0, full=True)
+                assert st["tables_full"] == 2 and st["rows_refreshed"] > 0
+                passes[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    def updater():
+        rng = np.random.default_rng(3)
+        try:
+            v = 1
+            while not stop.is_set():
+                for t, (k, _) in enumerate(tables):
+                    idx = rng.integers(0, k.size, 200)
+                    rows = base[t][idx] + np.float32(v)          # version v of a row = base + v (every element)
+                    ps.upsert("rfl", t, k[idx], rows.astype(np.float32))
+                v += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    def looker(sess, seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for it in range(60):
+                nk = [15000, 9000]
+                idx = [rng.integers(0, tables[t][0].size, nk[t]) for t in range(2)]
+                q = np.concatenate([tables[t][0][idx[t]] for t in range(2)]).astype(np.int64)
+                out = sess.lookup(q, nk).cpu().numpy()
+                off = 0
+                for t, D in enumerate((32, 16)):
+                    got = out[off:off + nk[t] * D].reshape(nk[t], D)
+                    off += nk[t] * D
+                    delta = got - base[t][idx[t]]
+                    # one version per row: every element of a row differs from the base by the same whole number >= 0
+                    d0 = delta[:, :1]
+                    if not (np.all(delta == d0) and np.all(d0 >= 0) and np.all(d0 == np.round(d0))):
+                        errs.append(f"session {seed} call {it} table {t}: a torn or foreign row")
+                        return
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=refresher), threading.Thread(target=updater), threading.Thread(target=looker, args=(s0, 1)),
+          threading.Thread(target=looker, args=(s1, 2))]
+    [t.start() for t in th]
+    [t.join() for t in th[2:]]
+    stop.set()
+    [t.join() for t in th[:2]]
+    assert not errs, errs[:3]
+    assert passes[0] >= 1
+    s0.close()
+    s1.close()
+
+
 def test_call_counter_wrap(monkeypatch):
     """The recency unit travels in 24 bits of a call's time token and wraps freely (the stamps in the bucket lines are the
     unit modulo 255 and repeat one value at the wrap); results stay exact and insertion keeps working across it.  Call clock,
