@@ -380,6 +380,7 @@ int hps_cache_num_tables(hps_cache_t* c) {
 }
 
 int hps_cache_on_device(hps_cache_t* c) { return c && c->cache ? 1 : 0; }
+uint64_t hps_cache_refresh_rows_uploaded(hps_cache_t* c) { return c && c->cache ? c->cache->refresh_rows_uploaded() : 0; }
 
 int hps_pool_numa_node(void) { return ThreadPool::NumaNode(); }
 uint64_t hps_pool_fast_overruns(void) { return ThreadPool::FastOverruns(); }
@@ -494,6 +495,9 @@ int hps_session_last_stats(hps_session_t* s, hps_lookup_stats_t* out) {
     out->key_bytes = s->s->last_key_bytes();
     out->scatter_ms = s->s->last_scatter_ms();
     out->insert_ms = s->s->last_insert_ms();
+    out->miss_much_mode = s->s->miss_much_mode() ? 1 : 0;
+    out->interact_separate = s->s->last_interact_separate() ? 1 : 0;
+    out->mode_flips = s->s->mode_flips();
     return Status::Ok();
   });
 }
@@ -513,6 +517,9 @@ int hps_session_set_option(hps_session_t* s, const char* name, int value) {
       s->s->set_fused_unique(value != 0);
     } else if (n == "narrow_publish") {
       s->s->set_narrow_publish(value != 0);
+    } else if (n == "interact_mode") {
+      if (value < 0 || value > 2) return Error(Code::kInvalidArg, "interact_mode must be 0 (separate steps), 1 (fused) or 2 (by the session's miss volume)");
+      s->s->set_interact_mode(value);
     } else if (n == "keys_by_kernel") {
       s->s->set_keys_by_kernel(value);
     } else if (n == "probe_in_lane") {
@@ -705,6 +712,7 @@ int hps_shard_entry_last_stats(hps_shard_entry_t* e, hps_shard_entry_stats_t* ou
     out->dedup_level = (uint32_t)st.dedup_level;
     out->transport = (uint32_t)st.transport;
     out->copied_bytes = st.copied_bytes;
+    out->dedup_flips = st.dedup_flips;
     for (uint32_t s = 0; s < e->s->num_shards() && s < 64; ++s) {
       out->sent[s] = st.sent[s]; out->passes[s] = st.passes[s]; out->shard_ms[s] = st.shard_ms[s];
       out->copy_wait_ms[s] = st.copy_wait_ms[s];

@@ -621,6 +621,7 @@ std::atomic<int> g_side_hi[kMaxSideDevices];   // sessions with a high-priority 
 LookupSession::~LookupSession() { Release(); }
 
 void LookupSession::Release() {
+  if (d_interact_emb_) { (void)hipSetDevice(device_); (void)hipFree(d_interact_emb_); d_interact_emb_ = nullptr; interact_emb_floats_ = 0; }
   if (!cache_) return;
   (void)hipSetDevice(device_);
   cache_->UnregisterSession(this);
@@ -954,7 +955,7 @@ Status LookupSession::lookup(const void* const* h_keys_per_table, float* const* 
     // round — nothing is on the link, and a kernel would wait for CUs behind the other session's gather (every key resident
     // 6.35 -> 5.4 G lookups/s): copies.  Same bound as the second-stream scatter and the probe's place in the lane.
     // (HPS_ZC_CONTROL=0 — no kernel of this library reads or writes host memory — keeps the copies)
-    const bool pull_keys = zc_control_ && h_keys_dev_ && (keys_by_kernel_ == 1 || (keys_by_kernel_ == 2 && last_miss_row_bytes_ > side_bytes_));
+    const bool pull_keys = zc_control_ && h_keys_dev_ && (keys_by_kernel_ == 1 || (keys_by_kernel_ == 2 && miss_much_.high));
     uint64_t seen = 0;
     auto stage = [&](int width) -> Status {
       std::atomic<uint64_t> high_or{0};
@@ -1239,6 +1240,7 @@ Status LookupSession::ReadBackCounts(size_t T, uint64_t N, bool exact) {
   }
   last_misses_ = misses;
   last_miss_row_bytes_ = row_bytes;
+  miss_much_.Update(row_bytes, side_bytes_);
   last_unique_ = uniq;
   last_unique_keys_ = uniq_keys;
   cache_->AdvanceClock(uniq);
@@ -1314,7 +1316,7 @@ Status LookupSession::LookupDevice(const int64_t* d_keys_flat, float* const* d_o
   // 99 % hit the call's chain is 0.73 instead of 0.81 ms and two sessions deliver 4.3 instead of 3.6-3.9 G lookups/s, every key
   // resident 6.0-6.2 instead of 5.6-5.8 G (profiles/round5/ab_probe_outside_the_lane.txt).  Calls that miss more (the
   // headline's 37 MB) are bound by PCIe either way and keep the probe in the lane, where it runs in 42 us instead of 50.
-  const bool probe_lane = exclusive_ && (probe_in_lane_ == 1 || (probe_in_lane_ == 2 && last_miss_row_bytes_ > side_bytes_));
+  const bool probe_lane = exclusive_ && (probe_in_lane_ == 1 || (probe_in_lane_ == 2 && miss_much_.high));
   if (probe_lane) cache_->LaneEnter(stream_);
   Mark(ev_t0_);
   const bool tail = fused_unique_ && ProbeTailAvailable(probe_variant_);
@@ -1510,6 +1512,37 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
   direct_lock = std::shared_lock<std::shared_mutex>(cache_->direct_mutex());
 
   std::vector<size_t> n(T, (size_t)batch);
+  // Which arrangement serves this call (session option "interact_mode"): the FUSED one below — probe, fetch, interaction reading
+  // cache slots and staged rows, OUTPUT0 never written — or the SEPARATE steps: an ordinary lookup into a buffer of the session's
+  // own, then the dense step's two kernels.  Fused saves the 2 x N x 4D bytes of OUTPUT0 (all keys resident: 0.34 against 0.56 ms
+  // per step) but keeps the cache read-locked from the probe to the interaction and fetches the misses before anything is
+  // gathered; while calls miss much the separate steps overlap the fetch with the hit gather (HandleMissesDirect's split) and come
+  // out ahead.  Adaptive (the default): separate while the last call's missed rows exceeded side_scatter_mb — the bound the other
+  // per-call switches use.
+  const bool separate = interact_mode_ == 0 || (interact_mode_ == 2 && miss_much_.high);
+  last_interact_separate_ = separate;
+  if (separate) {
+    direct_lock.unlock();   // (LookupDevice takes it itself)
+    const size_t D = dense->emb_dim();
+    if (interact_emb_floats_ < N * D) {
+      if (d_interact_emb_) HIP_TRY(hipFree(d_interact_emb_));
+      d_interact_emb_ = nullptr;
+      interact_emb_floats_ = 0;
+      const size_t want = std::max<size_t>(N * D, max_keys_ * D);
+      if (hipMalloc((void**)&d_interact_emb_, want * sizeof(float)) != hipSuccess)
+        return Error(Code::kInternal, "lookup_interact: out of device memory for the embedding buffer of the separate arrangement (", want * sizeof(float), " bytes)");
+      interact_emb_floats_ = want;
+    }
+    std::vector<float*> outs(T);
+    for (size_t t = 0; t < T; ++t) outs[t] = d_interact_emb_ + t * batch * D;
+    key_stage_ms_ = 0.f;
+    keys_narrow_ = false;
+    key_bytes_ = 8;
+    HPS_RETURN_IF_ERROR(TimedLookupDevice(d_keys_flat, outs.data(), n.data(), T));
+    HPS_RETURN_IF_ERROR(dense->Forward(d_dense_features, d_interact_emb_, batch, d_out_f16, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return Status::Ok();
+  }
   uint64_t N2 = 0;
   HPS_RETURN_IF_ERROR(PrepareCall(d_keys_flat, nullptr, n.data(), T, /*probe_only=*/true, &N2));
   const uint32_t epoch = h_call_->epoch;
@@ -1544,26 +1577,49 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
   if (e != hipSuccess) return Error(Code::kInternal, "lookup_interact launch failed: ", hipGetErrorString(e));
   last_async_ = false;
   table_async_.assign(T, 0);
-  // insert the missed rows (writer window = the insert kernel alone, as in HandleMissesDirect)
+  // The output is complete behind this point of the stream: that is what the caller waits for.  The insert of the missed rows
+  // is enqueued behind it and left running (defer_insert_, as in HandleMissesDirect): later readers of the cache are ordered
+  // behind it by the writer event, its statistics are read at the session's next call (round 5 waited for it here: 35 us of
+  // kernel + a writer window on the return path of every call that missed — 0.990 against 0.941 ms for the separate steps).
+  const bool defer = defer_insert_ && zc_control_;
+  uint32_t rows_seq = 0;
+  if (defer) {
+    if (timing_) (void)hipEventRecord(ev_c1_, stream_);
+    HPS_RETURN_IF_ERROR(PushWords((uint32_t)acc_words_, ev_done_, &rows_seq));
+  }
+  // (writer window = the insert kernel alone, as in HandleMissesDirect: the stream is drained before other sessions are made to wait)
   {
     const uint64_t est_bytes = (uint64_t)last_unique_ * dense->emb_dim() * sizeof(float);
     if (est_bytes > (2u << 20)) HIP_TRY(hipStreamSynchronize(stream_));
   }
   cache_->BeginWrite(stream_);
+  Mark(ev_i0_);
   e = LaunchCacheInsert(cache_->device_tables(), (uint32_t)T, d_md_, N, d_call_->key_start, w.uniq_keys, d_staging_, d_found_,
-                        cache_->InsertStamps(epoch), d_acc_, cu, stream_);
+                        cache_->InsertStamps(epoch), d_acc_, cu, stream_, Kt(ev_i0_, ev_i1_));
+  Mark(ev_i1_);
   cache_->EndWrite(stream_);
   if (e != hipSuccess) return Error(Code::kInternal, "cache insert launch failed: ", hipGetErrorString(e));
-  if (timing_) (void)hipEventRecord(ev_c1_, stream_);
-  HPS_RETURN_IF_ERROR(PushWords((uint32_t)acc_words_));
-  HPS_RETURN_IF_ERROR(WaitPushed());
+  if (defer) {
+    {
+      std::lock_guard<std::mutex> lk(deferred_mu_);
+      const Status ps2 = PushWords((uint32_t)kStatLines * kAccStride, ev_done2_, &deferred_seq_);
+      if (!ps2.ok()) return ps2;
+      deferred_pending_ = true;
+      deferred_timed_ = timing_;
+    }
+    HPS_RETURN_IF_ERROR(WaitPushedSeq(rows_seq, ev_done_));
+  } else {
+    if (timing_) (void)hipEventRecord(ev_c1_, stream_);
+    HPS_RETURN_IF_ERROR(PushWords((uint32_t)acc_words_));
+    HPS_RETURN_IF_ERROR(WaitPushed());
+  }
   if (timing_) {
     (void)hipEventElapsedTime(&last_gpu_ms_, ev_t0_, ev_t1_);
     (void)hipEventElapsedTime(&phase_ms_[1], ev_f0_, ev_f1_);
     (void)hipEventElapsedTime(&last_gpu_call_ms_, ev_t0_, ev_c1_);
   }
   HPS_RETURN_IF_ERROR(ReadBackCounts(T, N, false));
-  AddInsertStats();
+  if (!defer) AddInsertStats();
   return Status::Ok();
 }
 

@@ -92,7 +92,9 @@ class EmbeddingCache {
   struct InsertPacing { size_t piece_keys = 0; double link_share = 1.0; size_t max_threads = 0; };
   Status InsertKeys(HierParameterServer* ps, const std::vector<std::vector<int64_t>>& keys_per_table, const InsertPacing* pacing = nullptr,
                     uint64_t* row_bytes = nullptr);
-  uint64_t calls_so_far() const { return calls_.load(std::memory_order_relaxed); }   // lookup calls of all sessions (the refresh paces itself by it)
+  uint64_t calls_so_far() const { return calls_.load(std::memory_order_relaxed); }
+  // rows a refresh has uploaded so far, live (piece by piece; CacheCounters::refreshed moves only at the end of a slice)
+  uint64_t refresh_rows_uploaded() const { return refresh_rows_.load(std::memory_order_relaxed); }   // lookup calls of all sessions (the refresh paces itself by it)
   // blocks until every queued async insertion has finished
   void WaitAsync();
 
@@ -104,6 +106,7 @@ class EmbeddingCache {
   // positions in its change log as of the warm-up / the last two refreshes (HostTable::ChangeMark)
   std::mutex refresh_mu_;
   std::vector<uint64_t> seen_epoch_, seen_prev_, seen_last_;
+  std::atomic<uint64_t> refresh_rows_{0};
   // shard >= 0: this cache is shard `shard` of `num_shards` of a table-sharded model (ps.json "table_sharding": "hash"): it
   // is sized for, warmed with and only ever asked for the keys with mix64(key) mod num_shards == shard
   Status Init(const std::string& model, const InferenceParams& p, const std::vector<std::shared_ptr<HostTable>>& tables,
@@ -300,6 +303,8 @@ class LookupSession {
   void set_chain_gather(bool b) { chain_gather_ = b; }
   void set_probe_in_lane(int v) { probe_in_lane_ = v; }
   void set_keys_by_kernel(int v) { keys_by_kernel_ = v; }
+  void set_interact_mode(int v) { interact_mode_ = v; }        // lookup_interact: 0 separate steps, 1 fused, 2 by the last call's missed rows
+  bool last_interact_separate() const { return last_interact_separate_; }
   void set_narrow_publish(bool b) { narrow_publish_ = b; }
   void set_exclusive_kernels(bool b) { exclusive_ = b; }
   void set_fused_unique(bool b) { fused_unique_ = b; }
@@ -439,6 +444,11 @@ class LookupSession {
   bool direct_split_ = true;     // device-driven tier: the fetch kernel runs next to the call's own hit gather (round 3: +4 %)
   bool narrow_publish_ = true;   // a narrowed request's unique missed keys come back to the host as uint32 (option "narrow_publish")
   bool uniq_narrow_ = false;     // this call: h_uniq_keys_ holds uint32 keys
+  int interact_mode_ = 2;         // option "interact_mode" (lookup_interact): 0 = lookup into a buffer of the session + the dense step, 1 = the fused
+                                 // arrangement, 2 (default) = separate while the session's calls miss much (last call's missed rows > side_bytes_)
+  bool last_interact_separate_ = false;
+  float* d_interact_emb_ = nullptr;      // OUTPUT0 of the separate arrangement (allocated at its first use)
+  size_t interact_emb_floats_ = 0;
   int keys_by_kernel_ = 2;       // option "keys_by_kernel": staged keys are pulled into HBM by a kernel instead of copy-engine copies:
                                  // 0 never, 1 always, 2 (default) while the session's calls miss much (last call's missed rows > side_bytes_)
   int probe_in_lane_ = 2;        // option "probe_in_lane": 1 = K_P takes its turn in the kernel lane, 0 = it runs next to another session's
@@ -462,6 +472,29 @@ class LookupSession {
   void AddInsertStats();
 
   uint64_t last_misses_ = 0, last_unique_ = 0, last_unique_keys_ = 0, last_miss_row_bytes_ = 0;
+  // "This session's calls miss much": what the per-call switches steer by (keys_by_kernel 2, probe_in_lane 2, interact_mode 2).
+  // Round 5 compared the LAST call's missed rows with side_bytes_ on every call — traffic that sits on that bound flipped the
+  // arrangement call by call, and two sessions doing so in opposite phase was exactly the kind of stable bad mode the 20-ms
+  // blocks were.  Now a switch with hysteresis: up when a call's missed rows exceed the bound, down only when they fall below
+  // three quarters of it, and never sooner than kDwell calls after the last change.
+  struct MissMuch {
+    static constexpr uint32_t kDwell = 8;
+    bool high = false;
+    uint32_t since = kDwell;     // calls since the last change
+    uint64_t flips = 0;
+    void Update(uint64_t bytes, uint64_t bound) {
+      if (since < kDwell) { ++since; return; }
+      const bool want = high ? bytes * 4 >= bound * 3 : bytes > bound;
+      if (want != high) { high = want; since = 0; ++flips; }
+    }
+  };
+  MissMuch miss_much_;
+
+ public:
+  bool miss_much_mode() const { return miss_much_.high; }
+  uint64_t mode_flips() const { return miss_much_.flips; }
+
+ private:
   bool last_async_ = false;
   float last_gpu_ms_ = 0.f;
   float phase_ms_[4] = {0, 0, 0, 0};

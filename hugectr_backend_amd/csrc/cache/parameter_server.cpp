@@ -129,6 +129,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
     if (uq == 0) break;
     HPS_RETURN_IF_ERROR(ps->FetchMulti(jobs, pacing ? pacing->max_threads : 0));
     if (row_bytes) *row_bytes += fl * sizeof(float);
+    if (pacing) refresh_rows_.fetch_add(uq, std::memory_order_relaxed);
     HIP_TRY(hipMemcpyAsync(I.d_md, I.h_md, sizeof(MissDesc), hipMemcpyHostToDevice, I.stream));
     HIP_TRY(hipMemcpyAsync(I.d_ks, I.h_ks, sizeof(uint64_t) * (T + 1), hipMemcpyHostToDevice, I.stream));
     HIP_TRY(hipMemcpyAsync(I.d_keys, I.h_keys, uq * sizeof(int64_t), hipMemcpyHostToDevice, I.stream));

@@ -581,8 +581,15 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
   stats_.unique_keys = base[P_];
   if (dedup_ == 1) {
     constexpr uint64_t kAdaptiveMinKeys = 1u << 16;
-    if (level == 2 && N >= kAdaptiveMinKeys && stats_.unique_keys * 10 > N * 9) tile_only_left_ = 31;
-    else if (level == 1) tile_only_left_ = (stats_.unique_keys * 10 < N * 8) ? 0 : tile_only_left_ - 1;
+    // (back to both levels at once — the safe direction —, but then for at least 8 requests: traffic that alternates between the
+    //  two bounds, one request repeating little, the next much, would otherwise change the arrangement with every request)
+    if (level_hold_ > 0) --level_hold_;
+    if (level == 2 && N >= kAdaptiveMinKeys && stats_.unique_keys * 10 > N * 9 && level_hold_ == 0) { tile_only_left_ = 31; ++stats_.dedup_flips; }
+    else if (level == 1) {
+      const bool back = stats_.unique_keys * 10 < N * 8;
+      tile_only_left_ = back ? 0 : tile_only_left_ - 1;
+      if (tile_only_left_ == 0) { ++stats_.dedup_flips; if (back) level_hold_ = 8; }
+    }
   }
 
   // ---- every owner looks its bucket up, all of them side by side; rows land in d_out over the peer mappings (peer_store) or

@@ -70,6 +70,7 @@ struct ShardEntryStats {
   float key_stage_ms = 0.f;      // host keys: staging + upload enqueue
   int key_bytes = 8;             // bytes per key that crossed PCIe: 8, 4 (uint32 offsets) or 3 (packed)
   uint64_t misses = 0, unique_misses = 0;   // summed over the shards' lookups
+  uint64_t dedup_flips = 0;      // adaptive dedup: changes of level since the session was created
   int transport = 0;             // 0 peer_store, 1 staged_copy
   uint64_t copied_bytes = 0;     // staged_copy: row bytes the copy engines shipped into the entry GPU
   std::vector<float> copy_wait_ms;   // staged_copy: time each shard's worker spent waiting for its copies to land
@@ -96,7 +97,7 @@ class ShardedEntrySession {
   size_t max_keys() const { return max_keys_; }
   size_t shard_capacity() const { return shard_cap_; }
   LookupSession* shard_session(uint32_t s) { return s < sessions_.size() ? sessions_[s].get() : nullptr; }
-  void set_dedup(int level) { dedup_ = level; tile_only_left_ = 0; }   // 0 off, 1 adaptive (default), 2 always both levels
+  void set_dedup(int level) { dedup_ = level; tile_only_left_ = 0; level_hold_ = 0; }   // 0 off, 1 adaptive (default), 2 always both levels
   // 0 peer_store, 1 staged_copy; peer_store is refused when a shard's device cannot store into the entry device
   Status set_transport(int transport);
   int transport() const { return transport_; }
@@ -158,6 +159,7 @@ class ShardedEntrySession {
   size_t max_keys_ = 0, max_tiles_ = 0, shard_cap_ = 0;
   int dedup_ = 1;
   uint32_t tile_only_left_ = 0;    // adaptive dedup: requests left that skip the call-wide level
+  uint32_t level_hold_ = 0;        // ... requests left before the level may change again
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_[2] = {nullptr, nullptr};
   std::vector<std::unique_ptr<LookupSession>> sessions_;   // one per shard, on the shard's device

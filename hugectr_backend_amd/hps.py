@@ -75,7 +75,8 @@ class LookupStats(C.Structure):
     _fields_ = [("misses", C.c_uint64), ("unique_misses", C.c_uint64), ("async_insert", C.c_int32),
                 ("probe_gather_ms", C.c_float), ("phase_ms", C.c_float * 4), ("gpu_call_ms", C.c_float),
                 ("hit_gather_ms", C.c_float), ("unique_keys", C.c_uint64), ("key_stage_ms", C.c_float),
-                ("scatter_ms", C.c_float), ("insert_ms", C.c_float), ("keys_narrowed", C.c_int32), ("key_bytes", C.c_int32)]
+                ("scatter_ms", C.c_float), ("insert_ms", C.c_float), ("keys_narrowed", C.c_int32), ("key_bytes", C.c_int32),
+                ("miss_much_mode", C.c_int32), ("interact_separate", C.c_int32), ("mode_flips", C.c_uint64)]
 
 
 class RefreshStats(C.Structure):
@@ -88,7 +89,7 @@ class ShardEntryStats(C.Structure):
                 ("bucket_ms", C.c_float), ("lookup_ms", C.c_float), ("expand_ms", C.c_float), ("key_stage_ms", C.c_float),
                 ("num_shards", C.c_uint32), ("key_bytes", C.c_uint32), ("sent", C.c_uint64 * 64), ("passes", C.c_uint32 * 64),
                 ("shard_ms", C.c_float * 64), ("dedup_level", C.c_uint32), ("transport", C.c_uint32), ("copied_bytes", C.c_uint64),
-                ("copy_wait_ms", C.c_float * 64)]
+                ("copy_wait_ms", C.c_float * 64), ("dedup_flips", C.c_uint64)]
 
 
 def _load() -> C.CDLL:
@@ -127,6 +128,7 @@ def _load() -> C.CDLL:
         "hps_server_host_tier_keys": (C.c_int, [P, cp, u32, P, u64, C.POINTER(u64)]),
         "hps_cache_num_tables": (C.c_int, [P]),
         "hps_cache_on_device": (C.c_int, [P]),
+        "hps_cache_refresh_rows_uploaded": (u64, [P]),
         "hps_wake_copy_engines": (C.c_int, [C.c_int, C.c_char_p, u64]),
         "hps_pool_numa_node": (C.c_int, []),
         "hps_pool_fast_overruns": (u64, []),
@@ -195,7 +197,7 @@ EXPORTED_SYMBOLS = [
     "hps_server_refresh_embedding_cache", "hps_server_refresh_embedding_cache_ex", "hps_server_get_embedding_cache", "hps_server_load_table_arrays",
     "hps_server_load_table_synthetic", "hps_server_load_table_synthetic_shard", "hps_server_fetch", "hps_server_upsert",
     "hps_server_table_data", "hps_update_message_encode", "hps_server_update_source_stats", "hps_server_update_source_drain", "hps_server_update_source_stop", "hps_server_update_source_filtered",
-    "hps_cache_on_device", "hps_wake_copy_engines", "hps_pool_numa_node", "hps_pool_fast_overruns", "hps_bind_calling_thread", "hps_session_create_from_cache",
+    "hps_cache_on_device", "hps_cache_refresh_rows_uploaded", "hps_wake_copy_engines", "hps_pool_numa_node", "hps_pool_fast_overruns", "hps_bind_calling_thread", "hps_session_create_from_cache",
     "hps_shard_unique_id", "hps_shard_session_create", "hps_shard_group_create_local", "hps_shard_group_destroy",
     "hps_shard_session_create_local", "hps_shard_session_lookup", "hps_shard_session_lookup_host", "hps_shard_session_last_timing",
     "hps_shard_session_last_stats", "hps_shard_session_destroy",
@@ -283,6 +285,10 @@ class EmbeddingCache:
         c = CacheCounters()
         _check(LIB.hps_cache_counters(self._h, C.byref(c)))
         return c.as_dict()
+
+    def refresh_rows_uploaded(self) -> int:
+        """Rows the refreshes of this cache have uploaded so far (live, piece by piece)."""
+        return int(LIB.hps_cache_refresh_rows_uploaded(self._h))
 
     def query(self, table: int, keys) -> np.ndarray:
         keys = np.ascontiguousarray(keys, dtype=np.int64)

@@ -91,6 +91,13 @@ typedef struct hps_lookup_stats {
   float insert_ms;         /* HIP-event time of the cache-insert kernel (option "timing"=1; last staging chunk) */
   int32_t keys_narrowed;   /* 1: the call's pageable keys all fitted 32 bits and crossed PCIe narrower than 8 bytes */
   int32_t key_bytes;       /* bytes per key that crossed PCIe in the last host-keys call: 8, 4 (uint32) or 3 (packed, keys < 2^24) */
+  /* What the session's per-call switches steer by ("keys_by_kernel" 2, "probe_in_lane" 2, "interact_mode" 2): 1 while the
+   * session's calls MISS MUCH.  A switch with hysteresis — up when a call's missed rows exceed side_scatter_mb, down when they
+   * fall below three quarters of it, never sooner than 8 calls after the last change — so that traffic sitting on the bound does
+   * not flip the arrangement call by call.  mode_flips: changes since the session was created. */
+  int32_t miss_much_mode;
+  int32_t interact_separate;   /* last hps_session_lookup_interact_device call: 1 = served as lookup + dense step, 0 = fused */
+  uint64_t mode_flips;
 } hps_lookup_stats_t;
 
 const char* hps_last_error(void);
@@ -218,6 +225,9 @@ int hps_cache_num_tables(hps_cache_t* cache);
 int hps_cache_on_device(hps_cache_t* cache);
 int hps_cache_table_info(hps_cache_t* cache, uint32_t table, hps_cache_table_info_t* out);
 int hps_cache_counters(hps_cache_t* cache, hps_cache_counters_t* out);
+/* rows the refreshes of this cache have uploaded so far — live, piece by piece (hps_cache_counters' `refreshed` moves only when a
+ * slice of cache_refresh_percentage_per_iteration is through): what a monitor divides by time for the refresh rate */
+uint64_t hps_cache_refresh_rows_uploaded(hps_cache_t* cache);
 /* residency probe without side effects: slots[i] = slot index or -1 */
 int hps_cache_query(hps_cache_t* cache, uint32_t table, const int64_t* h_keys, uint64_t n, int32_t* h_slots);
 /* wait for queued async insertions */
@@ -283,7 +293,9 @@ int hps_session_last_stats(hps_session_t* session, hps_lookup_stats_t* out);
  * session's row copies, and go up as copy-engine copies otherwise; 1: always by kernel; 0: never),
  * "probe_in_lane" (default 2: the probe kernel runs next to another session's hit gather while this session's calls miss
  * little — last call's missed rows <= side_scatter_mb — and takes its turn in the kernel lane otherwise; 1: always in the
- * lane; 0: never) */
+ * lane; 0: never), "interact_mode" (hps_session_lookup_interact_device — default 2: the fused arrangement while the session's
+ * calls miss little, lookup into a buffer of the session + the dense step's kernels while they miss much; 1: always fused;
+ * 0: always the separate steps) */
 int hps_session_set_option(hps_session_t* session, const char* name, int value);
 
 /* ---- table sharding across GPUs (BASELINE config 3; not in the reference, which is replicas-only) ------------
@@ -369,6 +381,7 @@ typedef struct hps_shard_entry_stats {
   uint32_t transport;                  /* how the rows reached the entry GPU: 0 peer_store, 1 staged_copy */
   uint64_t copied_bytes;               /* staged_copy: row bytes the copy engines shipped into the entry GPU */
   float copy_wait_ms[64];              /* staged_copy: time each shard's worker waited for its copies to land */
+  uint64_t dedup_flips;                /* adaptive dedup: changes of level since the session was created (a level is kept for at least 8 requests) */
 } hps_shard_entry_stats_t;
 /* the cache of shard s of a table-sharded model (for residency queries, counters); *out = NULL when there is none */
 int hps_server_get_shard_cache(hps_server_t* server, const char* model, uint32_t shard, hps_cache_t** out);

@@ -86,7 +86,7 @@ def test_final_line_is_compact_and_round_trips():
     legs = back["legs"]
     for k in ("all_hit_2s_host_keys_Glps", "hit_999_2s_host_keys_Glps", "hit_99_2s_host_keys_Glps", "c1_triton_Mlps",
               "c4@0.5_p50_ms", "c4@0.9_p50_ms", "c4@0.99_p50_ms", "triton_abi_Glps", "triton_abi_p99_ms",
-              "triton_abi_slow_requests_ms", "wide_keys_95_8B_Glps", "device_driven_tier_Glps", "c5_dense_frac_of_hbm_peak",
+              "triton_abi_slow_requests", "wide_keys_95_8B_Glps", "device_driven_tier_Glps", "c5_dense_frac_of_hbm_peak",
               "c5_hit_95_fused_ms", "c3_logical_Glps"):
         assert k in legs, k
 

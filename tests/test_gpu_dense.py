@@ -176,6 +176,73 @@ def test_fused_lookup_interact_matches_unfused(T, D, B):
     assert cache.counters()["inserted"] > 0
 
 
+def test_lookup_interact_picks_the_arrangement_by_the_sessions_miss_volume():
+    """hps_session_lookup_interact_device serves a call either fused (probe, fetch, interaction reading cache slots and staged rows)
+    or as the separate steps (ordinary lookup into a buffer of the session, then the dense kernels) — session option
+    "interact_mode": 1 / 0 / 2 = by the session's miss volume (round 5: the fused call was slower than the separate steps at 95 % hit
+    and nothing selected between them).  All three give bit-identical f16 output; mode 2 runs fused while calls miss little,
+    separate once they miss much, and two sessions straddling the bound in opposite phase change mode at most once per 8 calls."""
+    import threading
+    import torch
+    from hugectr_backend_amd import hps
+    from hugectr_backend_amd.dense import DenseInteraction
+    T, D, B = 4, 64, 2048
+    tables, ps, cache, s0, op0, ws, bs, x = _fused_setup("fzmode", T, 40000, D, B, 1.0, seed=8)    # (every real key resident: only the absent ones miss)
+    s1 = hps.LookupSession.create(ps, "fzmode", cache)
+    op1 = DenseInteraction([w.cpu().numpy() for w in ws], [b.cpu().numpy() for b in bs], T, D)
+    rng = np.random.default_rng(4)
+
+    def request(missing):
+        parts = []
+        for t, (k, _) in enumerate(tables):
+            q = rng.choice(k, B).astype(np.int64)
+            pos = rng.choice(B, missing // T, replace=False)
+            q[pos] = -7 - rng.integers(0, 1 << 40, pos.size)                # keys that exist nowhere: unique misses, default rows
+            parts.append(q)
+        return torch.from_numpy(np.concatenate(parts)).cuda()
+
+    # (1) the three modes agree bit for bit, and say which arrangement ran
+    dq = request(400)
+    outs = {}
+    for mode in (1, 0, 2):
+        s0.set_option("interact_mode", mode)
+        outs[mode] = op0.lookup_interact(s0, dq, B, x)[:, : op0.out_dim].clone()
+        assert s0.last_stats().interact_separate == (1 if mode == 0 else 0), mode       # (mode 2: nothing missed much yet -> fused)
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[1], outs[2])
+    # (2) mode 2 on the bound: side_scatter_mb = 1 -> 4,096 rows of 256 bytes; calls alternate 1.2 x / 0.6 x that, opposite phase
+    bound_rows = (1 << 20) // (D * 4)
+    errs, final = [], [None, None]
+    calls = 120
+
+    def work(i, sess, op):
+        try:
+            sess.set_option("interact_mode", 2)
+            sess.set_option("side_scatter_mb", 1)
+            seen = set()
+            for c in range(calls):
+                dq_ = request(int(bound_rows * (1.2 if (c + i) % 2 == 0 else 0.6)))
+                got = op.lookup_interact(sess, dq_, B, x)[:, : op.out_dim]
+                st = sess.last_stats()
+                seen.add(int(st.interact_separate))
+                if c % 10 == 0:         # against the always-fused arrangement of the same call on the same session
+                    sess.set_option("interact_mode", 1)
+                    ref = op.lookup_interact(sess, dq_, B, x)[:, : op.out_dim]
+                    sess.set_option("interact_mode", 2)
+                    if not torch.equal(got, ref):
+                        errs.append((i, c))
+                        return
+            final[i] = (sess.last_stats().mode_flips, seen)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(0, s0, op0)), threading.Thread(target=work, args=(1, s1, op1))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[:3]
+    for flips, seen in final:
+        assert seen == {0, 1} and 2 <= flips <= (calls + calls // 10) // 8 + 1, (flips, seen)
+
+
 def test_fused_lookup_interact_two_sessions_and_guards():
     import threading
     import torch

@@ -407,6 +407,75 @@ def test_lookups_are_served_exactly_while_a_full_refresh_runs():
     s1.close()
 
 
+@pytest.mark.parametrize("direct", [False, True], ids=["host_gather", "ps_direct_access"])
+def test_per_call_switches_on_their_threshold_two_sessions_in_opposite_phase(direct):
+    """The per-call switches "keys_by_kernel" 2 and "probe_in_lane" 2 (and "interact_mode" 2, tests/test_gpu_dense.py) steer by
+    'this session's calls miss much'.  Round 5 compared the last call's missed rows with side_scatter_mb on every call: traffic on
+    the bound flipped the arrangement call by call.  Two sessions of one cache whose consecutive calls straddle the bound — missed
+    rows alternately 1.15 x and 0.65 x side_scatter_mb — in OPPOSITE phase for 240 calls each: rows exact, no call above three times
+    the median, and the mode (a switch with hysteresis and a dwell of 8 calls, hps_lookup_stats_t::mode_flips) changes at most once
+    per 8 calls."""
+    import threading
+    import torch
+    from hugectr_backend_amd import hps
+    T, R, D = 2, 200000, 64
+    tables = make_tables([(R, D)] * T, seed=61)
+    ps, cache, s0 = _mk(f"thr{int(direct)}", tables, maxcat=[1] * T, gpucacheper=1.0, max_batch=90000, defaults=[2.5, -1.0],
+                        extra={"ps_direct_access": direct})
+    s1 = hps.LookupSession.create(ps, f"thr{int(direct)}", cache)
+    bound_rows = (1 << 20) // (D * 4)                      # side_scatter_mb = 1: 4,096 rows of 256 bytes
+    nk = [85000, 85000]                                    # (a "big" request: its keys are staged in pieces by the pool)
+    rows_d = [torch.from_numpy(r).cuda() for _, r in tables]
+    dflt = [torch.full((D,), v, device="cuda") for v in (2.5, -1.0)]
+    calls = 240
+    errs, lat, final = [], [[], []], [None, None]
+
+    def work(i, sess):
+        try:
+            sess.set_option("side_scatter_mb", 1)
+            rng = np.random.default_rng(100 + i)
+            out = torch.empty(sum(nk) * D, dtype=torch.float32, device="cuda")
+            for c in range(calls):
+                miss = int(bound_rows * (1.15 if (c + i) % 2 == 0 else 0.65))
+                parts, idxs, absent = [], [], []
+                for t in range(T):
+                    idx = rng.integers(0, R, nk[t])
+                    q = tables[t][0][idx].astype(np.int64)
+                    m = miss // T
+                    pos = rng.choice(nk[t], m, replace=False)
+                    q[pos] = -10 - (np.arange(m, dtype=np.int64) + (c * 4 + t) * 100000)      # distinct keys that exist nowhere: m unique misses
+                    parts.append(q); idxs.append(idx); absent.append(pos)
+                q = np.concatenate(parts)
+                sess.lookup(q, nk, out=out)
+                st = sess.last_stats()
+                lat[i].append(float(st.phase_ms[3]) + float(st.key_stage_ms))                  # the call as the engine timed it
+                assert st.unique_misses == (miss // T) * T, (st.unique_misses, miss)
+                off = 0
+                for t in range(T):
+                    exp = rows_d[t][torch.from_numpy(idxs[t]).cuda()]
+                    exp[torch.from_numpy(absent[t]).cuda()] = dflt[t]
+                    got = out[off:off + nk[t] * D].view(nk[t], D)
+                    off += nk[t] * D
+                    if not torch.equal(got, exp):
+                        errs.append((i, c, t))
+                        return
+            final[i] = sess.last_stats()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(0, s0)), threading.Thread(target=work, args=(1, s1))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[:3]
+    for i in range(2):
+        med = float(np.median(lat[i]))
+        assert max(lat[i][5:]) < 3 * med, (i, med, max(lat[i][5:]), int(np.argmax(lat[i][5:])))
+        # 1.15 x the bound switches up, 0.65 x (below three quarters) down, each change then holds for 8 calls
+        assert 2 <= final[i].mode_flips <= calls // 8, final[i].mode_flips
+    s0.close()
+    s1.close()
+
+
 def test_call_counter_wrap(monkeypatch):
     """The recency unit travels in 24 bits of a call's time token and wraps freely (the stamps in the bucket lines are the
     unit modulo 255 and repeat one value at the wrap); results stay exact and insertion keeps working across it.  Call clock,

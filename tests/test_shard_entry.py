@@ -298,15 +298,69 @@ def test_call_wide_dedup_is_skipped_while_big_requests_repeat_little(plain_lru):
             ask(uniform(), 1)               # ... so the next ones skip the call-wide level
         st = ask(zipf(), 1)                 # the first repeating request still runs at the tile level (and finds repeats there)
         assert st.unique_keys < 0.8 * sum(nk)
-        ask(zipf(), 2)                      # back at once
-        ask(uniform(), 2)
+        ask(zipf(), 2)                      # back at once ...
+        for _ in range(7):
+            ask(uniform(), 2)               # ... and for at least 8 requests, whatever they look like (no flapping on traffic that alternates)
         for _ in range(31):
             ask(uniform(), 1)
         ask(uniform(), 2)                   # re-measured after 31 requests
+        assert e.last_stats().dedup_flips == 5       # 2 -> 1 -> 2 -> 1 -> 2 -> 1 (the re-measured request repeats little again)
         e.set_option("dedup", 2)
         for _ in range(3):
             ask(uniform(), 2)
         e.close()
+    finally:
+        ps.close()
+
+
+@pytest.mark.gpu
+def test_adaptive_dedup_on_its_threshold_two_entries_in_opposite_phase(plain_lru):
+    """Two entry sessions of one model, each fed requests that alternate between 'repeats little' (> 90 % of the keys travel) and
+    'repeats much' (< 80 %), in OPPOSITE phase, for 200 requests each: rows exact, no request slower than three times the median,
+    and the dedup level changes at most twice per 9 requests (back to both levels at once, then kept for 8)."""
+    import threading
+    import time
+    import torch
+    from hugectr_backend_amd import hps
+    tables = make_tables([(300000, 16)], seed=13)
+    keys, rows = tables[0]
+    ps = _server("thr", tables, 2, gpucacheper=1.0, hit_rate_threshold=1.0, maxcat=[1], max_batch=70000)
+    try:
+        entries = [hps.ShardedEntrySession.create(ps, "thr", 0) for _ in range(2)]
+        rows_d = torch.from_numpy(rows).cuda()
+        N, calls = 66000, 200
+        rng = np.random.default_rng(5)
+        little = [rng.permutation(keys.size)[:N] for _ in range(4)]                                   # all distinct: 100 % travel
+        much = [np.concatenate([rng.permutation(keys.size)[:N // 2]] * 2) for _ in range(4)]          # every key twice: 50 % travel
+        errs, lat, flips = [], [[], []], [0, 0]
+
+        def work(i):
+            try:
+                e = entries[i]
+                out = torch.empty(N * 16, dtype=torch.float32, device="cuda")
+                for c in range(calls):
+                    idx = (little if (c + i) % 2 == 0 else much)[c % 4]
+                    q = keys[idx].astype(np.int64)
+                    t0 = time.perf_counter()
+                    e.lookup(q, [N], out=out)
+                    lat[i].append(time.perf_counter() - t0)
+                    if not torch.equal(out.view(N, 16), rows_d[torch.from_numpy(idx).cuda()]):
+                        errs.append((i, c))
+                        return
+                flips[i] = int(e.last_stats().dedup_flips)
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs[:3]
+        for i in range(2):
+            med = float(np.median(lat[i]))
+            assert max(lat[i][5:]) < 3 * med + 0.002, (i, med, max(lat[i][5:]))          # (2 ms of slack for the interpreter's own pauses)
+            assert 2 <= flips[i] <= 2 * calls // 9 + 3, flips
+        for e in entries:
+            e.close()
     finally:
         ps.close()
 
