@@ -192,10 +192,12 @@ def test_lookup_interact_picks_the_arrangement_by_the_sessions_miss_volume():
     op1 = DenseInteraction([w.cpu().numpy() for w in ws], [b.cpu().numpy() for b in bs], T, D)
     rng = np.random.default_rng(4)
 
+    resident = [k[cache.query(t, k) >= 0] for t, (k, _) in enumerate(tables)]
+
     def request(missing):
         parts = []
-        for t, (k, _) in enumerate(tables):
-            q = rng.choice(k, B).astype(np.int64)
+        for t in range(T):
+            q = rng.choice(resident[t], B).astype(np.int64)
             pos = rng.choice(B, missing // T, replace=False)
             q[pos] = -7 - rng.integers(0, 1 << 40, pos.size)                # keys that exist nowhere: unique misses, default rows
             parts.append(q)
