@@ -600,7 +600,14 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
   std::vector<size_t> recv_base(P_ + 1, 0);
   for (uint32_t s = 0; s < P_; ++s) {
     const uint32_t total = base[s + 1] - base[s];
-    if (total) plans[s] = PlanShardPasses(counts + (size_t)s * T, T, staged ? std::min(sessions_[s]->max_keys(), piece_keys_) : sessions_[s]->max_keys());
+    if (total && !staged) plans[s] = PlanShardPasses(counts + (size_t)s * T, T, sessions_[s]->max_keys());
+    if (total && staged) {
+      // pieces of equal size: as many as shard_copy_piece_keys asks for, none of them a short tail (a piece costs ~0.15 ms of call
+      // overhead whatever it holds)
+      const size_t cap = std::min(sessions_[s]->max_keys(), piece_keys_);
+      const size_t pieces = (total + cap - 1) / cap;
+      plans[s] = PlanShardPasses(counts + (size_t)s * T, T, (total + pieces - 1) / pieces);
+    }
     size_t fl = 0;
     if (staged) for (const ShardPass& pass : plans[s]) fl += PieceFloats(pass, dims_);
     recv_base[s + 1] = recv_base[s] + fl;

@@ -148,7 +148,7 @@ class ShardedEntrySession {
   std::vector<StagedShard> staged_;
   float* d_recv_ = nullptr;         // entry device: the shards' blocks, shard-major, piece by piece
   size_t recv_floats_ = 0;
-  size_t piece_keys_ = 65536;
+  size_t piece_keys_ = 131072;
   int transport_ = 0;
   bool peers_ok_ = true;            // every shard device can store into the entry device
 

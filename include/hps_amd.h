@@ -363,7 +363,7 @@ int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint6
  * model instance of such a model.  Optional keys: "shard_capacity_factor" (default 2.0: a shard session holds that many
  * times its fair share of a full request; more is served in several passes), "shard_dedup" (default true: a key the request
  * repeats travels to its owner once), "shard_transport" ("peer_store", the default: as above | "staged_copy": every owner
- * gathers pieces of "shard_copy_piece_keys" (default 65,536) keys into local blocks with ordinary lookups, copy engines ship
+ * gathers pieces of at most "shard_copy_piece_keys" (default 131,072) keys into local blocks with ordinary lookups, copy engines ship
  * the blocks into the entry device's receive buffer — hipMemcpyPeerAsync, SDMA over xGMI — while the next piece is gathered,
  * and a kernel on the entry device puts the delivered rows into OUTPUT0; the bucket keys travel by copy too, so no kernel
  * touches another device's memory and peer access is not needed).  Same rows either way. */
