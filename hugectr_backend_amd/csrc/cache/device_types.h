@@ -107,7 +107,10 @@ struct CallWork {
                              // LAST ON PURPOSE: placed between call_tag and slot (every later field 8 bytes further into
                              // the kernel-argument block, the tail's wide scalar loads no longer aligned) the probe kernel
                              // took 50-51 us instead of 43, with the order on or off — same ISA but for the offsets
-                             // (profiles/round3/ab_probe_xcd_tiles.txt)
+                             // (profiles/round3/ab_probe_xcd_tiles.txt).  Round 6 tried the opposite direction — 8 bytes of padding
+                             // in front of `set`, so that set / set_mask / acc / uniq_keys form one 32-byte aligned group of the
+                             // argument block: 41.3-41.4 us against 41.5-41.8 (noise); left as it is
+                             // (profiles/round6/ab_callwork_tail_alignment.txt)
 };
 
 
