@@ -7,6 +7,7 @@
 #   pmc_{FETCH,WRITE}_SIZE_counter_collection.csv   separate --pmc passes (one session), kernels of one lookup call
 #   rocprof_summary.json                    tools/summarize_profile.py over the three
 #   bench_default.json / bench_extra.json   the driver's command, un-profiled: compact line / full result
+#   (rocprof_summary.json also splits hps_cache_insert_kernel's launches into cache warm-up and serving: insert_kernel_split)
 # (kernel traces are deleted: only the small summaries travel back and get committed under profiles/).
 set -u
 TAG=${1:-r1}
@@ -20,7 +21,7 @@ tail -2 $O/pytest_gpu.txt
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/bench.py --steps 20 --warmup 5 --no-extra-legs --no-cpu-baseline \
     > $O/bench_under_rocprofv3_kernel_trace.json 2> $O/kt.log
-rm -f $O/kt/kt_kernel_trace.csv $O/kt/*/kt_kernel_trace.csv
+# (the per-launch trace stays until tools/summarize_profile.py has split the insert kernel's launches into warm-up and serving)
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "hps_probe_tile|hps_miss_unique|hps_gather_hits|hps_miss_scatter|hps_cache_insert" --output-format csv -d $O/pmc_$C -o pmc -- \
       python $R/bench.py --steps 12 --warmup 4 --blocks 1 --sessions 1 --no-cpu-baseline --no-extra-legs > $O/pmc_$C.json 2> $O/pmc_$C.log
@@ -34,7 +35,7 @@ for C in FETCH_SIZE WRITE_SIZE; do cp $O/pmc_${C}_counter_collection.csv $O/pmc_
 python tools/summarize_profile.py $O $O/rocprof_summary.json > /dev/null
 find $O/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/rocprofv3_kernel_stats_bench.csv
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/*.log $O/pmc_FETCH_SIZE.json $O/pmc_WRITE_SIZE.json
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 cp bench_extra.json $O/bench_extra.json
 tail -c 600 $O/bench_default.json
 du -sh $O
