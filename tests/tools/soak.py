@@ -78,6 +78,8 @@ def main():
             errs.append((si, repr(e)))
             stop.set()
 
+    refreshed = [0, 0]
+
     def churn():
         i = 0
         try:
@@ -86,7 +88,10 @@ def main():
                 if i % 3 == 0:
                     t = (i // 3) % T
                     ps.load_table_arrays("soak", t, *tables[t])       # reload (same content) under the sessions
-                ps.refresh_embedding_cache("soak", 0)
+                # the default refresh (only what can differ: here the reloaded table), every fifth time the reference's full pass
+                st = ps.refresh_embedding_cache("soak", 0, full=(i % 5 == 4))
+                refreshed[0] += st["rows_refreshed"]
+                refreshed[1] += st["tables_unchanged"]
                 i += 1
         except Exception as e:  # noqa: BLE001
             errs.append(("churn", repr(e)))
@@ -101,8 +106,9 @@ def main():
     [x.join() for x in th]
     cache.wait_async()
     print(f"soak {'direct' if direct else 'host'} thr={thr}: {sum(calls)} lookups by {nsess} sessions in {time.time()-t0:.0f} s, "
-          f"errors: {errs if errs else 'none'}, counters {cache.counters()}")
-    sys.exit(1 if errs else 0)
+          f"errors: {errs if errs else 'none'}, counters {cache.counters()}, refresh: {refreshed[0]} rows re-read, {refreshed[1]} table passes skipped as unchanged, "
+          f"fork-join overruns {hps.pool_fast_overruns()}")
+    sys.exit(1 if errs or hps.pool_fast_overruns() else 0)
 
 
 if __name__ == "__main__":
