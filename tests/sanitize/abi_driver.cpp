@@ -62,6 +62,9 @@ int main(int argc, char** argv) {
     hps_shard_entry_t* e = nullptr;
     if (sharded) {
       if (hps_shard_entry_create(sv, "m", 0, &e) != 0) { bad.fetch_add(1); fprintf(stderr, "entry session: %s\n", hps_last_error()); return; }
+      // round 6: one of the three entry sessions moves its rows by staged copies (owners gather pieces, copy engines ship them,
+      // a kernel places them: csrc/cache/shard_entry.cpp ServeStaged), in small pieces so that several are in flight
+      if (id == 1 && (hps_shard_entry_set_option(e, "transport", 1) != 0 || hps_shard_entry_set_option(e, "copy_piece_keys", 1024) != 0)) { bad.fetch_add(1); return; }
     } else if (hps_session_create(sv, "m", cache, &s) != 0) { bad.fetch_add(1); fprintf(stderr, "session: %s\n", hps_last_error()); return; }
     std::mt19937_64 rng(100 + id);
     std::vector<int64_t> keys(T * kBatch);
@@ -123,7 +126,24 @@ int main(int argc, char** argv) {
     while (!stop.load()) {
       std::this_thread::sleep_for(std::chrono::milliseconds(40));
       if (hps_server_load_table_synthetic(sv, "m", (uint32_t)(i % T), kSeed, 0, R) != 0) { bad.fetch_add(1); break; }
-      if (gpu && hps_server_refresh_embedding_cache(sv, "m", 0) != 0) { bad.fetch_add(1); break; }
+      // round 6: the default refresh (only what can differ: the table just reloaded), every third time the reference's full pass,
+      // and an online update of a few rows (same contents: the recipe's rows) whose keys the next refreshes replay from the change log
+      hps_refresh_stats_t rst;
+      if (gpu && hps_server_refresh_embedding_cache_ex(sv, "m", 0, i % 3 == 2, &rst) != 0) { bad.fetch_add(1); break; }
+      {
+        const uint32_t t = (uint32_t)((i + 1) % T);
+        std::vector<int64_t> uk(64);
+        std::vector<float> ur((size_t)64 * kDims[t]);
+        const uint64_t tb = hps_synth_table_base(kSeed, t);
+        for (int q = 0; q < 64; ++q) {
+          uk[(size_t)q] = (int64_t)(((uint64_t)i * 7919u + (uint64_t)q * 104729u) % R);
+          for (uint32_t j = 0; j < kDims[t]; ++j) {
+            const uint32_t bits = hps_synth_elem_bits(hps_synth_row_base(tb, uk[(size_t)q]), j);
+            memcpy(&ur[(size_t)q * kDims[t] + j], &bits, 4);
+          }
+        }
+        if (hps_server_upsert(sv, "m", t, uk.data(), ur.data(), 64) != 0) { bad.fetch_add(1); break; }
+      }
       ++i;
     }
   });

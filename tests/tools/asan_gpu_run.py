@@ -88,7 +88,12 @@ def main():
                             return
                         if si == 0 and it == 5:
                             ps.load_table_arrays(name, 1, *tables[1])      # reload under the other session
+                            st_r = ps.refresh_embedding_cache(name, 0)     # (only what can differ: the reloaded table, in full)
+                            assert st_r["tables_full"] == 1 and st_r["tables_unchanged"] == T - 1, st_r
+                        if si == 0 and it == 8:
+                            ps.upsert(name, 0, tables[0][0][:300], tables[0][1][:300])    # an online update (same rows): change log
                             ps.refresh_embedding_cache(name, 0)
+                            ps.refresh_embedding_cache(name, 0, full=True)                # the reference's full pass, paced
                 except Exception as e:  # noqa: BLE001
                     failures.append((name, si, repr(e)))
 
@@ -116,6 +121,10 @@ def main():
         h = C.c_void_p()
         hps._check(hps.LIB.hps_shard_entry_create(ps._h, name.encode(), 0, C.byref(h)))
         entries.append(h)
+
+    # (round 6) the second entry session moves its rows by staged copies, in small pieces (csrc/cache/shard_entry.cpp ServeStaged)
+    hps._check(hps.LIB.hps_shard_entry_set_option(entries[1], b"transport", 1))
+    hps._check(hps.LIB.hps_shard_entry_set_option(entries[1], b"copy_piece_keys", 1024))
 
     def eworker(ei, seed):
         rng = np.random.default_rng(seed)
