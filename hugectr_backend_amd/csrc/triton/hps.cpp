@@ -10,7 +10,10 @@
 //   * KEYS handed over in GPU memory are used in place (hps.cc:587-597 asks for GPU memory, then memcpy's);
 //   * the lookup writes straight into Triton's output buffer when it is device memory instead of going
 //     through a private result buffer plus a second full-size copy (hps.cc:676-691);
-//   * no C++ exception crosses the C ABI (CK_CUDA_THROW_ at hps.cc:677-685 does).
+//   * no C++ exception crosses the C ABI (CK_CUDA_THROW_ at hps.cc:677-685 does);
+//   * several small requests of ONE Execute call (a dynamic batcher's hand-over) are served by one engine call instead of one
+//     blocking lookup each (hps.cc:406): all requests are validated first, the valid ones' keys merged table by table, every
+//     request's rows moved to its own output buffer; verdicts, parameters and statistics stay per request.
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
