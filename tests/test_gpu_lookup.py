@@ -495,8 +495,11 @@ def test_per_call_switches_on_their_threshold_two_sessions_in_opposite_phase(dir
         [t.join() for t in th]
         assert not errs, errs[:3]
         passes += 1
-        # (a timed pass during which the process was frozen by its CPU quota says nothing about the library: once more, three times at most)
-        if not verify and throttled() == thr0:
+        # A timed pass during which the process was frozen by its CPU quota says nothing about the library — and neither does one
+        # with a single 4-ms call in it: the boxes show such calls now and then whatever runs (a thread of the HIP runtime that
+        # releases work queued behind a cross-stream event loses its CPU for a scheduler tick).  A bad MODE — what this
+        # test is after — repeats; a tick does not: the pass is run again, three times at most, and the last one is judged.
+        if not verify and throttled() == thr0 and all(max(l[5:]) < 3 * float(np.median(l)) for l in lat):
             break
     calls *= passes
     quiet = passes < 4 or throttled() == thr0
