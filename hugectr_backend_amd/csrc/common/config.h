@@ -115,8 +115,10 @@ struct InferenceParams {  // backend.cpp:318-516
   int small_miss_insert_interval = 4;
   // "gpucache_refresh_changed_only" (default true): refresh_embedding_cache re-reads only rows that can differ from the host tier's
   // (tables reloaded or keys updated since the cache last looked); false: every resident row on every refresh, as the reference.
-  // "gpucache_refresh_link_share" (default 0.15, in (0, 1]): the share of the PCIe link (and of the cache's writer windows) a
-  // refresh takes while lookup sessions are serving; with nobody serving it runs at full speed.
+  // "gpucache_refresh_link_share" (default 0.15, in (0, 1]): the refresher's DUTY CYCLE while lookup sessions are serving — after a
+  // piece (32,768 rows: host gather on 4 threads, upload, insert) that took t it pauses for t x (1/share - 1), so the link, the
+  // serving pool and the cache's writer windows are its for at most that share of the time (measured: 1.5-2 GB/s of refresh under
+  // the headline's load); with nobody serving it runs at full speed.  1.0: unpaced, 262,144-row pieces (rounds 1-5).
   bool refresh_changed_only = true;
   double refresh_link_share = 0.15;
   // "ps_direct_access": the GPU resolves missed keys through a device-resident index of the host tier and reads

@@ -134,8 +134,9 @@ int hps_server_refresh_embedding_cache(hps_server_t* server, const char* model, 
 /* The same with a choice and an account of what it did.  By default a refresh re-reads only rows that CAN differ from the host
  * tier's: nothing for a table that was neither reloaded nor updated since the cache last looked, the resident ones among the
  * updated keys otherwise (ps.json "gpucache_refresh_changed_only": false, or full != 0 here: every resident row of every table,
- * as the reference does: docs/hierarchical_parameter_server.md:234-238).  While lookup sessions are serving, the upload takes
- * "gpucache_refresh_link_share" (default 0.15) of the link and of the cache's writer windows, in pieces of 32,768 rows. */
+ * as the reference does: docs/hierarchical_parameter_server.md:234-238).  While lookup sessions are serving, the refresher works in
+ * pieces of 32,768 rows with a duty cycle of "gpucache_refresh_link_share" (default 0.15: after a piece that took t it pauses
+ * for 5.7 t) — the link, the serving pool and the cache's writer windows are the sessions' for the rest of the time. */
 typedef struct hps_refresh_stats {
   uint64_t tables, tables_unchanged, tables_full;   /* tables looked at / skipped as unchanged / refreshed row by row in full */
   uint64_t keys_dumped;                             /* resident keys read back from the GPU for the full passes */
