@@ -1538,8 +1538,14 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
     key_stage_ms_ = 0.f;
     keys_narrow_ = false;
     key_bytes_ = 8;
+    // The bottom MLP needs nothing of the lookup: it goes down the session's SECOND stream first and runs next to the probe
+    // (a caller that runs lookup and dense step itself has it behind the lookup: 40 us of the call); the interaction waits for it.
+    const void* d_bottom = nullptr;
+    HPS_RETURN_IF_ERROR(dense->BottomMlp(d_dense_features, batch, copy_stream_, &d_bottom));
     HPS_RETURN_IF_ERROR(TimedLookupDevice(d_keys_flat, outs.data(), n.data(), T));
-    HPS_RETURN_IF_ERROR(dense->Forward(d_dense_features, d_interact_emb_, batch, d_out_f16, stream_));
+    HIP_TRY(hipEventRecord(ev_copy_, copy_stream_));     // (recorded after the lookup: behind the MLP and whatever the lookup put on that stream)
+    HIP_TRY(hipStreamWaitEvent(stream_, ev_copy_, 0));
+    HPS_RETURN_IF_ERROR(dense->Interact(d_interact_emb_, d_bottom, batch, d_out_f16, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     return Status::Ok();
   }

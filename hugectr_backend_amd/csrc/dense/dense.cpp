@@ -100,6 +100,14 @@ Status DenseInteraction::Forward(const float* d_dense, const float* d_emb, uint6
   return Status::Ok();
 }
 
+Status DenseInteraction::Interact(const float* d_emb, const void* d_bottom, uint64_t batch, void* d_out, hipStream_t stream) {
+  if (batch == 0) return Status::Ok();
+  if (!d_emb || !d_bottom || !d_out) return Error(Code::kInvalidArg, "dense interaction: null device pointer");
+  HIP_TRY(hipSetDevice(device_));
+  HIP_TRY(LaunchDenseInteract(d_emb, d_bottom, batch, num_tables_, emb_dim_, out_stride(), d_out, cu_count_, stream));
+  return Status::Ok();
+}
+
 Status DenseInteraction::BottomMlp(const float* d_dense, uint64_t batch, hipStream_t stream, const void** d_bottom) {
   if (!d_dense || !d_bottom) return Error(Code::kInvalidArg, "bottom MLP: null pointer");
   HIP_TRY(hipSetDevice(device_));

@@ -54,6 +54,8 @@ class DenseInteraction {
   Status Forward(const float* d_dense, const float* d_emb, uint64_t batch, void* d_out, hipStream_t stream);
   // First half only: the bottom MLP into the object's scratch, [batch][emb_dim] f16 (used by the fused lookup path)
   Status BottomMlp(const float* d_dense, uint64_t batch, hipStream_t stream, const void** d_bottom);
+  // Second half only: the dot interaction over OUTPUT0 and a bottom-MLP result of this object (BottomMlp's d_bottom)
+  Status Interact(const float* d_emb, const void* d_bottom, uint64_t batch, void* d_out, hipStream_t stream);
   int device() const { return device_; }
   int cu_count() const { return cu_count_; }
 
