@@ -2,6 +2,7 @@
 """Condense rocprofv3 output directories into the small summaries committed under profiles/.
 
     python tools/summarize_profile.py <dir with kt/ pmc_FETCH_SIZE/ pmc_WRITE_SIZE/> <out.json>
+    python tools/summarize_profile.py --latest <rocprof_summary.json> profiles/pmc_latest.json <round> "<source>"
 
 Kernel stats: top rows of *_kernel_stats.csv (names shortened).  PMC: mean FETCH_SIZE / WRITE_SIZE of every kernel
 of a lookup call, converted as MI355X_MICROARCH.md §HBM prescribes: both counters are in KiB; on gfx950
@@ -97,5 +98,15 @@ def main(d, out):
     print(json.dumps(res)[:1500])
 
 
+def write_latest(summary_json, latest_json, round_no, source):
+    """profiles/pmc_latest.json: what bench.py copies into roofline.traffic (it cannot run the profiler on itself)."""
+    r = json.load(open(summary_json))
+    json.dump({"round": int(round_no), "workload_keys": 1703936, "dim": 128, "source": source, "pmc": r["pmc"],
+               "pmc_by_kernel": r["pmc_by_kernel"], "insert_kernel_split": r.get("insert_kernel_split")}, open(latest_json, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if sys.argv[1] == "--latest":   # --latest <rocprof_summary.json> <profiles/pmc_latest.json> <round> <source text>
+        write_latest(*sys.argv[2:6])
+    else:
+        main(sys.argv[1], sys.argv[2])
