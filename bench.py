@@ -94,7 +94,7 @@ def parse_args():
                     help="N>1: skip the BASELINE config 3 leg (one table sharded over the ranks, RCCL all-to-all)")
     ap.add_argument("--shard-rows", type=int, default=1 << 28,
                     help="rows of the sharded table in total (config 3 names 1e9 = 512 GB; default 2^28 = 137 GB)")
-    ap.add_argument("--copy-piece-keys", type=int, default=131072, help="config 3, staged_copy transport: keys per piece an owner gathers and ships")
+    ap.add_argument("--copy-piece-keys", type=int, default=0, help="config 3, staged_copy transport: keys per piece an owner gathers and ships (0: automatic — 131,072 for a shard on another GPU, one piece for a shard on the entry GPU)")
     ap.add_argument("--selftest-timeout", type=float, default=30.0, help="N>1: deadline of the multi-GPU first-contact self-test (peer access, 4-KB peer stores, per-pair GB/s, one RCCL all-reduce)")
     ap.add_argument("--no-selftest", action="store_true", help="N>1: skip the multi-GPU self-test")
     ap.add_argument("--sharded-steps", type=int, default=50)

@@ -729,7 +729,7 @@ int hps_shard_entry_set_option(hps_shard_entry_t* e, const char* name, int value
     else if (n == "timing") e->s->set_timing(value != 0);
     else if (n == "transport") return e->s->set_transport(value);
     else if (n == "copy_piece_keys") {
-      if (value < 1024) return Error(Code::kInvalidArg, "copy_piece_keys must be >= 1024");
+      if (value != 0 && value < 1024) return Error(Code::kInvalidArg, "copy_piece_keys must be 0 (automatic) or >= 1024");
       e->s->set_piece_keys((size_t)value);
     }
     else return Error(Code::kInvalidArg, "unknown option '", n, "'");

@@ -255,7 +255,13 @@ size_t ShardedEntrySession::PieceFloats(const ShardPass& pass, const std::vector
 Status ShardedEntrySession::EnsureStaged() {
   uint32_t maxd = 1;
   for (uint32_t d : dims_) maxd = std::max(maxd, d);
-  const size_t want = piece_keys_ * maxd + 4 * dims_.size() + 4;
+  // a block holds the largest piece any shard may be asked for (automatic mode: a co-located shard's whole bucket)
+  size_t piece_max = 1024;
+  for (uint32_t s = 0; s < P_; ++s) {
+    const size_t w = piece_keys_ ? piece_keys_ : (shard_device_[s] == device_ ? sessions_[s]->max_keys() : kAutoPieceKeys);
+    piece_max = std::max(piece_max, std::min(sessions_[s]->max_keys(), w));
+  }
+  const size_t want = piece_max * maxd + 4 * dims_.size() + 4;
   if (staged_.size() == P_ && staged_[0].stage_floats >= want) return Status::Ok();
   FreeStaged();
   staged_.resize(P_);
@@ -604,7 +610,9 @@ Status ShardedEntrySession::Run(const int64_t* d_keys_flat, float* const* d_out,
     if (total && staged) {
       // pieces of equal size: as many as shard_copy_piece_keys asks for, none of them a short tail (a piece costs ~0.15 ms of call
       // overhead whatever it holds)
-      const size_t cap = std::min(sessions_[s]->max_keys(), piece_keys_);
+      // (automatic: a shard on the entry GPU itself ships with a local copy — nothing to put the next lookup under: one piece)
+      const size_t want = piece_keys_ ? piece_keys_ : (shard_device_[s] == device_ ? sessions_[s]->max_keys() : kAutoPieceKeys);
+      const size_t cap = std::min(sessions_[s]->max_keys(), want);
       const size_t pieces = (total + cap - 1) / cap;
       plans[s] = PlanShardPasses(counts + (size_t)s * T, T, (total + pieces - 1) / pieces);
     }

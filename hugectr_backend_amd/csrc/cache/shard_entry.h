@@ -101,7 +101,7 @@ class ShardedEntrySession {
   // 0 peer_store, 1 staged_copy; peer_store is refused when a shard's device cannot store into the entry device
   Status set_transport(int transport);
   int transport() const { return transport_; }
-  void set_piece_keys(size_t keys) { if (keys >= 1024) piece_keys_ = keys; }   // staged_copy: keys per piece (from the next request on)
+  void set_piece_keys(size_t keys) { if (keys == 0 || keys >= 1024) piece_keys_ = keys; }   // staged_copy: keys per piece, 0 = automatic (from the next request on)
   void set_timing(bool b);   // forwards to the shard sessions (per-kernel times in their own statistics)
 
  private:
@@ -148,7 +148,8 @@ class ShardedEntrySession {
   std::vector<StagedShard> staged_;
   float* d_recv_ = nullptr;         // entry device: the shards' blocks, shard-major, piece by piece
   size_t recv_floats_ = 0;
-  size_t piece_keys_ = 131072;
+  size_t piece_keys_ = 0;           // 0: automatic (kAutoPieceKeys for a remote shard, one piece for a shard on the entry GPU)
+  static constexpr size_t kAutoPieceKeys = 131072;
   int transport_ = 0;
   bool peers_ok_ = true;            // every shard device can store into the entry device
 

@@ -321,8 +321,8 @@ Status ParseParameterServerJson(const Json& root, ParameterServerConfig* out) {
       else if (!(transport.empty() || transport == "peer_store"))
         return Error(Code::kInvalidArg, "Model '", p.model_name, "': shard_transport must be \"peer_store\" or \"staged_copy\", got '", transport, "'");
       HPS_RETURN_IF_ERROR(ParseField(p.shard_copy_piece_keys, j, "shard_copy_piece_keys", false));
-      if (p.shard_copy_piece_keys < 1024 || p.shard_copy_piece_keys > (1u << 24))
-        return Error(Code::kInvalidArg, "Model '", p.model_name, "': shard_copy_piece_keys must be in [1024, 16777216]");
+      if (p.shard_copy_piece_keys != 0 && (p.shard_copy_piece_keys < 1024 || p.shard_copy_piece_keys > (1u << 24)))
+        return Error(Code::kInvalidArg, "Model '", p.model_name, "': shard_copy_piece_keys must be 0 (automatic) or in [1024, 16777216]");
       if (p.table_sharding) {
         if (!p.use_gpu_embedding_cache)
           return Error(Code::kInvalidArg, "Model '", p.model_name, "': table_sharding shards the GPU caches and needs gpucache = true");

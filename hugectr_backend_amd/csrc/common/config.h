@@ -134,9 +134,10 @@ struct InferenceParams {  // backend.cpp:318-516
   bool shard_dedup = true;              // "shard_dedup": a key the request repeats travels to its owner once
   // "shard_transport": "peer_store" (default: the owners' kernels store rows straight into the entry GPU's output over peer
   // mappings) | "staged_copy" (owners gather pieces into local blocks, copy engines ship them — hipMemcpyPeerAsync — and a kernel
-  // on the entry GPU puts the rows in place; csrc/cache/shard_entry.h).  "shard_copy_piece_keys": keys per piece (default 131,072)
+  // on the entry GPU puts the rows in place; csrc/cache/shard_entry.h).  "shard_copy_piece_keys": keys per piece; 0 (default) =
+  // automatic: 131,072 for a shard on another GPU, ONE piece for a shard on the entry GPU itself (its copy is local: nothing to overlap)
   bool shard_transport_staged = false;
-  size_t shard_copy_piece_keys = 131072;
+  size_t shard_copy_piece_keys = 0;
   size_t num_shards() const { return table_sharding ? deployed_devices.size() : 1; }
   size_t num_tables() const { return sparse_model_files.size(); }
 };

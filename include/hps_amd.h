@@ -364,7 +364,7 @@ int hps_shard_unpermute_device(const float* d_rows, const int32_t* d_perm, uint6
  * model instance of such a model.  Optional keys: "shard_capacity_factor" (default 2.0: a shard session holds that many
  * times its fair share of a full request; more is served in several passes), "shard_dedup" (default true: a key the request
  * repeats travels to its owner once), "shard_transport" ("peer_store", the default: as above | "staged_copy": every owner
- * gathers pieces of at most "shard_copy_piece_keys" (default 131,072) keys into local blocks with ordinary lookups, copy engines ship
+ * gathers pieces of at most "shard_copy_piece_keys" keys (default 0 = automatic: 131,072 for a shard on another GPU, one piece for a shard on the entry GPU itself) into local blocks with ordinary lookups, copy engines ship
  * the blocks into the entry device's receive buffer — hipMemcpyPeerAsync, SDMA over xGMI — while the next piece is gathered,
  * and a kernel on the entry device puts the delivered rows into OUTPUT0; the bucket keys travel by copy too, so no kernel
  * touches another device's memory and peer access is not needed).  Same rows either way. */
@@ -398,7 +398,7 @@ int hps_shard_entry_last_stats(hps_shard_entry_t* entry, hps_shard_entry_stats_t
  * of 1,024 keys and call-wide, the call-wide level skipped for 31 requests after a big request of which more than 90 %
  * travelled anyway; 2: always both levels), "timing" (0/1: forwarded to the shard sessions), "transport" (0 peer_store,
  * 1 staged_copy: from the next request on; 0 is refused where peer access is not available), "copy_piece_keys" (staged_copy:
- * keys per piece, >= 1024) */
+ * keys per piece, >= 1024, or 0 = automatic) */
 int hps_shard_entry_set_option(hps_shard_entry_t* entry, const char* name, int value);
 /* keys a shard session of this entry holds per call */
 uint64_t hps_shard_entry_shard_capacity(hps_shard_entry_t* entry);

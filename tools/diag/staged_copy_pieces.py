@@ -36,5 +36,5 @@ def run(label, steps=20):
     print(f"{label:28s} {N / dt / 1e9:6.3f} G lookups/s  request {dt * 1e3:6.3f} ms | key stage {pm[0]:.3f} bucket {pm[1]:.3f} shard lookups {pm[2]:.3f} (slowest shard {pm[4]:.3f}, waiting for copies {pm[5]:.3f}, pieces {int(pm[6])}) expand {pm[3]:.3f}", flush=True)
 e.set_option("transport", 0); run("peer_store")
 e.set_option("transport", 1)
-for pk in (32768, 65536, 131072, 262144, 1 << 20):
-    e.set_option("copy_piece_keys", pk); run(f"staged_copy piece {pk}")
+for pk in (32768, 65536, 131072, 262144, 1 << 20, 0):
+    e.set_option("copy_piece_keys", pk); run(f"staged_copy piece {pk if pk else 'automatic'}")
