@@ -1543,10 +1543,11 @@ Status LookupSession::lookup_interact(DenseInteraction* dense, const int64_t* d_
     const void* d_bottom = nullptr;
     HPS_RETURN_IF_ERROR(dense->BottomMlp(d_dense_features, batch, copy_stream_, &d_bottom));
     HPS_RETURN_IF_ERROR(TimedLookupDevice(d_keys_flat, outs.data(), n.data(), T));
-    HIP_TRY(hipEventRecord(ev_copy_, copy_stream_));     // (recorded after the lookup: behind the MLP and whatever the lookup put on that stream)
-    HIP_TRY(hipStreamWaitEvent(stream_, ev_copy_, 0));
-    HPS_RETURN_IF_ERROR(dense->Interact(d_interact_emb_, d_bottom, batch, d_out_f16, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    // The interaction follows the MLP on the SECOND stream (in order behind it, no event needed) — not on the first: that one
+    // still holds the insert kernel the lookup left running behind it, which waits for other sessions' gathers to release the
+    // cache; the rows the interaction reads are complete (the lookup returned).
+    HPS_RETURN_IF_ERROR(dense->Interact(d_interact_emb_, d_bottom, batch, d_out_f16, copy_stream_));
+    HIP_TRY(hipStreamSynchronize(copy_stream_));
     return Status::Ok();
   }
   uint64_t N2 = 0;

@@ -35,6 +35,7 @@ ModelInstanceState::~ModelInstanceState() {
     (void)hipFree(d_result_);
   }
   if (h_result_) (void)hipHostFree(h_result_);
+  if (rows_stream_) { (void)hipSetDevice(device_id_); (void)hipStreamDestroy(rows_stream_); }
 }
 
 TRITONSERVER_Error* ModelInstanceState::LoadHPSInstance() {
@@ -183,9 +184,14 @@ TRITONSERVER_Error* ModelInstanceState::ProcessCoalesced(const std::vector<const
   }
   if (!seg_src.empty()) {
     if (hipSetDevice(device_id_) != hipSuccess) return HPS_TRITON_ERROR(INTERNAL, "hipSetDevice(", device_id_, ") failed");
-    hipStream_t st = sharded_entry_ ? sharded_entry_->stream() : lookupsession_->stream();
-    hipError_t e = LaunchSegmentedCopy(seg_src.data(), seg_dst.data(), seg_bytes.data(), seg_src.size(), st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    // A stream of the instance's own, NOT the session's: the session's stream may still hold the insert kernel the lookup left
+    // running behind it (and that kernel waits for other sessions' gathers to release the cache) — the rows in the result buffer
+    // are complete (the lookup returned), nothing else has to be waited for.
+    if (!rows_stream_) {
+      if (hipStreamCreateWithFlags(&rows_stream_, hipStreamNonBlocking) != hipSuccess) return HPS_TRITON_ERROR(INTERNAL, "failed to create the instance's copy stream");
+    }
+    hipError_t e = LaunchSegmentedCopy(seg_src.data(), seg_dst.data(), seg_bytes.data(), seg_src.size(), rows_stream_);
+    if (e == hipSuccess) e = hipStreamSynchronize(rows_stream_);
     if (e != hipSuccess) return HPS_TRITON_ERROR(INTERNAL, "failed to move a coalesced call's rows to the requests' output buffers: ", hipGetErrorString(e));
   }
   return nullptr;

@@ -2,6 +2,8 @@
 // Counterpart of the reference's ModelInstanceState (/root/reference/hps_backend/include/model_instance_state.hpp,
 // src/model_instance_state.cpp).
 #pragma once
+#include <hip/hip_runtime_api.h>
+
 #include <memory>
 #include <string>
 #include <vector>
@@ -83,6 +85,7 @@ class ModelInstanceState {
   size_t h_result_elems_ = 0;
   std::vector<float> cpu_result_;         // coalesced call of a model without GPU cache
   uint64_t coalesced_calls_ = 0;
+  hipStream_t rows_stream_ = nullptr;     // the segmented copy of a coalesced call's rows (created at its first use)
 };
 
 }}  // namespace hps::triton
