@@ -328,9 +328,20 @@ def test_refresh_takes_only_rows_that_can_differ():
     st = ps.refresh_embedding_cache("rf", 0, full=True)
     assert st["tables_full"] == 3 and st["rows_refreshed"] == sum(n_res) == st["keys_dumped"]
     assert st["row_bytes"] >= n_res[0] * 64 + n_res[1] * 32 + n_res[2] * 16
+    # (5) more updates than the change log holds (4 M keys): the log is cut, the cache can no longer tell what changed — a full pass
+    #     of that table, nothing for the others
+    k0, r0 = tables[0]
+    big = np.tile(k0, 180)[: 1_050_000]
+    for _ in range(5):
+        ps.upsert("rf", 0, big, np.tile(r0, (180, 1))[: big.size])
+    n_res0 = int((cache.query(0, k0) >= 0).sum())
+    st = ps.refresh_embedding_cache("rf", 0)
+    assert (st["tables_unchanged"], st["tables_full"]) == (2, 1) and st["rows_refreshed"] == n_res0, st
+    st = ps.refresh_embedding_cache("rf", 0)
+    assert st["tables_unchanged"] == 3 and st["rows_refreshed"] == 0
     s.close()
     ps.close()
-    # (5) ps.json gpucache_refresh_changed_only = false: every refresh is a full one
+    # (6) ps.json gpucache_refresh_changed_only = false: every refresh is a full one
     ps, cache, s = _mk("rf2", tables[:1], maxcat=[1], gpucacheper=0.5, max_batch=4096, extra={"gpucache_refresh_changed_only": False})
     st = ps.refresh_embedding_cache("rf2", 0)
     assert st["tables_full"] == 1 and st["rows_refreshed"] == int((cache.query(0, tables[0][0]) >= 0).sum()) > 0
