@@ -74,7 +74,7 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
   if (static_) return Status::Ok();
   auto tables = ps->tables_of(model_);
   if (tables.size() != T) return Error(Code::kNotFound, "InsertKeys: model '", model_, "' is not loaded");
-  std::lock_guard<std::mutex> lk(ins_mu_);
+  std::unique_lock<std::mutex> lk(ins_mu_);
   HIP_TRY(hipSetDevice(cfg_.device_id_));
   size_t maxD = 1;
   for (size_t t = 0; t < T; ++t) maxD = std::max<size_t>(maxD, cfg_.embedding_vec_size_[t]);
@@ -149,7 +149,17 @@ Status EmbeddingCache::InsertKeys(HierParameterServer* ps, const std::vector<std
       if (calls_now != calls_seen) {
         const double took = std::chrono::duration<double>(std::chrono::steady_clock::now() - piece_t0).count();
         const double pause = std::min(0.05, took * (1.0 / pacing->link_share - 1.0));
+        // The pause is spent WITHOUT the inserter: the background inserts of async-insert models and the update consumer use the
+        // same stream and staging, and would otherwise stand still behind a refresh that sleeps most of the time.  Nothing of this
+        // call is in flight here (the stream was drained); its statistics so far are handed in before the lock goes.
+        HIP_TRY(hipMemcpyAsync(I.h_stats, I.d_stats, (size_t)kStatLines * kAccStride * sizeof(uint32_t), hipMemcpyDeviceToHost, I.stream));
+        HIP_TRY(hipStreamSynchronize(I.stream));
+        AddStatLines(I.h_stats);
+        lk.unlock();
         std::this_thread::sleep_for(std::chrono::duration<double>(pause));
+        lk.lock();
+        HIP_TRY(hipSetDevice(cfg_.device_id_));
+        HIP_TRY(hipMemsetAsync(I.d_stats, 0, (size_t)kStatLines * kAccStride * sizeof(uint32_t), I.stream));
       }
       calls_seen = calls_so_far();
     }
