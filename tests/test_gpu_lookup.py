@@ -471,8 +471,8 @@ def test_per_call_switches_on_their_threshold_two_sessions_in_opposite_phase(dir
     """The per-call switches "keys_by_kernel" 2 and "probe_in_lane" 2 (and "interact_mode" 2, tests/test_gpu_dense.py) steer by
     'this session's calls miss much'.  Round 5 compared the last call's missed rows with side_scatter_mb on every call: traffic on
     the bound flipped the arrangement call by call.  Two sessions of one cache whose consecutive calls straddle the bound — missed
-    rows alternately 1.15 x and 0.65 x side_scatter_mb — in OPPOSITE phase for 240 calls each: rows exact, no call above three times
-    the median, and the mode (a switch with hysteresis and a dwell of 8 calls, hps_lookup_stats_t::mode_flips) changes at most once
+    rows alternately 1.15 x and 0.65 x side_scatter_mb — in OPPOSITE phase for 240 calls each: rows exact, at most one call in 50 above three
+    times the median (the boxes' lone 4-ms scheduler-tick calls are not a mode), and the mode (a switch with hysteresis and a dwell of 8 calls, hps_lookup_stats_t::mode_flips) changes at most once
     per 8 calls."""
     import threading
     import torch
@@ -561,11 +561,14 @@ def test_per_call_switches_on_their_threshold_two_sessions_in_opposite_phase(dir
         if not verify and throttled() == thr0 and all(max(l[5:]) < 3 * float(np.median(l)) for l in lat):
             break
     calls *= passes
-    quiet = passes < 4 or throttled() == thr0
+    # Judged: a MODE, not a tick.  After up to three timed passes the last one may still hold a lone 4-ms call (some boxes of the pool
+    # show them in every leg, with or without this library's switches: profiles/round6/r6z's hit_999 leg has a 7-ms call with nothing
+    # switching at all) — what a bad arrangement would do is slow MANY calls: at most one call in 50 may exceed 3 x the median, and
+    # the 97th percentile must not.
     for i in range(2):
-        med = float(np.median(lat[i]))
-        worst = max(lat[i][5:]) if quiet else float(np.percentile(lat[i][5:], 99))
-        assert worst < 3 * med, (i, med, worst, int(np.argmax(lat[i][5:])), quiet)
+        a = np.asarray(lat[i][5:])
+        med = float(np.median(a))
+        assert float(np.percentile(a, 97)) < 3 * med and float((a > 3 * med).mean()) <= 0.02, (i, med, float(a.max()), float((a > 3 * med).mean()))
         # 1.15 x the bound switches up, 0.65 x (below three quarters) down, each change then holds for 8 calls
         assert 2 <= final[i].mode_flips <= calls // 8, final[i].mode_flips
     s0.close()

@@ -377,10 +377,10 @@ def test_adaptive_dedup_on_its_threshold_two_entries_in_opposite_phase(plain_lru
                 quiet = True
                 if all(max(l[5:]) < 3 * float(np.median(l)) for l in lat):     # (a lone scheduler-tick call does not repeat; a bad mode does)
                     break
-        for i in range(2):
-            med = float(np.median(lat[i]))
-            worst = max(lat[i][5:]) if quiet else float(np.percentile(lat[i][5:], 99))
-            assert worst < 3 * med, (i, med, worst, quiet)
+        for i in range(2):      # (a mode, not a tick: see tests/test_gpu_lookup.py — at most one call in 50 above 3 x the median)
+            a = np.asarray(lat[i][5:])
+            med = float(np.median(a))
+            assert float(np.percentile(a, 97)) < 3 * med and float((a > 3 * med).mean()) <= 0.02, (i, med, float(a.max()), quiet)
             assert 2 <= flips[i] <= 2 * calls * passes // 9 + 3, flips
         for e in entries:
             e.close()
