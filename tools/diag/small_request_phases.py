@@ -15,12 +15,12 @@ for t in range(2):
 ps.create_embedding_cache_per_model("m")
 cache = ps.get_embedding_cache("m", 0)
 s = hps.LookupSession.create(ps, "m", cache)
-s.set_option("timing", 1)
 rng = np.random.default_rng(0)
 res = [np.arange(200000)[cache.query(t, np.arange(200000, dtype=np.int64)) >= 0] for t in range(2)]
 nk = [2048, 26624]
 out = torch.empty(2048 + 26624 * 16, dtype=torch.float32, device="cuda")
-for hit in (1.0, 0.9):
+for hit, timing in ((1.0, 1), (1.0, 0), (0.99, 1), (0.99, 0), (0.9, 1), (0.9, 0)):
+    s.set_option("timing", timing)
     rec = []
     for it in range(300):
         q = np.concatenate([np.where(rng.random(n) < hit, rng.choice(res[t], n), rng.integers(200000, R, n)) for t, n in enumerate(nk)]).astype(np.int64)
@@ -30,4 +30,4 @@ for hit in (1.0, 0.9):
         st = s.last_stats()
         rec.append((dt, st.key_stage_ms, st.phase_ms[0], st.phase_ms[1], st.phase_ms[2], st.phase_ms[3], st.gpu_call_ms, st.probe_gather_ms, st.hit_gather_ms, st.scatter_ms))
     a = np.median(np.array(rec[50:]), axis=0)
-    print(f"hit {hit}: python call {a[0]:.3f} ms | key staging {a[1]:.3f} | engine: counts on host {a[2]:.3f}, ps fetch {a[3]:.3f}, tail {a[4]:.3f}, whole {a[5]:.3f} | GPU span {a[6]:.3f} (probe {a[7]:.3f}, gather {a[8]:.3f}, scatter {a[9]:.3f})")
+    print(f"hit {hit} timing {timing}: python call {a[0]:.3f} ms | key staging {a[1]:.3f} | engine: counts on host {a[2]:.3f}, ps fetch {a[3]:.3f}, tail {a[4]:.3f}, whole {a[5]:.3f} | GPU span {a[6]:.3f} (probe {a[7]:.3f}, gather {a[8]:.3f}, scatter {a[9]:.3f})")
