@@ -397,6 +397,15 @@ def compact_line(res, limit=COMPACT_LIMIT):
         put(f"c3_single_entry_{tag_}_rows_GBps_into_entry", bt_.get("rows_GBps_into_entry_gpu"))
         put(f"c3_single_entry_{tag_}_all_instances_Glps", _scale(_dig(bt_, ("all_instances_at_once", "lookups_per_s")), G))
     put("c3_single_entry_parity", c3e.get("parity"))
+    if res.get("multi_gpu_selftest") and c3e.get("by_transport"):
+        # which "shard_transport" this run says to ship (tools/choose_transport.py = INTEGRATION.md 4.1; null on logical shards)
+        try:
+            sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
+            import choose_transport
+            ch_ = choose_transport.decide(res)
+            put("c3_transport_choice", f"{ch_['shard_transport']} ({ch_['confidence']})" if ch_["ok"] else "none: " + (ch_["reasons"][0][:40] if ch_["reasons"] else "?"))
+        except Exception as e_:  # noqa: BLE001 — a diagnostic must not cost the line
+            put("c3_transport_choice", "error: " + repr(e_)[:40])
     put("c3_single_entry_error", (str(c3e["error"])[:120] if c3e.get("error") else None))
     put("c3_triton_Glps", _scale(g(ex, "c3_sharded_triton", "lookups_per_s"), G))
     put("c3_triton_p50_ms", g(ex, "c3_sharded_triton", "p50_request_ms"))

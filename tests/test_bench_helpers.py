@@ -118,8 +118,8 @@ def test_final_line_says_what_was_measured():
     res["extra_legs"]["sharded_c3_single_entry"] = {
         "shards": 2, "shard_devices": [0, 1], "lookups_per_s": 1.5e9, "parity": True, "transports": ["peer_store", "staged_copy"],
         "uniform": {"lookups_per_s": 1.5e9, "p50_request_ms": 1.1, "rows_GBps_into_entry_gpu": 300.0},
-        "by_transport": {"peer_store": {"uniform": {"lookups_per_s": 1.5e9, "rows_GBps_into_entry_gpu": 300.0, "all_instances_at_once": {"lookups_per_s": 2.5e9}}},
-                         "staged_copy": {"uniform": {"lookups_per_s": 1.2e9, "rows_GBps_into_entry_gpu": 250.0, "all_instances_at_once": {"lookups_per_s": 2.0e9}}}}}
+        "by_transport": {"peer_store": {"uniform": {"parity": True, "lookups_per_s": 1.5e9, "rows_GBps_into_entry_gpu": 300.0, "all_instances_at_once": {"lookups_per_s": 2.5e9}}},
+                         "staged_copy": {"uniform": {"parity": True, "lookups_per_s": 1.2e9, "rows_GBps_into_entry_gpu": 250.0, "all_instances_at_once": {"lookups_per_s": 2.0e9}}}}}
     line = json.dumps(bench.compact_line(res))
     assert len(line) < 4096
     back = json.loads(line)
@@ -135,10 +135,13 @@ def test_final_line_says_what_was_measured():
     for k in ("c3_single_entry_store_Glps", "c3_single_entry_copy_Glps", "c3_single_entry_store_rows_GBps_into_entry",
               "c3_single_entry_copy_rows_GBps_into_entry", "c3_single_entry_store_all_instances_Glps", "c3_single_entry_copy_all_instances_Glps"):
         assert back["legs"][k] > 0, k
+    # ... and the decision tools/choose_transport.py draws from them
+    assert back["legs"]["c3_transport_choice"] == "peer_store (measured)"
     # a self-test that did not come back is named, not dropped
     res["multi_gpu_selftest"] = {"timeout": True, "stuck_in": "4-KB peer store 2->5", "seconds": 20.0, "wall_seconds": 20.0}
     back = json.loads(json.dumps(bench.compact_line(res)))
     assert back["multi_gpu_selftest"]["timeout"] is True and "2->5" in back["multi_gpu_selftest"]["stuck_in"]
+    assert back["legs"]["c3_transport_choice"].startswith("none: the self-test did not finish")
 
 
 def test_no_stale_flags():

@@ -66,6 +66,7 @@ def test_plain_gpus_2_also_measures_both_config3_variants_and_the_cpu_baseline(t
     st = compact["multi_gpu_selftest"]
     assert st["devices"] == [0] and st["timeout"] is False and st["error"] is None and st["rccl_allreduce_ok"] is True, st
     assert "xgmi_pair_GBps_min" in compact and "xgmi_pair_GBps_median" in compact       # (no pair on a one-GPU box: nulls)
+    assert legs["c3_transport_choice"].startswith("none: every shard sat on ONE device")     # tools/choose_transport.py: nothing to choose from here
     bt = d["extra_legs"]["sharded_c3_single_entry"]["by_transport"]
     assert bt["staged_copy"]["uniform"]["parity"] and bt["staged_copy"]["uniform"]["row_bytes_copied_per_request"] > 0
     assert bt["peer_store"]["uniform"]["row_bytes_copied_per_request"] == 0
