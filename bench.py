@@ -1234,6 +1234,11 @@ def main():
                                 f"the last GPU has finished its {K} steps = max over GPUs), every step a fresh batch; value = the MEDIAN block",
             },
             "block_ms": [b * 1e3 for b in block_s],
+            # replica 0's kernels call by call (completion order; us, the kernels' own timestamps) and block by block: does a kernel
+            # drift inside the timed region, do a few calls carry the mean (profiles/round6/box_gather_probe_14_boxes.txt)
+            "gather_us_per_call": [int(round(r[2] * 1e3)) for r in reps[0].rec],
+            "kernel_us_by_block": [[round(float(np.mean([r[c] for r in reps[0].rec[b0:b0 + K]])) * 1e3, 1) for c in (1, 2, 3, 4)]
+                                   for b0 in range(0, len(reps[0].rec), K)],
             "value_min_max_over_blocks": [n_rep * K * N / max(block_s), n_rep * K * N / min(block_s)],
             # the spread the median hides: mean / slowest / fastest block, and how many blocks took more than 1.15 x the median
             "value_mean": n_rep * K * N * len(block_s) / sum(block_s),
