@@ -31,7 +31,7 @@ def batch():
         k[hit] = res[t][rng.integers(0, res[t].size, int(hit.sum()))]
         q[t * B:(t + 1) * B] = k
     return q
-NB = 460
+NB = 600
 batches = [batch() for _ in range(NB)]   # every request of the run is a fresh batch (a repeated one would find its misses cached)
 next_b = [0]
 def fresh(n):
@@ -58,6 +58,9 @@ class Pool:
         while True:
             self.go[i].wait(); self.go[i].clear()
             s, a = self.jobs[i]
+            if i and STAGGER_US:   # sub-call i starts i x STAGGER_US after the first (out of phase on purpose)
+                t_end = time.perf_counter() + i * STAGGER_US * 1e-6
+                while time.perf_counter() < t_end: pass
             s.lookup_packed(*a)
             self.done[i].set()
     def run(self, jobs):
@@ -66,6 +69,7 @@ class Pool:
         for i in range(len(jobs)):
             self.done[i].wait(); self.done[i].clear()
 pool = Pool(4)
+STAGGER_US = 0
 
 def one_in_flight(k, steps):
     """k = 1: the whole request on session 0; k = 2 / 4: split by tables over sessions 1-2 / 3-6"""
@@ -106,5 +110,11 @@ for rnd in range(2):
     for k in (1, 2, 4):
         g, p50, p99 = one_in_flight(k, 40)
         print(f"one request in flight, {k} session(s): {g:.3f} G lookups/s  p50 {p50:.3f} ms  p99 {p99:.3f} ms  (hit rate of the last request {last_hit:.4f})", flush=True)
+    if rnd == 1:
+        for st_us in (100, 200, 300, 400):
+            STAGGER_US = st_us
+            g, p50, p99 = one_in_flight(2, 30)
+            print(f"one request in flight, 2 sessions, second sub-call {st_us} us later: {g:.3f} G lookups/s  p50 {p50:.3f} ms  p99 {p99:.3f} ms", flush=True)
+        STAGGER_US = 0
     g, p50, p99 = two_independent(40)
     print(f"two requests in flight, one session each: {g:.3f} G lookups/s  p50 {p50:.3f} ms  p99 {p99:.3f} ms  (hit rate of the last requests {1.0 - (S[1].last_stats().misses + S[2].last_stats().misses) / (2 * T * B):.4f})", flush=True)
