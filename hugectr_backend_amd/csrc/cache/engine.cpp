@@ -1784,8 +1784,11 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
     } else {
       HIP_TRY(hipMemcpyAsync(d_md_, h_md_, sizeof(MissDesc), hipMemcpyHostToDevice, ss));
     }
-    // upload piece: 4 MB (8- and 16-MB pieces: no gain, profiles/round4/ab_upload_piece_size_and_sessions.txt)
-    constexpr size_t kPieceFloats = (size_t)4 * (1u << 20) / sizeof(float);
+    // upload piece: 4 MB (8- and 16-MB pieces: no gain, profiles/round4/ab_upload_piece_size_and_sessions.txt) — reached by doubling
+    // from a first piece of 512 KB: the link starts after 1,000 gathered rows instead of 8,000.  A lone request's p50 1.18 -> 1.14 ms
+    // (four interleaved pairs), two requests in flight 1.57 -> 1.55 ms at the same rate (profiles/round6/ab_first_upload_piece.txt)
+    constexpr size_t kPieceFloats = (size_t)4 * (1u << 20) / sizeof(float), kFirstPieceFloats = (size_t)512 * 1024 / sizeof(float);
+    size_t piece_floats = kFirstPieceFloats;
     std::vector<HierParameterServer::FetchJob> jobs;
     size_t piece_begin = SIZE_MAX, piece_end = 0;
     bool used_copy_stream = false;
@@ -1815,8 +1818,10 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
       if (hi == lo) continue;
       const uint32_t D = tables_[t]->dim();
       // a big table is cut into several pieces of its own
-      const uint32_t rows_per_piece = (uint32_t)std::max<size_t>(1, kPieceFloats / D);
-      for (uint32_t r = lo; r < hi; r += rows_per_piece) {
+      for (uint32_t r = lo; r < hi;) {
+        // (the first pieces of a call are smaller: the link starts sooner; doubling up to 4 MB)
+        const size_t room = piece_begin == SIZE_MAX ? piece_floats : piece_floats - std::min(piece_floats, piece_end - piece_begin);
+        const uint32_t rows_per_piece = (uint32_t)std::max<size_t>(1, std::max<size_t>(room, D) / D);
         const uint32_t re = std::min(hi, r + rows_per_piece);
         const size_t off = md.stage_off[t] + (size_t)(r - lo) * D;
         jobs.push_back({tables_[t].get(), uniq_narrow_ ? nullptr : h_uniq_keys_ + c.key_start[t] + r, re - r, h_staging_ + off, D,
@@ -1825,7 +1830,11 @@ Status LookupSession::HandleMisses(uint64_t N, uint32_t epoch) {
                         uniq_narrow_ ? c.key_base[t] : 0});
         piece_begin = std::min(piece_begin, off);
         piece_end = std::max(piece_end, off + (size_t)(re - r) * D);
-        if (piece_end - piece_begin >= kPieceFloats) HPS_RETURN_IF_ERROR(flush());
+        if (piece_end - piece_begin >= piece_floats) {
+          HPS_RETURN_IF_ERROR(flush());
+          piece_floats = std::min(kPieceFloats, piece_floats * 2);
+        }
+        r = re;
       }
     }
     HPS_RETURN_IF_ERROR(flush());

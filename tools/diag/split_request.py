@@ -31,7 +31,7 @@ def batch():
         k[hit] = res[t][rng.integers(0, res[t].size, int(hit.sum()))]
         q[t * B:(t + 1) * B] = k
     return q
-NB = 600
+NB = 1500
 batches = [batch() for _ in range(NB)]   # every request of the run is a fresh batch (a repeated one would find its misses cached)
 next_b = [0]
 def fresh(n):
