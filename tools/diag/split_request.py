@@ -8,7 +8,8 @@ sys.path.insert(0, ".")
 from hugectr_backend_amd import hps
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-T, B, D, HIT = 26, 65536, 128, 0.957
+import os
+T, B, D, HIT = 26, 65536, 128, float(os.environ.get("HIT", "0.957"))
 C = int(R * 0.2)
 cfg = {"supportlonglong": True, "volatile_db": {"type": "hash_map", "num_partitions": 8},
        "models": [{"model": "m", "sparse_files": [f"synthetic://t{t}" for t in range(T)], "num_of_worker_buffer_in_pool": 7,
@@ -31,7 +32,7 @@ def batch():
         k[hit] = res[t][rng.integers(0, res[t].size, int(hit.sum()))]
         q[t * B:(t + 1) * B] = k
     return q
-NB = 1500
+NB = int(os.environ.get('NB', '600'))
 batches = [batch() for _ in range(NB)]   # every request of the run is a fresh batch (a repeated one would find its misses cached)
 next_b = [0]
 def fresh(n):
@@ -106,6 +107,12 @@ def two_independent(steps):
 S[0].lookup_packed(*args(batches[3], outs[0], ALL)); torch.cuda.synchronize(); ref = outs[0].clone(); outs[0].zero_()
 pool.run([(S[1 + i], args(batches[3], outs[0], p)) for i, p in enumerate(parts(2))]); torch.cuda.synchronize()
 print("split-by-tables rows identical to the whole-request call:", bool(torch.equal(ref.view(torch.int32), outs[0].view(torch.int32))))
+if os.environ.get("ONLY_TWO"):
+    for rnd in range(3):
+        g1, a50, a99 = one_in_flight(1, 40)
+        g, p50, p99 = two_independent(60)
+        print(f"[{os.environ.get('HPS_AMD_LIB_DIR', 'product lib')}] hit {HIT}: one in flight {g1:.3f} G p50 {a50:.3f} | two in flight {g:.3f} G lookups/s  p50 {p50:.3f} ms  p99 {p99:.3f} ms", flush=True)
+    sys.exit(0)
 for rnd in range(2):
     for k in (1, 2, 4):
         g, p50, p99 = one_in_flight(k, 40)
