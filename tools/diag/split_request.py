@@ -1,7 +1,9 @@
 """Diagnostic: ONE request in flight, served (a) by one lookup session, (b) split by tables over two / four sessions of the same cache
 driven side by side (each sub-call names the other tables with NUMKEYS 0), against (c) two independent sessions with one request each
 (the headline's arrangement).  Config 2's call shape: 26 tables x 65,536 keys x 128 fp32, ~95.7 % hit, host keys, synchronous insert.
-    python tools/diag/split_request.py [rows_per_table=2000000]"""
+    python tools/diag/split_request.py [rows_per_table=2000000]
+Environment: HIT=<resident draw probability, default 0.957>, NB=<distinct batches generated, default 600: every request must be a fresh one>,
+ONLY_TWO=1 (three readings of one-in-flight / two-in-flight only — for alternating two builds of the library via HPS_AMD_LIB_DIR)."""
 import sys, time, threading
 import numpy as np, torch
 sys.path.insert(0, ".")
