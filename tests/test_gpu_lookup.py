@@ -1367,3 +1367,27 @@ def test_never_used_slots_of_a_cold_cache_stay_claimable_whatever_the_clock_read
         assert (slots >= 0).all(), f"call {call}: {int((slots < 0).sum())} of 50 missed keys found no slot in a cache that is {call * 50 / 80000:.0%} full"
     c = cache.counters()
     assert c["inserted"] == 200 * 50 and c["dropped"] == 0
+
+
+def test_missed_rows_go_up_in_growing_pieces_across_tables_of_any_width():
+    """The host-gather tier uploads a call's missed rows in pieces of 0.5, 1, 2, then 4 MB (engine.cpp HandleMisses): a piece ends where
+    its size is reached — in the middle of a table or across several — whatever the row width.  Tables of D = 1 / 3 / 100 / 128 / 1024 with
+    nearly every key of a big call missing (a cold, small cache), twice (the second call finds what the first inserted), rows bit-exact."""
+    from oracle import hps_oracle as O
+    rng = np.random.default_rng(5120)
+    spec = [(60000, 1), (50000, 3), (40000, 100), (70000, 128), (9000, 1024)]
+    tables = make_tables(spec)
+    maxcat = [6, 5, 4, 7, 1]
+    ps, cache, s = _mk("ramp", tables, maxcat=maxcat, defaults=[0.5, -0.5, 1.5, 0.0, 2.0], gpucacheper=0.05, max_batch=8192)
+    co = O.COracle()
+    for k, r in tables:
+        co.add_table_arrays(k, r)
+    for it in range(2):
+        nk = [8192 * m for m in maxcat]
+        q = _queries(rng, tables, nk, miss_frac=0.02)
+        out = s.lookup(q, nk).cpu().numpy()
+        ref = co.lookup(q, nk, [0.5, -0.5, 1.5, 0.0, 2.0])
+        assert np.array_equal(_bits(out), _bits(ref)), it
+        st = s.last_stats()
+        # (a cold 5-% cache: most of the call's distinct keys are missed rows — tens of MB in the 1024-wide and 128-wide tables)
+        assert st.unique_misses > 60000, st.unique_misses
